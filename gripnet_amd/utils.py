@@ -1,0 +1,139 @@
+"""Host-side layout helpers for the supergraph propagation path.
+
+These restate the *input layout contract* the drug-drug (dd) internal layer and
+the DistMult decoder rely on (reference: gripnet/utils.py:132-148 `to_bidirection`,
+`get_range_list`; :168-198 `process_edge_multirelational`):
+
+  * per relation r the directed edge list is ``cat(fwd_r, reversed fwd_r)``;
+  * relations are concatenated in id order;
+  * ``edge_type`` repeats r once per directed edge;
+  * ``range_list[r] = (start, end)`` is the half-open cumulative range.
+
+They run on the host once per dataset; nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+EPS = 1e-13  # reference: gripnet/utils.py:10
+
+
+def to_bidirection(edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None):
+    """Append the reversed copy of every edge (reference: gripnet/utils.py:132-138)."""
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    if edge_type is None:
+        return both
+    return both, torch.cat([edge_type, edge_type])
+
+
+def remove_bidirection(edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None):
+    """Keep only edges with src > dst (reference: gripnet/utils.py:122-129)."""
+    keep = (edge_index[0] > edge_index[1]).nonzero().view(-1)
+    if edge_type is None:
+        return edge_index[:, keep]
+    return edge_index[:, keep], edge_type[keep]
+
+
+def get_range_list(parts: Sequence[torch.Tensor], is_node: bool = False) -> torch.Tensor:
+    """Cumulative half-open ranges of a list of blocks (reference: gripnet/utils.py:141-148)."""
+    axis = 0 if is_node else 1
+    sizes = [int(p.shape[axis]) for p in parts]
+    ends = np.cumsum(sizes, dtype=np.int64)
+    starts = ends - np.asarray(sizes, dtype=np.int64)
+    return torch.from_numpy(np.stack([starts, ends], axis=1).reshape(-1, 2).astype(np.int64))
+
+
+def process_edge_multirelational(
+    raw_edge_list: Sequence[torch.Tensor],
+    p: float = 0.9,
+    rng: Optional[np.random.RandomState] = None,
+):
+    """Bernoulli(p) train/test split per relation, then the bidirectional type-sorted layout.
+
+    Reference: gripnet/utils.py:168-198.  The reference draws from numpy's *global*
+    RNG; pass ``rng`` for a private stream (``None`` keeps the global one).
+    Returns ``train_idx, train_et, train_range, test_idx, test_et, test_range``.
+    """
+    draw = (rng or np.random).binomial
+    tr_blocks: List[torch.Tensor] = []
+    te_blocks: List[torch.Tensor] = []
+    tr_types: List[torch.Tensor] = []
+    te_types: List[torch.Tensor] = []
+    for rel, fwd in enumerate(raw_edge_list):
+        in_train = draw(1, p, fwd.shape[1]).astype(bool)
+        tr = to_bidirection(fwd[:, torch.from_numpy(np.flatnonzero(in_train))])
+        te = to_bidirection(fwd[:, torch.from_numpy(np.flatnonzero(~in_train))])
+        tr_blocks.append(tr)
+        te_blocks.append(te)
+        tr_types.append(torch.full((tr.shape[1],), rel, dtype=torch.long))
+        te_types.append(torch.full((te.shape[1],), rel, dtype=torch.long))
+    return (
+        torch.cat(tr_blocks, dim=1),
+        torch.cat(tr_types),
+        get_range_list(tr_blocks),
+        torch.cat(te_blocks, dim=1),
+        torch.cat(te_types),
+        get_range_list(te_blocks),
+    )
+
+
+def process_data_multiclass(pairs: torch.Tensor, n_class: int):
+    """Group (node, class) pairs by class (reference: gripnet/utils.py:250-263)."""
+    nodes, labels, bounds = [], [], [0]
+    for c in range(n_class):
+        sel = pairs[0][pairs[1] == c]
+        nodes.append(sel)
+        labels.append(torch.full((sel.shape[0],), c, dtype=torch.int64))
+        bounds.append(bounds[-1] + int(sel.shape[0]))
+    return torch.cat(nodes), torch.cat(labels), [[bounds[c], bounds[c + 1]] for c in range(n_class)]
+
+
+def negative_sampling(pos_edge_index: torch.Tensor, num_nodes: int,
+                      rng: Optional[np.random.RandomState] = None) -> torch.Tensor:
+    """Uniform negative pairs that avoid every positive pair (host side).
+
+    Reference: gripnet/utils.py:98-112.  Same rejection scheme (draw E linear ids in
+    [0, n^2), redraw those that hit a positive).  The reference recovers ``row`` with a
+    true division followed by ``.long()`` (utils.py:111), which is exact only while
+    n^2 < 2^24; integer division is used here instead.
+    """
+    choice = (rng or np.random).choice
+    lin = (pos_edge_index[0] * num_nodes + pos_edge_index[1]).cpu().numpy()
+    perm = choice(num_nodes ** 2, lin.shape[0])
+    bad = np.flatnonzero(np.isin(perm, lin))
+    while bad.size:
+        perm[bad] = choice(num_nodes ** 2, bad.size)
+        bad = bad[np.isin(perm[bad], lin)]
+    perm = torch.from_numpy(perm.astype(np.int64))
+    out = torch.stack([perm // num_nodes, perm % num_nodes], dim=0)
+    return out.to(pos_edge_index.device)
+
+
+def typed_negative_sampling(pos_edge_index: torch.Tensor, num_nodes: int, range_list,
+                            rng: Optional[np.random.RandomState] = None) -> torch.Tensor:
+    """Per-relation negative sampling (reference: gripnet/utils.py:115-119)."""
+    parts = [negative_sampling(pos_edge_index[:, int(s):int(e)], num_nodes, rng) for s, e in range_list]
+    return torch.cat(parts, dim=1)
+
+
+def profile(fn):
+    """No-op stand-in for ``pytorch_memlab.profile`` (reference: GripNet-pose.py:18,112)."""
+    return fn
+
+
+def shard_edge_ranges(num_edges: int, world_size: int) -> List[Tuple[int, int]]:
+    """Split ``[0, num_edges)`` into ``world_size`` contiguous ranges balanced by edge count.
+
+    Boundaries may fall inside a relation; the type-sorted layout keeps each shard a
+    contiguous slice of ``edge_index``.
+    """
+    base, extra = divmod(int(num_edges), int(world_size))
+    out, lo = [], 0
+    for k in range(world_size):
+        hi = lo + base + (1 if k < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
