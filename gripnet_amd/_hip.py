@@ -1,0 +1,346 @@
+"""ctypes binding of libgripnet_hip.so (the C ABI declared in include/gripnet_hip.h).
+
+Nothing here depends on libtorch's ABI: tensors cross the boundary as raw device pointers,
+sizes, leading dimensions and the current HIP stream.  There is no CPU fallback: if the
+library is missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgripnet_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
+
+_p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gripnet_hip.h one to one
+SIGNATURES = {
+    "gn_version": (_int, []),
+    "gn_last_error": (C.c_char_p, []),
+    "gn_gcn_plan_create": (_int, [_p, _p, _p, _i64, _i64, _int, _p, C.POINTER(_p)]),
+    "gn_bipartite_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_graph_plan_destroy": (None, [_p]),
+    "gn_graph_plan_input_edges": (_i64, [_p]),
+    "gn_graph_plan_nnz": (_i64, [_p]),
+    "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
+    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p]),
+    "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
+    "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
+    "gn_softmax_rows_f32": (_int, [_p, _i64, _i64, _i64, _p]),
+    "gn_rgcn_plan_create": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_rgcn_plan_destroy": (None, [_p]),
+    "gn_rgcn_plan_input_edges": (_i64, [_p]),
+    "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
+    "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _sz, _p]),
+    "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p]),
+    "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
+}
+
+
+class GripNetHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise RuntimeError(
+                    "gripnet_amd: {} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C gripnet_amd/csrc`). There is no CPU fallback.".format(_LIB_PATH))
+            lib = C.CDLL(_LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            if lib.gn_version() < 100:
+                raise RuntimeError("gripnet_amd: libgripnet_hip.so is older than this package")
+            _lib = lib
+    return _lib
+
+
+def check(status: int):
+    if status == GN_OK:
+        return
+    msg = load().gn_last_error().decode("utf-8", "replace")
+    if status == GN_ERR_INDEX_RANGE:
+        raise IndexError(msg)
+    if status == GN_ERR_INVALID_ARG:
+        raise ValueError(msg)
+    raise GripNetHipError(status, msg)
+
+
+class KernelTimer:
+    """Optional per-entry-point device timing: while active, every launch made through this
+    module is bracketed by HIP events on the launching stream (used by bench.py's roofline)."""
+
+    def __init__(self, only=None):
+        self.events = {}
+        self.only = None if only is None else set(only)
+
+    def __enter__(self):
+        global _timer
+        self._prev, _timer = _timer, self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = self._prev
+
+    def add(self, name, start, stop):
+        self.events.setdefault(name, []).append((start, stop))
+
+    def summary(self):
+        """name -> (calls, total_ms); synchronises."""
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+
+_timer = None
+
+
+def _call(name, *args, tag=None):
+    fn = getattr(load(), name)
+    t = _timer
+    if t is None or (t.only is not None and name not in t.only):
+        return check(fn(*args))
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    status = fn(*args)
+    stop.record()
+    t.add(tag or name, start, stop)
+    return check(status)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "gripnet_amd runs on an MI355X only: got a {} tensor on {} (no CPU fallback; "
+                "move the model and the data to 'cuda')".format(tuple(t.shape), t.device))
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def f32_rows(t: torch.Tensor) -> torch.Tensor:
+    """fp32 2-D view whose rows are contiguous (any row stride); copies only if it must."""
+    if t.dtype != torch.float32:
+        raise TypeError("gripnet_amd computes in fp32; got {}".format(t.dtype))
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D feature matrix, got shape {}".format(tuple(t.shape)))
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def i64_vec(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.int64:
+        raise TypeError("indices must be int64 (torch.long), got {}".format(t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def edge_rows(edge_index: torch.Tensor):
+    """(tensor kept alive, src pointer, dst pointer, E) of a [2, E] int64 edge_index."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must have shape [2, E], got {}".format(tuple(edge_index.shape)))
+    ei = i64_vec(edge_index)
+    e = int(ei.shape[1])
+    base = ei.data_ptr()
+    return ei, base, base + 8 * e, e
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---- thin typed wrappers ---------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=False, a_rows=None,
+         batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
+    m = (a.shape[0] if a_rows is None else a_rows.shape[0]) if m is None else m
+    k = a.shape[1] if k is None else k
+    n = b.shape[-1] if n is None else n
+    _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
+                          ptr(b), ld(b) if ldb is None else ldb, stride_b,
+                          ptr(out), ld(out) if ldc is None else ldc, stride_c,
+          m, n, k, batch, ptr(bias), int(bool(relu)), stream_ptr(a.device))
+    return out
+
+
+def merge(dst: torch.Tensor, src: torch.Tensor, mode: int, src2=None):
+    _call("gn_merge_f32", ptr(dst), ld(dst), ptr(src), ld(src), ptr(src2), 0 if src2 is None else ld(src2),
+          dst.shape[0], dst.shape[1], mode, stream_ptr(dst.device))
+    return dst
+
+
+class GraphPlan:
+    """Owner of a gn_graph_plan handle (the cached normalised graph of one GCN-style layer)."""
+
+    def __init__(self, handle, device, kind):
+        self._h, self.device, self.kind = handle, device, kind
+        self._export = None
+
+    @classmethod
+    def gcn(cls, edge_index, num_nodes, edge_weight=None, improved=False):
+        lib = load()
+        require_gpu(edge_index, edge_weight)
+        ei, src, dst, e = edge_rows(edge_index)
+        w = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()
+        if w is not None and w.numel() != e:
+            raise ValueError("edge_weight has {} entries for {} edges".format(w.numel(), e))
+        h = _p()
+        with torch.cuda.device(ei.device):
+            check(lib.gn_gcn_plan_create(src, dst, ptr(w), e, int(num_nodes), int(bool(improved)),
+                                         stream_ptr(ei.device), C.byref(h)))
+        return cls(h, ei.device, "gcn")
+
+    @classmethod
+    def bipartite(cls, edge_index, num_sources, num_targets, edge_weight=None):
+        lib = load()
+        require_gpu(edge_index, edge_weight)
+        ei, src, dst, e = edge_rows(edge_index)
+        w = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()
+        if w is not None and w.numel() != e:
+            raise ValueError("edge_weight has {} entries for {} edges".format(w.numel(), e))
+        h = _p()
+        with torch.cuda.device(ei.device):
+            check(lib.gn_bipartite_plan_create(src, dst, ptr(w), e, int(num_sources), int(num_targets),
+                                               stream_ptr(ei.device), C.byref(h)))
+        return cls(h, ei.device, "bipartite")
+
+    @property
+    def input_edges(self) -> int:
+        return int(load().gn_graph_plan_input_edges(self._h))
+
+    @property
+    def nnz(self) -> int:
+        return int(load().gn_graph_plan_nnz(self._h))
+
+    def export(self):
+        """(edge_index' [2,E'] int64, norm [E'] fp32) in the reference's order."""
+        if self._export is None:
+            n = self.nnz
+            ei = torch.empty((2, n), dtype=torch.int64, device=self.device)
+            nrm = torch.empty((n,), dtype=torch.float32, device=self.device)
+            check(load().gn_graph_plan_export(self._h, ptr(ei), ptr(nrm), stream_ptr(self.device)))
+            self._export = (ei, nrm)
+        return self._export
+
+    def __iter__(self):          # lets `edge_index, norm = conv.cached_result` keep working
+        return iter(self.export())
+
+    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor):
+        _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(bias), int(bool(relu)),
+              ptr(out), ld(out), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gn_graph_plan_destroy(h)
+
+
+class RgcnPlan:
+    """Owner of a gn_rgcn_plan handle (static multi-relational graph of one supervertex)."""
+
+    def __init__(self, edge_index, range_list, num_nodes, edge_lo=None, edge_hi=None):
+        lib = load()
+        require_gpu(edge_index)
+        ei, src, dst, e = edge_rows(edge_index)
+        rl = torch.as_tensor(range_list).to("cpu", torch.int64).contiguous()   # tiny; host copy once
+        if rl.dim() != 2 or rl.shape[1] != 2:
+            raise ValueError("range_list must have shape [R, 2], got {}".format(tuple(rl.shape)))
+        lo = 0 if edge_lo is None else int(edge_lo)
+        hi = e if edge_hi is None else int(edge_hi)
+        h = _p()
+        with torch.cuda.device(ei.device):
+            check(lib.gn_rgcn_plan_create(src, dst, rl.data_ptr(), 1, rl.shape[0], e, int(num_nodes), lo, hi,
+                                          stream_ptr(ei.device), C.byref(h)))
+        self._h, self.device = h, ei.device
+        self.num_nodes, self.num_relations, self.num_edges = int(num_nodes), int(rl.shape[0]), e
+        self.edge_lo, self.edge_hi = lo, hi
+        self._ws = None
+
+    def _workspace(self, fin, fout, bases):
+        need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def forward(self, x, basis, att, root, bias, relu, out, partial=False):
+        ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0])
+        _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
+              ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), int(bool(partial)),
+              ptr(out), ld(out), ptr(ws), need, stream_ptr(x.device))
+        return out
+
+    def finalize(self, summed, x, root, bias, relu, out):
+        _call("gn_rgcn_finalize_f32", self._h, ptr(summed), ld(summed), ptr(x), ld(x), x.shape[1], ptr(root),
+              ptr(bias), root.shape[1], int(bool(relu)), ptr(out), ld(out), stream_ptr(x.device))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gn_rgcn_plan_destroy(h)
+
+
+_error_flags = {}
+
+
+def error_flag(device) -> torch.Tensor:
+    """Per-device int32 word the decoder kernels OR index-range errors into (checked lazily)."""
+    key = (device.type, device.index)
+    if key not in _error_flags:
+        _error_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _error_flags[key]
+
+
+def raise_if_index_errors(device=None):
+    """Synchronising check of the decoder error word; raises IndexError like the reference's
+    advanced indexing would (gripnet/decoder.py:20)."""
+    for key, flag in list(_error_flags.items()):
+        if device is not None and (device.type, device.index) != key:
+            continue
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError("DistMult decoder saw an edge endpoint or relation id outside its table")
+
+
+def distmult(z, u_v, edge_type, weight, sigmoid, out):
+    ei, u, v, e = edge_rows(u_v)
+    et = i64_vec(edge_type)
+    if et.numel() != e:
+        raise ValueError("edge_type has {} entries for {} edges".format(et.numel(), e))
+    _call("gn_distmult_forward_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight),
+          ld(weight), weight.shape[0], e, int(bool(sigmoid)), ptr(out),
+          ptr(error_flag(z.device)), stream_ptr(z.device))
+    return out
+
+
+def softmax_rows(x):
+    _call("gn_softmax_rows_f32", ptr(x), ld(x), x.shape[0], x.shape[1], stream_ptr(x.device))
+    return x

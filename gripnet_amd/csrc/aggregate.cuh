@@ -1,0 +1,125 @@
+// Destination-major gather-reduce shared by the GCN-style layers and the general RGCN path.
+//
+//   out[i, :] = act( (sum_{p in row i} coef[p] * T[col[p], :]) / max(1, rowdiv[i]) + addend[i, :] + bias )
+//
+// One 64-lane wave owns one destination row at a time.  The wave reads 64 (col, coef) pairs
+// with one coalesced load each, then walks them S = 64/LPE at a time: every group of LPE
+// lanes covers the feature row of one neighbour with 16-byte loads (VEC = 4), so a wave
+// keeps S independent row gathers in flight.  The S partial sums are folded with cross-lane
+// shuffles, in a fixed order: results are bitwise reproducible run to run.
+#pragma once
+
+#include "common.h"
+
+namespace gn {
+
+struct AggArgs {
+    const int32_t* rowptr;
+    const uint32_t* col;
+    const float* coef;     // nullable (all ones)
+    const float* table;
+    int64_t ld_table;
+    int features;
+    const float* rowdiv;   // nullable
+    const float* addend;   // nullable
+    int64_t ld_addend;
+    const float* bias;     // nullable
+    int relu;
+    float* out;
+    int64_t ld_out;
+    int rows;
+};
+
+template <int VEC, int LPE>
+__global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
+    constexpr int S = kWave / LPE;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / LPE;
+    const int j = lane % LPE;
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+
+    for (int row = wave; row < a.rows; row += n_waves) {
+        const int begin = a.rowptr[row], end = a.rowptr[row + 1];
+        for (int cb = 0; cb * LPE * VEC < a.features; ++cb) {
+            const int fcol = (cb * LPE + j) * VEC;
+            const bool active = fcol < a.features;
+            float acc[VEC];
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+
+            for (int base = begin; base < end; base += kWave) {
+                const int mine = base + lane;
+                const uint32_t c = mine < end ? a.col[mine] : 0u;
+                const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+                const int cnt = min(kWave, end - base);
+                for (int it = 0; it * S < cnt; ++it) {
+                    const int idx = it * S + slot;
+                    const uint32_t cc = (uint32_t)__shfl((int)c, idx);
+                    const float vv = __shfl(v, idx);
+                    if (idx < cnt && active) {
+                        const float* src = a.table + (int64_t)cc * a.ld_table + fcol;
+                        if constexpr (VEC == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(src);
+                            acc[0] += vv * t.x; acc[1] += vv * t.y; acc[2] += vv * t.z; acc[3] += vv * t.w;
+                        } else {
+                            acc[0] += vv * src[0];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = LPE; off < kWave; off <<= 1) {
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) acc[t] += __shfl_xor(acc[t], off);
+            }
+            if (slot == 0 && active) {
+                const float div = a.rowdiv ? fmaxf(a.rowdiv[row], 1.0f) : 1.0f;
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    float val = a.rowdiv ? acc[t] / div : acc[t];
+                    if (a.addend) val += a.addend[(int64_t)row * a.ld_addend + fcol + t];
+                    if (a.bias) val += a.bias[fcol + t];
+                    if (a.relu) val = fmaxf(val, 0.f);
+                    acc[t] = val;
+                }
+                float* dst = a.out + (int64_t)row * a.ld_out + fcol;
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+                    dst[0] = acc[0];
+                }
+            }
+        }
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int VEC>
+inline void launch_aggregate_lpe(const AggArgs& a, int lpe, int grid, hipStream_t st) {
+    switch (lpe) {
+        case 1: k_aggregate<VEC, 1><<<grid, 256, 0, st>>>(a); break;
+        case 2: k_aggregate<VEC, 2><<<grid, 256, 0, st>>>(a); break;
+        case 4: k_aggregate<VEC, 4><<<grid, 256, 0, st>>>(a); break;
+        case 8: k_aggregate<VEC, 8><<<grid, 256, 0, st>>>(a); break;
+        case 16: k_aggregate<VEC, 16><<<grid, 256, 0, st>>>(a); break;
+        case 32: k_aggregate<VEC, 32><<<grid, 256, 0, st>>>(a); break;
+        default: k_aggregate<VEC, 64><<<grid, 256, 0, st>>>(a); break;
+    }
+}
+
+inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
+    if (a.rows == 0 || a.features == 0) return GN_OK;
+    const bool vec = (a.features % 4 == 0) && (a.ld_table % 4 == 0) && (a.ld_out % 4 == 0) && aligned16(a.table) &&
+                     aligned16(a.out);
+    const int units = vec ? a.features / 4 : a.features;
+    int lpe = 1;
+    while (lpe < units && lpe < kWave) lpe <<= 1;
+    const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), 256 * 8);
+    if (vec) launch_aggregate_lpe<4>(a, lpe, grid, st); else launch_aggregate_lpe<1>(a, lpe, grid, st);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // namespace gn

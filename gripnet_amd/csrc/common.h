@@ -1,0 +1,114 @@
+// Shared host-side helpers for the gfx950 supergraph propagation library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "gripnet_hip.h"
+
+namespace gn {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+// ---- per-thread error message ------------------------------------------------------------
+inline char* error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+inline gn_status fail(gn_status code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define GN_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return gn::fail(GN_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                            \
+    } while (0)
+
+#define GN_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return gn::fail(GN_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define GN_LAUNCH_CHECK() GN_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Device buffer owned by a plan.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        if (count == 0) {
+            p = nullptr;
+            return hipSuccess;
+        }
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// Grid size for a memory-bound grid-stride kernel: enough blocks to fill 256 CUs, capped.
+inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 8) {
+    int64_t g = ceil_div(work_items, block);
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return static_cast<int>(g);
+}
+
+}  // namespace gn
+
+// ---- plan layouts (shared between the builders and the kernels' launchers) --------------
+struct gn_graph_plan {
+    int64_t input_edges = 0;  // E the plan was built from (the reference's cache key)
+    int64_t nnz = 0;          // stored coefficients (E' for GCN, E for bipartite)
+    int64_t rows = 0;         // destination rows of the CSR
+    int64_t table_rows = 0;   // rows of the gathered table (N for GCN, num_sources for bipartite)
+    int64_t max_row_nnz = 0;
+    int is_gcn = 0;
+    // destination-major CSR streamed by the aggregation kernel
+    gn::DevBuf<int32_t> rowptr;   // [rows + 1]
+    gn::DevBuf<int32_t> col;      // [nnz]
+    gn::DevBuf<float> coef;       // [nnz]
+    // reference-order copies kept for myGCN.norm parity (GCN plans only)
+    gn::DevBuf<int64_t> ref_edge_index;  // [2, nnz]
+    gn::DevBuf<float> ref_norm;          // [nnz]
+};
+
+struct gn_rgcn_plan {
+    int64_t input_edges = 0;   // full E
+    int64_t edge_lo = 0, edge_hi = 0;
+    int64_t shard_edges = 0;
+    int64_t num_nodes = 0;
+    int64_t num_relations = 0;
+    int64_t max_row_nnz = 0;
+    gn::DevBuf<float> indeg;       // [N] in-degree over the FULL graph, as float (divisor of the mean)
+    // general path: destination-major CSR over the shard, column = relation * N + src
+    gn::DevBuf<int32_t> rowptr;    // [N + 1]
+    gn::DevBuf<uint32_t> key;      // [shard_edges]
+    // relation-major segments of the shard (fast path): filled by rgcn_fast.hip
+    gn::DevBuf<int32_t> seg_rel;    // [n_seg] relation id of each work segment
+    gn::DevBuf<int32_t> seg_begin;  // [n_seg + 1] offsets into packed
+    gn::DevBuf<uint32_t> packed;    // [shard_edges] (dst << 16 | src), sorted by dst inside a segment
+    int64_t n_seg = 0;
+    int fast_ok = 0;
+};

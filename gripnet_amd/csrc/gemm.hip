@@ -1,0 +1,171 @@
+// Dense fp32 contractions on the CDNA4 matrix cores, plus the small element-wise merges.
+//
+// v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain (no reduced-precision path exists on
+// gfx950), so these GEMMs keep the reference's fp32 numerics.  One wave owns a 16-row x
+// (up to 64)-column output tile: the A fragment (one float4 per lane per 16-deep K chunk) is
+// reused across the column tiles.  The K index inside a chunk is permuted (lane group q,
+// element j  <->  k = 4q + j) identically for A and B, which lets A be read with one 16-byte
+// load per lane instead of four strided dwords.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kColTiles = 4;  // 16-column tiles per wave (A-fragment reuse)
+
+struct GemmArgs {
+    const float* a; int64_t lda, stride_a; const int64_t* a_rows; int64_t a_table_rows;
+    const float* b; int64_t ldb, stride_b;
+    float* c; int64_t ldc, stride_c;
+    int m, n, k;
+    const float* bias; int relu; int a_vec_ok;
+};
+
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15;   // row inside the tile for A, column inside the tile for B / C
+    const int q = lane >> 4;   // K group for A/B, row group for C
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    const int col0 = blockIdx.y * (16 * kColTiles);
+    if (row0 >= g.m) return;   // wave-uniform
+    const int64_t batch = blockIdx.z;
+    const float* __restrict__ A = g.a + batch * g.stride_a;
+    const float* __restrict__ B = g.b + batch * g.stride_b;
+    float* __restrict__ C = g.c + batch * g.stride_c;
+
+    const int arow = row0 + r;
+    int64_t a_src_row = -1;
+    if (arow < g.m) {
+        a_src_row = g.a_rows ? g.a_rows[arow] : arow;
+        if (g.a_rows && (uint64_t)a_src_row >= (uint64_t)g.a_table_rows) a_src_row = -1;  // out of table -> zeros
+    }
+    const float* __restrict__ arow_ptr = (a_src_row >= 0) ? A + a_src_row * g.lda : nullptr;
+
+    f32x4 acc[kColTiles];
+#pragma unroll
+    for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < g.k; k0 += 16) {
+        const int kb = k0 + 4 * q;
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        if (arow_ptr) {
+            if (g.a_vec_ok && kb + 3 < g.k) {
+                const float4 t = *reinterpret_cast<const float4*>(arow_ptr + kb);
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (kb + j < g.k) av[j] = arow_ptr[kb + j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) {
+            const int col = col0 + 16 * t + r;
+            if (col0 + 16 * t >= g.n) break;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = kb + j;
+                const float bv = (kk < g.k && col < g.n) ? B[(int64_t)kk * g.ldb + col] : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kColTiles; ++t) {
+        const int col = col0 + 16 * t + r;
+        if (col >= g.n) continue;
+        const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * q + i;
+            if (row < g.m) {
+                float v = acc[t][i] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                C[(int64_t)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+__global__ void k_merge(float* __restrict__ dst, int64_t ld_dst, const float* __restrict__ src, int64_t ld_src,
+                        const float* __restrict__ src2, int64_t ld_src2, int64_t rows, int cols, int mode) {
+    const int64_t total = rows * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / cols;
+        const int c = (int)(t - i * cols);
+        const float s = src[i * ld_src + c];
+        float* d = dst + i * ld_dst + c;
+        switch (mode) {
+            case 0: *d = s; break;
+            case 1: *d = fabsf(s); break;
+            case 2: *d = (*d + fabsf(s)) / 2.0f; break;
+            case 3: *d = (*d + fmaxf(s, 0.f)) / 2.0f; break;
+            default: *d = (*d + s + src2[i * ld_src2 + c]) / 3.0f; break;
+        }
+    }
+}
+
+// One wave per row: max, exp, sum, divide (decoder.py:43).
+__global__ void k_softmax_rows(float* __restrict__ x, int64_t ld, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < rows; i += n_waves) {
+        float* row = x + i * ld;
+        float mx = -INFINITY;
+        for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, row[c]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int c = lane; c < cols; c += 64) sum += expf(row[c] - mx);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int c = lane; c < cols; c += 64) row[c] = expf(row[c] - mx) / sum;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
+                      const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
+                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int relu, void* stream) {
+    GN_REQUIRE(m >= 0 && n >= 0 && k >= 0 && batch >= 0, "negative GEMM size");
+    if (m == 0 || n == 0 || batch == 0) return GN_OK;
+    GN_REQUIRE(a && b && c, "GEMM operand pointer is null");
+    GN_REQUIRE(lda >= k && ldb >= n && ldc >= n, "leading dimension smaller than the row length");
+    GN_REQUIRE(m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31) && batch <= 65535, "GEMM size out of range");
+    GemmArgs g;
+    g.a = a; g.lda = lda; g.stride_a = stride_a; g.a_rows = a_rows; g.a_table_rows = a_table_rows;
+    g.b = b; g.ldb = ldb; g.stride_b = stride_b;
+    g.c = c; g.ldc = ldc; g.stride_c = stride_c;
+    g.m = (int)m; g.n = (int)n; g.k = (int)k; g.bias = bias; g.relu = relu;
+    g.a_vec_ok = ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
+    dim3 grid((unsigned)gn::ceil_div(m, 64), (unsigned)gn::ceil_div(n, 16 * kColTiles), (unsigned)batch);
+    k_gemm_f32<<<grid, 256, 0, gn::as_stream(stream)>>>(g);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, const float* src2,
+                       int64_t ld_src2, int64_t rows, int64_t cols, int mode, void* stream) {
+    GN_REQUIRE(rows >= 0 && cols >= 0 && cols < (1ll << 31), "bad merge size");
+    GN_REQUIRE(mode >= 0 && mode <= 4, "unknown merge mode %d", mode);
+    if (rows == 0 || cols == 0) return GN_OK;
+    GN_REQUIRE(dst && src && (mode != 4 || src2), "merge operand pointer is null");
+    k_merge<<<gn::stream_grid(rows * cols, 256), 256, 0, gn::as_stream(stream)>>>(dst, ld_dst, src, ld_src, src2,
+                                                                                ld_src2, rows, (int)cols, mode);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, void* stream) {
+    GN_REQUIRE(rows >= 0 && cols >= 0 && cols < (1ll << 31), "bad softmax size");
+    if (rows == 0 || cols == 0) return GN_OK;
+    GN_REQUIRE(x != nullptr, "softmax operand is null");
+    k_softmax_rows<<<gn::stream_grid(rows * 64, 256), 256, 0, gn::as_stream(stream)>>>(x, ld, rows, (int)cols);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,451 @@
+// One-time graph preprocessing ("plans") for the supergraph propagation kernels.
+//
+// A plan is what the reference caches on its first forward (myGCN.cached_result,
+// gripnet/layers.py:83-90) plus the destination-major re-encoding the gfx950 kernels stream:
+// int32 columns + fp32 coefficients in a CSR whose rows keep the reference's edge order
+// (stable sort), so per-destination sums run in the same order as the reference's sequential
+// scatter_add.  Plan construction is not on the steady-state path; it may synchronise.
+#include "common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+using gn::DevBuf;
+
+// ---- small device helpers ------------------------------------------------------------------
+__device__ __forceinline__ int lower_bound_i32(const int32_t* a, int n, int v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// keep[e] = 1 for valid non-loop edges; last_loop[i] = largest e with src=dst=i (or -1).
+__global__ void k_mark_edges(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E,
+                             int64_t n_src, int64_t n_dst, int drop_loops, int32_t* __restrict__ keep,
+                             int32_t* __restrict__ last_loop, int32_t* __restrict__ err) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e == E) { keep[e] = 0; break; }   // sentinel so that the exclusive scan yields the total
+        int64_t s = src[e], d = dst[e];
+        bool ok = (uint64_t)s < (uint64_t)n_src && (uint64_t)d < (uint64_t)n_dst;
+        if (!ok) { atomicOr(err, 1); keep[e] = 0; continue; }
+        if (drop_loops && s == d) {
+            atomicMax(&last_loop[s], (int32_t)e);
+            keep[e] = 0;
+        } else {
+            keep[e] = 1;
+        }
+    }
+}
+
+// Non-loop edges keep their input order; then (GCN) one loop per node in node order.
+__global__ void k_compact(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                          const float* __restrict__ w, int64_t E, int64_t n_loops, float fill,
+                          const int32_t* __restrict__ keep, const int32_t* __restrict__ pos,
+                          const int32_t* __restrict__ last_loop, int32_t* __restrict__ src2,
+                          int32_t* __restrict__ dst2, float* __restrict__ w2, int32_t* __restrict__ iota) {
+    const int32_t kept = pos[E];
+    const int64_t total = E + n_loops;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        if (t < E) {
+            if (keep[t]) {
+                int32_t p = pos[t];
+                src2[p] = (int32_t)src[t];
+                dst2[p] = (int32_t)dst[t];
+                w2[p] = w ? w[t] : 1.0f;
+                iota[p] = p;
+            }
+        } else {
+            int32_t i = (int32_t)(t - E);
+            int32_t p = kept + i;
+            int32_t ll = last_loop[i];
+            src2[p] = i;
+            dst2[p] = i;
+            w2[p] = (ll >= 0) ? (w ? w[ll] : 1.0f) : fill;
+            iota[p] = p;
+        }
+    }
+}
+
+__global__ void k_rowptr(const int32_t* __restrict__ sorted_dst, int nnz, int rows, int32_t* __restrict__ rowptr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= rows) rowptr[i] = lower_bound_i32(sorted_dst, nnz, i);
+}
+
+// deg[i] = sum of weights into i in stored order (+ extra), dis = deg^-1/2 with inf -> 0.
+__global__ void k_degree(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+                         const float* __restrict__ w2, int rows, float extra, float* __restrict__ dis) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    float deg = 0.0f;
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) deg += w2[perm[p]];
+    deg += extra;
+    float r = 1.0f / sqrtf(deg);
+    if (r == INFINITY) r = 0.0f;
+    dis[i] = r;
+}
+
+// GCN: norm in the reference's order, then the CSR copies.
+__global__ void k_gcn_norm(const int32_t* __restrict__ src2, const int32_t* __restrict__ dst2,
+                           const float* __restrict__ w2, const float* __restrict__ dis, int nnz,
+                           int64_t* __restrict__ ref_ei, float* __restrict__ ref_norm) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int s = src2[p], d = dst2[p];
+    ref_ei[p] = s;
+    ref_ei[(int64_t)nnz + p] = d;
+    ref_norm[p] = dis[s] * w2[p] * dis[d];
+}
+
+__global__ void k_fill_csr(const int32_t* __restrict__ perm, const int32_t* __restrict__ src2,
+                           const float* __restrict__ coef_in, int nnz, int32_t* __restrict__ col,
+                           float* __restrict__ coef) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int o = perm[p];
+    col[p] = src2[o];
+    coef[p] = coef_in[o];
+}
+
+// Bipartite: coefficient = (1 * w) * dis[target]  (deg of a source is its self loop only).
+__global__ void k_bip_coef(const int32_t* __restrict__ dst2, const float* __restrict__ w2,
+                           const float* __restrict__ dis, int nnz, float* __restrict__ coef) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    coef[p] = (1.0f * w2[p]) * dis[dst2[p]];
+}
+
+int bits_for(int64_t n) {
+    int b = 1;
+    while (((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+struct Temp {  // scoped device scratch for plan construction
+    std::vector<void*> ptrs;
+    ~Temp() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+};
+
+gn_status sort_by_dst(Temp& tmp, const int32_t* keys_in, int32_t* keys_out, const int32_t* vals_in,
+                      int32_t* vals_out, int64_t n, int64_t key_range, hipStream_t st) {
+    if (n == 0) return GN_OK;
+    size_t bytes = 0;
+    GN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0,
+                                     bits_for(key_range), st));
+    char* scratch = nullptr;
+    GN_HIP(tmp.get(&scratch, bytes));
+    GN_HIP(rocprim::radix_sort_pairs(scratch, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0,
+                                     bits_for(key_range), st));
+    return GN_OK;
+}
+
+gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* w, int64_t E, int64_t n_src,
+                           int64_t n_dst, bool gcn, int improved, hipStream_t st, gn_graph_plan* plan) {
+    const int64_t n_loops = gcn ? n_dst : 0;
+    Temp tmp;
+    int32_t *keep, *pos, *last_loop, *err;
+    GN_HIP(tmp.get(&keep, E + 1));
+    GN_HIP(tmp.get(&pos, E + 1));
+    GN_HIP(tmp.get(&last_loop, n_dst + 1));
+    GN_HIP(tmp.get(&err, 1));
+    GN_HIP(hipMemsetAsync(last_loop, 0xFF, (n_dst + 1) * sizeof(int32_t), st));
+    GN_HIP(hipMemsetAsync(err, 0, sizeof(int32_t), st));
+    k_mark_edges<<<gn::stream_grid(E + 1, 256), 256, 0, st>>>(src, dst, E, n_src, n_dst, gcn ? 1 : 0, keep,
+                                                             last_loop, err);
+    GN_LAUNCH_CHECK();
+    {
+        size_t bytes = 0;
+        GN_HIP(rocprim::exclusive_scan(nullptr, bytes, keep, pos, 0, (size_t)(E + 1), rocprim::plus<int32_t>(), st));
+        char* scratch = nullptr;
+        GN_HIP(tmp.get(&scratch, bytes));
+        GN_HIP(rocprim::exclusive_scan(scratch, bytes, keep, pos, 0, (size_t)(E + 1), rocprim::plus<int32_t>(), st));
+    }
+    int32_t kept = 0, bad = 0;
+    GN_HIP(hipMemcpyAsync(&kept, pos + E, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipMemcpyAsync(&bad, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    if (bad) return gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld) x [0,%lld)",
+                             (long long)n_src, (long long)n_dst);
+    const int64_t nnz = (int64_t)kept + n_loops;
+    if (nnz >= ((int64_t)1 << 31)) return gn::fail(GN_ERR_UNSUPPORTED, "more than 2^31 stored edges");
+
+    int32_t *src2, *dst2, *iota, *sorted_dst, *perm;
+    float *w2, *dis, *coef_ref;
+    GN_HIP(tmp.get(&src2, nnz));
+    GN_HIP(tmp.get(&dst2, nnz));
+    GN_HIP(tmp.get(&iota, nnz));
+    GN_HIP(tmp.get(&sorted_dst, nnz));
+    GN_HIP(tmp.get(&perm, nnz));
+    GN_HIP(tmp.get(&w2, nnz));
+    GN_HIP(tmp.get(&dis, n_dst));
+    GN_HIP(tmp.get(&coef_ref, nnz));
+    if (E + n_loops > 0) {
+        k_compact<<<gn::stream_grid(E + n_loops, 256), 256, 0, st>>>(src, dst, w, E, n_loops, improved ? 2.0f : 1.0f,
+                                                                   keep, pos, last_loop, src2, dst2, w2, iota);
+        GN_LAUNCH_CHECK();
+    }
+    gn_status s = sort_by_dst(tmp, dst2, sorted_dst, iota, perm, nnz, n_dst, st);
+    if (s != GN_OK) return s;
+
+    plan->input_edges = E;
+    plan->nnz = nnz;
+    plan->rows = n_dst;
+    plan->table_rows = n_src;
+    plan->is_gcn = gcn ? 1 : 0;
+    GN_HIP(plan->rowptr.alloc(n_dst + 1));
+    GN_HIP(plan->col.alloc(nnz));
+    GN_HIP(plan->coef.alloc(nnz));
+    k_rowptr<<<(int)gn::ceil_div(n_dst + 1, 256), 256, 0, st>>>(sorted_dst, (int)nnz, (int)n_dst, plan->rowptr.p);
+    GN_LAUNCH_CHECK();
+    if (n_dst > 0) {
+        k_degree<<<(int)gn::ceil_div(n_dst, 256), 256, 0, st>>>(plan->rowptr.p, perm, w2, (int)n_dst,
+                                                               gcn ? 0.0f : 1.0f, dis);
+        GN_LAUNCH_CHECK();
+    }
+    if (nnz > 0) {
+        const int g = (int)gn::ceil_div(nnz, 256);
+        if (gcn) {
+            GN_HIP(plan->ref_edge_index.alloc(2 * nnz));
+            GN_HIP(plan->ref_norm.alloc(nnz));
+            k_gcn_norm<<<g, 256, 0, st>>>(src2, dst2, w2, dis, (int)nnz, plan->ref_edge_index.p, plan->ref_norm.p);
+            GN_LAUNCH_CHECK();
+            k_fill_csr<<<g, 256, 0, st>>>(perm, src2, plan->ref_norm.p, (int)nnz, plan->col.p, plan->coef.p);
+        } else {
+            k_bip_coef<<<g, 256, 0, st>>>(dst2, w2, dis, (int)nnz, coef_ref);
+            GN_LAUNCH_CHECK();
+            k_fill_csr<<<g, 256, 0, st>>>(perm, src2, coef_ref, (int)nnz, plan->col.p, plan->coef.p);
+        }
+        GN_LAUNCH_CHECK();
+    }
+    std::vector<int32_t> rp(n_dst + 1);
+    GN_HIP(hipMemcpyAsync(rp.data(), plan->rowptr.p, (n_dst + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    int64_t mx = 0;
+    for (int64_t i = 0; i < n_dst; ++i) mx = std::max<int64_t>(mx, rp[i + 1] - rp[i]);
+    plan->max_row_nnz = mx;
+    return GN_OK;
+}
+
+void free_graph_plan(gn_graph_plan* p) {
+    p->rowptr.release();
+    p->col.release();
+    p->coef.release();
+    p->ref_edge_index.release();
+    p->ref_norm.release();
+}
+
+// ---- RGCN ------------------------------------------------------------------------------------
+__global__ void k_indegree(const int64_t* __restrict__ dst, int64_t E, int64_t N, int32_t* __restrict__ cnt,
+                           int32_t* __restrict__ err) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t d = dst[e];
+        if ((uint64_t)d < (uint64_t)N) atomicAdd(&cnt[d], 1); else atomicOr(err, 1);
+    }
+}
+
+__global__ void k_i32_to_f32(const int32_t* __restrict__ a, int n, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)a[i];
+}
+
+// key = relation(e) * N + src(e); relation found from the range starts (edges are type-sorted).
+__global__ void k_rel_keys(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                           const int64_t* __restrict__ range_start, int R, int64_t lo, int64_t hi, int64_t N,
+                           int32_t* __restrict__ dst32, uint32_t* __restrict__ key, int32_t* __restrict__ err) {
+    for (int64_t e = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x) {
+        int a = 0, b = R;  // last r with range_start[r] <= e
+        while (b - a > 1) {
+            int mid = (a + b) >> 1;
+            if (range_start[mid] <= e) a = mid; else b = mid;
+        }
+        int64_t s = src[e], d = dst[e];
+        bool ok = (uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N;
+        if (!ok) { atomicOr(err, 1); s = 0; d = 0; }
+        dst32[e - lo] = (int32_t)d;
+        key[e - lo] = (uint32_t)((int64_t)a * N + s);
+    }
+}
+
+}  // namespace
+
+// Implemented in rgcn_fast.hip: relation-major segments for the LDS-resident path.
+gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
+                                      const std::vector<int64_t>& ranges_host, hipStream_t st);
+
+extern "C" {
+
+int gn_version(void) { return GN_VERSION; }
+const char* gn_last_error(void) { return gn::error_buffer(); }
+
+gn_status gn_gcn_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t E, int64_t N,
+                             int improved, void* stream, gn_graph_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(E >= 0 && N >= 0, "negative size (E=%lld, N=%lld)", (long long)E, (long long)N);
+    GN_REQUIRE(E == 0 || (src && dst), "edge pointers are null");
+    if (E + N >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31))
+        return gn::fail(GN_ERR_UNSUPPORTED, "graph too large for the int32 plan encoding");
+    gn_graph_plan* p = new gn_graph_plan();
+    gn_status s = build_graph_plan(src, dst, w, E, N, N, true, improved, gn::as_stream(stream), p);
+    if (s != GN_OK) { free_graph_plan(p); delete p; return s; }
+    *out = p;
+    return GN_OK;
+}
+
+gn_status gn_bipartite_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t E,
+                                   int64_t n_src, int64_t n_tgt, void* stream, gn_graph_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(E >= 0 && n_src >= 0 && n_tgt >= 0, "negative size");
+    GN_REQUIRE(E == 0 || (src && dst), "edge pointers are null");
+    if (E >= ((int64_t)1 << 31) || n_src >= ((int64_t)1 << 31) || n_tgt >= ((int64_t)1 << 31))
+        return gn::fail(GN_ERR_UNSUPPORTED, "graph too large for the int32 plan encoding");
+    gn_graph_plan* p = new gn_graph_plan();
+    gn_status s = build_graph_plan(src, dst, w, E, n_src, n_tgt, false, 0, gn::as_stream(stream), p);
+    if (s != GN_OK) { free_graph_plan(p); delete p; return s; }
+    *out = p;
+    return GN_OK;
+}
+
+void gn_graph_plan_destroy(gn_graph_plan* plan) {
+    if (!plan) return;
+    free_graph_plan(plan);
+    delete plan;
+}
+
+int64_t gn_graph_plan_input_edges(const gn_graph_plan* plan) { return plan ? plan->input_edges : -1; }
+int64_t gn_graph_plan_nnz(const gn_graph_plan* plan) { return plan ? plan->nnz : -1; }
+
+gn_status gn_graph_plan_export(const gn_graph_plan* plan, int64_t* ei_out, float* norm_out, void* stream) {
+    GN_REQUIRE(plan && plan->is_gcn, "export needs a GCN plan");
+    GN_REQUIRE(plan->nnz == 0 || (ei_out && norm_out), "output pointers are null");
+    if (plan->nnz == 0) return GN_OK;
+    GN_HIP(hipMemcpyAsync(ei_out, plan->ref_edge_index.p, 2 * plan->nnz * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                          gn::as_stream(stream)));
+    GN_HIP(hipMemcpyAsync(norm_out, plan->ref_norm.p, plan->nnz * sizeof(float), hipMemcpyDeviceToDevice,
+                          gn::as_stream(stream)));
+    return GN_OK;
+}
+
+gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int64_t* range_list, int on_host,
+                              int64_t R, int64_t E, int64_t N, int64_t lo, int64_t hi, void* stream,
+                              gn_rgcn_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(R >= 0 && E >= 0 && N >= 0, "negative size");
+    GN_REQUIRE(E == 0 || (src && dst), "edge pointers are null");
+    GN_REQUIRE(R == 0 || range_list, "range_list is null");
+    GN_REQUIRE(0 <= lo && lo <= hi && hi <= E, "edge sub-range [%lld,%lld) outside [0,%lld)", (long long)lo,
+               (long long)hi, (long long)E);
+    if (E >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31) || R * N >= ((int64_t)1 << 32))
+        return gn::fail(GN_ERR_UNSUPPORTED, "graph too large for the 32-bit plan encoding (R*N must be < 2^32)");
+    hipStream_t st = gn::as_stream(stream);
+
+    std::vector<int64_t> ranges(2 * R);
+    if (R > 0) {
+        if (on_host) {
+            memcpy(ranges.data(), range_list, 2 * R * sizeof(int64_t));
+        } else {
+            GN_HIP(hipMemcpyAsync(ranges.data(), range_list, 2 * R * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            GN_HIP(hipStreamSynchronize(st));
+        }
+    }
+    int64_t cursor = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        if (ranges[2 * r] != cursor || ranges[2 * r + 1] < ranges[2 * r])
+            return gn::fail(GN_ERR_INVALID_ARG, "range_list must tile [0,E) in relation order (row %lld is [%lld,%lld), expected start %lld)",
+                            (long long)r, (long long)ranges[2 * r], (long long)ranges[2 * r + 1], (long long)cursor);
+        cursor = ranges[2 * r + 1];
+    }
+    if (cursor != E)
+        return gn::fail(GN_ERR_INVALID_ARG, "range_list covers %lld edges but edge_index has %lld", (long long)cursor,
+                        (long long)E);
+
+    gn_rgcn_plan* p = new gn_rgcn_plan();
+    auto bail = [&](gn_status s) { gn_rgcn_plan_destroy(p); return s; };
+#define GN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(gn::fail(GN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
+    p->input_edges = E; p->edge_lo = lo; p->edge_hi = hi; p->shard_edges = hi - lo;
+    p->num_nodes = N; p->num_relations = R;
+    Temp tmp;
+    int32_t *cnt, *err, *dst32, *sorted_dst;
+    int64_t* starts_dev;
+    uint32_t* key;
+    GN_TRY(tmp.get(&cnt, N));
+    GN_TRY(tmp.get(&err, 1));
+    GN_TRY(tmp.get(&dst32, p->shard_edges));
+    GN_TRY(tmp.get(&sorted_dst, p->shard_edges));
+    GN_TRY(tmp.get(&key, p->shard_edges));
+    GN_TRY(tmp.get(&starts_dev, R + 1));
+    GN_TRY(hipMemsetAsync(cnt, 0, (N ? N : 1) * sizeof(int32_t), st));
+    GN_TRY(hipMemsetAsync(err, 0, sizeof(int32_t), st));
+    std::vector<int64_t> starts(R + 1, E);
+    for (int64_t r = 0; r < R; ++r) starts[r] = ranges[2 * r];
+    GN_TRY(hipMemcpyAsync(starts_dev, starts.data(), (R + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    GN_TRY(p->indeg.alloc(N));
+    GN_TRY(p->rowptr.alloc(N + 1));
+    GN_TRY(p->key.alloc(p->shard_edges));
+    if (E > 0) {
+        k_indegree<<<gn::stream_grid(E, 256), 256, 0, st>>>(dst, E, N, cnt, err);
+        GN_TRY(hipGetLastError());
+    }
+    if (N > 0) {
+        k_i32_to_f32<<<(int)gn::ceil_div(N, 256), 256, 0, st>>>(cnt, (int)N, p->indeg.p);
+        GN_TRY(hipGetLastError());
+    }
+    if (p->shard_edges > 0) {
+        k_rel_keys<<<gn::stream_grid(p->shard_edges, 256), 256, 0, st>>>(src, dst, starts_dev, (int)R, lo, hi, N,
+                                                                        dst32, key, err);
+        GN_TRY(hipGetLastError());
+        size_t bytes = 0;
+        GN_TRY(rocprim::radix_sort_pairs(nullptr, bytes, dst32, sorted_dst, key, p->key.p, (size_t)p->shard_edges, 0,
+                                         bits_for(N), st));
+        char* scratch = nullptr;
+        GN_TRY(tmp.get(&scratch, bytes));
+        GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, dst32, sorted_dst, key, p->key.p, (size_t)p->shard_edges, 0,
+                                         bits_for(N), st));
+    }
+    k_rowptr<<<(int)gn::ceil_div(N + 1, 256), 256, 0, st>>>(sorted_dst, (int)p->shard_edges, (int)N, p->rowptr.p);
+    GN_TRY(hipGetLastError());
+    int32_t bad = 0;
+    std::vector<int32_t> rp(N + 1);
+    GN_TRY(hipMemcpyAsync(&bad, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_TRY(hipMemcpyAsync(rp.data(), p->rowptr.p, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_TRY(hipStreamSynchronize(st));
+    if (bad) return bail(gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld)", (long long)N));
+    for (int64_t i = 0; i < N; ++i) p->max_row_nnz = std::max<int64_t>(p->max_row_nnz, rp[i + 1] - rp[i]);
+    gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
+    if (fs != GN_OK) return bail(fs);
+#undef GN_TRY
+    *out = p;
+    return GN_OK;
+}
+
+void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
+    if (!p) return;
+    p->indeg.release();
+    p->rowptr.release();
+    p->key.release();
+    p->seg_rel.release();
+    p->seg_begin.release();
+    p->packed.release();
+    delete p;
+}
+
+int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan) { return plan ? plan->input_edges : -1; }
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// Multi-relational internal layer (myRGCN, gripnet/layers.py:165-197): general path.
+//
+// Transform-then-gather ordering: W_r = att[r,:] . basis, H_r = X W_r for
+// every relation (two MFMA GEMMs), then one destination-major gather-reduce over the
+// [R*N, out] table with the global mean, the root term and the activation in the epilogue.
+// Works for any shape; the table lives in HBM / Infinity Cache (sized for 288 GB parts).
+// The LDS-resident specialisation for small supervertices is in rgcn_fast.hip.
+#include "aggregate.cuh"
+
+// rgcn_fast.hip
+bool gn_rgcn_fast_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
+                               const float* basis, const float* att, int64_t bases, const float* root,
+                               const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
+                               void* ws, size_t ws_bytes, hipStream_t st);
+
+namespace {
+
+size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+
+struct GeneralWs {
+    size_t w_off, h_off, xr_off, total;
+};
+
+GeneralWs general_layout(const gn_rgcn_plan* plan, int64_t fin, int64_t fout) {
+    GeneralWs l;
+    l.w_off = 0;
+    l.h_off = align_up((size_t)plan->num_relations * fin * fout * sizeof(float));
+    l.xr_off = l.h_off + align_up((size_t)plan->num_relations * plan->num_nodes * fout * sizeof(float));
+    l.total = l.xr_off + align_up((size_t)plan->num_nodes * fout * sizeof(float));
+    return l;
+}
+
+__global__ void k_rgcn_finalize(const float* __restrict__ summed, int64_t ld_s, const float* __restrict__ indeg,
+                                int relu, float* __restrict__ out, int64_t ld_o, int64_t rows, int cols) {
+    const int64_t total = rows * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / cols;
+        const int c = (int)(t - i * cols);
+        float v = summed[i * ld_s + c] / fmaxf(indeg[i], 1.0f) + out[i * ld_o + c];   // out holds x.root + bias
+        if (relu) v = fmaxf(v, 0.f);
+        out[i * ld_o + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
+    if (!plan || fin <= 0 || fout <= 0) return 0;
+    size_t general = general_layout(plan, fin, fout).total;
+    size_t fast = gn_rgcn_fast_applicable(plan, fin, fout, bases) ? gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases) : 0;
+    return general > fast ? general : fast;
+}
+
+gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
+                              const float* basis, const float* att, int64_t bases, const float* root,
+                              const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
+    const int64_t N = plan->num_nodes, R = plan->num_relations;
+    if (N == 0) return GN_OK;
+    GN_REQUIRE(x && basis && att && out && (partial || root), "operand pointer is null");
+    GN_REQUIRE(ld_x >= fin && ld_out >= fout, "leading dimension smaller than the row length");
+    GN_REQUIRE(workspace_bytes >= gn_rgcn_workspace_bytes(plan, fin, fout, bases) && (workspace || workspace_bytes == 0),
+               "workspace too small: need %zu bytes", gn_rgcn_workspace_bytes(plan, fin, fout, bases));
+    hipStream_t st = gn::as_stream(stream);
+
+    if (gn_rgcn_fast_applicable(plan, fin, fout, bases))
+        return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, out,
+                                    ld_out, workspace, workspace_bytes, st);
+
+    const GeneralWs l = general_layout(plan, fin, fout);
+    char* ws = static_cast<char*>(workspace);
+    float* W = reinterpret_cast<float*>(ws + l.w_off);
+    float* H = reinterpret_cast<float*>(ws + l.h_off);
+    float* XR = reinterpret_cast<float*>(ws + l.xr_off);
+    gn_status s;
+    if (R > 0) {
+        // K7: W[R, fin*fout] = att[R,B] @ basis[B, fin*fout]   (layers.py:172-173)
+        s = gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, R, fin * fout, bases, 1,
+                        nullptr, 0, stream);
+        if (s != GN_OK) return s;
+        // H[r] = X @ W[r] for all relations; grid.z carries the relation, in slabs of 32768
+        for (int64_t r0 = 0; r0 < R; r0 += 32768) {
+            const int64_t nb = std::min<int64_t>(32768, R - r0);
+            s = gn_gemm_f32(x, ld_x, 0, nullptr, 0, W + r0 * fin * fout, fout, fin * fout, H + r0 * N * fout, fout,
+                            N * fout, N, fout, fin, nb, nullptr, 0, stream);
+            if (s != GN_OK) return s;
+        }
+    }
+    if (!partial) {
+        // K12: x @ root (+ bias) goes in as the addend of the gather epilogue (layers.py:193-196)
+        s = gn_gemm_f32(x, ld_x, 0, nullptr, 0, root, fout, 0, XR, fout, 0, N, fout, fin, 1, bias, 0, stream);
+        if (s != GN_OK) return s;
+    }
+    gn::AggArgs a;
+    a.rowptr = plan->rowptr.p;
+    a.col = plan->key.p;
+    a.coef = nullptr;
+    a.table = H;
+    a.ld_table = fout;
+    a.features = (int)fout;
+    a.rowdiv = partial ? nullptr : plan->indeg.p;
+    a.addend = partial ? nullptr : XR;
+    a.ld_addend = fout;
+    a.bias = nullptr;
+    a.relu = partial ? 0 : relu;
+    a.out = out;
+    a.ld_out = ld_out;
+    a.rows = (int)N;
+    return gn::launch_aggregate(a, st);
+}
+
+gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* summed, int64_t ld_summed, const float* x,
+                               int64_t ld_x, int64_t fin, const float* root, const float* bias, int64_t fout,
+                               int relu, float* out, int64_t ld_out, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    GN_REQUIRE(fin > 0 && fout > 0 && fout < (1ll << 31), "feature counts must be positive");
+    const int64_t N = plan->num_nodes;
+    if (N == 0) return GN_OK;
+    GN_REQUIRE(summed && x && root && out, "operand pointer is null");
+    GN_REQUIRE(summed != out, "finalize cannot run in place");
+    gn_status s = gn_gemm_f32(x, ld_x, 0, nullptr, 0, root, fout, 0, out, ld_out, 0, N, fout, fin, 1, bias, 0, stream);
+    if (s != GN_OK) return s;
+    k_rgcn_finalize<<<gn::stream_grid(N * fout, 256), 256, 0, gn::as_stream(stream)>>>(
+        summed, ld_summed, plan->indeg.p, relu, out, ld_out, N, (int)fout);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // extern "C"

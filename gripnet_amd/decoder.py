@@ -1,0 +1,55 @@
+"""Decoders with the reference's names and signatures (gripnet/decoder.py), on the gfx950 kernels.
+
+  multiRelaInnerProductDecoder  decoder.py:10-26   DistMult link scorer
+  multiClassInnerProductDecoder decoder.py:29-50   linear + softmax node classifier
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.nn import Module, Parameter
+
+from . import _hip
+
+
+class multiRelaInnerProductDecoder(Module):
+    """``sigmoid(sum_k z[u,k] z[v,k] D[r,k])`` (reference decoder.py:19-23)."""
+
+    def __init__(self, in_dim, num_et):
+        super().__init__()
+        self.num_et, self.in_dim = num_et, in_dim
+        self.weight = Parameter(torch.empty(num_et, in_dim))
+        self.reset_parameters()
+
+    def forward(self, z, edge_index, edge_type, sigmoid=True):
+        _hip.require_gpu(z, edge_index, edge_type, self.weight)
+        z = _hip.f32_rows(z)
+        if z.shape[1] != self.in_dim:
+            raise ValueError("expected {} features, got {}".format(self.in_dim, z.shape[1]))
+        out = torch.empty((edge_index.shape[1],), dtype=torch.float32, device=z.device)
+        return _hip.distmult(z, edge_index, edge_type, self.weight, sigmoid, out)
+
+    def reset_parameters(self):
+        self.weight.data.normal_(std=1 / np.sqrt(self.in_dim))                   # decoder.py:25-26
+
+
+class multiClassInnerProductDecoder(Module):
+    """``softmax(z[node_list] @ W)`` (reference decoder.py:38-45)."""
+
+    def __init__(self, in_dim, num_class):
+        super().__init__()
+        self.num_class, self.in_dim = num_class, in_dim
+        self.weight = Parameter(torch.empty(in_dim, num_class))
+        self.reset_parameters()
+
+    def forward(self, z, node_list, softmax=True):
+        _hip.require_gpu(z, node_list, self.weight)
+        z = _hip.f32_rows(z)
+        nodes = _hip.i64_vec(node_list)
+        pred = torch.empty((nodes.shape[0], self.num_class), dtype=torch.float32, device=z.device)
+        _hip.gemm(z, self.weight, pred, a_rows=nodes)                            # decoder.py:42
+        return _hip.softmax_rows(pred) if softmax else pred
+
+    def reset_parameters(self):
+        bound = np.sqrt(6.0 / (self.weight.size(-2) + self.weight.size(-1)))     # decoder.py:47-49
+        self.weight.data.uniform_(-bound, bound)

@@ -1,0 +1,247 @@
+"""Supergraph propagation modules with the reference's names, signatures and state-dict keys,
+computed by the gfx950 kernels behind the C ABI (include/gripnet_hip.h).
+
+Mirrors gripnet/layers.py of the reference:
+  myGCN      layers.py:15-105   GCN-style conv (internal homogeneous layers, external layer)
+  myRGCN     layers.py:108-205  basis-decomposed relational conv with a GLOBAL mean
+  homoGraph  layers.py:208-319  internal layer stack of one supervertex
+  interGraph layers.py:322-387  external (inter-supervertex) layer
+
+Forward only; all tensors must be fp32 / int64 on the GPU (no CPU fallback).  What the
+reference caches on first use (normalised edge list) is a *plan* here; the cache protocol
+(keyed by edge count, RuntimeError on mismatch) is the reference's (layers.py:75-90).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch.nn import Module, Parameter
+
+from . import _hip
+
+
+def _cat_slots(widths, n_rows, device):
+    """Pre-laid-out concat buffer: the layers write their slice in place (layers.py:309,376)."""
+    out = torch.empty((n_rows, int(sum(widths))), dtype=torch.float32, device=device)
+    views, lo = [], 0
+    for w in widths:
+        views.append(out[:, lo:lo + w])
+        lo += w
+    return out, views
+
+
+class myGCN(Module):
+    """``out = A_norm (x W) + b`` (reference layers.py:15-105)."""
+
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, bias=True, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached = improved, cached
+        self.cached_result = None
+        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = math.sqrt(6.0 / (self.weight.size(-2) + self.weight.size(-1)))   # layers.py:43-44
+        self.weight.data.uniform_(-bound, bound)
+        if self.bias is not None:
+            self.bias.data.fill_(0)
+        self.cached_result = None
+        self.cached_num_edges = None
+
+    @staticmethod
+    def norm(edge_index, num_nodes, edge_weight, improved=False, dtype=None):
+        """(edge_index', norm) exactly as layers.py:52-69 returns them (built on the GPU)."""
+        plan = _hip.GraphPlan.gcn(edge_index, num_nodes, edge_weight, improved)
+        ei, nrm = plan.export()
+        return ei, (nrm if dtype in (None, torch.float32) else nrm.to(dtype))
+
+    def _plan(self, edge_index, build):
+        """The reference's cache protocol (layers.py:75-90): keyed by the edge count only."""
+        if self.cached and self.cached_result is not None:
+            if edge_index.size(1) != self.cached_num_edges:
+                raise RuntimeError("Cached {} number of edges, but found {}".format(
+                    self.cached_num_edges, edge_index.size(1)))
+        if not self.cached or self.cached_result is None:
+            self.cached_num_edges = edge_index.size(1)
+            self.cached_result = build()
+        return self.cached_result
+
+    def _run(self, plan, x, n_out, out, relu):
+        x = _hip.f32_rows(x)
+        xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
+        _hip.gemm(x, self.weight, xw)                                            # layers.py:73
+        if out is None:
+            out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
+        return plan.aggregate(xw, self.bias, relu, out)                          # layers.py:92-100
+
+    def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False):
+        _hip.require_gpu(x, edge_index, edge_weight, self.weight)
+        n = x.size(0)
+        plan = self._plan(edge_index, lambda: _hip.GraphPlan.gcn(edge_index, n, edge_weight, self.improved))
+        return self._run(plan, x, n, _out, _relu)
+
+    def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False):
+        """The conv as interGraph uses it (layers.py:363-368), in closed form: rows are targets."""
+        _hip.require_gpu(x, inter_edge_index, edge_weight, self.weight)
+        n_src = x.size(0)
+        plan = self._plan(inter_edge_index,
+                          lambda: _hip.GraphPlan.bipartite(inter_edge_index, n_src, n_target, edge_weight))
+        return self._run(plan, x, n_target, _out, _relu)
+
+    def __repr__(self):
+        return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
+
+
+class myRGCN(Module):
+    """``out[i] = mean_{e: dst=i} x[src_e] W_{r(e)} + x[i] root (+ b)``, ``W_r = sum_b att[r,b] basis[b]``
+    with the mean over ALL incoming edges of all relations (reference layers.py:108-205)."""
+
+    def __init__(self, in_channels, out_channels, num_relations, num_bases, after_relu, bias=False, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_relations, self.num_bases, self.after_relu = num_relations, num_bases, after_relu
+        self.basis = Parameter(torch.empty(num_bases, in_channels, out_channels))
+        self.att = Parameter(torch.empty(num_relations, num_bases))
+        self.root = Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._plan = None
+        self._plan_key = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.att.data.normal_(std=1 / np.sqrt(self.num_bases))                   # layers.py:152
+        std = 2 / self.in_channels if self.after_relu else 1 / np.sqrt(self.in_channels)
+        self.root.data.normal_(std=std)
+        self.basis.data.normal_(std=std)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def plan_for(self, edge_index, range_list, num_nodes, edge_lo=None, edge_hi=None):
+        """Plan of the static relational graph, rebuilt when the edge tensor changes."""
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
+               id(range_list), getattr(range_list, "_version", 0), num_nodes, edge_lo, edge_hi)
+        if self._plan is None or self._plan_key != key:
+            self._plan = _hip.RgcnPlan(edge_index, range_list, num_nodes, edge_lo, edge_hi)
+            self._plan_key = key
+        return self._plan
+
+    def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False):
+        # edge_type is accepted and unused, as in the reference (the relation of an edge is the
+        # range_list row that contains it, layers.py:171-186)
+        _hip.require_gpu(x, edge_index, self.basis)
+        x = _hip.f32_rows(x)
+        if x.shape[1] != self.in_channels:
+            raise ValueError("expected {} input features, got {}".format(self.in_channels, x.shape[1]))
+        if range_list.shape[0] != self.num_relations:
+            raise ValueError("range_list has {} rows for {} relations".format(range_list.shape[0], self.num_relations))
+        plan = self.plan_for(edge_index, range_list, x.shape[0])
+        out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
+                                                        device=x.device)
+        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out)
+
+    def __repr__(self):
+        return "{}({}, {}, num_relations={})".format(self.__class__.__name__, self.in_channels,
+                                                     self.out_channels, self.num_relations)
+
+
+class homoGraph(Module):
+    """Internal layer stack of one supervertex (reference layers.py:208-319):
+    ``h_l = relu(conv_l(h_{l-1}))`` for every layer, optional concat of the input and all layers."""
+
+    def __init__(self, nhid_list, requires_grad=True, start_graph=False, in_dim=None, multi_relational=False,
+                 n_rela=None, n_base=32):
+        super().__init__()
+        self.multi_relational = multi_relational
+        self.start_graph = start_graph
+        self.out_dim = nhid_list[-1]
+        self.n_cov = len(nhid_list) - 1
+        self.nhid_list = list(nhid_list)
+        if start_graph:
+            self.embedding = Parameter(torch.empty(in_dim, nhid_list[0]))
+            self.embedding.requires_grad = requires_grad
+            self.reset_parameters()
+        if multi_relational:
+            assert n_rela is not None
+            self.conv_list = torch.nn.ModuleList([
+                myRGCN(nhid_list[i], nhid_list[i + 1], n_rela, n_base, after_relu=i > 0)
+                for i in range(len(nhid_list) - 1)])
+        else:
+            self.conv_list = torch.nn.ModuleList([
+                myGCN(nhid_list[i], nhid_list[i + 1], cached=True) for i in range(len(nhid_list) - 1)])
+
+    def reset_parameters(self):
+        self.embedding.data.normal_()
+
+    def forward(self, x, homo_edge_index, edge_weight=None, edge_type=None, range_list=None, if_catout=False):
+        if self.start_graph:
+            x = self.embedding                                                  # layers.py:261-262
+        if self.multi_relational:
+            assert edge_type is not None
+            assert range_list is not None
+        _hip.require_gpu(x, homo_edge_index)
+        x = _hip.f32_rows(x)
+        n = x.shape[0]
+        if if_catout:
+            out, slots = _cat_slots([x.shape[1]] + [c.out_channels for c in self.conv_list], n, x.device)
+            _hip.merge(slots[0], x, 0)                                           # slot 0 <- input
+        else:
+            out, slots = None, [None] * (len(self.conv_list) + 1)
+        h = x
+        for i, net in enumerate(self.conv_list):                                 # conv + ReLU fused, every layer
+            if self.multi_relational:
+                h = net(h, homo_edge_index, edge_type, range_list, _out=slots[i + 1], _relu=True)
+            else:
+                h = net(h, homo_edge_index, edge_weight, _out=slots[i + 1], _relu=True)
+        return out if if_catout else h
+
+
+class interGraph(Module):
+    """External layer source supervertex -> target supervertex (reference layers.py:322-387)."""
+
+    def __init__(self, source_dim, target_dim, n_target, target_feat_dim=32, requires_grad=True,
+                 if_one_external=True):
+        super().__init__()
+        self.source_dim, self.target_dim = source_dim, target_dim
+        self.target_feat_dim, self.n_target = target_feat_dim, n_target
+        self.if_one_external = if_one_external
+        if not self.if_one_external:
+            self.conv = myGCN(source_dim, target_dim, cached=True)
+            return
+        self.target_feat = Parameter(torch.empty(n_target, target_feat_dim))
+        self.target_feat.requires_grad = requires_grad
+        if target_dim != target_feat_dim:                                        # exists even if unused
+            self.target_feat_down = Parameter(torch.empty(target_feat_dim, target_dim))
+            self.target_feat_down.requires_grad = requires_grad
+            self.target_feat_down.data.normal_()
+        self.conv = myGCN(source_dim, target_dim, cached=True)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.target_feat.data.normal_()
+
+    def forward(self, x, inter_edge_index, edge_weight=None, if_relu=True, mod="cat"):
+        _hip.require_gpu(x, inter_edge_index)
+        dev = x.device
+        if not self.if_one_external:                                             # layers.py:372-373
+            return self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
+        if mod == "cat":                                                         # layers.py:375-376
+            out, (y, tf) = _cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
+            self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu)
+            _hip.merge(tf, self.target_feat, 1)
+            return out
+        y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
+        if y.shape[1] == self.target_feat.shape[1]:                              # layers.py:378-379
+            return _hip.merge(y, self.target_feat, 2)
+        down = torch.empty_like(y)                                               # layers.py:381-384
+        _hip.gemm(self.target_feat, self.target_feat_down, down)
+        return _hip.merge(y, down, 3)

@@ -1,0 +1,95 @@
+"""Counterparts of the reference drivers' model assembly and forward call sequence.
+
+The reference builds its encoder inline in every script (``Model(gg, gd, dd, dmt)`` whose own
+``forward`` is ``pass``, GripNet-pose.py:73-99) and spells the call order out in ``train()``
+(GripNet-pose.py:117-138).  This module is that harness for the build's own benchmarks and
+tests: same hyper-parameters, same call order and keyword arguments, same state-dict keys.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch.nn import Module
+
+from . import _hip
+from .decoder import multiClassInnerProductDecoder, multiRelaInnerProductDecoder
+from .layers import homoGraph, interGraph
+
+POSE_HPARAMS = dict(gg_nhids=[32, 16, 16], gd_out=[16, 32])     # GripNet-pose.py:86-89
+
+
+class PoseModel(Module):
+    """gg (gene internal) -> gd (external) -> dd (drug internal, relational) -> dmt (DistMult)."""
+
+    def __init__(self, n_g_node, n_d_node, n_dd_edge_type, gg_nhids=None, gd_out=None, n_base=32):
+        super().__init__()
+        gg_nhids = list(gg_nhids or POSE_HPARAMS["gg_nhids"])
+        gd_out = list(gd_out or POSE_HPARAMS["gd_out"])
+        dd_nhids = [sum(gd_out), 32]
+        self.gg = homoGraph(gg_nhids, start_graph=True, in_dim=n_g_node)                       # pose.py:95
+        self.gd = interGraph(sum(gg_nhids), gd_out[0], n_d_node, target_feat_dim=gd_out[-1])   # pose.py:96
+        self.dd = homoGraph(dd_nhids, multi_relational=True, n_rela=n_dd_edge_type, n_base=n_base)  # pose.py:97
+        self.dmt = multiRelaInnerProductDecoder(sum(dd_nhids), n_dd_edge_type)                 # pose.py:98
+
+    def encode(self, data):
+        z = self.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)    # pose.py:117-119
+        z = self.gd(z, data.gd_edge_index, mod="cat", if_relu=True)                            # pose.py:120
+        return self.dd(z, data.train_idx, edge_type=data.train_et, range_list=data.train_range,
+                       if_catout=True)                                                         # pose.py:121-127
+
+    def forward(self, data, sigmoid=True):
+        z = self.encode(data)
+        score = self.dmt(z, data.train_idx, data.train_et, sigmoid=sigmoid)                    # pose.py:137
+        return z, score
+
+
+class AminerModel(Module):
+    """pp -> pa -> aa -> mcip (GripNet-aminer.py:96-108,124-130; freebase-b is the same shape)."""
+
+    def __init__(self, n_p_node, n_a_node, n_class, pp_nhids=(128, 64, 64), pa_out=(64, 64), aa_hidden=(128, 32)):
+        super().__init__()
+        pp_nhids, pa_out = list(pp_nhids), list(pa_out)
+        aa_nhids = [sum(pa_out)] + list(aa_hidden)
+        self.pp = homoGraph(pp_nhids, start_graph=True, in_dim=n_p_node)
+        self.pa = interGraph(sum(pp_nhids), pa_out[0], n_a_node, target_feat_dim=pa_out[-1])
+        self.aa = homoGraph(aa_nhids)
+        self.mcip = multiClassInnerProductDecoder(sum(aa_nhids), n_class)
+
+    def forward(self, data, node_list, softmax=True):
+        z = self.pp(None, data.pp_edge_idx, edge_weight=data.pp_edge_weight, if_catout=True)
+        z = self.pa(z, data.pa_edge_idx, if_relu=True, mod="cat")
+        z = self.aa(z, data.aa_edge_idx, edge_weight=data.aa_edge_weight, if_catout=True)
+        return z, self.mcip(z, node_list, softmax=softmax)
+
+
+class FreebaseCModel(Module):
+    """pp -> pa, qq -> qa, (z + z1 + aa_embeddings) / 3 -> aa -> mcip
+    (GripNet-freebase-c.py:102-136,150-165; freebase-d is the same shape)."""
+
+    def __init__(self, n_p_node, n_q_node, n_a_node, n_class, pp_nhids=(256, 128, 128), qq_nhids=(256, 128, 128),
+                 pa_out=(128, 128), aa_hidden=(32,)):
+        super().__init__()
+        pp_nhids, qq_nhids, pa_out = list(pp_nhids), list(qq_nhids), list(pa_out)
+        aa_nhids = [pa_out[-1]] + list(aa_hidden)
+        self.pp = homoGraph(pp_nhids, start_graph=True, in_dim=n_p_node)
+        self.pa = interGraph(sum(pp_nhids), pa_out[0], n_a_node, target_feat_dim=pa_out[-1], if_one_external=False)
+        self.qq = homoGraph(qq_nhids, start_graph=True, in_dim=n_q_node)
+        self.qa = interGraph(sum(qq_nhids), pa_out[0], n_a_node, target_feat_dim=pa_out[-1], if_one_external=False)
+        self.aa_embeddings = torch.nn.Parameter(torch.empty(n_a_node, aa_nhids[0]).normal_())
+        self.aa = homoGraph(aa_nhids)
+        self.mcip = multiClassInnerProductDecoder(aa_nhids[-1], n_class)
+
+    def forward(self, data, node_list, softmax=True):
+        z = self.pp(None, data.pp_edge_idx, edge_weight=data.pp_edge_weight, if_catout=True)
+        z = self.pa(z, data.pa_edge_idx, mod="add", if_relu=True)
+        z1 = self.qq(None, data.qq_edge_idx, edge_weight=data.qq_edge_weight, if_catout=True)
+        z1 = self.qa(z1, data.qa_edge_idx, mod="add", if_relu=True)
+        merged = _hip.merge(z, z1, 4, src2=self.aa_embeddings)                   # (z + z1 + aae) / 3
+        z = self.aa(merged, data.aa_edge_idx, edge_weight=data.aa_edge_weight)
+        return z, self.mcip(z, node_list, softmax=softmax)
+
+
+def load_reference_state(model: Module, state: Dict[str, torch.Tensor], strict: bool = True):
+    """Load a state dict saved by the reference (GripNet-pose.py:236; keys of SURVEY App. B.2)."""
+    return model.load_state_dict(state, strict=strict)

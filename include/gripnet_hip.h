@@ -1,0 +1,156 @@
+/*
+ * gripnet_hip.h - C ABI of the MI355X (gfx950) supergraph propagation engine.
+ *
+ * The reference (NYXFLOWER/GripNet) has no FFI layer: its hot path is Python that calls into
+ * ATen / torch_geometric / torch_scatter.  This header is the boundary a maintainer binds
+ * instead of those calls; every entry point names the reference lines it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - feature matrices are row-major fp32 with an explicit leading dimension (elements);
+ *   - node / edge indices are int64, exactly as the reference's torch.long tensors;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous with respect to
+ *     the host except the *_plan_create functions, which synchronise `stream` once;
+ *   - outputs and scratch are caller-allocated; the library owns only what hangs off an
+ *     opaque plan handle (the cached CSR / normalisation / counts of one static graph);
+ *   - every function returns a gn_status; gn_last_error() gives the calling thread's message;
+ *   - re-entrant and thread-safe on distinct plans; no global mutable state.
+ */
+#ifndef GRIPNET_HIP_H
+#define GRIPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_VERSION 100 /* 0.1.0 */
+
+#if defined(GN_BUILDING)
+#define GN_API __attribute__((visibility("default")))
+#else
+#define GN_API
+#endif
+
+typedef enum gn_status {
+    GN_OK = 0,
+    GN_ERR_INVALID_ARG = 1,   /* null pointer, negative size, unsupported shape          */
+    GN_ERR_HIP = 2,           /* a HIP runtime call failed (message carries hipGetErrorString) */
+    GN_ERR_INDEX_RANGE = 3,   /* an edge endpoint / relation id is outside its table     */
+    GN_ERR_UNSUPPORTED = 4,   /* sizes beyond what the 32-bit plan encoding can hold     */
+    GN_ERR_EDGE_COUNT = 5     /* plan was built for a different number of edges          */
+} gn_status;
+
+typedef struct gn_graph_plan gn_graph_plan; /* GCN-style graphs (square or bipartite)  */
+typedef struct gn_rgcn_plan gn_rgcn_plan;   /* multi-relational graph of one supervertex */
+
+GN_API int gn_version(void);
+/* Message of the last failing call made by this thread ("" if none). */
+GN_API const char* gn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * GCN-style normalised graph.  Replaces myGCN.norm + its cache (gripnet/layers.py:52-69,
+ * 83-90): drops existing self loops, appends one loop per node (weight = that node's last
+ * listed loop weight, else 1, or 2 if `improved`), deg = sum of weights by DESTINATION,
+ * norm = deg[src]^-1/2 * w * deg[dst]^-1/2 (inf -> 0).  The plan holds edge_index'
+ * (non-loops in input order, then loops 0..N-1) and norm in the reference's order, plus a
+ * destination-major CSR (int32 columns, fp32 coefficients) used by gn_graph_aggregate_f32.
+ * w may be NULL (all ones).
+ */
+GN_API gn_status gn_gcn_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t num_edges,
+                             int64_t num_nodes, int improved, void* stream, gn_graph_plan** plan);
+
+/* External (inter-supervertex) layer graph.  Replaces the index shift, zero padding and the
+ * dead self loops of interGraph.forward (gripnet/layers.py:363-368) by their closed form:
+ * coefficient of edge s->t is w_e * (1 + sum of weights into t)^-1/2; rows are targets. */
+GN_API gn_status gn_bipartite_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t num_edges,
+                                   int64_t num_sources, int64_t num_targets, void* stream, gn_graph_plan** plan);
+
+GN_API void gn_graph_plan_destroy(gn_graph_plan* plan);
+/* Number of edges the plan was built from (the reference's cache key, layers.py:76-84). */
+GN_API int64_t gn_graph_plan_input_edges(const gn_graph_plan* plan);
+/* Number of stored coefficients: E' = non-loop edges + N for a GCN plan, E for a bipartite plan. */
+GN_API int64_t gn_graph_plan_nnz(const gn_graph_plan* plan);
+/* Copy edge_index' ([2, E'] int64) and norm ([E'] fp32) in the reference's order (GCN plans). */
+GN_API gn_status gn_graph_plan_export(const gn_graph_plan* plan, int64_t* edge_index_out, float* norm_out, void* stream);
+
+/* out[i, :] = act( sum_{e: dst(e)=i} coef_e * xw[src(e), :] + bias ),  i in [0, rows).
+ * Replaces propagate/message/update of myGCN (gripnet/layers.py:92-100) and the ReLU that
+ * always follows (layers.py:279,305,370).  xw = x @ W is computed first with gn_gemm_f32,
+ * as the reference does (layers.py:73).  bias may be NULL.  `out` may be a column slice of a
+ * wider matrix (ld_out), which is how the concat of layers.py:309,376 is written in place. */
+GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw, int64_t num_features,
+                                 const float* bias, int relu, float* out, int64_t ld_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
+ *   C[b] = act( gather_rows(A[b]) @ B[b] + bias ),  b in [0, batch).
+ * Replaces torch.matmul at gripnet/layers.py:73,172-173,193,383 and decoder.py:42.
+ * a_rows (int64, may be NULL) selects rows of A (z[node_list], decoder.py:42).
+ * stride_* are batch strides in elements (0 = shared operand). */
+GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
+                      const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
+                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int relu, void* stream);
+
+/* Element-wise merges of the external layer (gripnet/layers.py:375-384) and slot copies of the
+ * concat outputs:  mode 0: dst = src;  1: dst = |src|;  2: dst = (dst + |src|) / 2;
+ * 3: dst = (dst + relu(src)) / 2;  4: dst = (dst + src + src2) / 3 (freebase-c merge,
+ * GripNet-freebase-c.py:158-162). */
+GN_API gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, const float* src2,
+                       int64_t ld_src2, int64_t rows, int64_t cols, int mode, void* stream);
+
+/* Row softmax in place (decoder.py:43). */
+GN_API gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-relational internal layer (myRGCN, gripnet/layers.py:165-197).
+ * The plan caches what depends only on the (static) dd graph: per-destination in-degree over
+ * ALL relations (the global mean of layers.py:131) and the relation-major / destination-major
+ * edge encodings the kernels stream.  range_list ([R,2] int64, half-open, must tile [0,E) in
+ * order as produced by utils.get_range_list) may live on the host or on the device.
+ * edge_lo/edge_hi select a contiguous edge sub-range (multi-GPU sharding by relation / edge
+ * range); in-degrees are always over the full [0,E) graph.
+ */
+GN_API gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int64_t* range_list,
+                              int range_list_on_host, int64_t num_relations, int64_t num_edges,
+                              int64_t num_nodes, int64_t edge_lo, int64_t edge_hi, void* stream,
+                              gn_rgcn_plan** plan);
+GN_API void gn_rgcn_plan_destroy(gn_rgcn_plan* plan);
+GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
+
+/* Bytes of caller-provided scratch gn_rgcn_forward_f32 needs for these shapes. */
+GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features,
+                               int64_t num_bases);
+
+/* partial == 0:  out[i,:] = act( (sum_{e: dst=i} x[src_e] W_{r(e)}) / max(1, indeg_i) + x[i] root + bias )
+ * partial == 1:  out[i,:] = sum_{e in [edge_lo,edge_hi): dst=i} x[src_e] W_{r(e)}   (un-normalised
+ *                shard contribution; all-reduce it, then call gn_rgcn_finalize_f32)
+ * with W_r = sum_b att[r,b] basis[b]  (layers.py:172-173).  bias may be NULL. */
+GN_API gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t in_features,
+                              const float* basis, const float* att, int64_t num_bases, const float* root,
+                              const float* bias, int64_t out_features, int relu, int partial, float* out,
+                              int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i,:] = act( summed[i,:] / max(1, indeg_i) + x[i] root + bias )  (layers.py:131,191-197). */
+GN_API gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* summed, int64_t ld_summed, const float* x,
+                               int64_t ld_x, int64_t in_features, const float* root, const float* bias,
+                               int64_t out_features, int relu, float* out, int64_t ld_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * DistMult decoder (multiRelaInnerProductDecoder.forward, gripnet/decoder.py:19-23):
+ *   out[e] = sigma?( sum_k z[u_e,k] * z[v_e,k] * D[r_e,k] ).
+ * Consumes the raw int64 edge_index rows and edge_type every call (negative samples change
+ * every epoch, GripNet-pose.py:131), so nothing is cached.  An endpoint or relation outside its
+ * table yields NaN for that edge and sets bit 0 of *error_flag (device int32, may be NULL). */
+GN_API gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
+                                  const int64_t* u, const int64_t* v, const int64_t* edge_type,
+                                  const float* d, int64_t ld_d, int64_t num_relations, int64_t num_edges,
+                                  int apply_sigmoid, float* out, int32_t* error_flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIPNET_HIP_H */

@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/gripnet_hip.h declares (no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import gripnet_amd
+from gripnet_amd import _hip
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "gripnet_hip.h")).read()
+    return sorted(set(re.findall(r"GN_API[^;(]*?\b(gn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    names = declared_symbols()
+    assert len(names) >= 15
+    assert sorted(_hip.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_hip.library_path()), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_hip.library_path())
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert _hip.load().gn_version() == 100
+    assert _hip.load().gn_last_error() is not None
+
+
+def test_no_cpu_fallback():
+    m = gripnet_amd.homoGraph([4, 4], start_graph=True, in_dim=3)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(None, torch.zeros(2, 2, dtype=torch.long))
+    d = gripnet_amd.multiRelaInnerProductDecoder(4, 2)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        d(torch.zeros(3, 4), torch.zeros(2, 2, dtype=torch.long), torch.zeros(2, dtype=torch.long))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "gripnet_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh")):
+                text = open(os.path.join(root, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), os.path.join(root, f)
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("pose_tiny")
+    from gripnet_amd.pipeline import PoseModel
+    model = PoseModel(g.meta["n_g"], g.meta["n_d"], g.meta["R"])
+    want = {k[3:]: v.shape for k, v in g.arrays.items() if k.startswith("sd.")}
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert have == {k: tuple(s) for k, s in want.items()}
+    assert model.gg.out_dim == 16 and model.gg.n_cov == 2 and model.dd.out_dim == 32
+
+
+def test_cache_protocol_is_keyed_by_edge_count_only():
+    conv = gripnet_amd.myGCN(4, 4, cached=True)
+    conv.cached_result, conv.cached_num_edges = object(), 7
+    with pytest.raises(RuntimeError, match="Cached 7 number of edges, but found 3"):
+        conv._plan(torch.zeros(2, 3, dtype=torch.long), lambda: None)
+    assert conv._plan(torch.zeros(2, 7, dtype=torch.long), lambda: None) is conv.cached_result
+    conv.reset_parameters()
+    assert conv.cached_result is None and conv.cached_num_edges is None

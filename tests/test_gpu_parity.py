@@ -1,0 +1,322 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors and the CPU oracle.
+
+Bar (BASELINE.json north_star): index outputs bit-exact; fp32 outputs within 1e-4 abs of the
+reference.  Most checks are held to a tighter 2e-5 so that regressions show early.
+"""
+import numpy as np
+import pytest
+import torch
+
+import gripnet_amd
+from gripnet_amd import _hip
+from gripnet_amd.pipeline import AminerModel, FreebaseCModel, PoseModel
+from gripnet_amd.synth import Data, make_pose
+from oracle import gripnet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # the contract
+TIGHT = 2e-5    # what we actually expect
+
+
+def close(a, b, atol=TIGHT):
+    a, b = torch.as_tensor(a).detach().cpu(), torch.as_tensor(b).detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), "non-finite values in the HIP output"
+    err = (a.double() - b.double()).abs().max().item() if a.numel() else 0.0
+    assert err <= atol, "max abs err {:.3e} > {:.1e}".format(err, atol)
+
+
+def load_into(module, state, dev):
+    module.load_state_dict(state)
+    return module.to(dev)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_library_is_the_hip_one(gpu):
+    assert _hip.load().gn_version() == 100
+    assert "libgripnet_hip.so" in open("/proc/self/maps").read()
+
+
+def test_norm_known_answer(gpu, golden):
+    g = golden("norm_known")
+    ei2, norm = gripnet_amd.myGCN.norm(g.t("edge_index", gpu), 3, None, improved=True, dtype=torch.float32)
+    assert torch.equal(ei2.cpu(), torch.tensor([[0, 1, 0, 1, 2], [1, 0, 0, 1, 2]]))
+    close(norm, torch.tensor([1 / 3, 1 / 3, 2 / 3, 2 / 3, 1.0]), 1e-6)
+
+
+def test_norm_cases_bit_exact_indices(gpu, golden):
+    g = golden("norm_cases")
+    for i, spec in enumerate(g.meta["cases"]):
+        p = "c{}.".format(i)
+        w = g.t(p + "edge_weight", gpu) if spec["weighted"] else None
+        ei2, norm = gripnet_amd.myGCN.norm(g.t(p + "edge_index", gpu), spec["num_nodes"], w,
+                                           improved=spec["improved"])
+        assert ei2.dtype == torch.int64
+        assert torch.equal(ei2.cpu(), g.t(p + "out.edge_index")), "case {}".format(i)
+        close(norm, g.t(p + "out.norm"), 1e-6)
+
+
+def test_gcn_forward_and_cache(gpu, golden):
+    g = golden("gcn_forward")
+    conv = load_into(gripnet_amd.myGCN(g.meta["fin"], g.meta["fout"], cached=True), g.state(""), gpu)
+    ei, w = g.t("edge_index", gpu), g.t("edge_weight", gpu)
+    close(conv(g.t("x0", gpu), ei, w), g.t("out.y0"))
+    plan = conv.cached_result
+    close(conv(g.t("x1", gpu), ei, w), g.t("out.y1"))
+    assert conv.cached_result is plan                       # second call served from the cache
+    cached_ei, cached_norm = conv.cached_result             # unpacks like the reference's tuple
+    ref_ei, ref_norm = orc.gcn_norm(g.t("edge_index"), g.meta["n"], g.t("edge_weight"))
+    assert torch.equal(cached_ei.cpu(), ref_ei)
+    close(cached_norm, ref_norm, 1e-6)
+    with pytest.raises(RuntimeError, match="Cached 300 number of edges, but found 299"):
+        conv(g.t("x0", gpu), ei[:, :299], w[:299])
+    # same edge count, different edges: the stale graph is reused silently, like the reference
+    close(conv(g.t("x0", gpu), ei.flip(0), w), g.t("out.y0"))
+    nb = load_into(gripnet_amd.myGCN(g.meta["fin"], 20, cached=False, bias=False), g.state("nb."), gpu)
+    close(nb(g.t("x0", gpu), ei), g.t("out.y_nobias_unweighted"))
+
+
+def test_inter_cases(gpu, golden):
+    g = golden("inter_cases")
+    x, ei, w = g.t("x", gpu), g.t("edge_index", gpu), g.t("edge_weight", gpu)
+    for v in g.meta["variants"]:
+        m = gripnet_amd.interGraph(g.meta["source_dim"], v["target_dim"], g.meta["n_target"],
+                                   target_feat_dim=v["target_feat_dim"], if_one_external=v["if_one_external"])
+        m = load_into(m, g.state(v["tag"] + "."), gpu)
+        before = ei.clone()
+        y = m(x, ei, w if v["weighted"] else None, if_relu=v["if_relu"], mod=v["mod"])
+        assert torch.equal(before, ei)                      # caller's tensor is not mutated
+        close(y, g.t(v["tag"] + ".out"))
+
+
+def test_rgcn_cases(gpu, golden):
+    g = golden("rgcn_cases")
+    x, ei, et, rl = g.t("x", gpu), g.t("edge_index", gpu), g.t("edge_type", gpu), g.t("range_list", gpu)
+    for v in g.meta["variants"]:
+        m = gripnet_amd.myRGCN(g.meta["fin"], g.meta["fout"], g.meta["R"], g.meta["B"], v["after_relu"], bias=v["bias"])
+        m = load_into(m, g.state(v["tag"] + "."), gpu)
+        close(m(x, ei, et, rl), g.t(v["tag"] + ".out"))
+        close(m(x, ei, et, rl.cpu()), g.t(v["tag"] + ".out"))     # range_list may stay on the host
+
+
+def test_homo_cases(gpu, golden):
+    g = golden("homo_cases")
+    x, ei, w = g.t("x", gpu), g.t("edge_index", gpu), g.t("edge_weight", gpu)
+    m = load_into(gripnet_amd.homoGraph([12, 8, 8]), g.state("gcn2."), gpu)
+    close(m(x, ei, w, if_catout=True), g.t("gcn2.out_cat"))
+    close(m(x, ei, w, if_catout=False), g.t("gcn2.out_nocat"))
+    m = load_into(gripnet_amd.homoGraph([10, 16], start_graph=True, in_dim=g.meta["n"]), g.state("start1."), gpu)
+    close(m(torch.full((3, 3), 7.0, device=gpu), ei, None, if_catout=True), g.t("start1.out_cat"))
+    m = load_into(gripnet_amd.homoGraph([12, 8, 6], multi_relational=True, n_rela=3, n_base=5), g.state("rgcn2."), gpu)
+    close(m(x, g.t("rel.edge_index", gpu), edge_type=g.t("rel.edge_type", gpu), range_list=g.t("rel.range_list", gpu),
+            if_catout=True), g.t("rgcn2.out_cat"))
+    with pytest.raises(AssertionError):
+        m(x, g.t("rel.edge_index", gpu), if_catout=True)    # missing edge_type / range_list
+
+
+def test_decoder_cases(gpu, golden):
+    g = golden("decoder_cases")
+    z, ei, et = g.t("z", gpu), g.t("edge_index", gpu), g.t("edge_type", gpu)
+    dm = load_into(gripnet_amd.multiRelaInnerProductDecoder(g.meta["F"], g.meta["R"]), g.state("dmt."), gpu)
+    close(dm(z, ei, et), g.t("dmt.out_sigmoid"))
+    close(dm(z, ei, et, sigmoid=False), g.t("dmt.out_logits"))
+    mc = load_into(gripnet_amd.multiClassInnerProductDecoder(g.meta["F"], g.meta["n_class"]), g.state("mcip."), gpu)
+    close(mc(z, g.t("node_list", gpu)), g.t("mcip.out_softmax"))
+    close(mc(z, g.t("node_list", gpu), softmax=False), g.t("mcip.out_logits"))
+    # strided z (a column slice of a wider matrix) takes the same path
+    wide = torch.zeros(z.shape[0], z.shape[1] + 8, device=gpu)
+    wide[:, 4:4 + z.shape[1]] = z
+    close(dm(wide[:, 4:4 + z.shape[1]], ei, et), g.t("dmt.out_sigmoid"))
+
+
+def pose_data_from_golden(g, dev):
+    return Data(gg_edge_index=g.t("gg_edge_index", dev), edge_weight=g.t("edge_weight", dev),
+                gd_edge_index=g.t("gd_edge_index", dev), train_idx=g.t("train_idx", dev),
+                train_et=g.t("train_et", dev), train_range=g.t("train_range", dev))
+
+
+@pytest.mark.parametrize("scale", ["tiny", "small"])
+def test_pose_pipeline_vs_reference(gpu, golden, scale):
+    g = golden("pose_" + scale)
+    model = load_into(PoseModel(g.meta["n_g"], g.meta["n_d"], g.meta["R"]), g.state("", strip=False), gpu)
+    data = pose_data_from_golden(g, gpu)
+    with torch.no_grad():
+        for _ in range(2):                                   # 2nd pass runs from the cached plans
+            z_gg = model.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)
+            z_gd = model.gd(z_gg, data.gd_edge_index, mod="cat", if_relu=True)
+            z_dd, score = model(data)
+            close(z_gg, g.t("out.z_gg"))
+            close(z_gd, g.t("out.z_gd"))
+            close(z_dd, g.t("out.z_dd"))
+            close(score, g.t("out.score"))
+        close(model(data, sigmoid=False)[1], g.t("out.logits"), TOL)
+
+
+def test_nc_pipelines_vs_reference(gpu, golden):
+    g = golden("aminer_tiny")
+    m = AminerModel(g.meta["n_p"], g.meta["n_a"], g.meta["n_class"], pp_nhids=g.meta["pp_nhids"],
+                    pa_out=g.meta["pa_out"], aa_hidden=g.meta["aa_nhids"][1:])
+    m = load_into(m, g.state("", strip=False), gpu)
+    data = Data(**{k: g.t(k, gpu) for k in ("pp_edge_idx", "pa_edge_idx", "aa_edge_idx", "pp_edge_weight", "aa_edge_weight")})
+    with torch.no_grad():
+        z, score = m(data, g.t("node_list", gpu))
+    close(z, g.t("out.z"))
+    close(score, g.t("out.score"))
+
+    g = golden("freebase_c_tiny")
+    m = FreebaseCModel(g.meta["n_p"], g.meta["n_q"], g.meta["n_a"], g.meta["n_class"], pp_nhids=g.meta["pp_nhids"],
+                       qq_nhids=g.meta["qq_nhids"], pa_out=g.meta["pa_out"], aa_hidden=g.meta["aa_nhids"][1:])
+    sd = g.state("", strip=False)
+    sd["aa_embeddings"] = g.t("aa_embeddings")
+    m = load_into(m, sd, gpu)
+    data = Data(**{k: g.t(k, gpu) for k in ("pp_edge_idx", "pa_edge_idx", "qq_edge_idx", "qa_edge_idx", "aa_edge_idx",
+                                            "pp_edge_weight", "qq_edge_weight", "aa_edge_weight")})
+    with torch.no_grad():
+        z, score = m(data, g.t("node_list", gpu))
+    close(z, g.t("out.z"))
+    close(score, g.t("out.score"))
+
+
+# ---- error behaviour -------------------------------------------------------------------------
+def test_errors(gpu):
+    ei = torch.tensor([[0, 1, 5], [1, 0, 2]], device=gpu)
+    with pytest.raises(IndexError):
+        gripnet_amd.myGCN.norm(ei, 4, None)
+    conv = gripnet_amd.myRGCN(4, 4, 2, 2, False).to(gpu)
+    x = torch.randn(6, 4, device=gpu)
+    with pytest.raises(ValueError, match="range_list"):
+        conv(x, ei, None, torch.tensor([[0, 2], [1, 3]]))          # overlapping ranges
+    with pytest.raises(ValueError, match="range_list"):
+        conv(x, ei, None, torch.tensor([[0, 1], [1, 2]]))          # does not cover E
+    dm = gripnet_amd.multiRelaInnerProductDecoder(4, 2).to(gpu)
+    out = dm(x, ei, torch.tensor([0, 1, 9], device=gpu))          # relation 9 does not exist
+    assert torch.isnan(out[2]) and torch.isfinite(out[:2]).all()
+    with pytest.raises(IndexError):
+        _hip.raise_if_index_errors(gpu)
+    _hip.raise_if_index_errors(gpu)                                # flag was cleared
+
+
+def test_empty_inputs(gpu):
+    dm = gripnet_amd.multiRelaInnerProductDecoder(8, 2).to(gpu)
+    out = dm(torch.randn(3, 8, device=gpu), torch.zeros(2, 0, dtype=torch.long, device=gpu),
+             torch.zeros(0, dtype=torch.long, device=gpu))
+    assert out.shape == (0,)
+    conv = gripnet_amd.myGCN(5, 3).to(gpu)                          # no edges: self loops only
+    x = torch.randn(4, 5, device=gpu)
+    y = conv(x, torch.zeros(2, 0, dtype=torch.long, device=gpu))
+    close(y, x.cpu() @ conv.weight.detach().cpu() + conv.bias.detach().cpu())
+    rg = gripnet_amd.myRGCN(5, 3, 2, 2, False).to(gpu)              # no edges: root term only
+    y = rg(x, torch.zeros(2, 0, dtype=torch.long, device=gpu), None, torch.zeros(2, 2, dtype=torch.long))
+    close(y, x.cpu() @ rg.root.detach().cpu())
+
+
+# ---- randomised cross-checks against the oracle -----------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_random_graphs_vs_oracle(gpu, seed):
+    gen = torch.Generator().manual_seed(1000 + seed)
+    n = int(torch.randint(1, 400, (1,), generator=gen))
+    e = int(torch.randint(0, 5000, (1,), generator=gen))
+    fin = [3, 16, 33, 48, 64, 7][seed]
+    fout = [5, 16, 32, 8, 128, 12][seed]
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    w = torch.rand(e, generator=gen) + 0.1
+    x = torch.randn(n, fin, generator=gen)
+    conv = gripnet_amd.myGCN(fin, fout, improved=bool(seed % 2)).to(gpu)
+    conv.bias.data.normal_()
+    y = conv(x.to(gpu), ei.to(gpu), w.to(gpu))
+    close(y, orc.gcn_forward(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), ei, w, improved=bool(seed % 2)))
+
+    R, B = [1, 3, 7, 2, 5, 4][seed], [2, 4, 3, 8, 1, 6][seed]
+    sizes = torch.randint(0, 900, (R,), generator=gen).tolist()
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    rei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    rg = gripnet_amd.myRGCN(fin, fout, R, B, False, bias=bool(seed % 2)).to(gpu)
+    y = rg(x.to(gpu), rei.to(gpu), None, rl)
+    sd = {k: v.detach().cpu() for k, v in rg.state_dict().items()}
+    close(y, orc.rgcn_forward(x, rei, rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
+
+    dm = gripnet_amd.multiRelaInnerProductDecoder(fout, R).to(gpu)
+    et = torch.randint(0, R, (rei.shape[1],), generator=gen)
+    z = torch.randn(n, fout, generator=gen)
+    close(dm(z.to(gpu), rei.to(gpu), et.to(gpu), sigmoid=False),
+          orc.distmult(z, rei, et, dm.weight.detach().cpu(), sigmoid=False))
+
+
+def test_rgcn_sharded_partials_sum_to_full(gpu):
+    """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
+    (the multi-GPU contract, here run sequentially on one device)."""
+    data = make_pose("small").to(gpu)
+    n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
+    conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
+    conv.bias.data.normal_()
+    x = torch.randn(n, fin, device=gpu)
+    full = conv(x, data.train_idx, None, data.train_range, _relu=True)
+    for world in (2, 3, 8):
+        total = torch.zeros(n, fout, device=gpu)
+        for lo, hi in gripnet_amd.utils.shard_edge_ranges(data.train_idx.shape[1], world):
+            plan = _hip.RgcnPlan(data.train_idx, data.train_range, n, lo, hi)
+            part = torch.empty(n, fout, device=gpu)
+            plan.forward(x, conv.basis, conv.att, None, None, False, part, partial=True)
+            total += part
+        out = torch.empty(n, fout, device=gpu)
+        plan.finalize(total, x, conv.root, conv.bias, True, out)
+        close(out, full)
+
+
+# ---- full-size checks (BASELINE.json configs) ---------------------------------------------------
+def test_pose0_syn_vs_oracle(gpu):
+    data = make_pose("pose0-syn")
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range, sigmoid=False)
+    model = model.to(gpu)
+    data = data.to(gpu)
+    with torch.no_grad():
+        z, logits = model(data, sigmoid=False)
+        _, score = model(data)
+    close(z, ref["z_dd"], TOL)
+    close(logits, ref["score"], TOL)
+    close(score, torch.sigmoid(ref["score"]), TOL)
+    _hip.raise_if_index_errors(gpu)
+
+
+def test_pose2_syn_properties(gpu):
+    """Largest configuration: size-independent properties instead of a CPU run."""
+    data = make_pose("pose2-syn").to(gpu)
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    with torch.no_grad():
+        z, score = model(data)
+        z2, score2 = model(data)
+    assert torch.equal(z, z2) and torch.equal(score, score2)            # run-to-run reproducible
+    assert torch.isfinite(z).all() and torch.isfinite(score).all()
+    assert (z >= 0).all()                                              # cat of ReLU / abs blocks
+    # DistMult is symmetric in (u, v) and every relation block is cat(fwd, reversed fwd)
+    rl = data.train_range.cpu()
+    for r in (0, 1, 17, rl.shape[0] - 1):
+        s, e = int(rl[r, 0]), int(rl[r, 1])
+        half = (e - s) // 2
+        assert torch.equal(score[s:s + half], score[s + half:e])
+    # decoder on a random subset == decoder on the full list, gathered
+    pick = torch.randint(0, data.train_idx.shape[1], (100000,), device=gpu)
+    with torch.no_grad():
+        sub = model.dmt(z, data.train_idx[:, pick], data.train_et[pick])
+    assert torch.equal(sub, score[pick])
+    # RGCN is linear in the edge set: two half shards add up to the layer's un-normalised sum
+    conv = model.dd.conv_list[0]
+    x = z[:, :48].contiguous()
+    n, E = data.n_d_node, data.train_idx.shape[1]
+    parts = []
+    for lo, hi in ((0, E // 3), (E // 3, E)):
+        plan = _hip.RgcnPlan(data.train_idx, data.train_range, n, lo, hi)
+        p = torch.empty(n, 32, device=gpu)
+        plan.forward(x, conv.basis, conv.att, None, None, False, p, partial=True)
+        parts.append(p)
+    out = torch.empty(n, 32, device=gpu)
+    plan.finalize(parts[0] + parts[1], x, conv.root, None, True, out)
+    close(out, z[:, 48:], TOL)
+    _hip.raise_if_index_errors(gpu)
