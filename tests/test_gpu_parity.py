@@ -59,7 +59,8 @@ def test_norm_cases_bit_exact_indices(gpu, golden):
 
 def test_gcn_forward_and_cache(gpu, golden):
     g = golden("gcn_forward")
-    conv = load_into(gripnet_amd.myGCN(g.meta["fin"], g.meta["fout"], cached=True), g.state(""), gpu)
+    conv = load_into(gripnet_amd.myGCN(g.meta["fin"], g.meta["fout"], cached=True),
+                     {"weight": g.t("sd.weight"), "bias": g.t("sd.bias")}, gpu)
     ei, w = g.t("edge_index", gpu), g.t("edge_weight", gpu)
     close(conv(g.t("x0", gpu), ei, w), g.t("out.y0"))
     plan = conv.cached_result

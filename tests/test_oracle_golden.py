@@ -40,7 +40,7 @@ def test_norm_cases(golden):
 
 def test_gcn_forward(golden):
     g = golden("gcn_forward")
-    sd = g.state("")
+    sd = {"weight": g.t("sd.weight"), "bias": g.t("sd.bias")}
     ei, w = g.t("edge_index"), g.t("edge_weight")
     cache = orc.gcn_norm(ei, g.meta["n"], w)
     close(orc.gcn_forward(g.t("x0"), sd["weight"], sd["bias"], ei, w), g.t("out.y0"))
