@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gripnet_hip.h"
@@ -46,6 +47,12 @@ inline gn_status fail(gn_status code, const char* fmt, ...) {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// GN_DISABLE_FAST=1 forces the general kernels (used by the parity tests to cover both paths).
+inline bool fast_paths_disabled() {
+    const char* e = getenv("GN_DISABLE_FAST");
+    return e && e[0] == '1';
+}
 
 // Device buffer owned by a plan.
 template <typename T>

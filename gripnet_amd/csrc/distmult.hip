@@ -95,6 +95,7 @@ extern "C" gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64
     GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
     GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31), "table too large");
     if (e == 0) return GN_OK;
+    GN_REQUIRE(n > 0 && r > 0, "edges given but the node or relation table is empty");
     GN_REQUIRE(z && u && v && et && d && out, "operand pointer is null");
     GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
     hipStream_t st = gn::as_stream(stream);

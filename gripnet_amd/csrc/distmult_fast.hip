@@ -1,10 +1,251 @@
-// LDS-resident specialisation of the DistMult decoder for small node tables.
-// (placeholder until the fast path lands: reports "not applicable", general path is used)
+// LDS-resident DistMult decoder for small node tables (the drug supervertex: n_d = 645, F = 80).
+//
+// The decoder streams 24 B of indices per edge but gathers 2 x F x 4 B of node features per
+// edge; served from L2 that gather is ~40x the HBM stream.  Here the node table lives in LDS:
+// the feature dimension is cut into P column phases so that n x width x 4 B fits the CU's
+// 160 KB, a persistent workgroup (one per CU) keeps one column phase resident and walks its
+// contiguous edge range once per phase, carrying the partial sums through `out`.
+//
+// Per wave: 64 (u, v, r) triples arrive with three coalesced loads.  Each quad of lanes owns 4
+// consecutive edges; the edge being worked on is broadcast inside the quad with DPP (quad_perm,
+// no LDS traffic), the quad's 4 lanes cover the phase's columns of z[u] and z[v] with
+// ds_read_b128 (16 edges in flight per wave step), the relation row D[r] stays in registers
+// while r does not change (type-sorted positives), and the quad's partial products are folded
+// with two DPP adds.
 #include "common.h"
 
-bool gn_distmult_fast_applicable(int64_t, int64_t, int64_t, int64_t, const void*, const void*) { return false; }
-gn_status gn_distmult_fast_forward(const float*, int64_t, int64_t, int64_t, const int64_t*, const int64_t*,
-                                   const int64_t*, const float*, int64_t, int64_t, int64_t, int, float*, int32_t*,
-                                   hipStream_t) {
-    return gn::fail(GN_ERR_UNSUPPORTED, "fast DistMult path not built");
+namespace {
+
+constexpr int kMaxPhases = 8;
+constexpr int kThreads = 1024;
+constexpr size_t kLdsBudget = 150 * 1024;   // of 160 KB; the rest is left to the runtime
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DmFastArgs {
+    const float* z; int64_t ld_z; int n; int features;
+    const int64_t* u; const int64_t* v; const int64_t* et;
+    const float* d; int64_t ld_d; int r;
+    int64_t e; int64_t edges_per_wg; int sigmoid; float* out; int32_t* err;
+    int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row_sum16(float x) {
+    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);   // row_half_mirror
+    x = dpp_add<0x140>(x);   // row_mirror
+    return x;
+}
+
+// One edge per QUAD (4 lanes), 16 edges per wave step.  Lane l4 of the quad covers the 16-byte
+// chunks l4, l4+4, ... of the phase's columns, so a 48-column phase is 3 x (2 ds_read_b128 + a
+// few FMAs) per lane and the per-edge fold is two DPP adds.
+// UNIFORM_R: the whole 64-edge batch has one relation whose D chunks already sit in `dreg`;
+// otherwise each step gathers its D chunks from L2.
+// W4 > 0: the phase width (in float4 chunks) is a compile-time constant; W4 == 0: runtime w4.
+template <int S, int W4, int CPL, bool UNIFORM_R>
+__device__ __forceinline__ void quad_step(const char* __restrict__ lds, int w4, int l4, int iu, int iv, int ir,
+                                          const float* __restrict__ dcol, int64_t ld_d, const f32x4 (&dreg)[CPL],
+                                          float& result) {
+    constexpr int kBcast = S * 0x55;     // quad_perm [S,S,S,S]
+    const int uu = dpp_i<kBcast>(iu), vv = dpp_i<kBcast>(iv);
+    const int width4 = W4 > 0 ? W4 : w4;
+    const char* pu = lds + __umul24(uu, width4 * 16) + l4 * 16;
+    const char* pv = lds + __umul24(vv, width4 * 16) + l4 * 16;
+    const float* dr = dcol;
+    if constexpr (!UNIFORM_R) dr = dcol + (int64_t)dpp_i<kBcast>(ir) * ld_d;
+    // all LDS reads (and D gathers) of the step are issued before any of them is consumed
+    f32x4 P[CPL], Q[CPL], D[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const bool present = W4 > 0 ? (4 * i < W4) : (4 * i < w4);
+        const bool ragged = W4 > 0 ? (4 * i + 3 >= W4) : true;   // only the last chunk group can be partial
+        const bool live = present && (!ragged || (l4 + 4 * i < width4));
+        const int off = live ? 64 * i : 0;
+        if (W4 > 0 && !present) continue;
+        P[i] = *reinterpret_cast<const f32x4*>(pu + off);
+        Q[i] = *reinterpret_cast<const f32x4*>(pv + off);
+        if constexpr (UNIFORM_R) D[i] = dreg[i]; else D[i] = *reinterpret_cast<const f32x4*>(dr + off / 4);
+        if (!live) D[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x2 acc2 = {0.f, 0.f};             // two running sums -> v_pk_mul_f32 / v_pk_fma_f32
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        if (W4 > 0 && 4 * i >= W4) continue;
+        const f32x2 lo = P[i].xy * Q[i].xy, hi = P[i].zw * Q[i].zw;
+        acc2 = lo * D[i].xy + acc2;
+        acc2 = hi * D[i].zw + acc2;
+    }
+    float acc = acc2.x + acc2.y;
+    acc = dpp_add<0xB1>(acc);            // quad_perm [1,0,3,2]
+    acc = dpp_add<0x4E>(acc);            // quad_perm [2,3,0,1]
+    if (l4 == S) result = acc;
+}
+
+struct Batch {            // one lane's edge of a 64-edge batch
+    int64_t u, v, r;
+    float carried;
+};
+
+__device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, int64_t hi, bool carry) {
+    Batch b;
+    b.u = b.v = b.r = 0;
+    b.carried = 0.f;
+    if (mine < hi) {
+        b.u = a.u[mine]; b.v = a.v[mine]; b.r = a.et[mine];
+        if (carry) b.carried = a.out[mine];
+    }
+    return b;
+}
+
+template <int W4, int CPL>
+__device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, int c0, int w4, bool first, bool last,
+                                          int64_t wg_lo, int64_t wg_hi, int wave, int lane) {
+    const int l4 = lane & 3;
+    const float* dcol = a.d + c0 + 4 * l4;
+    int cur_r = -1;                                         // wave-uniform: relation whose chunks sit in dreg
+    f32x4 dreg[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) dreg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int64_t kStride = (kThreads / 64) * 64;
+
+    int64_t e0 = wg_lo + wave * 64;
+    Batch nxt = load_batch(a, e0 + lane, wg_hi, !first);
+    for (; e0 < wg_hi; e0 += kStride) {
+        const int64_t mine = e0 + lane;
+        const Batch cur = nxt;
+        nxt = load_batch(a, mine + kStride, wg_hi, !first);   // in flight while this batch computes
+        const bool ok = (uint64_t)cur.u < (uint64_t)a.n && (uint64_t)cur.v < (uint64_t)a.n &&
+                        (uint64_t)cur.r < (uint64_t)a.r;
+        const int iu = ok ? (int)cur.u : 0, iv = ok ? (int)cur.v : 0;
+        int ir = ok ? (int)cur.r : 0;
+        // padding lanes of a ragged tail copy lane 0's relation so that they do not break uniformity
+        const int r0 = __builtin_amdgcn_readfirstlane(ir);
+        if (mine >= wg_hi) ir = r0;
+        float result = 0.f;
+        if (__all(ir == r0)) {                              // wave-uniform branch
+            if (r0 != cur_r) {
+                cur_r = r0;
+#pragma unroll
+                for (int i = 0; i < CPL; ++i)
+                    dreg[i] = (l4 + 4 * i < w4) ? *reinterpret_cast<const f32x4*>(dcol + (int64_t)r0 * a.ld_d + 16 * i)
+                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            quad_step<0, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<1, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<2, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<3, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+        } else {
+            quad_step<0, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<1, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<2, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<3, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+        }
+        if (mine < wg_hi) {
+            float total = cur.carried + result;
+            if (last) {
+                if (a.sigmoid) total = 1.0f / (1.0f + expf(-total));
+                if (!ok) {
+                    total = __builtin_nanf("");
+                    if (a.err) atomicOr(a.err, 1);
+                }
+            }
+            a.out[mine] = total;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
+    extern __shared__ float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t wg_lo = (int64_t)blockIdx.x * a.edges_per_wg;
+    const int64_t wg_hi = min(a.e, wg_lo + a.edges_per_wg);
+    const char* lds = reinterpret_cast<const char*>(lds4);
+
+    for (int ph = 0; ph < a.n_phases; ++ph) {
+        const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
+        __syncthreads();                                    // everyone is done with the previous phase's table
+        for (int idx = tid; idx < a.n * w4; idx += kThreads) {
+            const int row = idx / w4, c4 = idx - row * w4;
+            lds4[idx] = *reinterpret_cast<const float4*>(a.z + (int64_t)row * a.ld_z + c0 + 4 * c4);
+        }
+        __syncthreads();
+        const bool first = ph == 0, last = ph == a.n_phases - 1;
+        switch (w4) {                                       // common widths get compile-time addressing
+            case 16: run_phase<16, 4>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 12: run_phase<12, 3>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 8: run_phase<8, 2>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 4: run_phase<4, 1>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            default: run_phase<0, 4>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+        }
+    }
+}
+
+// Column phases: as few as possible; each at most 64 columns (4 lanes x 4 chunks x float4) with
+// n x width x 4 B inside the LDS budget; widths are multiples of 16 columns except the last.
+int plan_phases(int64_t n, int64_t f, int* c0, int* width) {
+    if (n <= 0 || f <= 0 || f % 4 != 0) return 0;
+    int64_t max_w = (int64_t)(kLdsBudget / (n * 4)) / 16 * 16;
+    if (max_w > 64) max_w = 64;
+    if (max_w < 16) return 0;
+    const int64_t phases = gn::ceil_div(f, max_w);
+    if (phases > kMaxPhases) return 0;
+    int64_t c = 0;
+    int k = 0;
+    while (c < f) {
+        const int64_t w = std::min(max_w, f - c);
+        c0[k] = (int)c;
+        width[k] = (int)w;
+        c += w;
+        ++k;
+    }
+    return k;
+}
+
+}  // namespace
+
+bool gn_distmult_fast_applicable(int64_t n, int64_t f, int64_t ld_z, int64_t ld_d, const void* z, const void* d) {
+    if (gn::fast_paths_disabled()) return false;
+    if (n < 1 || n > 65535 || f < 4 || f % 4 != 0 || ld_z % 4 != 0 || ld_d % 4 != 0) return false;
+    if (((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) != 0) return false;
+    int c0[kMaxPhases], w[kMaxPhases];
+    const int phases = plan_phases(n, f, c0, w);
+    return phases >= 1 && phases <= 4;   // beyond that the general (L2-gather) kernel is the better choice
+}
+
+gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
+                                   const int64_t* v, const int64_t* et, const float* d, int64_t ld_d, int64_t r,
+                                   int64_t e, int sigmoid, float* out, int32_t* err, hipStream_t st) {
+    GN_REQUIRE(r >= 1, "no relations");
+    DmFastArgs a;
+    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.features = (int)f; a.u = u; a.v = v; a.et = et;
+    a.d = d; a.ld_d = ld_d; a.r = (int)r; a.e = e; a.sigmoid = sigmoid; a.out = out; a.err = err;
+    a.n_phases = plan_phases(n, f, a.c0, a.width);
+    int max_w = 0;
+    for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
+    const size_t lds_bytes = (size_t)n * max_w * sizeof(float);
+    // one workgroup per CU; every workgroup's range is a multiple of 64 edges
+    int64_t groups = std::min<int64_t>(256, gn::ceil_div(e, 64 * (kThreads / 64)));
+    if (groups < 1) groups = 1;
+    a.edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
+    groups = gn::ceil_div(e, a.edges_per_wg);
+    static thread_local bool configured = false;
+    if (!configured) {
+        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_lds),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    k_distmult_lds<<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
 }

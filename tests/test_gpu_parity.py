@@ -179,6 +179,30 @@ def test_nc_pipelines_vs_reference(gpu, golden):
     close(score, g.t("out.score"))
 
 
+@pytest.fixture(params=["fast", "general"])
+def kernel_path(request, monkeypatch):
+    """Run a test once with the LDS-resident fast paths and once with the general kernels."""
+    monkeypatch.setenv("GN_DISABLE_FAST", "1" if request.param == "general" else "0")
+    return request.param
+
+
+def test_both_kernel_paths_on_pose_small(gpu, golden, kernel_path):
+    g = golden("pose_small")
+    model = load_into(PoseModel(g.meta["n_g"], g.meta["n_d"], g.meta["R"]), g.state("", strip=False), gpu)
+    data = pose_data_from_golden(g, gpu)
+    with torch.no_grad():
+        z_dd, score = model(data)
+        logits = model(data, sigmoid=False)[1]
+    close(z_dd, g.t("out.z_dd"))
+    close(score, g.t("out.score"))
+    close(logits, g.t("out.logits"), TOL)
+    # unsorted relation ids and a shuffled edge list must give the same scores, permuted
+    perm = torch.randperm(data.train_idx.shape[1], device=gpu)
+    with torch.no_grad():
+        shuffled = model.dmt(z_dd, data.train_idx[:, perm], data.train_et[perm])
+    close(shuffled, g.t("out.score")[perm.cpu()])
+
+
 # ---- error behaviour -------------------------------------------------------------------------
 def test_errors(gpu):
     ei = torch.tensor([[0, 1, 5], [1, 0, 2]], device=gpu)
