@@ -112,10 +112,15 @@ struct gn_rgcn_plan {
     // general path: destination-major CSR over the shard, column = relation * N + src
     gn::DevBuf<int32_t> rowptr;    // [N + 1]
     gn::DevBuf<uint32_t> key;      // [shard_edges]
-    // relation-major segments of the shard (fast path): filled by rgcn_fast.hip
-    gn::DevBuf<int32_t> seg_rel;    // [n_seg] relation id of each work segment
-    gn::DevBuf<int32_t> seg_begin;  // [n_seg + 1] offsets into packed
-    gn::DevBuf<uint32_t> packed;    // [shard_edges] (dst << 16 | src), sorted by dst inside a segment
+    // LDS-resident path (rgcn_fast.hip): work items = (relation, source tile, <= chunk edges)
+    gn::DevBuf<int32_t> seg_rel;    // [n_items] relation of each work item
+    gn::DevBuf<int32_t> item_tile;  // [n_items] source tile of each work item
+    gn::DevBuf<int32_t> seg_begin;  // [n_items * buckets + 1] bucket offsets into packed
+    gn::DevBuf<uint32_t> packed;    // [shard_edges] (dst << 16 | src - tile base), bucket-sorted inside an item
+    gn::DevBuf<int32_t> wg_begin;   // [groups + 1] ranges into wg_items
+    gn::DevBuf<int32_t> wg_items;   // item ids per persistent workgroup
     int64_t n_seg = 0;
+    int fast_groups = 0, fast_ts = 0, fast_ts_pad = 0;
+    size_t fast_lds_bytes = 0;
     int fast_ok = 0;
 };

@@ -441,8 +441,11 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->rowptr.release();
     p->key.release();
     p->seg_rel.release();
+    p->item_tile.release();
     p->seg_begin.release();
     p->packed.release();
+    p->wg_begin.release();
+    p->wg_items.release();
     delete p;
 }
 

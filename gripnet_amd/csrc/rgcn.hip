@@ -50,9 +50,8 @@ extern "C" {
 
 size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     if (!plan || fin <= 0 || fout <= 0) return 0;
-    size_t general = general_layout(plan, fin, fout).total;
-    size_t fast = gn_rgcn_fast_applicable(plan, fin, fout, bases) ? gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases) : 0;
-    return general > fast ? general : fast;
+    if (gn_rgcn_fast_applicable(plan, fin, fout, bases)) return gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases);
+    return general_layout(plan, fin, fout).total;
 }
 
 gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
