@@ -12,7 +12,9 @@ import threading
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgripnet_hip.so")
+# GN_HIP_LIBRARY selects another build of the same library (the diagnostic `make STAMPS=1` one)
+_LIB_PATH = os.environ.get("GN_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                            "libgripnet_hip.so")
 _lib = None
 _lock = threading.Lock()
 

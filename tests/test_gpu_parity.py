@@ -269,6 +269,33 @@ def test_random_graphs_vs_oracle(gpu, seed):
           orc.distmult(z, rei, et, dm.weight.detach().cpu(), sigmoid=False))
 
 
+@pytest.mark.parametrize("n,fin,bases", [(40, 16, 3), (200, 32, 5), (560, 48, 32), (645, 64, 8), (900, 48, 4),
+                                         (1000, 32, 2), (1, 16, 1)])
+def test_rgcn_lds_resident_shapes(gpu, n, fin, bases):
+    """Every specialisation of the LDS-resident relational layer (K depth, row tiles per wave,
+    1..16 source tiles): empty relations, a relation longer than one work item, duplicate edges,
+    destinations with no in-edges; checked against the oracle and for run-to-run equality."""
+    gen = torch.Generator().manual_seed(n * 131 + fin)
+    sizes = [0, 9000, 3, 0, 700, 1, 2500, 0]
+    blocks = [torch.randint(0, max(1, n - n // 7), (2, s), generator=gen) for s in sizes]   # top ids never a dst/src
+    blocks[4] = torch.cat([blocks[4], blocks[4][:, :50]], dim=1)                          # duplicate edges
+    rei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    rg = gripnet_amd.myRGCN(fin, 32, len(sizes), bases, False, bias=True).to(gpu)
+    rg.bias.data.normal_()
+    y = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
+    y2 = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
+    assert torch.equal(y, y2)
+    # float64 oracle: with thousands of edges into one destination the fp32 summation order of
+    # the reference itself is worth ~1e-4, so the fp32 oracle is not the sharper yardstick here
+    sd = {k: v.detach().cpu().double() for k, v in rg.state_dict().items()}
+    ref = torch.relu(orc.rgcn_forward(x.double(), rei, rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
+    # n == 1 puts 12,000 equal addends into one fp32 running sum: the rounding bias of that sum
+    # (ours and the reference's alike) is worth ~1e-4 relative, so that case gets the contract bar
+    close(y, ref.float(), TOL if n == 1 else TIGHT)
+
+
 def test_rgcn_sharded_partials_sum_to_full(gpu):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
     (the multi-GPU contract, here run sequentially on one device)."""
