@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay the launch-bound stages as hipGraphs (measured slower than eager launches at "
+                         "the current kernel times, so off by default)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -94,51 +97,56 @@ def main():
 
     E_dd = int(data.train_idx.shape[1])
     lo, hi = shard_edge_ranges(E_dd, world)[rank]
-    conv = model.dd.conv_list[0]
     n_d = data.n_d_node
-
-    if world == 1:
-        def step():
-            return model(data)
-    else:
-        plan = _hip.RgcnPlan(data.train_idx, data.train_range, n_d, lo, hi)
-        my_idx = data.train_idx[:, lo:hi].contiguous()
-        my_et = data.train_et[lo:hi].contiguous()
-        partial = torch.empty((n_d, 32), dtype=torch.float32, device=dev)
-
-        def step():
-            z = model.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)
-            z = model.gd(z, data.gd_edge_index, mod="cat", if_relu=True)
-            out = torch.empty((n_d, 80), dtype=torch.float32, device=dev)
-            _hip.merge(out[:, :48], z, 0)
-            plan.forward(z, conv.basis, conv.att, None, None, False, partial, partial=True)
-            dist.all_reduce(partial)                                   # [n_d, 32] fp32 over xGMI
-            plan.finalize(partial, z, conv.root, conv.bias, True, out[:, 48:])
-            return out, model.dmt(out, my_idx, my_et)
+    CANDIDATES = {"gn_rgcn_forward_f32": "drugs", "gn_distmult_forward_f32": "decode"}
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def per_entry_us(fn, n):
+        """us per call of every entry point, HIP events around each launch (eager)."""
+        with _hip.KernelTimer() as t:
+            for _ in range(n):
+                fn()
+        return {k: 1e3 * tot / calls for k, (calls, tot) in t.summary().items()}, \
+               {k: 1e3 * tot / n for k, (calls, tot) in t.summary().items()}
+
     with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):          # the first call also builds the plans
+        if world == 1:
+            from gripnet_amd.pipeline import PoseStages
+            eager = PoseStages(model, data, graphs=False)
+            for _ in range(3):                        # builds the plans
+                eager.step()
+            per_call0, breakdown = per_entry_us(eager.step, 5)
+            dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
+            # --graphs: the launch-bound stages replay as hipGraphs; the stage that holds the dominant entry
+            # point stays eager between them so that it is bracketed by HIP events in EVERY timed step
+            stages = PoseStages(model, data, graphs=True, eager_stage=CANDIDATES[dom]) if args.graphs else eager
+            step = stages.step
+        else:
+            from gripnet_amd.pipeline import Graphed
+            from gripnet_amd.sharded import ShardedPoseForward
+            fwd = ShardedPoseForward(model, data, rank, world)
+            for _ in range(3):
+                fwd()
+            per_call0, breakdown = per_entry_us(fwd, 5)
+            dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
+            if args.graphs:                           # replicated gene layers as one graph; the collective is never captured
+                fwd.kernels.encode_genes = Graphed(fwd.kernels.encode_genes).capture()
+            step = fwd
+
+        for _ in range(max(args.warmup, 1)):
             z, score = step()
         fence()
-        # Only the two dominant-kernel candidates are bracketed by HIP events inside the timed
-        # region (4 event records per step); the full per-entry-point breakdown is taken afterwards.
-        timer = _hip.KernelTimer(only=("gn_distmult_forward_f32", "gn_rgcn_forward_f32"))
+        timer = _hip.KernelTimer(only=(dom,))
         t0 = time.perf_counter()
         with timer:
             for _ in range(args.steps):
                 z, score = step()
         fence()
         elapsed = time.perf_counter() - t0
-        breakdown = _hip.KernelTimer()
-        with breakdown:
-            for _ in range(5):
-                step()
-        fence()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,15 +157,11 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = A * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (HIP events inside the timed region) ------------------
-    calls = timer.summary()
+    # ---- roofline of the dominant entry point (HIP events on its stream, inside the timed region) ----
     alg = algorithmic_bytes(data, hi - lo, E_dd)
-    per_call = {k: 1e3 * tot / n for k, (n, tot) in calls.items()}            # us per call
     stage_bytes = {"gn_distmult_forward_f32": alg["dmt"], "gn_rgcn_forward_f32": alg["dd"]}
-    # the two graph-aggregate entry points run several times per step with different graphs; the
-    # dominant candidates are the decoder and the relational layer
-    dom = max(stage_bytes, key=lambda k: per_call.get(k, 0.0))
-    dom_us = per_call[dom]
+    calls, total_ms = timer.summary()[dom]
+    dom_us = 1e3 * total_ms / calls
     achieved = stage_bytes[dom] / (dom_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -168,7 +172,8 @@ def main():
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_us": round(dom_us, 2)}
+                "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_us": round(dom_us, 2),
+                "timed_launches": calls}
 
     result = {
         "metric": "edges aggregated/sec, GripNet forward on pose-0", "value": value, "unit": "edges/s",
@@ -177,10 +182,11 @@ def main():
         "config": {"workload": args.workload if world == 1 else "{} x{} dd relation shards".format(args.workload, world),
                    "edges_aggregated_per_step": A, "n_g": data.n_g_node, "n_d": n_d, "relations": data.n_dd_edge_type,
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
-                   "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world)},
+                   "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
+                   "launch": "hipGraph replay of the launch-bound stages; {} eager, HIP-event timed".format(dom) if args.graphs else "eager"},
         "roofline": roofline,
-        "entry_point_us_per_step": {k: round(1e3 * tot / 5, 2) for k, (n, tot) in sorted(breakdown.summary().items())},
-        "edges_scored_per_sec": (hi - lo) / (per_call["gn_distmult_forward_f32"] * 1e-6),
+        "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
+        "edges_scored_per_sec": (hi - lo) / (per_call0["gn_distmult_forward_f32"] * 1e-6),
     }
 
     # ---- CPU baseline + parity in the same run (rank 0, N = 1) ---------------------------------

@@ -15,9 +15,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kColTiles = 4;  // 16-column tiles per wave (A-fragment reuse)
 
 struct GemmArgs {
-    const float* a; int64_t lda, stride_a; const int64_t* a_rows; int64_t a_table_rows;
-    const float* b; int64_t ldb, stride_b;
-    float* c; int64_t ldc, stride_c;
+    const float* __restrict__ a; int64_t lda, stride_a; const int64_t* __restrict__ a_rows; int64_t a_table_rows;
+    const float* __restrict__ b; int64_t ldb, stride_b;
+    float* __restrict__ c; int64_t ldc, stride_c;
     int m, n, k;
     const float* bias; int relu; int a_vec_ok;
 };
@@ -35,13 +35,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     const float* __restrict__ B = g.b + batch * g.stride_b;
     float* __restrict__ C = g.c + batch * g.stride_c;
 
+    // Every load below is unconditional (clamped index, zeroed by select afterwards): a load under a
+    // condition is waited for on its own, an unconditional batch is issued back to back.
     const int arow = row0 + r;
-    int64_t a_src_row = -1;
-    if (arow < g.m) {
-        a_src_row = g.a_rows ? g.a_rows[arow] : arow;
-        if (g.a_rows && (uint64_t)a_src_row >= (uint64_t)g.a_table_rows) a_src_row = -1;  // out of table -> zeros
+    int64_t a_src_row = min(arow, g.m - 1);
+    bool a_ok = arow < g.m;
+    if (g.a_rows) {
+        a_src_row = g.a_rows[a_src_row];
+        a_ok = a_ok && (uint64_t)a_src_row < (uint64_t)g.a_table_rows;      // out of table -> zeros
+        if (!a_ok) a_src_row = 0;
     }
-    const float* __restrict__ arow_ptr = (a_src_row >= 0) ? A + a_src_row * g.lda : nullptr;
+    const float* __restrict__ arow_ptr = A + a_src_row * g.lda;
+    const int n_tiles = min(kColTiles, (g.n - col0 + 15) / 16);             // wave-uniform
 
     f32x4 acc[kColTiles];
 #pragma unroll
@@ -49,26 +54,29 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 
     for (int k0 = 0; k0 < g.k; k0 += 16) {
         const int kb = k0 + 4 * q;
-        float av[4] = {0.f, 0.f, 0.f, 0.f};
-        if (arow_ptr) {
-            if (g.a_vec_ok && kb + 3 < g.k) {
-                const float4 t = *reinterpret_cast<const float4*>(arow_ptr + kb);
-                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-            } else {
+        float av[4], bv[kColTiles][4];
+        if (g.a_vec_ok && k0 + 16 <= g.k) {                                 // wave-uniform
+            const float4 t = *reinterpret_cast<const float4*>(arow_ptr + kb);
+            av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (kb + j < g.k) av[j] = arow_ptr[kb + j];
-            }
+            for (int j = 0; j < 4; ++j) av[j] = arow_ptr[min(kb + j, g.k - 1)];
         }
 #pragma unroll
         for (int t = 0; t < kColTiles; ++t) {
-            const int col = col0 + 16 * t + r;
-            if (col0 + 16 * t >= g.n) break;  // wave-uniform
+            const int col = min(col0 + 16 * t + r, g.n - 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = kb + j;
-                const float bv = (kk < g.k && col < g.n) ? B[(int64_t)kk * g.ldb + col] : 0.f;
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[t], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j) bv[t][j] = B[(int64_t)min(kb + j, g.k - 1) * g.ldb + col];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = (a_ok && kb + j < g.k) ? av[j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) {
+            if (t >= n_tiles) break;
+            const bool col_ok = col0 + 16 * t + r < g.n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], (col_ok && kb + j < g.k) ? bv[t][j] : 0.f, acc[t], 0, 0, 0);
         }
     }
 #pragma unroll

@@ -325,8 +325,10 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
 }
 
 // Wt[r][col * fin + k] = sum_b att[r, b] * basis[b, k, col]       (layers.py:172-173, transposed)
-// One wave = 16 relations x (16 k x 16 col): the B fragments are 64-byte row segments of basis,
-// and every lane ends up with 16 consecutive k of one (relation, col) -> 16-byte stores.
+// One wave = 16 relations x (kWtK k x 16 col): the B fragments are 64-byte row segments of basis,
+// and every lane ends up with kWtK consecutive k of one (relation, col) -> 16-byte stores.
+constexpr int kWtK = 4;
+
 struct WtArgs {
     const float* __restrict__ att; const float* __restrict__ basis; float* __restrict__ wt;
     int relations, bases, fin, fout;
@@ -336,50 +338,47 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_t(WtArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16;
-    const int kblocks = g.fin / 16, cblocks = g.fout / 16;
+    const int kblocks = g.fin / kWtK, cblocks = g.fout / 16;
     const int combo = blockIdx.y * 4 + wave;
     if (combo >= kblocks * cblocks) return;                  // wave-uniform
-    const int k0 = (combo / cblocks) * 16, col0 = (combo % cblocks) * 16;
+    const int k0 = (combo / cblocks) * kWtK, col0 = (combo % cblocks) * 16;
     const int arow = row0 + c16;
-    f32x4 acc[16];
+    f32x4 acc[kWtK];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < kWtK; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // All loads are unconditional (clamped indices, zeroed by select afterwards): a conditional load
     // would be waited for one by one instead of being batched ahead of the MFMA chain.
     const int arow_c = min(arow, g.relations - 1);
     for (int b0 = 0; b0 < g.bases; b0 += 16) {
-        float av[4], bv[16][4];
+        float av[4], bv[kWtK][4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int b = b0 + 4 * q + jj, bc = min(b, g.bases - 1);
             av[jj] = g.att[(int64_t)arow_c * g.bases + bc];
             const float* __restrict__ bp = g.basis + ((int64_t)bc * g.fin + k0) * g.fout + col0 + c16;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) bv[t][jj] = bp[t * g.fout];
+            for (int t = 0; t < kWtK; ++t) bv[t][jj] = bp[t * g.fout];
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const bool live = (b0 + 4 * q + jj) < g.bases;
             av[jj] = (live && arow < g.relations) ? av[jj] : 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) bv[t][jj] = live ? bv[t][jj] : 0.f;
+            for (int t = 0; t < kWtK; ++t) bv[t][jj] = live ? bv[t][jj] : 0.f;
         }
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
+        for (int t = 0; t < kWtK; ++t)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[t][jj], acc[t], 0, 0, 0);
     }
-    // lane (c16, q), element i: W[row0 + 4q + i][k0 + t][col0 + c16], t = 0..15
+    // lane (c16, q), element i: W[row0 + 4q + i][k0 + t][col0 + c16], t = 0..kWtK-1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * q + i;
         if (row >= g.relations) continue;
         float* o = g.wt + ((int64_t)row * g.fout + col0 + c16) * g.fin + k0;
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
-            *reinterpret_cast<f32x4*>(o + 4 * t4) =
-                (f32x4){acc[4 * t4][i], acc[4 * t4 + 1][i], acc[4 * t4 + 2][i], acc[4 * t4 + 3][i]};
+        *reinterpret_cast<f32x4*>(o) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
     }
 }
 
@@ -552,8 +551,11 @@ __global__ void k_emit_padded(const uint64_t* __restrict__ key2_sorted, const ui
     if (p >= n) return;
     const uint64_t k = key2_sorted[p];
     const int sg = (int)(k >> 32) * kNB + (int)((k >> 16) & 0xffffu);
-    const bool end = p == n - 1 || key2_sorted[p + 1] != k;
-    out[pad_off[sg] + (p - slot_off[sg])] = (packed_sorted[p] & 0x7fffffffu) | (end ? kEndFlag : 0u);
+    // a run also "ends" every 64 words of its slot list: no fp32 running sum is longer than 64 addends
+    // before it is folded into the accumulator row (bounds the rounding bias of hub destinations)
+    const int pos = p - slot_off[sg];
+    const bool end = p == n - 1 || key2_sorted[p + 1] != k || (pos & 63) == 63;
+    out[pad_off[sg] + pos] = (packed_sorted[p] & 0x7fffffffu) | (end ? kEndFlag : 0u);
 }
 
 int bits_for(int64_t n) {
@@ -818,7 +820,7 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     WtArgs wa;
     wa.att = att; wa.basis = basis; wa.wt = Wt; wa.relations = (int)R; wa.bases = (int)bases; wa.fin = (int)fin;
     wa.fout = (int)fout;
-    dim3 wgrid((unsigned)gn::ceil_div(R, 16), (unsigned)gn::ceil_div((fin / 16) * (fout / 16), 4));
+    dim3 wgrid((unsigned)gn::ceil_div(R, 16), (unsigned)gn::ceil_div((fin / kWtK) * (fout / 16), 4));
     k_rgcn_weights_t<<<wgrid, 256, 0, st>>>(wa);
     GN_LAUNCH_CHECK();
     FastArgs a;

@@ -93,3 +93,94 @@ class FreebaseCModel(Module):
 def load_reference_state(model: Module, state: Dict[str, torch.Tensor], strict: bool = True):
     """Load a state dict saved by the reference (GripNet-pose.py:236; keys of SURVEY App. B.2)."""
     return model.load_state_dict(state, strict=strict)
+
+
+class Graphed:
+    """A launch-bound stage captured once into a hipGraph and replayed (torch.cuda.CUDAGraph on
+    ROCm).  ``fn`` must be free of host synchronisation and read only static tensors; the library's
+    entry points launch on torch's current stream, so they are captured like any torch op."""
+
+    def __init__(self, fn):
+        self.fn, self.graph, self.out = fn, None, None
+
+    def capture(self):
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # plans / workspaces are created here, not in the capture
+            for _ in range(2):
+                self.fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self.fn()
+        return self
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
+class PoseStages:
+    """The steady-state forward of PoseModel cut into three stages with static buffers, so that the
+    launch-bound ones can be replayed as hipGraphs and the relational layer can be bracketed by HIP
+    events on its own (bench.py's roofline):
+
+        genes()   gg -> gd                         -> x      [n_d, 48]
+        drugs()   dd: concat slot 0 + myRGCN       -> z      [n_d, 80]
+        decode()  DistMult on the positive edges   -> score  [E]
+
+    Same calls and keyword arguments as PoseModel.forward / GripNet-pose.py:117-138.
+    """
+
+    def __init__(self, model: PoseModel, data, graphs: bool = True, edge_index=None, edge_type=None,
+                 eager_stage: str = "drugs"):
+        self.model, self.data = model, data
+        self.conv = model.dd.conv_list[0]
+        dev = data.train_idx.device
+        n_d = int(data.n_d_node)
+        self.idx = data.train_idx if edge_index is None else edge_index      # decoder's edge list (a shard's slice)
+        self.et = data.train_et if edge_type is None else edge_type
+        self.z = torch.empty((n_d, self.conv.in_channels + self.conv.out_channels), dtype=torch.float32, device=dev)
+        self._genes, self._drugs, self._decode = self._genes_eager, self._drugs_eager, self._decode_eager
+        self.x = None
+        if graphs:                                   # every stage but `eager_stage` becomes a graph
+            with torch.no_grad():
+                self._genes = Graphed(self._genes_eager).capture()
+                self.x = self._genes()
+                if eager_stage != "drugs":
+                    self._drugs = Graphed(self._drugs_eager).capture()
+                self._drugs()
+                if eager_stage != "decode":
+                    self._decode = Graphed(self._decode_eager).capture()
+
+    def _genes_eager(self):
+        d = self.data
+        z = self.model.gg(None, d.gg_edge_index, edge_weight=d.edge_weight, if_catout=True)
+        return self.model.gd(z, d.gd_edge_index, mod="cat", if_relu=True)
+
+    def _decode_eager(self):
+        return self.model.dmt(self.z, self.idx, self.et)
+
+    def genes(self):
+        self.x = self._genes()
+        return self.x
+
+    def drugs(self):
+        return self._drugs()
+
+    def _drugs_eager(self):
+        fin = self.conv.in_channels
+        _hip.merge(self.z[:, :fin], self.x, 0)
+        d = self.data
+        self.conv(self.x, d.train_idx, d.train_et, d.train_range, _out=self.z[:, fin:], _relu=True)
+        return self.z
+
+    def decode(self):
+        return self._decode()
+
+    def step(self):
+        self.genes()
+        self.drugs()
+        return self.z, self.decode()

@@ -269,6 +269,37 @@ def test_random_graphs_vs_oracle(gpu, seed):
           orc.distmult(z, rei, et, dm.weight.detach().cpu(), sigmoid=False))
 
 
+@pytest.mark.parametrize("fout", [16, 32, 64, 128, 20])
+def test_gcn_skewed_degrees_and_empty_rows(gpu, fout):
+    """Destination-major aggregation on skewed graphs, one case per lanes-per-neighbour specialisation:
+    a hub with thousands of neighbours, isolated nodes, trailing targets without edges, duplicate edges;
+    square (self loops) and bipartite graphs."""
+    gen = torch.Generator().manual_seed(77 + fout)
+    n, fin = 700, 24
+    ei = torch.randint(0, n - 50, (2, 6000), generator=gen)             # nodes >= n-50 stay isolated
+    hub = torch.stack([torch.randint(0, n - 50, (3000,), generator=gen), torch.full((3000,), 5)])
+    ei = torch.cat([ei, hub, ei[:, :200]], dim=1)
+    w = torch.rand(ei.shape[1], generator=gen) + 0.1
+    x = torch.randn(n, fin, generator=gen)
+    conv = gripnet_amd.myGCN(fin, fout).to(gpu)
+    conv.bias.data.normal_()
+    y = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True)
+    ref = torch.relu(orc.gcn_forward(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), ei, w))
+    close(y, ref)
+    # bipartite: 300 sources -> 90 targets, the last 20 targets and target 3 have no edge at all
+    src = torch.randint(0, 300, (2500,), generator=gen)
+    tgt = torch.randint(0, 70, (2500,), generator=gen)
+    tgt[tgt == 3] = 4
+    tgt[:1200] = 9                                                       # a hub target
+    bei = torch.stack([src, tgt])
+    ig = gripnet_amd.interGraph(fin, fout, 90, target_feat_dim=fout, if_one_external=False).to(gpu)
+    ig.conv.bias.data.normal_()
+    xs = torch.randn(300, fin, generator=gen)
+    yb = ig(xs.to(gpu), bei.to(gpu), if_relu=False)
+    sd = {"g.conv.weight": ig.conv.weight.detach().cpu(), "g.conv.bias": ig.conv.bias.detach().cpu()}
+    close(yb, orc.inter_forward_closed(sd, "g.", xs, bei, 90))
+
+
 @pytest.mark.parametrize("n,fin,bases", [(40, 16, 3), (200, 32, 5), (560, 48, 32), (645, 64, 8), (900, 48, 4),
                                          (1000, 32, 2), (1, 16, 1)])
 def test_rgcn_lds_resident_shapes(gpu, n, fin, bases):
@@ -276,6 +307,7 @@ def test_rgcn_lds_resident_shapes(gpu, n, fin, bases):
     1..16 source tiles): empty relations, a relation longer than one work item, duplicate edges,
     destinations with no in-edges; checked against the oracle and for run-to-run equality."""
     gen = torch.Generator().manual_seed(n * 131 + fin)
+    torch.manual_seed(n * 17 + fin)                                   # layer weights come from the global RNG
     sizes = [0, 9000, 3, 0, 700, 1, 2500, 0]
     blocks = [torch.randint(0, max(1, n - n // 7), (2, s), generator=gen) for s in sizes]   # top ids never a dst/src
     blocks[4] = torch.cat([blocks[4], blocks[4][:, :50]], dim=1)                          # duplicate edges
@@ -287,13 +319,12 @@ def test_rgcn_lds_resident_shapes(gpu, n, fin, bases):
     y = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
     y2 = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
     assert torch.equal(y, y2)
-    # float64 oracle: with thousands of edges into one destination the fp32 summation order of
-    # the reference itself is worth ~1e-4, so the fp32 oracle is not the sharper yardstick here
+    # float64 oracle: with thousands of edges into one destination (n == 1: all 12,000 of them) the
+    # reference's own sequential fp32 sum is off by ~1e-4; the kernel folds its running sums every 64
+    # addends, so it is held to the tight bar against the exact result
     sd = {k: v.detach().cpu().double() for k, v in rg.state_dict().items()}
     ref = torch.relu(orc.rgcn_forward(x.double(), rei, rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
-    # n == 1 puts 12,000 equal addends into one fp32 running sum: the rounding bias of that sum
-    # (ours and the reference's alike) is worth ~1e-4 relative, so that case gets the contract bar
-    close(y, ref.float(), TOL if n == 1 else TIGHT)
+    close(y, ref.float())
 
 
 def test_rgcn_sharded_partials_sum_to_full(gpu):

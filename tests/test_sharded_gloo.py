@@ -1,0 +1,144 @@
+"""The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.
+
+What runs here is the product's orchestration (gripnet_amd/sharded.py: edge-range sharding, the
+one all-reduce, finalisation, per-rank decoder slices).  The arithmetic behind it is injected: the
+CPU oracle stands in for the HIP kernels (there is no GPU in this container and the product has no
+CPU fallback), which is the oracle's job as a checker.  The result of the 2-rank run must equal the
+oracle's single-process forward.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleShardKernels:
+    """Same five operations as gripnet_amd.sharded.HipShardKernels, computed by the CPU oracle."""
+
+    def __init__(self, sd, data, lo, hi):
+        from oracle import gripnet_oracle as orc
+        self.orc, self.sd, self.data, self.lo, self.hi = orc, sd, data, lo, hi
+
+    def encode_genes(self):
+        o, d = self.orc, self.data
+        z = o.homo_forward(self.sd, "gg.", None, d.gg_edge_index, d.edge_weight, if_catout=True)
+        return o.inter_forward(self.sd, "gd.", z, d.gd_edge_index, None, if_relu=True, mod="cat")
+
+    def partial(self, x, out):
+        # un-normalised sum over my edge range: relation of an edge = range_list row that holds it
+        d, sd = self.data, self.sd
+        basis, att = sd["dd.conv_list.0.basis"], sd["dd.conv_list.0.att"]
+        w = (att @ basis.reshape(basis.shape[0], -1)).view(att.shape[0], basis.shape[1], basis.shape[2])
+        out.zero_()
+        for r in range(d.train_range.shape[0]):
+            s, e = max(int(d.train_range[r, 0]), self.lo), min(int(d.train_range[r, 1]), self.hi)
+            if s < e:
+                out.index_add_(0, d.train_idx[1, s:e], x.index_select(0, d.train_idx[0, s:e]) @ w[r])
+        return out
+
+    def finalize(self, summed, x, out):
+        d = self.data
+        n = x.shape[0]
+        cnt = torch.zeros(n).index_add_(0, d.train_idx[1], torch.ones(d.train_idx.shape[1]))
+        out.copy_(torch.relu(summed / cnt.clamp(min=1).view(-1, 1) + x @ self.sd["dd.conv_list.0.root"]))
+        return out
+
+    def copy_into(self, dst, src):
+        dst.copy_(src)
+        return dst
+
+    def score(self, z, sigmoid=True):
+        d = self.data
+        return self.orc.distmult(z, d.train_idx[:, self.lo:self.hi], d.train_et[self.lo:self.hi],
+                                 self.sd["dmt.weight"], sigmoid=sigmoid)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gripnet_amd.pipeline import PoseModel
+        from gripnet_amd.sharded import ShardedPoseForward
+        from gripnet_amd.synth import make_pose
+        from gripnet_amd.utils import shard_edge_ranges
+        data = make_pose("small")
+        torch.manual_seed(1111)
+        model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        lo, hi = shard_edge_ranges(int(data.train_idx.shape[1]), world)[rank]
+        fwd = ShardedPoseForward(model, data, rank, world, kernels=OracleShardKernels(sd, data, lo, hi))
+        assert (fwd.edge_lo, fwd.edge_hi) == (lo, hi)
+        z, score = fwd()
+        # every rank holds the same z; rank 0 gathers the score slices in rank order
+        zs = [torch.empty_like(z) for _ in range(world)]
+        dist.all_gather(zs, z)
+        sizes = [b - a for a, b in shard_edge_ranges(int(data.train_idx.shape[1]), world)]
+        parts = [torch.empty(s) for s in sizes]
+        if rank == 0:
+            parts[0] = score
+            for r in range(1, world):
+                dist.recv(parts[r], src=r)
+            q.put((z, [t for t in zs], torch.cat(parts), sd, lo, hi))
+        else:
+            dist.send(score.contiguous(), dst=0)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_forward_equals_single_process():
+    sys.path.insert(0, REPO)
+    from gripnet_amd.synth import make_pose
+    from oracle import gripnet_oracle as orc
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    z, zs, score, sd, lo, hi = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    data = make_pose("small")
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range)
+    assert (lo, hi) == (0, (data.train_idx.shape[1] + 1) // 2)
+    for other in zs:
+        assert torch.equal(other, z)                          # replicated result, bit for bit after the all-reduce
+    assert (z - ref["z_dd"]).abs().max().item() <= 1e-5       # sum order differs from 1 rank: not bit-exact
+    assert score.shape == ref["score"].shape
+    assert (score - ref["score"]).abs().max().item() <= 1e-5
+
+
+def test_world_size_one_needs_no_process_group():
+    sys.path.insert(0, REPO)
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.sharded import ShardedPoseForward
+    from gripnet_amd.synth import make_pose
+    from oracle import gripnet_oracle as orc
+    data = make_pose("tiny")
+    torch.manual_seed(3)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    E = int(data.train_idx.shape[1])
+    fwd = ShardedPoseForward(model, data, 0, 1, kernels=OracleShardKernels(sd, data, 0, E))
+    z, score = fwd(sigmoid=False)
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range, sigmoid=False)
+    assert (z - ref["z_dd"]).abs().max().item() <= 1e-5
+    assert (score - ref["score"]).abs().max().item() <= 1e-5
