@@ -32,7 +32,7 @@ SIGNATURES = {
     "gn_graph_plan_input_edges": (_i64, [_p]),
     "gn_graph_plan_nnz": (_i64, [_p]),
     "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
-    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p]),
+    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
     "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "gn_softmax_rows_f32": (_int, [_p, _i64, _i64, _i64, _p]),
@@ -40,10 +40,33 @@ SIGNATURES = {
     "gn_rgcn_plan_destroy": (None, [_p]),
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
     "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
-    "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _sz, _p]),
-    "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p]),
+    "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
+    "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
 }
+
+
+class SideCopy(C.Structure):
+    """gn_side_copy: a concat slot filled by the launch that produces its neighbour slot."""
+    _fields_ = [("src", _p), ("ld_src", _i64), ("dst", _p), ("ld_dst", _i64), ("rows", _i64), ("cols", _i64),
+                ("mode", _int)]
+
+
+def side_copy(spec):
+    """spec = (src, dst, mode) of 2-D fp32 tensors with equal shapes, or None."""
+    if spec is None:
+        return None
+    src, dst, mode = spec
+    src = f32_rows(src)
+    if tuple(src.shape) != tuple(dst.shape):
+        raise ValueError("side copy shapes differ: {} vs {}".format(tuple(src.shape), tuple(dst.shape)))
+    sc = SideCopy(src.data_ptr(), ld(src), dst.data_ptr(), ld(dst), src.shape[0], src.shape[1], int(mode))
+    sc._keep = (src, dst)
+    return sc
+
+
+def _ref(sc):
+    return None if sc is None else C.byref(sc)
 
 
 class GripNetHipError(RuntimeError):
@@ -71,7 +94,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype, fn.argtypes = res, args
-            if lib.gn_version() < 100:
+            if lib.gn_version() < 101:
                 raise RuntimeError("gripnet_amd: libgripnet_hip.so is older than this package")
             _lib = lib
     return _lib
@@ -254,9 +277,10 @@ class GraphPlan:
     def __iter__(self):          # lets `edge_index, norm = conv.cached_result` keep working
         return iter(self.export())
 
-    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor):
+    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None):
+        sc = side_copy(side)
         _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(bias), int(bool(relu)),
-              ptr(out), ld(out), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
+              ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
         return out
 
     def __del__(self):
@@ -292,16 +316,18 @@ class RgcnPlan:
             self._ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
         return self._ws, need
 
-    def forward(self, x, basis, att, root, bias, relu, out, partial=False):
+    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None):
         ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0])
+        sc = side_copy(side)
         _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
               ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), int(bool(partial)),
-              ptr(out), ld(out), ptr(ws), need, stream_ptr(x.device))
+              ptr(out), ld(out), _ref(sc), ptr(ws), need, stream_ptr(x.device))
         return out
 
-    def finalize(self, summed, x, root, bias, relu, out):
+    def finalize(self, summed, x, root, bias, relu, out, side=None):
+        sc = side_copy(side)
         _call("gn_rgcn_finalize_f32", self._h, ptr(summed), ld(summed), ptr(x), ld(x), x.shape[1], ptr(root),
-              ptr(bias), root.shape[1], int(bool(relu)), ptr(out), ld(out), stream_ptr(x.device))
+              ptr(bias), root.shape[1], int(bool(relu)), ptr(out), ld(out), _ref(sc), stream_ptr(x.device))
         return out
 
     def __del__(self):

@@ -28,6 +28,7 @@ struct AggArgs {
     float* out;
     int64_t ld_out;
     int rows;
+    gn_side_copy side = {nullptr, 0, nullptr, 0, 0, 0, 0};   // optional fused row copy (dst == nullptr: none)
 };
 
 template <int VEC, int LPE>
@@ -39,6 +40,14 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
     const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
 
+    if (a.side.dst) {                                          // concat slot: streamed up front by the whole grid
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, c = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + c];
+            a.side.dst[i * a.side.ld_dst + c] = a.side.mode ? fabsf(v) : v;
+        }
+    }
     for (int row = wave; row < a.rows; row += n_waves) {
         const int begin = a.rowptr[row], end = a.rowptr[row + 1];
         for (int cb = 0; cb * LPE * VEC < a.features; ++cb) {
@@ -107,6 +116,17 @@ inline void launch_aggregate_lpe(const AggArgs& a, int lpe, int grid, hipStream_
         case 32: k_aggregate<VEC, 32><<<grid, 256, 0, st>>>(a); break;
         default: k_aggregate<VEC, 64><<<grid, 256, 0, st>>>(a); break;
     }
+}
+
+inline gn_status check_side(const gn_side_copy* side, int64_t rows, gn_side_copy* out) {
+    *out = gn_side_copy{nullptr, 0, nullptr, 0, 0, 0, 0};
+    if (!side || side->rows == 0 || side->cols == 0) return GN_OK;
+    GN_REQUIRE(side->src && side->dst && side->rows > 0 && side->cols > 0, "side copy has a null pointer or a negative size");
+    GN_REQUIRE(side->rows <= rows, "side copy has %lld rows, the launch only %lld", (long long)side->rows, (long long)rows);
+    GN_REQUIRE(side->ld_src >= side->cols && side->ld_dst >= side->cols, "side copy leading dimension smaller than its row");
+    GN_REQUIRE(side->mode == 0 || side->mode == 1, "unknown side copy mode %d", side->mode);
+    *out = *side;
+    return GN_OK;
 }
 
 inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {

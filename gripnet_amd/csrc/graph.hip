@@ -4,7 +4,7 @@
 
 extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw,
                                             int64_t num_features, const float* bias, int relu, float* out,
-                                            int64_t ld_out, void* stream) {
+                                            int64_t ld_out, const gn_side_copy* side, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(num_features >= 0 && num_features < (1ll << 31), "bad feature count");
     if (plan->rows == 0 || num_features == 0) return GN_OK;
@@ -25,5 +25,7 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.out = out;
     a.ld_out = ld_out;
     a.rows = (int)plan->rows;
+    gn_status ss = gn::check_side(side, plan->rows, &a.side);
+    if (ss != GN_OK) return ss;
     return gn::launch_aggregate(a, gn::as_stream(stream));
 }

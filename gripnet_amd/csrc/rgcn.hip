@@ -13,7 +13,7 @@ size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64
 gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                                const float* basis, const float* att, int64_t bases, const float* root,
                                const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
-                               void* ws, size_t ws_bytes, hipStream_t st);
+                               const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
 namespace {
 
@@ -33,7 +33,16 @@ GeneralWs general_layout(const gn_rgcn_plan* plan, int64_t fin, int64_t fout) {
 }
 
 __global__ void k_rgcn_finalize(const float* __restrict__ summed, int64_t ld_s, const float* __restrict__ indeg,
-                                int relu, float* __restrict__ out, int64_t ld_o, int64_t rows, int cols) {
+                                int relu, float* __restrict__ out, int64_t ld_o, int64_t rows, int cols,
+                                gn_side_copy side) {
+    if (side.dst) {                                            // concat slot 0
+        const int64_t stotal = side.rows * side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < stotal; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / side.cols, c = t - i * side.cols;
+            const float v = side.src[i * side.ld_src + c];
+            side.dst[i * side.ld_dst + c] = side.mode ? fabsf(v) : v;
+        }
+    }
     const int64_t total = rows * cols;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t / cols;
@@ -57,7 +66,7 @@ size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fo
 gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                               const float* basis, const float* att, int64_t bases, const float* root,
                               const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              const gn_side_copy* side, void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
@@ -67,10 +76,13 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     GN_REQUIRE(workspace_bytes >= gn_rgcn_workspace_bytes(plan, fin, fout, bases) && (workspace || workspace_bytes == 0),
                "workspace too small: need %zu bytes", gn_rgcn_workspace_bytes(plan, fin, fout, bases));
     hipStream_t st = gn::as_stream(stream);
+    gn_side_copy sc;
+    gn_status ss = gn::check_side(side, N, &sc);
+    if (ss != GN_OK) return ss;
 
     if (gn_rgcn_fast_applicable(plan, fin, fout, bases))
         return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, out,
-                                    ld_out, workspace, workspace_bytes, st);
+                                    ld_out, sc, workspace, workspace_bytes, st);
 
     const GeneralWs l = general_layout(plan, fin, fout);
     char* ws = static_cast<char*>(workspace);
@@ -111,22 +123,26 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     a.out = out;
     a.ld_out = ld_out;
     a.rows = (int)N;
+    a.side = sc;
     return gn::launch_aggregate(a, st);
 }
 
 gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* summed, int64_t ld_summed, const float* x,
                                int64_t ld_x, int64_t fin, const float* root, const float* bias, int64_t fout,
-                               int relu, float* out, int64_t ld_out, void* stream) {
+                               int relu, float* out, int64_t ld_out, const gn_side_copy* side, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(fin > 0 && fout > 0 && fout < (1ll << 31), "feature counts must be positive");
     const int64_t N = plan->num_nodes;
     if (N == 0) return GN_OK;
     GN_REQUIRE(summed && x && root && out, "operand pointer is null");
     GN_REQUIRE(summed != out, "finalize cannot run in place");
+    gn_side_copy sc;
+    gn_status ss = gn::check_side(side, N, &sc);
+    if (ss != GN_OK) return ss;
     gn_status s = gn_gemm_f32(x, ld_x, 0, nullptr, 0, root, fout, 0, out, ld_out, 0, N, fout, fin, 1, bias, 0, stream);
     if (s != GN_OK) return s;
     k_rgcn_finalize<<<gn::stream_grid(N * fout, 256), 256, 0, gn::as_stream(stream)>>>(
-        summed, ld_summed, plan->indeg.p, relu, out, ld_out, N, (int)fout);
+        summed, ld_summed, plan->indeg.p, relu, out, ld_out, N, (int)fout, sc);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

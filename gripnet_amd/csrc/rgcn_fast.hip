@@ -388,6 +388,7 @@ struct FinArgs {
     const float* __restrict__ indeg; const float* __restrict__ x; int64_t ld_x; int fin;
     const float* __restrict__ root; const float* __restrict__ bias;
     int relu; int partial; float* out; int64_t ld_out;
+    gn_side_copy side;
 };
 
 __global__ __launch_bounds__(256) void k_rgcn_slab_finalize(FinArgs a) {
@@ -399,6 +400,12 @@ __global__ __launch_bounds__(256) void k_rgcn_slab_finalize(FinArgs a) {
     __shared__ float row[kFout];
     const int f = threadIdx.x & (kLpr - 1), pp = threadIdx.x >> 3;
     const int i = blockIdx.x;
+    if (a.side.dst && i < a.side.rows) {                       // concat slot 0: this block copies its row
+        for (int c = threadIdx.x; c < a.side.cols; c += 256) {
+            const float v = a.side.src[(int64_t)i * a.side.ld_src + c];
+            a.side.dst[(int64_t)i * a.side.ld_dst + c] = a.side.mode ? fabsf(v) : v;
+        }
+    }
     // x[i] . root[:, c], K split 8 ways (unconditional clamped loads, zeroed by select)
     float xr = 0.f;
     if (!a.partial) {
@@ -809,7 +816,7 @@ size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64
 gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                                const float* basis, const float* att, int64_t bases, const float* root,
                                const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
-                               void* ws, size_t ws_bytes, hipStream_t st) {
+                               const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st) {
     GN_REQUIRE(ld_x % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld_x %% 4 == 0");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
     GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
@@ -840,6 +847,7 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     FinArgs f;
     f.slabs = slabs; f.groups = groups; f.n = (int)N; f.indeg = plan->indeg.p; f.x = x; f.ld_x = ld_x;
     f.fin = (int)fin; f.root = root; f.bias = bias; f.relu = relu; f.partial = partial; f.out = out; f.ld_out = ld_out;
+    f.side = side;
     k_rgcn_slab_finalize<<<(int)N, 256, 0, st>>>(f);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -73,27 +73,27 @@ class myGCN(Module):
             self.cached_result = build()
         return self.cached_result
 
-    def _run(self, plan, x, n_out, out, relu):
+    def _run(self, plan, x, n_out, out, relu, side):
         x = _hip.f32_rows(x)
         xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
         _hip.gemm(x, self.weight, xw)                                            # layers.py:73
         if out is None:
             out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
-        return plan.aggregate(xw, self.bias, relu, out)                          # layers.py:92-100
+        return plan.aggregate(xw, self.bias, relu, out, side)                    # layers.py:92-100
 
-    def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False):
+    def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None):
         _hip.require_gpu(x, edge_index, edge_weight, self.weight)
         n = x.size(0)
         plan = self._plan(edge_index, lambda: _hip.GraphPlan.gcn(edge_index, n, edge_weight, self.improved))
-        return self._run(plan, x, n, _out, _relu)
+        return self._run(plan, x, n, _out, _relu, _side)
 
-    def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False):
+    def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None):
         """The conv as interGraph uses it (layers.py:363-368), in closed form: rows are targets."""
         _hip.require_gpu(x, inter_edge_index, edge_weight, self.weight)
         n_src = x.size(0)
         plan = self._plan(inter_edge_index,
                           lambda: _hip.GraphPlan.bipartite(inter_edge_index, n_src, n_target, edge_weight))
-        return self._run(plan, x, n_target, _out, _relu)
+        return self._run(plan, x, n_target, _out, _relu, _side)
 
     def __repr__(self):
         return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
@@ -135,7 +135,7 @@ class myRGCN(Module):
             self._plan_key = key
         return self._plan
 
-    def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False):
+    def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False, _side=None):
         # edge_type is accepted and unused, as in the reference (the relation of an edge is the
         # range_list row that contains it, layers.py:171-186)
         _hip.require_gpu(x, edge_index, self.basis)
@@ -147,7 +147,7 @@ class myRGCN(Module):
         plan = self.plan_for(edge_index, range_list, x.shape[0])
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
-        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out)
+        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side)
 
     def __repr__(self):
         return "{}({}, {}, num_relations={})".format(self.__class__.__name__, self.in_channels,
@@ -191,17 +191,19 @@ class homoGraph(Module):
         _hip.require_gpu(x, homo_edge_index)
         x = _hip.f32_rows(x)
         n = x.shape[0]
+        side = None
         if if_catout:
             out, slots = _cat_slots([x.shape[1]] + [c.out_channels for c in self.conv_list], n, x.device)
-            _hip.merge(slots[0], x, 0)                                           # slot 0 <- input
+            side = (x, slots[0], 0)                          # slot 0 <- input, copied by the first layer's launch
         else:
             out, slots = None, [None] * (len(self.conv_list) + 1)
         h = x
         for i, net in enumerate(self.conv_list):                                 # conv + ReLU fused, every layer
             if self.multi_relational:
-                h = net(h, homo_edge_index, edge_type, range_list, _out=slots[i + 1], _relu=True)
+                h = net(h, homo_edge_index, edge_type, range_list, _out=slots[i + 1], _relu=True, _side=side)
             else:
-                h = net(h, homo_edge_index, edge_weight, _out=slots[i + 1], _relu=True)
+                h = net(h, homo_edge_index, edge_weight, _out=slots[i + 1], _relu=True, _side=side)
+            side = None
         return out if if_catout else h
 
 
@@ -236,8 +238,8 @@ class interGraph(Module):
             return self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if mod == "cat":                                                         # layers.py:375-376
             out, (y, tf) = _cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
-            self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu)
-            _hip.merge(tf, self.target_feat, 1)
+            self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu,
+                                        _side=(self.target_feat, tf, 1))     # |target_feat| slot, same launch
             return out
         y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if y.shape[1] == self.target_feat.shape[1]:                              # layers.py:378-379

@@ -172,9 +172,9 @@ class PoseStages:
 
     def _drugs_eager(self):
         fin = self.conv.in_channels
-        _hip.merge(self.z[:, :fin], self.x, 0)
         d = self.data
-        self.conv(self.x, d.train_idx, d.train_et, d.train_range, _out=self.z[:, fin:], _relu=True)
+        self.conv(self.x, d.train_idx, d.train_et, d.train_range, _out=self.z[:, fin:], _relu=True,
+                  _side=(self.x, self.z[:, :fin], 0))
         return self.z
 
     def decode(self):

@@ -45,12 +45,9 @@ class HipShardKernels:
         c = self.conv
         return self.plan.forward(x, c.basis, c.att, None, None, False, out, partial=True)
 
-    def finalize(self, summed, x, out):
-        c = self.conv
-        return self.plan.finalize(summed, x, c.root, c.bias, True, out)
-
-    def copy_into(self, dst, src):
-        return self._hip.merge(dst, src, 0)
+    def finalize(self, summed, x, out, slot0):
+        c = self.conv                                           # concat slot 0 is copied by the same launch
+        return self.plan.finalize(summed, x, c.root, c.bias, True, out, side=(x, slot0, 0))
 
     def score(self, z, sigmoid=True):
         return self.model.dmt(z, self.idx, self.et, sigmoid=sigmoid)
@@ -80,8 +77,8 @@ class ShardedPoseForward:
         k = self.kernels
         x = k.encode_genes()                                          # [n_d, in_dim], replicated
         out = torch.empty((self.n_d, self.in_dim + self.out_dim), dtype=torch.float32, device=x.device)
-        k.copy_into(out[:, :self.in_dim], x)                          # concat slot 0 (layers.py:264-266)
         k.partial(x, self._partial)                                   # un-normalised sum over my edge range
         self.all_reduce(self._partial)                                # the one exchange step of the path
-        k.finalize(self._partial, x, out[:, self.in_dim:])            # mean / root / bias / ReLU (layers.py:191-197,305)
+        # mean / root / bias / ReLU (layers.py:191-197,305) and concat slot 0 (layers.py:264-266)
+        k.finalize(self._partial, x, out[:, self.in_dim:], out[:, :self.in_dim])
         return out, k.score(out, sigmoid=sigmoid)

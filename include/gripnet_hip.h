@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 100 /* 0.1.0 */
+#define GN_VERSION 101 /* 0.1.1 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -43,6 +43,16 @@ typedef enum gn_status {
     GN_ERR_UNSUPPORTED = 4,   /* sizes beyond what the 32-bit plan encoding can hold     */
     GN_ERR_EDGE_COUNT = 5     /* plan was built for a different number of edges          */
 } gn_status;
+
+/* Optional row-wise side copy fused into an aggregation launch: the concat slots the reference fills
+ * with torch.cat (gripnet/layers.py:264-266,309,376).  dst[i, 0:cols] = src[i, 0:cols] (mode 0) or
+ * |src[i, 0:cols]| (mode 1) for i in [0, rows); rows must not exceed the rows of the launch. */
+typedef struct gn_side_copy {
+    const float* src; int64_t ld_src;
+    float* dst; int64_t ld_dst;
+    int64_t rows, cols;
+    int mode;
+} gn_side_copy;
 
 typedef struct gn_graph_plan gn_graph_plan; /* GCN-style graphs (square or bipartite)  */
 typedef struct gn_rgcn_plan gn_rgcn_plan;   /* multi-relational graph of one supervertex */
@@ -83,7 +93,8 @@ GN_API gn_status gn_graph_plan_export(const gn_graph_plan* plan, int64_t* edge_i
  * as the reference does (layers.py:73).  bias may be NULL.  `out` may be a column slice of a
  * wider matrix (ld_out), which is how the concat of layers.py:309,376 is written in place. */
 GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw, int64_t num_features,
-                                 const float* bias, int relu, float* out, int64_t ld_out, void* stream);
+                                 const float* bias, int relu, float* out, int64_t ld_out,
+                                 const gn_side_copy* side /* nullable */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
@@ -132,12 +143,14 @@ GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_featu
 GN_API gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t in_features,
                               const float* basis, const float* att, int64_t num_bases, const float* root,
                               const float* bias, int64_t out_features, int relu, int partial, float* out,
-                              int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+                              int64_t ld_out, const gn_side_copy* side /* nullable */, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* out[i,:] = act( summed[i,:] / max(1, indeg_i) + x[i] root + bias )  (layers.py:131,191-197). */
 GN_API gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* summed, int64_t ld_summed, const float* x,
                                int64_t ld_x, int64_t in_features, const float* root, const float* bias,
-                               int64_t out_features, int relu, float* out, int64_t ld_out, void* stream);
+                               int64_t out_features, int relu, float* out, int64_t ld_out,
+                               const gn_side_copy* side /* nullable */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * DistMult decoder (multiRelaInnerProductDecoder.forward, gripnet/decoder.py:19-23):

@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleShardKernels:
-    """Same five operations as gripnet_amd.sharded.HipShardKernels, computed by the CPU oracle."""
+    """Same four operations as gripnet_amd.sharded.HipShardKernels, computed by the CPU oracle."""
 
     def __init__(self, sd, data, lo, hi):
         from oracle import gripnet_oracle as orc
@@ -42,16 +42,13 @@ class OracleShardKernels:
                 out.index_add_(0, d.train_idx[1, s:e], x.index_select(0, d.train_idx[0, s:e]) @ w[r])
         return out
 
-    def finalize(self, summed, x, out):
+    def finalize(self, summed, x, out, slot0):
         d = self.data
         n = x.shape[0]
         cnt = torch.zeros(n).index_add_(0, d.train_idx[1], torch.ones(d.train_idx.shape[1]))
         out.copy_(torch.relu(summed / cnt.clamp(min=1).view(-1, 1) + x @ self.sd["dd.conv_list.0.root"]))
+        slot0.copy_(x)
         return out
-
-    def copy_into(self, dst, src):
-        dst.copy_(src)
-        return dst
 
     def score(self, z, sigmoid=True):
         d = self.data
