@@ -335,13 +335,16 @@ struct WtArgs {
 };
 
 __global__ __launch_bounds__(256) void k_rgcn_weights_t(WtArgs g) {
+    // block = 16 relations x (16 k x 16 col); wave w owns k0 + 4w .. k0 + 4w + 3.  The tile is transposed
+    // through LDS so that every 64-byte run of Wt (16 consecutive k of one (relation, col)) leaves in
+    // one store instruction: 16-byte pieces scattered over four waves cost a memory transaction each.
+    __shared__ float tile[16][16][17];                       // [rel][col][k], padded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16;
-    const int kblocks = g.fin / kWtK, cblocks = g.fout / 16;
-    const int combo = blockIdx.y * 4 + wave;
-    if (combo >= kblocks * cblocks) return;                  // wave-uniform
-    const int k0 = (combo / cblocks) * kWtK, col0 = (combo % cblocks) * 16;
+    const int cblocks = g.fout / 16;
+    const int kb16 = (blockIdx.y / cblocks) * 16, col0 = (blockIdx.y % cblocks) * 16;
+    const int k0 = kb16 + wave * kWtK;
     const int arow = row0 + c16;
     f32x4 acc[kWtK];
 #pragma unroll
@@ -374,11 +377,21 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_t(WtArgs g) {
     }
     // lane (c16, q), element i: W[row0 + 4q + i][k0 + t][col0 + c16], t = 0..kWtK-1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 4 * q + i;
-        if (row >= g.relations) continue;
-        float* o = g.wt + ((int64_t)row * g.fout + col0 + c16) * g.fin + k0;
-        *reinterpret_cast<f32x4*>(o) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < kWtK; ++t) tile[4 * q + i][c16][wave * kWtK + t] = acc[t][i];
+    __syncthreads();
+    // 16 rel x 16 col x 4 float4 along k = 1024 float4, four per thread; four lanes cover one 64-byte run
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        const int k4 = idx & 3, col = (idx >> 2) & 15, rel = idx >> 6;
+        const int row = row0 + rel;
+        if (row < g.relations) {
+            const float* t = &tile[rel][col][4 * k4];
+            float* o = g.wt + ((int64_t)row * g.fout + col0 + col) * g.fin + kb16 + 4 * k4;
+            *reinterpret_cast<f32x4*>(o) = (f32x4){t[0], t[1], t[2], t[3]};
+        }
     }
 }
 
@@ -827,7 +840,7 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     WtArgs wa;
     wa.att = att; wa.basis = basis; wa.wt = Wt; wa.relations = (int)R; wa.bases = (int)bases; wa.fin = (int)fin;
     wa.fout = (int)fout;
-    dim3 wgrid((unsigned)gn::ceil_div(R, 16), (unsigned)gn::ceil_div((fin / kWtK) * (fout / 16), 4));
+    dim3 wgrid((unsigned)gn::ceil_div(R, 16), (unsigned)((fin / 16) * (fout / 16)));
     k_rgcn_weights_t<<<wgrid, 256, 0, st>>>(wa);
     GN_LAUNCH_CHECK();
     FastArgs a;
