@@ -33,6 +33,8 @@ SIGNATURES = {
     "gn_graph_plan_nnz": (_i64, [_p]),
     "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
     "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
+    "gn_graph_plan_build_transpose": (_int, [_p, _p]),
+    "gn_graph_aggregate_t_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
     "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "gn_softmax_rows_f32": (_int, [_p, _i64, _i64, _i64, _p]),
@@ -43,6 +45,7 @@ SIGNATURES = {
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
+    "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p]),
 }
 
 
@@ -240,7 +243,9 @@ class GraphPlan:
         with torch.cuda.device(ei.device):
             check(lib.gn_gcn_plan_create(src, dst, ptr(w), e, int(num_nodes), int(bool(improved)),
                                          stream_ptr(ei.device), C.byref(h)))
-        return cls(h, ei.device, "gcn")
+        plan = cls(h, ei.device, "gcn")
+        plan.n_rows = plan.n_table = int(num_nodes)
+        return plan
 
     @classmethod
     def bipartite(cls, edge_index, num_sources, num_targets, edge_weight=None):
@@ -254,7 +259,9 @@ class GraphPlan:
         with torch.cuda.device(ei.device):
             check(lib.gn_bipartite_plan_create(src, dst, ptr(w), e, int(num_sources), int(num_targets),
                                                stream_ptr(ei.device), C.byref(h)))
-        return cls(h, ei.device, "bipartite")
+        plan = cls(h, ei.device, "bipartite")
+        plan.n_rows, plan.n_table = int(num_targets), int(num_sources)
+        return plan
 
     @property
     def input_edges(self) -> int:
@@ -281,6 +288,14 @@ class GraphPlan:
         sc = side_copy(side)
         _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(bias), int(bool(relu)),
               ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
+        return out
+
+    def aggregate_t(self, g: torch.Tensor, out: torch.Tensor):
+        """out[s] = sum over edges leaving s of coef * g[dst]: gradient of `aggregate` w.r.t. its table."""
+        if not getattr(self, "_has_t", False):
+            check(load().gn_graph_plan_build_transpose(self._h, stream_ptr(g.device)))
+            self._has_t = True
+        _call("gn_graph_aggregate_t_f32", self._h, ptr(g), ld(g), g.shape[1], ptr(out), ld(out), stream_ptr(g.device))
         return out
 
     def __del__(self):
@@ -367,6 +382,14 @@ def distmult(z, u_v, edge_type, weight, sigmoid, out):
           ld(weight), weight.shape[0], e, int(bool(sigmoid)), ptr(out),
           ptr(error_flag(z.device)), stream_ptr(z.device))
     return out
+
+
+def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd):
+    ei, u, v, e = edge_rows(u_v)
+    et = i64_vec(edge_type)
+    _call("gn_distmult_backward_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
+          weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), stream_ptr(z.device))
+    return dz, dd
 
 
 def softmax_rows(x):

@@ -1,0 +1,118 @@
+"""Backward pass of the supergraph propagation path.
+
+The reference trains full-batch: every epoch calls ``loss.backward()`` through the layers
+(GripNet-pose.py:140-146).  When autograd is recording, the modules in layers.py / decoder.py route
+through the ``torch.autograd.Function``s below instead of the slot-fused inference path.  The sparse
+parts of every gradient run in HIP kernels behind the C ABI (transposed normalised adjacency,
+DistMult scatter); the small dense contractions of the backward pass (dW = x^T g, dx = g W^T) are plain
+library GEMMs (torch.matmul -> rocBLAS / hipBLASLt).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+
+
+def recording(*tensors) -> bool:
+    """True when autograd is on and at least one of the tensors takes part in it."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class GcnConvFn(torch.autograd.Function):
+    """``act(A_norm (x W) + b)`` over a cached plan (myGCN.forward, gripnet/layers.py:71-100, with the ReLU
+    that follows it at layers.py:279,305,370).  ``n_out`` rows: N for a square graph, n_target for the
+    external layer's closed form."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, plan, n_out, relu):
+        x = _hip.f32_rows(x.detach())
+        w = weight.detach()
+        xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
+        _hip.gemm(x, w, xw)
+        out = torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=x.device)
+        plan.aggregate(xw, None if bias is None else bias.detach(), relu, out)
+        ctx.plan, ctx.relu, ctx.has_bias = plan, bool(relu), bias is not None
+        ctx.save_for_backward(x, w, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        g = _hip.f32_rows(g.contiguous())
+        if ctx.relu:                                           # gradient passes where the output is positive
+            g = _hip.merge(torch.empty_like(g), g, 5, src2=out)
+        gxw = torch.empty((ctx.plan.n_table, g.shape[1]), dtype=torch.float32, device=g.device)
+        ctx.plan.aggregate_t(g, gxw)                           # A_norm^T g  (HIP, source-major CSR)
+        dx = gxw @ w.t() if ctx.needs_input_grad[0] else None
+        dw = x.t() @ gxw if ctx.needs_input_grad[1] else None
+        db = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None
+
+
+class RgcnConvFn(torch.autograd.Function):
+    """``act(mean_{e: dst=i} x[src_e] W_{r(e)} + x[i] root + b)`` (myRGCN.forward, layers.py:165-197)."""
+
+    @staticmethod
+    def forward(ctx, x, basis, att, root, bias, plan, relu):
+        xc = _hip.f32_rows(x.detach())
+        out = torch.empty((xc.shape[0], basis.shape[2]), dtype=torch.float32, device=xc.device)
+        plan.forward(xc, basis.detach(), att.detach(), root.detach(), None if bias is None else bias.detach(), relu, out)
+        ctx.plan, ctx.relu = plan, bool(relu)
+        ctx.save_for_backward(xc, basis, att, root, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("backward of the relational layer (myRGCN) is not implemented yet "
+                                  "(SURVEY.md section 8f row 1); run it under torch.no_grad()")
+
+
+class DistMultFn(torch.autograd.Function):
+    """``sigma?(sum_k z[u,k] z[v,k] D[r,k])`` (decoder.py:19-23) with the scatter gradients in HIP."""
+
+    @staticmethod
+    def forward(ctx, z, weight, edge_index, edge_type, sigmoid):
+        zc = _hip.f32_rows(z.detach())
+        w = weight.detach()
+        out = torch.empty((edge_index.shape[1],), dtype=torch.float32, device=zc.device)
+        _hip.distmult(zc, edge_index, edge_type, w, sigmoid, out)
+        ctx.sigmoid = bool(sigmoid)
+        ctx.save_for_backward(zc, w, edge_index, edge_type, out if sigmoid else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, w, ei, et, out = ctx.saved_tensors
+        g = g.contiguous().to(torch.float32)
+        if ctx.sigmoid:
+            g = g * out * (1.0 - out)                          # d sigma(s) / d s
+        dz = torch.empty_like(z)
+        dd = torch.empty_like(w)
+        _hip.distmult_backward(z, ei, et, w, g, dz, dd)
+        return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None
+
+
+class ClassLogitsFn(torch.autograd.Function):
+    """``z[node_list] @ W`` (decoder.py:42); forward on the MFMA row-gather GEMM."""
+
+    @staticmethod
+    def forward(ctx, z, weight, node_list):
+        zc = _hip.f32_rows(z.detach())
+        w = weight.detach()
+        nodes = _hip.i64_vec(node_list)
+        out = torch.empty((nodes.shape[0], w.shape[1]), dtype=torch.float32, device=zc.device)
+        _hip.gemm(zc, w, out, a_rows=nodes)
+        ctx.save_for_backward(zc, w, nodes)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, w, nodes = ctx.saved_tensors
+        g = g.contiguous()
+        dz = dw = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.zeros_like(z).index_add_(0, nodes, g @ w.t())
+        if ctx.needs_input_grad[1]:
+            dw = z.index_select(0, nodes).t() @ g
+        return dz, dw, None

@@ -99,6 +99,11 @@ struct gn_graph_plan {
     // reference-order copies kept for myGCN.norm parity (GCN plans only)
     gn::DevBuf<int64_t> ref_edge_index;  // [2, nnz]
     gn::DevBuf<float> ref_norm;          // [nnz]
+    // source-major CSR of the same coefficients (built on demand for the backward pass)
+    int has_transpose = 0;
+    gn::DevBuf<int32_t> t_rowptr;        // [table_rows + 1]
+    gn::DevBuf<int32_t> t_col;           // [nnz] destination row of every stored coefficient
+    gn::DevBuf<float> t_coef;            // [nnz]
 };
 
 struct gn_rgcn_plan {

@@ -1,0 +1,147 @@
+// Backward of the DistMult decoder (autograd of multiRelaInnerProductDecoder.forward,
+// gripnet/decoder.py:19-23, as used by the loss of GripNet-pose.py:140-146):
+//
+//   s_e = sum_k z[u_e,k] z[v_e,k] D[r_e,k]        gs_e = d loss / d s_e   (the caller folds the sigmoid in)
+//   dz[u_e,:] += gs_e * z[v_e,:] * D[r_e,:]       dz[v_e,:] += gs_e * z[u_e,:] * D[r_e,:]
+//   dD[r_e,:] += gs_e * z[u_e,:] * z[v_e,:]
+//
+// The scatter targets are tiny (n x F and R x F) and hit millions of times, so they are privatised:
+// per column phase of 16 features a persistent workgroup keeps the z columns and a dz accumulator in
+// LDS (2 x n x 64 B), walks its contiguous edge range with 16 lanes per edge (one lane per column,
+// four edges per wave step), accumulates dz with LDS float atomics, keeps the dD row of the current
+// relation in a register while the relation id does not change (type-sorted edge lists), and adds its
+// LDS accumulator to dz with one global atomic per element at the end of the phase.  Float atomics
+// make the summation order, hence the last bits of the gradients, vary from run to run.
+// Larger node tables take the general kernel (global atomics per edge).
+#include "common.h"
+
+namespace {
+
+constexpr int kCw = 16;                       // columns per phase = lanes per edge
+constexpr int kThreads = 1024;
+constexpr size_t kLdsBudget = 158 * 1024;
+
+struct BwdArgs {
+    const float* __restrict__ z; int64_t ld_z; int n; int features;
+    const int64_t* __restrict__ u; const int64_t* __restrict__ v; const int64_t* __restrict__ et;
+    const float* __restrict__ d; int64_t ld_d; int r;
+    const float* __restrict__ gs; int64_t e; int64_t edges_per_wg;
+    float* dz; int64_t ld_dz; float* dd; int64_t ld_dd;
+};
+
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(kThreads) void k_distmult_bwd(BwdArgs a) {
+    extern __shared__ float lds[];
+    float* zp = lds;                                   // [n][kCw]   (LDS_TABLE only)
+    float* dzp = lds + (size_t)a.n * kCw;              // [n][kCw]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & (kCw - 1), grp = lane >> 4;   // column inside the phase, edge slot inside the step
+    const int64_t wg_lo = (int64_t)blockIdx.x * a.edges_per_wg;
+    const int64_t wg_hi = min(a.e, wg_lo + a.edges_per_wg);
+    constexpr int64_t kStride = (kThreads / 64) * 64;
+
+    for (int c0 = 0; c0 < a.features; c0 += kCw) {
+        const bool col_ok = c0 + c < a.features;
+        if constexpr (LDS_TABLE) {
+            __syncthreads();
+            for (int i = tid; i < a.n * kCw; i += kThreads) {
+                const int row = i / kCw, cc = i % kCw;
+                zp[i] = c0 + cc < a.features ? a.z[(int64_t)row * a.ld_z + c0 + cc] : 0.f;
+                dzp[i] = 0.f;
+            }
+            __syncthreads();
+        }
+        int cur_r = -1;                                  // relation whose dD partial sits in racc (per 16-lane group)
+        float racc = 0.f, dreg = 0.f;
+        for (int64_t e0 = wg_lo + wave * 64; e0 < wg_hi; e0 += kStride) {
+            const int64_t mine = e0 + lane;
+            int iu = 0, iv = 0, ir = 0;
+            float g = 0.f;
+            if (mine < wg_hi) {
+                const int64_t uu = a.u[mine], vv = a.v[mine], rr = a.et[mine];
+                const bool ok = (uint64_t)uu < (uint64_t)a.n && (uint64_t)vv < (uint64_t)a.n && (uint64_t)rr < (uint64_t)a.r;
+                if (ok) { iu = (int)uu; iv = (int)vv; ir = (int)rr; g = a.gs[mine]; }   // out-of-table edges contribute nothing
+            }
+            const int cnt = (int)min((int64_t)64, wg_hi - e0);
+            for (int t = 0; t * 4 < cnt; ++t) {
+                const int srcl = t * 4 + grp;
+                const int eu = __shfl(iu, srcl), ev = __shfl(iv, srcl), er = __shfl(ir, srcl);
+                const float eg = __shfl(g, srcl);
+                if (srcl < cnt && col_ok) {
+                    if (er != cur_r) {                   // uniform inside the 16-lane group
+                        if (cur_r >= 0) atomicAdd(&a.dd[(int64_t)cur_r * a.ld_dd + c0 + c], racc);
+                        cur_r = er;
+                        racc = 0.f;
+                        dreg = a.d[(int64_t)er * a.ld_d + c0 + c];
+                    }
+                    float zu, zv;
+                    if constexpr (LDS_TABLE) {
+                        zu = zp[eu * kCw + c];
+                        zv = zp[ev * kCw + c];
+                    } else {
+                        zu = a.z[(int64_t)eu * a.ld_z + c0 + c];
+                        zv = a.z[(int64_t)ev * a.ld_z + c0 + c];
+                    }
+                    const float w = eg * dreg;
+                    if constexpr (LDS_TABLE) {
+                        atomicAdd(&dzp[eu * kCw + c], w * zv);
+                        atomicAdd(&dzp[ev * kCw + c], w * zu);
+                    } else {
+                        atomicAdd(&a.dz[(int64_t)eu * a.ld_dz + c0 + c], w * zv);
+                        atomicAdd(&a.dz[(int64_t)ev * a.ld_dz + c0 + c], w * zu);
+                    }
+                    racc += eg * zu * zv;
+                }
+            }
+        }
+        if (cur_r >= 0 && col_ok) atomicAdd(&a.dd[(int64_t)cur_r * a.ld_dd + c0 + c], racc);
+        if constexpr (LDS_TABLE) {
+            __syncthreads();
+            for (int i = tid; i < a.n * kCw; i += kThreads) {
+                const int row = i / kCw, cc = i % kCw;
+                const float val = dzp[i];
+                if (c0 + cc < a.features && val != 0.f) atomicAdd(&a.dz[(int64_t)row * a.ld_dz + c0 + cc], val);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
+                                              const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
+                                              int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
+                                              float* dd, int64_t ld_dd, void* stream) {
+    GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
+    GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31), "table too large");
+    GN_REQUIRE((n == 0 || f == 0 || dz) && (r == 0 || f == 0 || dd), "gradient output pointer is null");
+    GN_REQUIRE(ld_dz >= f && ld_dd >= f, "leading dimension smaller than the row length");
+    hipStream_t st = gn::as_stream(stream);
+    if (n > 0 && f > 0) GN_HIP(hipMemset2DAsync(dz, ld_dz * sizeof(float), 0, f * sizeof(float), n, st));
+    if (r > 0 && f > 0) GN_HIP(hipMemset2DAsync(dd, ld_dd * sizeof(float), 0, f * sizeof(float), r, st));
+    if (e == 0 || f == 0) return GN_OK;
+    GN_REQUIRE(n > 0 && r > 0, "edges given but the node or relation table is empty");
+    GN_REQUIRE(z && u && v && et && d && grad_logit, "operand pointer is null");
+    GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
+    BwdArgs a;
+    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.features = (int)f; a.u = u; a.v = v; a.et = et; a.d = d; a.ld_d = ld_d;
+    a.r = (int)r; a.gs = grad_logit; a.e = e; a.dz = dz; a.ld_dz = ld_dz; a.dd = dd; a.ld_dd = ld_dd;
+    int64_t groups = std::min<int64_t>(256, gn::ceil_div(e, 64 * (kThreads / 64)));
+    if (groups < 1) groups = 1;
+    a.edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
+    groups = gn::ceil_div(e, a.edges_per_wg);
+    const size_t lds_bytes = (size_t)n * kCw * 2 * sizeof(float);
+    if (lds_bytes <= kLdsBudget && !gn::fast_paths_disabled()) {
+        static thread_local bool configured = false;
+        if (!configured) {
+            GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_bwd<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = true;
+        }
+        k_distmult_bwd<true><<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
+    } else {
+        k_distmult_bwd<false><<<(unsigned)groups, kThreads, 0, st>>>(a);
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}

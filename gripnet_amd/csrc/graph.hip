@@ -29,3 +29,31 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     if (ss != GN_OK) return ss;
     return gn::launch_aggregate(a, gn::as_stream(stream));
 }
+
+// Backward of the aggregation with respect to its table: gxw[s, :] = sum_{e: src(e)=s} coef_e * g[dst(e), :]
+// (the transpose of the normalised adjacency applied to the output gradient).
+extern "C" gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float* g, int64_t ld_g,
+                                              int64_t num_features, float* out, int64_t ld_out, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    GN_REQUIRE(plan->has_transpose, "call gn_graph_plan_build_transpose first");
+    GN_REQUIRE(num_features >= 0 && num_features < (1ll << 31), "bad feature count");
+    if (plan->table_rows == 0 || num_features == 0) return GN_OK;
+    GN_REQUIRE(g && out, "feature pointers are null");
+    GN_REQUIRE(ld_g >= num_features && ld_out >= num_features, "leading dimension smaller than the row length");
+    gn::AggArgs a;
+    a.rowptr = plan->t_rowptr.p;
+    a.col = reinterpret_cast<const uint32_t*>(plan->t_col.p);
+    a.coef = plan->t_coef.p;
+    a.table = g;
+    a.ld_table = ld_g;
+    a.features = (int)num_features;
+    a.rowdiv = nullptr;
+    a.addend = nullptr;
+    a.ld_addend = 0;
+    a.bias = nullptr;
+    a.relu = 0;
+    a.out = out;
+    a.ld_out = ld_out;
+    a.rows = (int)plan->table_rows;
+    return gn::launch_aggregate(a, gn::as_stream(stream));
+}

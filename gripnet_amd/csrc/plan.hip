@@ -122,6 +122,30 @@ __global__ void k_bip_coef(const int32_t* __restrict__ dst2, const float* __rest
     coef[p] = (1.0f * w2[p]) * dis[dst2[p]];
 }
 
+// row_of[p] = destination row that holds CSR position p; iota[p] = p
+__global__ void k_expand_rows(const int32_t* __restrict__ rowptr, int rows, int nnz, int32_t* __restrict__ row_of,
+                              int32_t* __restrict__ iota) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int lo = 0, hi = rows;                 // last row with rowptr[row] <= p
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    row_of[p] = lo;
+    iota[p] = p;
+}
+
+__global__ void k_fill_transpose(const int32_t* __restrict__ perm, const int32_t* __restrict__ row_of,
+                                 const float* __restrict__ coef, int nnz, int32_t* __restrict__ t_col,
+                                 float* __restrict__ t_coef) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz) return;
+    const int p = perm[q];
+    t_col[q] = row_of[p];
+    t_coef[q] = coef[p];
+}
+
 int bits_for(int64_t n) {
     int b = 1;
     while (((int64_t)1 << b) < n) ++b;
@@ -247,6 +271,9 @@ void free_graph_plan(gn_graph_plan* p) {
     p->coef.release();
     p->ref_edge_index.release();
     p->ref_norm.release();
+    p->t_rowptr.release();
+    p->t_col.release();
+    p->t_coef.release();
 }
 
 // ---- RGCN ------------------------------------------------------------------------------------
@@ -339,6 +366,37 @@ gn_status gn_graph_plan_export(const gn_graph_plan* plan, int64_t* ei_out, float
                           gn::as_stream(stream)));
     GN_HIP(hipMemcpyAsync(norm_out, plan->ref_norm.p, plan->nnz * sizeof(float), hipMemcpyDeviceToDevice,
                           gn::as_stream(stream)));
+    return GN_OK;
+}
+
+gn_status gn_graph_plan_build_transpose(gn_graph_plan* plan, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    if (plan->has_transpose) return GN_OK;
+    hipStream_t st = gn::as_stream(stream);
+    const int64_t nnz = plan->nnz, rows = plan->rows, srcs = plan->table_rows;
+    GN_HIP(plan->t_rowptr.alloc(srcs + 1));
+    GN_HIP(plan->t_col.alloc(nnz));
+    GN_HIP(plan->t_coef.alloc(nnz));
+    Temp tmp;
+    int32_t *row_of, *iota, *sorted_src, *perm;
+    GN_HIP(tmp.get(&row_of, nnz));
+    GN_HIP(tmp.get(&iota, nnz));
+    GN_HIP(tmp.get(&sorted_src, nnz));
+    GN_HIP(tmp.get(&perm, nnz));
+    if (nnz > 0) {
+        const int g = (int)gn::ceil_div(nnz, 256);
+        k_expand_rows<<<g, 256, 0, st>>>(plan->rowptr.p, (int)rows, (int)nnz, row_of, iota);
+        GN_LAUNCH_CHECK();
+        // stable sort by source: inside a source row the destinations keep the CSR (= reference) order
+        gn_status s = sort_by_dst(tmp, plan->col.p, sorted_src, iota, perm, nnz, srcs, st);
+        if (s != GN_OK) return s;
+        k_fill_transpose<<<g, 256, 0, st>>>(perm, row_of, plan->coef.p, (int)nnz, plan->t_col.p, plan->t_coef.p);
+        GN_LAUNCH_CHECK();
+    }
+    k_rowptr<<<(int)gn::ceil_div(srcs + 1, 256), 256, 0, st>>>(sorted_src, (int)nnz, (int)srcs, plan->t_rowptr.p);
+    GN_LAUNCH_CHECK();
+    GN_HIP(hipStreamSynchronize(st));       // scratch is freed on return
+    plan->has_transpose = 1;
     return GN_OK;
 }
 

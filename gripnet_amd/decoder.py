@@ -10,6 +10,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import _hip
+from .autograd import ClassLogitsFn, DistMultFn, recording
 
 
 class multiRelaInnerProductDecoder(Module):
@@ -23,6 +24,8 @@ class multiRelaInnerProductDecoder(Module):
 
     def forward(self, z, edge_index, edge_type, sigmoid=True):
         _hip.require_gpu(z, edge_index, edge_type, self.weight)
+        if recording(z, self.weight):
+            return DistMultFn.apply(z, self.weight, edge_index, edge_type, sigmoid)
         z = _hip.f32_rows(z)
         if z.shape[1] != self.in_dim:
             raise ValueError("expected {} features, got {}".format(self.in_dim, z.shape[1]))
@@ -44,6 +47,9 @@ class multiClassInnerProductDecoder(Module):
 
     def forward(self, z, node_list, softmax=True):
         _hip.require_gpu(z, node_list, self.weight)
+        if recording(z, self.weight):
+            logits = ClassLogitsFn.apply(z, self.weight, node_list)
+            return torch.softmax(logits, dim=1) if softmax else logits
         z = _hip.f32_rows(z)
         nodes = _hip.i64_vec(node_list)
         pred = torch.empty((nodes.shape[0], self.num_class), dtype=torch.float32, device=z.device)

@@ -20,6 +20,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import _hip
+from .autograd import GcnConvFn, RgcnConvFn, recording
 
 
 def _cat_slots(widths, n_rows, device):
@@ -74,6 +75,11 @@ class myGCN(Module):
         return self.cached_result
 
     def _run(self, plan, x, n_out, out, relu, side):
+        if recording(x, self.weight, self.bias):                                 # training: autograd path
+            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu)
+            if side is not None or out is not None:
+                raise RuntimeError("slot-fused outputs are an inference path; autograd builds its own concat")
+            return y
         x = _hip.f32_rows(x)
         xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
         _hip.gemm(x, self.weight, xw)                                            # layers.py:73
@@ -145,6 +151,10 @@ class myRGCN(Module):
         if range_list.shape[0] != self.num_relations:
             raise ValueError("range_list has {} rows for {} relations".format(range_list.shape[0], self.num_relations))
         plan = self.plan_for(edge_index, range_list, x.shape[0])
+        if recording(x, self.basis, self.att, self.root, self.bias):             # training: autograd path
+            if _out is not None or _side is not None:
+                raise RuntimeError("slot-fused outputs are an inference path; autograd builds its own concat")
+            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu)
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
         return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side)
@@ -189,6 +199,15 @@ class homoGraph(Module):
             assert edge_type is not None
             assert range_list is not None
         _hip.require_gpu(x, homo_edge_index)
+        if recording(x, *self.parameters()):                                     # training: plain concat, autograd-tracked
+            outs, h = [x], x
+            for net in self.conv_list:
+                if self.multi_relational:
+                    h = net(h, homo_edge_index, edge_type, range_list, _relu=True)
+                else:
+                    h = net(h, homo_edge_index, edge_weight, _relu=True)
+                outs.append(h)
+            return torch.cat(outs, dim=1) if if_catout else h
         x = _hip.f32_rows(x)
         n = x.shape[0]
         side = None
@@ -234,6 +253,15 @@ class interGraph(Module):
     def forward(self, x, inter_edge_index, edge_weight=None, if_relu=True, mod="cat"):
         _hip.require_gpu(x, inter_edge_index)
         dev = x.device
+        if recording(x, *self.parameters()):                                     # training: autograd-tracked glue
+            y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
+            if not self.if_one_external:
+                return y
+            if mod == "cat":
+                return torch.cat([y, torch.abs(self.target_feat)], dim=1)
+            if y.shape[1] == self.target_feat.shape[1]:
+                return (y + torch.abs(self.target_feat)) / 2
+            return (y + torch.relu(self.target_feat @ self.target_feat_down)) / 2
         if not self.if_one_external:                                             # layers.py:372-373
             return self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if mod == "cat":                                                         # layers.py:375-376

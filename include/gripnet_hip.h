@@ -96,6 +96,14 @@ GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* 
                                  const float* bias, int relu, float* out, int64_t ld_out,
                                  const gn_side_copy* side /* nullable */, void* stream);
 
+/* Backward pass of the GCN-style layers (autograd of GripNet-pose.py:140-146 through layers.py:92-100).
+ * gn_graph_plan_build_transpose adds the source-major CSR of the same coefficients to a plan (once;
+ * synchronises `stream`); gn_graph_aggregate_t_f32 then computes, for every source row s,
+ *   gxw[s, :] = sum_{e: src(e)=s} coef_e * g[dst(e), :]        (d loss / d (x W) from d loss / d out). */
+GN_API gn_status gn_graph_plan_build_transpose(gn_graph_plan* plan, void* stream);
+GN_API gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float* g, int64_t ld_g, int64_t num_features,
+                                   float* out, int64_t ld_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
  *   C[b] = act( gather_rows(A[b]) @ B[b] + bias ),  b in [0, batch).
@@ -109,7 +117,8 @@ GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, cons
 /* Element-wise merges of the external layer (gripnet/layers.py:375-384) and slot copies of the
  * concat outputs:  mode 0: dst = src;  1: dst = |src|;  2: dst = (dst + |src|) / 2;
  * 3: dst = (dst + relu(src)) / 2;  4: dst = (dst + src + src2) / 3 (freebase-c merge,
- * GripNet-freebase-c.py:158-162). */
+ * GripNet-freebase-c.py:158-162).  Backward helpers:  5: dst = src2 > 0 ? src : 0 (ReLU mask by the
+ * saved output);  6: dst = src * sign(src2) (gradient of |.|). */
 GN_API gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, const float* src2,
                        int64_t ld_src2, int64_t rows, int64_t cols, int mode, void* stream);
 
@@ -162,6 +171,16 @@ GN_API gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64_t n
                                   const int64_t* u, const int64_t* v, const int64_t* edge_type,
                                   const float* d, int64_t ld_d, int64_t num_relations, int64_t num_edges,
                                   int apply_sigmoid, float* out, int32_t* error_flag, void* stream);
+
+/* Backward of the DistMult decoder (autograd of decoder.py:19-23 under the loss of GripNet-pose.py:140-146).
+ * grad_logit[e] = d loss / d s_e (the caller folds the sigmoid derivative in).  dz [n, F] and dD [R, F]
+ * are overwritten:  dz[u_e] += g_e z[v_e] * D[r_e],  dz[v_e] += g_e z[u_e] * D[r_e],  dD[r_e] += g_e z[u_e] * z[v_e].
+ * Edges with an id outside its table contribute nothing.  Accumulation uses float atomics: the last
+ * bits of the gradients may differ from run to run. */
+GN_API gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
+                                   const int64_t* u, const int64_t* v, const int64_t* edge_type, const float* d,
+                                   int64_t ld_d, int64_t num_relations, int64_t num_edges, const float* grad_logit,
+                                   float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,209 @@
+"""Gradients of the HIP path (autograd Functions over the C ABI) against torch autograd through the CPU
+oracle (the backward pass GripNet-pose.py:140-146 needs).
+
+Same seeded inputs and weights on both sides; the loss is a fixed random projection of the output so
+that every output element carries a different gradient.  Bar: 1e-4 abs on every gradient (the
+reference's own tolerance for fp32); checks use 2e-5 unless stated.
+"""
+import pytest
+import torch
+
+import gripnet_amd
+from gripnet_amd.pipeline import AminerModel, FreebaseCModel
+from gripnet_amd.synth import make_nc
+from oracle import gripnet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-5
+
+
+def close(a, b, atol=TIGHT, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= atol, "{}: max abs err {:.3e} > {:.1e}".format(what, err, atol)
+
+
+def leaf(t):
+    return t.detach().clone().requires_grad_(True)
+
+
+def test_gcn_conv_gradients(gpu):
+    gen = torch.Generator().manual_seed(5)
+    n, fin, fout, e = 300, 24, 16, 4000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ew = torch.rand(e, generator=gen) + 0.1
+    x = torch.randn(n, fin, generator=gen)
+    proj = torch.randn(n, fout, generator=gen)
+    torch.manual_seed(9)
+    conv = gripnet_amd.myGCN(fin, fout).to(gpu)
+    conv.bias.data.normal_()
+    for relu in (False, True):
+        xg = leaf(x.to(gpu))
+        conv.zero_grad()
+        y = conv(xg, ei.to(gpu), ew.to(gpu), _relu=relu)
+        (y * proj.to(gpu)).sum().backward()
+        xr, wr, br = leaf(x), leaf(conv.weight.cpu()), leaf(conv.bias.cpu())
+        yr = orc.gcn_forward(xr, wr, br, ei, ew)
+        yr = torch.relu(yr) if relu else yr
+        (yr * proj).sum().backward()
+        close(y, yr, what="forward")
+        close(xg.grad, xr.grad, what="dx relu={}".format(relu))
+        close(conv.weight.grad, wr.grad, 1e-4, what="dW")          # K = 300 rows summed in a different order
+        close(conv.bias.grad, br.grad, 1e-4, what="db")
+
+
+@pytest.mark.parametrize("mod,tfd,one_ext", [("cat", 20, True), ("add", 12, True), ("add", 20, True), ("cat", 20, False)])
+def test_inter_graph_gradients(gpu, mod, tfd, one_ext):
+    gen = torch.Generator().manual_seed(11)
+    n_src, n_tgt, fin, fout, e = 200, 60, 18, 12, 900
+    ei = torch.stack([torch.randint(0, n_src, (e,), generator=gen), torch.randint(0, n_tgt - 5, (e,), generator=gen)])
+    x = torch.randn(n_src, fin, generator=gen)
+    torch.manual_seed(13)
+    m = gripnet_amd.interGraph(fin, fout, n_tgt, target_feat_dim=tfd, if_one_external=one_ext).to(gpu)
+    m.conv.bias.data.normal_()
+    xg = leaf(x.to(gpu))
+    y = m(xg, ei.to(gpu), if_relu=True, mod=mod)
+    proj = torch.randn(y.shape, generator=gen)
+    (y * proj.to(gpu)).sum().backward()
+    sd = {"g." + k: leaf(v.cpu()) for k, v in m.state_dict().items()}
+    xr = leaf(x)
+    yr = orc.inter_forward(sd, "g.", xr, ei, None, if_relu=True, mod=mod, n_target=n_tgt)
+    (yr * proj).sum().backward()
+    close(y, yr, what="forward")
+    close(xg.grad, xr.grad, what="dx")
+    for k, p in m.named_parameters():
+        ref = sd["g." + k].grad
+        if ref is None:                                       # parameter not on this branch (e.g. target_feat_down)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        else:
+            close(p.grad, ref, 1e-4, what=k)
+
+
+def test_homo_graph_gcn_gradients(gpu):
+    gen = torch.Generator().manual_seed(17)
+    n, e = 150, 1200
+    a = torch.randint(0, n, (2, e), generator=gen)
+    ei = torch.cat([a, a.flip(0)], dim=1)
+    torch.manual_seed(19)
+    m = gripnet_amd.homoGraph([10, 8, 6], start_graph=True, in_dim=n).to(gpu)
+    for c in m.conv_list:
+        c.bias.data.normal_()
+    y = m(None, ei.to(gpu), None, if_catout=True)
+    proj = torch.randn(y.shape, generator=gen)
+    (y * proj.to(gpu)).sum().backward()
+    sd = {"h." + k: leaf(v.cpu()) for k, v in m.state_dict().items()}
+    yr = orc.homo_forward(sd, "h.", None, ei, None, if_catout=True)
+    (yr * proj).sum().backward()
+    close(y, yr, what="forward")
+    for k, p in m.named_parameters():
+        close(p.grad, sd["h." + k].grad, 1e-4, what=k)
+
+
+@pytest.mark.parametrize("sigmoid", [True, False])
+@pytest.mark.parametrize("n,f,shuffle", [(100, 80, False), (645, 80, False), (37, 20, True), (3000, 24, True)])
+def test_distmult_gradients(gpu, sigmoid, n, f, shuffle):
+    gen = torch.Generator().manual_seed(23 + n)
+    R, e = 7, 5000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[:, :50] = ei[:, 50:100]                                # repeated edges
+    ei[1, 100:120] = ei[0, 100:120]                           # u == v
+    et = torch.sort(torch.randint(0, R, (e,), generator=gen)).values
+    if shuffle:
+        et = et[torch.randperm(e, generator=gen)]
+    z = torch.randn(n, f, generator=gen) * 0.5
+    proj = torch.randn(e, generator=gen)
+    torch.manual_seed(29)
+    dm = gripnet_amd.multiRelaInnerProductDecoder(f, R).to(gpu)
+    zg = leaf(z.to(gpu))
+    s = dm(zg, ei.to(gpu), et.to(gpu), sigmoid=sigmoid)
+    (s * proj.to(gpu)).sum().backward()
+    zr, wr = leaf(z), leaf(dm.weight.cpu())
+    sr = orc.distmult(zr, ei, et, wr, sigmoid=sigmoid)
+    (sr * proj).sum().backward()
+    close(s, sr, what="forward")
+    close(zg.grad, zr.grad, 1e-4, what="dz")                  # hundreds of atomics per row, order varies
+    close(dm.weight.grad, wr.grad, 1e-4, what="dD")
+
+
+def test_multiclass_decoder_gradients(gpu):
+    gen = torch.Generator().manual_seed(31)
+    n, f, c = 90, 40, 6
+    z = torch.randn(n, f, generator=gen)
+    nodes = torch.randint(0, n, (70,), generator=gen)
+    torch.manual_seed(37)
+    mc = gripnet_amd.multiClassInnerProductDecoder(f, c).to(gpu)
+    for softmax in (True, False):
+        mc.zero_grad()
+        zg = leaf(z.to(gpu))
+        p = mc(zg, nodes.to(gpu), softmax=softmax)
+        proj = torch.randn(p.shape, generator=gen)
+        (p * proj.to(gpu)).sum().backward()
+        zr, wr = leaf(z), leaf(mc.weight.cpu())
+        pr = orc.multiclass(zr, nodes, wr, softmax=softmax)
+        (pr * proj).sum().backward()
+        close(p, pr, what="forward")
+        close(zg.grad, zr.grad, what="dz")
+        close(mc.weight.grad, wr.grad, what="dW")
+
+
+def _nll(pred, labels):
+    return -torch.log(pred[torch.arange(labels.shape[0]), labels] + 1e-13).mean()      # GripNet-aminer.py:133
+
+
+def test_aminer_training_step_gradients(gpu):
+    """One full training-step gradient of the aminer-style model (GripNet-aminer.py:124-135): every
+    parameter gradient against torch autograd through the oracle."""
+    data = make_nc("tiny")
+    torch.manual_seed(41)
+    model = AminerModel(data.n_p_node, data.n_a_node, data.n_a_type, pp_nhids=(16, 8, 8), pa_out=(8, 8), aa_hidden=(16, 8))
+    sd = {k: leaf(v) for k, v in model.state_dict().items()}
+    nodes = torch.arange(0, data.n_a_node, 2)
+    labels = data.a_label[nodes]
+    model = model.to(gpu)
+    data_gpu = make_nc("tiny").to(gpu)                       # Data.to moves in place: keep a CPU copy for the oracle
+    z, pred = model(data_gpu, nodes.to(gpu))
+    loss = _nll(pred, labels.to(gpu))
+    loss.backward()
+    ref = orc.aminer_forward(sd, data.pp_edge_idx, data.pp_edge_weight, data.pa_edge_idx, data.aa_edge_idx,
+                             data.aa_edge_weight, nodes)
+    loss_ref = _nll(ref["score"], labels)
+    loss_ref.backward()
+    close(loss, loss_ref, what="loss")
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:
+            continue
+        close(p.grad, sd[k].grad, 1e-4, what=k)
+    # and an optimiser step moves the loss down, as the reference's train() expects (GripNet-aminer.py:134-135)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        _, pred = model(data_gpu, nodes.to(gpu))
+        l2 = _nll(pred, labels.to(gpu))
+        l2.backward()
+        opt.step()
+        losses.append(float(l2))
+    assert losses[-1] < losses[0]
+
+
+def test_freebase_c_training_step_gradients(gpu):
+    data = make_nc("tiny")
+    torch.manual_seed(43)
+    model = FreebaseCModel(data.n_p_node, data.n_q_node, data.n_a_node, data.n_a_type, pp_nhids=(16, 8, 8),
+                           qq_nhids=(16, 8, 8), pa_out=(8, 8), aa_hidden=(8,))
+    sd = {k: leaf(v) for k, v in model.state_dict().items()}
+    nodes = torch.arange(1, data.n_a_node, 2)
+    labels = data.a_label[nodes]
+    model = model.to(gpu)
+    z, pred = model(make_nc("tiny").to(gpu), nodes.to(gpu))
+    _nll(pred, labels.to(gpu)).backward()
+    ref = orc.freebase_c_forward(sd, data.pp_edge_idx, data.pp_edge_weight, data.pa_edge_idx, data.qq_edge_idx,
+                                 data.qq_edge_weight, data.qa_edge_idx, sd["aa_embeddings"], data.aa_edge_idx,
+                                 data.aa_edge_weight, nodes, data.n_a_node)
+    _nll(ref["score"], labels).backward()
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:
+            continue
+        close(p.grad, sd[k].grad, 1e-4, what=k)
