@@ -28,6 +28,7 @@ SIGNATURES = {
     "gn_last_error": (C.c_char_p, []),
     "gn_gcn_plan_create": (_int, [_p, _p, _p, _i64, _i64, _int, _p, C.POINTER(_p)]),
     "gn_bipartite_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_sum_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_graph_plan_destroy": (None, [_p]),
     "gn_graph_plan_input_edges": (_i64, [_p]),
     "gn_graph_plan_nnz": (_i64, [_p]),
@@ -201,6 +202,10 @@ def edge_rows(edge_index: torch.Tensor):
     return ei, base, base + 8 * e, e
 
 
+def e_count(edge_index):
+    return int(edge_index.shape[1])
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -260,6 +265,20 @@ class GraphPlan:
             check(lib.gn_bipartite_plan_create(src, dst, ptr(w), e, int(num_sources), int(num_targets),
                                                stream_ptr(ei.device), C.byref(h)))
         plan = cls(h, ei.device, "bipartite")
+        plan.n_rows, plan.n_table = int(num_targets), int(num_sources)
+        return plan
+
+    @classmethod
+    def plain_sum(cls, edge_index, num_sources, num_targets):
+        """out[t] = sum of table[s] over the edges s -> t (no normalisation)."""
+        lib = load()
+        require_gpu(edge_index)
+        ei, src, dst, e = edge_rows(edge_index)
+        h = _p()
+        with torch.cuda.device(ei.device):
+            check(lib.gn_sum_plan_create(src, dst, None, e, int(num_sources), int(num_targets),
+                                         stream_ptr(ei.device), C.byref(h)))
+        plan = cls(h, ei.device, "sum")
         plan.n_rows, plan.n_table = int(num_targets), int(num_sources)
         return plan
 
@@ -324,6 +343,24 @@ class RgcnPlan:
         self.num_nodes, self.num_relations, self.num_edges = int(num_nodes), int(rl.shape[0]), e
         self.edge_lo, self.edge_hi = lo, hi
         self._ws = None
+        self._edge_index, self._range_list, self._grad = ei, rl, None
+
+    def grad_plans(self):
+        """(reversed-graph relational plan, (relation, source)-major sum plan, in-degree divisor) for the
+        backward pass; built on first use, full edge range only."""
+        if self._grad is None:
+            if (self.edge_lo, self.edge_hi) != (0, self.num_edges):
+                raise NotImplementedError("backward of a sharded relational layer")
+            ei, n, R = self._edge_index, self.num_nodes, self.num_relations
+            rev = RgcnPlan(ei.flip(0).contiguous(), self._range_list, n)
+            sizes = (self._range_list[:, 1] - self._range_list[:, 0]).to(self.device)
+            rel = torch.repeat_interleave(torch.arange(R, device=self.device), sizes)      # relation of every edge
+            keyed = torch.stack([ei[1], rel * n + ei[0]])                                  # dst -> (relation, src) row
+            pairs = GraphPlan.plain_sum(keyed, n, R * n)
+            deg = torch.zeros(n, dtype=torch.float32, device=self.device)
+            deg.index_add_(0, ei[1], torch.ones(e_count(ei), dtype=torch.float32, device=self.device))
+            self._grad = (rev, pairs, deg.clamp_(min=1.0))
+        return self._grad
 
     def _workspace(self, fin, fout, bases):
         need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases))

@@ -64,8 +64,37 @@ class RgcnConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("backward of the relational layer (myRGCN) is not implemented yet "
-                                  "(SURVEY.md section 8f row 1); run it under torch.no_grad()")
+        # out[i] = (sum_{e: dst=i} x[src_e] W_{r(e)}) / deg_i + x[i] root + b,   W_r = sum_b att[r,b] basis[b]
+        x, basis, att, root, out = ctx.saved_tensors
+        g = _hip.f32_rows(g.contiguous())
+        if ctx.relu:
+            g = _hip.merge(torch.empty_like(g), g, 5, src2=out)
+        n, fin = x.shape
+        B, _, fout = basis.shape
+        R = att.shape[0]
+        rev, pairs, deg = ctx.plan.grad_plans()
+        gm = g / deg.view(-1, 1)                                            # gradient of the un-normalised sum
+        dx = dbasis = datt = droot = dbias = None
+        if ctx.needs_input_grad[0]:
+            # dx[s] = sum_{e: src=s} gm[dst_e] W_{r(e)}^T: the same relational layer on the reversed graph
+            # with the transposed bases, un-normalised (HIP, general path), plus the root term
+            dxe = torch.empty((n, fin), dtype=torch.float32, device=x.device)
+            rev.forward(gm, basis.detach().transpose(1, 2).contiguous(), att.detach(), None, None, False, dxe, partial=True)
+            dx = dxe + g @ root.detach().t()
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # dW_r = X^T Q_r,  Q_r[s] = sum_{e in r, src=s} gm[dst_e]   (HIP gather-reduce, (relation, source) rows)
+            q = torch.empty((R * n, fout), dtype=torch.float32, device=x.device)
+            pairs.aggregate(gm, None, False, q)
+            dw = torch.matmul(x.t(), q.view(R, n, fout)).reshape(R, fin * fout)            # [R, fin*fout]
+            if ctx.needs_input_grad[1]:
+                dbasis = (att.detach().t() @ dw).view(B, fin, fout)
+            if ctx.needs_input_grad[2]:
+                datt = dw @ basis.detach().reshape(B, fin * fout).t()
+        if ctx.needs_input_grad[3]:
+            droot = x.t() @ g
+        if ctx.needs_input_grad[4]:
+            dbias = g.sum(dim=0)
+        return dx, dbasis, datt, droot, dbias, None, None
 
 
 class DistMultFn(torch.autograd.Function):

@@ -179,7 +179,8 @@ gn_status sort_by_dst(Temp& tmp, const int32_t* keys_in, int32_t* keys_out, cons
 }
 
 gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* w, int64_t E, int64_t n_src,
-                           int64_t n_dst, bool gcn, int improved, hipStream_t st, gn_graph_plan* plan) {
+                           int64_t n_dst, bool gcn, int improved, hipStream_t st, gn_graph_plan* plan,
+                           bool raw = false) {
     const int64_t n_loops = gcn ? n_dst : 0;
     Temp tmp;
     int32_t *keep, *pos, *last_loop, *err;
@@ -249,6 +250,8 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
             k_gcn_norm<<<g, 256, 0, st>>>(src2, dst2, w2, dis, (int)nnz, plan->ref_edge_index.p, plan->ref_norm.p);
             GN_LAUNCH_CHECK();
             k_fill_csr<<<g, 256, 0, st>>>(perm, src2, plan->ref_norm.p, (int)nnz, plan->col.p, plan->coef.p);
+        } else if (raw) {                                  // plain weighted sum: coefficient = edge weight
+            k_fill_csr<<<g, 256, 0, st>>>(perm, src2, w2, (int)nnz, plan->col.p, plan->coef.p);
         } else {
             k_bip_coef<<<g, 256, 0, st>>>(dst2, w2, dis, (int)nnz, coef_ref);
             GN_LAUNCH_CHECK();
@@ -344,6 +347,21 @@ gn_status gn_bipartite_plan_create(const int64_t* src, const int64_t* dst, const
         return gn::fail(GN_ERR_UNSUPPORTED, "graph too large for the int32 plan encoding");
     gn_graph_plan* p = new gn_graph_plan();
     gn_status s = build_graph_plan(src, dst, w, E, n_src, n_tgt, false, 0, gn::as_stream(stream), p);
+    if (s != GN_OK) { free_graph_plan(p); delete p; return s; }
+    *out = p;
+    return GN_OK;
+}
+
+gn_status gn_sum_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t E, int64_t n_src,
+                             int64_t n_dst, void* stream, gn_graph_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(E >= 0 && n_src >= 0 && n_dst >= 0, "negative size");
+    GN_REQUIRE(E == 0 || (src && dst), "edge pointers are null");
+    if (E >= ((int64_t)1 << 31) || n_src >= ((int64_t)1 << 31) || n_dst >= ((int64_t)1 << 31))
+        return gn::fail(GN_ERR_UNSUPPORTED, "graph too large for the int32 plan encoding");
+    gn_graph_plan* p = new gn_graph_plan();
+    gn_status s = build_graph_plan(src, dst, w, E, n_src, n_dst, false, 0, gn::as_stream(stream), p, true);
     if (s != GN_OK) { free_graph_plan(p); delete p; return s; }
     *out = p;
     return GN_OK;

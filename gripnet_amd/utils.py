@@ -137,3 +137,29 @@ def shard_edge_ranges(num_edges: int, world_size: int) -> List[Tuple[int, int]]:
         out.append((lo, hi))
         lo = hi
     return out
+
+
+# ---- evaluation metrics (host side, scikit-learn; reference: gripnet/utils.py:28-52) ----------------
+def _to_numpy(*tensors):
+    return [t.detach().cpu().numpy() for t in tensors]
+
+
+def auprc_auroc_ap(target_tensor: torch.Tensor, score_tensor: torch.Tensor):
+    """(area under the precision-recall curve, ROC AUC, average precision) of binary link scores."""
+    from sklearn import metrics
+    y, pred = _to_numpy(target_tensor, score_tensor)
+    precision, recall, _ = metrics.precision_recall_curve(y, pred)
+    return metrics.auc(recall, precision), metrics.roc_auc_score(y, pred), metrics.average_precision_score(y, pred)
+
+
+def micro_macro(target_tensor: torch.Tensor, score_tensor: torch.Tensor):
+    """(micro-F1, macro-F1) of predicted class ids."""
+    from sklearn import metrics
+    y, pred = _to_numpy(target_tensor, score_tensor)
+    return metrics.f1_score(y, pred, average="micro"), metrics.f1_score(y, pred, average="macro")
+
+
+def acc(target_tensor: torch.Tensor, score_tensor: torch.Tensor):
+    from sklearn.metrics import accuracy_score
+    y, pred = _to_numpy(target_tensor, score_tensor)
+    return accuracy_score(y, pred)

@@ -79,6 +79,12 @@ GN_API gn_status gn_gcn_plan_create(const int64_t* src, const int64_t* dst, cons
 GN_API gn_status gn_bipartite_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t num_edges,
                                    int64_t num_sources, int64_t num_targets, void* stream, gn_graph_plan** plan);
 
+/* Plain (un-normalised) weighted-sum graph: out[t] = sum_{e: dst(e)=t} w_e * table[src(e)], w NULL = ones.
+ * Used by the backward pass of the relational layer (rows = (relation, source) pairs, autograd of
+ * gripnet/layers.py:178-189). */
+GN_API gn_status gn_sum_plan_create(const int64_t* src, const int64_t* dst, const float* w, int64_t num_edges,
+                             int64_t num_sources, int64_t num_targets, void* stream, gn_graph_plan** plan);
+
 GN_API void gn_graph_plan_destroy(gn_graph_plan* plan);
 /* Number of edges the plan was built from (the reference's cache key, layers.py:76-84). */
 GN_API int64_t gn_graph_plan_input_edges(const gn_graph_plan* plan);

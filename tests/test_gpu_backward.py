@@ -207,3 +207,75 @@ def test_freebase_c_training_step_gradients(gpu):
         if sd[k].grad is None:
             continue
         close(p.grad, sd[k].grad, 1e-4, what=k)
+
+
+@pytest.mark.parametrize("n,fin,fout,bias", [(100, 48, 32, False), (40, 12, 20, True), (645, 48, 32, False)])
+def test_rgcn_conv_gradients(gpu, n, fin, fout, bias):
+    gen = torch.Generator().manual_seed(47 + n)
+    sizes = [300, 0, 1200, 5, 40, 700]
+    blocks = [torch.randint(0, max(1, n - 3), (2, s), generator=gen) for s in sizes]     # last nodes: no edges
+    ei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    proj = torch.randn(n, fout, generator=gen)
+    torch.manual_seed(53)
+    rg = gripnet_amd.myRGCN(fin, fout, len(sizes), 5, False, bias=bias).to(gpu)
+    if bias:
+        rg.bias.data.normal_()
+    xg = leaf(x.to(gpu))
+    y = rg(xg, ei.to(gpu), None, rl, _relu=True)
+    (y * proj.to(gpu)).sum().backward()
+    sd = {k: leaf(v.cpu()) for k, v in rg.state_dict().items()}
+    xr = leaf(x)
+    yr = torch.relu(orc.rgcn_forward(xr, ei, rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
+    (yr * proj).sum().backward()
+    close(y, yr, what="forward")
+    close(xg.grad, xr.grad, 1e-4, what="dx")
+    for k, p in rg.named_parameters():
+        close(p.grad, sd[k].grad, 2e-4 if k == "basis" else 1e-4, what=k)     # basis: sums over R x n terms
+
+
+@pytest.mark.parametrize("scale", ["tiny", "small"])
+def test_pose_training_step_gradients(gpu, scale):
+    """The reference's training step (GripNet-pose.py:117-146): encoder, decoder on positive and negative
+    edges, log loss, backward; every parameter gradient against torch autograd through the oracle."""
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.synth import make_pose
+    from gripnet_amd.utils import EPS
+    data = make_pose(scale)
+    torch.manual_seed(59)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: leaf(v) for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(61)
+    neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=gen)
+
+    def loss_fn(pos, negs):
+        return -torch.log(pos + EPS).mean() - torch.log(1 - negs + EPS).mean()          # GripNet-pose.py:140-142
+
+    model = model.to(gpu)
+    dg = make_pose(scale).to(gpu)
+    z = model.encode(dg)
+    loss = loss_fn(model.dmt(z, dg.train_idx, dg.train_et), model.dmt(z, neg.to(gpu), dg.train_et))
+    loss.backward()
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range)
+    neg_ref = orc.distmult(ref["z_dd"], neg, data.train_et, sd["dmt.weight"])
+    loss_ref = loss_fn(ref["score"], neg_ref)
+    loss_ref.backward()
+    close(loss, loss_ref, what="loss")
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:                                 # gd.target_feat_down is unused in cat mode
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale_k = max(1.0, float(sd[k].grad.abs().max()))
+        close(p.grad / scale_k, sd[k].grad / scale_k, 1e-4, what=k)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)       # GripNet-pose.py:104
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        z = model.encode(dg)
+        l2 = loss_fn(model.dmt(z, dg.train_idx, dg.train_et), model.dmt(z, neg.to(gpu), dg.train_et))
+        l2.backward()
+        opt.step()
+        losses.append(float(l2))
+    assert losses[-1] < losses[0], losses
