@@ -27,6 +27,7 @@ struct BwdArgs {
     const float* __restrict__ d; int64_t ld_d; int r;
     const float* __restrict__ gs; int64_t e; int64_t edges_per_wg;
     float* dz; int64_t ld_dz; float* dd; int64_t ld_dd;
+    float* slabs;                     // LDS path: [groups][n][features] per-workgroup dz partials
 };
 
 template <bool LDS_TABLE>
@@ -96,22 +97,52 @@ __global__ __launch_bounds__(kThreads) void k_distmult_bwd(BwdArgs a) {
         }
         if (cur_r >= 0 && col_ok) atomicAdd(&a.dd[(int64_t)cur_r * a.ld_dd + c0 + c], racc);
         if constexpr (LDS_TABLE) {
+            // the accumulator leaves as a slab (plain stores): 64-byte pieces in different rows are the slow
+            // shape for global float atomics, and a fixed-order reduction kernel follows anyway
             __syncthreads();
+            float* slab = a.slabs + (size_t)blockIdx.x * a.n * a.features;
             for (int i = tid; i < a.n * kCw; i += kThreads) {
                 const int row = i / kCw, cc = i % kCw;
-                const float val = dzp[i];
-                if (c0 + cc < a.features && val != 0.f) atomicAdd(&a.dz[(int64_t)row * a.ld_dz + c0 + cc], val);
+                if (c0 + cc < a.features) slab[(size_t)row * a.features + c0 + cc] = dzp[i];
             }
         }
     }
 }
 
+// dz[row, c] = sum over workgroups of slab[g][row][c], fixed order
+__global__ void k_distmult_bwd_reduce(const float* __restrict__ slabs, int groups, int64_t total, int features,
+                                      float* __restrict__ dz, int64_t ld_dz) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < groups; ++g) s += slabs[(size_t)g * total + t];
+    const int64_t row = t / features;
+    dz[row * ld_dz + (t - row * features)] = s;
+}
+
+int64_t bwd_groups(int64_t e, int64_t* edges_per_wg) {
+    int64_t groups = std::min<int64_t>(256, gn::ceil_div(e, 64 * (kThreads / 64)));
+    if (groups < 1) groups = 1;
+    *edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
+    return gn::ceil_div(e, *edges_per_wg);
+}
+
+bool bwd_lds_path(int64_t n) { return (size_t)n * kCw * 2 * sizeof(float) <= kLdsBudget && !gn::fast_paths_disabled(); }
+
 }  // namespace
+
+extern "C" size_t gn_distmult_backward_workspace_bytes(int64_t n, int64_t f, int64_t e) {
+    if (n <= 0 || f <= 0 || e <= 0 || !bwd_lds_path(n)) return 0;
+    int64_t per = 0;
+    return (size_t)bwd_groups(e, &per) * n * f * sizeof(float);
+}
 
 extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
                                               const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
                                               int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
-                                              float* dd, int64_t ld_dd, void* stream) {
+                                              float* dd, int64_t ld_dd, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
     GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
     GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31), "table too large");
     GN_REQUIRE((n == 0 || f == 0 || dz) && (r == 0 || f == 0 || dd), "gradient output pointer is null");
@@ -126,12 +157,12 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
     BwdArgs a;
     a.z = z; a.ld_z = ld_z; a.n = (int)n; a.features = (int)f; a.u = u; a.v = v; a.et = et; a.d = d; a.ld_d = ld_d;
     a.r = (int)r; a.gs = grad_logit; a.e = e; a.dz = dz; a.ld_dz = ld_dz; a.dd = dd; a.ld_dd = ld_dd;
-    int64_t groups = std::min<int64_t>(256, gn::ceil_div(e, 64 * (kThreads / 64)));
-    if (groups < 1) groups = 1;
-    a.edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
-    groups = gn::ceil_div(e, a.edges_per_wg);
+    const int64_t groups = bwd_groups(e, &a.edges_per_wg);
     const size_t lds_bytes = (size_t)n * kCw * 2 * sizeof(float);
-    if (lds_bytes <= kLdsBudget && !gn::fast_paths_disabled()) {
+    a.slabs = static_cast<float*>(workspace);
+    if (bwd_lds_path(n)) {
+        GN_REQUIRE(workspace && workspace_bytes >= gn_distmult_backward_workspace_bytes(n, f, e),
+                   "workspace too small: need %zu bytes", gn_distmult_backward_workspace_bytes(n, f, e));
         static thread_local bool configured = false;
         if (!configured) {
             GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_bwd<true>),
@@ -139,6 +170,9 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
             configured = true;
         }
         k_distmult_bwd<true><<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
+        GN_LAUNCH_CHECK();
+        k_distmult_bwd_reduce<<<(unsigned)gn::ceil_div(n * f, 256), 256, 0, st>>>(a.slabs, (int)groups, n * f, (int)f, dz,
+                                                                               ld_dz);
     } else {
         k_distmult_bwd<false><<<(unsigned)groups, kThreads, 0, st>>>(a);
     }
