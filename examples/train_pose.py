@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gripnet_amd.decoder import multiRelaInnerProductDecoder         # reference: from gripnet.decoder import ...
 from gripnet_amd.layers import homoGraph, interGraph                  # reference: from gripnet.layers import ...
 from gripnet_amd.synth import make_pose
-from gripnet_amd.utils import EPS, auprc_auroc_ap, typed_negative_sampling
+from gripnet_amd.utils import EPS, auprc_auroc_ap, device_negative_sampler
 
 
 class Model(torch.nn.Module):                                         # GripNet-pose.py:73-82
@@ -51,6 +51,9 @@ def main():
                   homoGraph(dd_nhids, multi_relational=True, n_rela=n_et),
                   multiRelaInnerProductDecoder(sum(dd_nhids), n_et)).to(device)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.01)         # GripNet-pose.py:104
+    # the reference calls typed_negative_sampling(train_idx, n_d, train_range) every epoch (host numpy,
+    # one Python iteration per relation, GripNet-pose.py:131); same distribution, drawn on the GPU
+    sampler = device_negative_sampler(data.train_idx, n_d, data.train_range)
 
     def train(epoch):                                                 # GripNet-pose.py:112-172
         model.train()
@@ -59,7 +62,7 @@ def main():
         z = model.gd(z, data.gd_edge_index, mod="cat", if_relu=True)
         z = model.dd(z, data.train_idx, edge_type=data.train_et, range_list=data.train_range, if_catout=True)
         pos_index = data.train_idx
-        neg_index = typed_negative_sampling(data.train_idx, n_d, data.train_range.cpu()).to(device)
+        neg_index = sampler.sample(seed=epoch)
         pos_score = model.dmt(z, pos_index, data.train_et)
         neg_score = model.dmt(z, neg_index, data.train_et)
         loss = -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()

@@ -48,6 +48,9 @@ SIGNATURES = {
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
+    "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_negative_sampler_destroy": (None, [_p]),
+    "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
 }
 
 
@@ -406,8 +409,11 @@ def raise_if_index_errors(device=None):
     for key, flag in list(_error_flags.items()):
         if device is not None and (device.type, device.index) != key:
             continue
-        if int(flag.item()) != 0:
+        bits = int(flag.item())
+        if bits != 0:
             flag.zero_()
+            if bits & 2:
+                raise RuntimeError("negative sampler: a relation's positive pairs leave no pair to draw")
             raise IndexError("DistMult decoder saw an edge endpoint or relation id outside its table")
 
 
@@ -430,6 +436,40 @@ def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd):
     _call("gn_distmult_backward_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
           weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), ptr(ws), need, stream_ptr(z.device))
     return dz, dd
+
+
+class NegativeSampler:
+    """Device-side typed negative sampling for one static positive edge list (reference:
+    gripnet/utils.py:98-119, called once per epoch at GripNet-pose.py:131).
+
+        sampler = NegativeSampler(data.train_idx, n_d_node, data.train_range)
+        neg_index = sampler.sample(seed=epoch)          # [2, E] int64 on the GPU, no host round trip
+    """
+
+    def __init__(self, pos_edge_index, num_nodes, range_list=None):
+        lib = load()
+        require_gpu(pos_edge_index)
+        ei, u, v, e = edge_rows(pos_edge_index)
+        if range_list is None:
+            range_list = [[0, e]]
+        rl = torch.as_tensor(range_list).to("cpu", torch.int64).contiguous().view(-1, 2)
+        h = _p()
+        with torch.cuda.device(ei.device):
+            check(lib.gn_negative_sampler_create(u, v, rl.data_ptr(), rl.shape[0], e, int(num_nodes),
+                                                 stream_ptr(ei.device), C.byref(h)))
+        self._h, self.device, self.num_edges = h, ei.device, e
+
+    def sample(self, seed: int = 0) -> torch.Tensor:
+        out = torch.empty((2, self.num_edges), dtype=torch.int64, device=self.device)
+        base = out.data_ptr()
+        _call("gn_negative_sampler_sample", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, base, base + 8 * self.num_edges,
+              ptr(error_flag(self.device)), stream_ptr(self.device))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gn_negative_sampler_destroy(h)
 
 
 def softmax_rows(x):

@@ -1,0 +1,157 @@
+// Device-side typed negative sampling.
+//
+// The reference draws the negative edges of every epoch on the host (gripnet/utils.py:98-119): per
+// relation block, E_r linear pair ids uniformly from [0, n^2) with numpy, np.isin against that block's
+// positive pairs, redraw the hits until none is left, copy back to the device; one Python iteration per
+// relation (964 on PoSE) and a device -> host -> device round trip per epoch.  Here the positive pairs
+// are sorted once per graph into (relation, u*n+v) keys (a "sampler", like a plan), and one kernel
+// draws every negative: thread e finds its relation block, draws from a counter-based generator
+// keyed by (seed, e, attempt), rejects a draw that is a positive of the same block by binary search,
+// and writes (u, v) as int64.  Same distribution as the reference (uniform over the non-positive
+// pairs of the block, with replacement); not the same random stream (numpy's global RNG cannot be
+// replayed on the device, and the reference's own stream changes with every call).
+#include "common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <vector>
+
+struct gn_negative_sampler {
+    int64_t num_edges = 0, num_nodes = 0, num_relations = 0;
+    gn::DevBuf<uint64_t> keys;      // [E] sorted (relation << 40) | (u * n + v)
+    gn::DevBuf<int64_t> starts;     // [R + 1] block starts
+};
+
+namespace {
+
+constexpr int kMaxAttempts = 4096;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {     // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ int relation_of(const int64_t* __restrict__ starts, int R, int64_t e) {
+    int a = 0, b = R;                                       // last r with starts[r] <= e
+    while (b - a > 1) {
+        int mid = (a + b) >> 1;
+        if (starts[mid] <= e) a = mid; else b = mid;
+    }
+    return a;
+}
+
+__global__ void k_pair_keys(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
+                            const int64_t* __restrict__ starts, int R, int64_t E, int64_t n,
+                            uint64_t* __restrict__ keys, int32_t* __restrict__ err) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t uu = u[e], vv = v[e];
+        if ((uint64_t)uu >= (uint64_t)n || (uint64_t)vv >= (uint64_t)n) { atomicOr(err, 1); keys[e] = ~0ull; continue; }
+        keys[e] = ((uint64_t)relation_of(starts, R, e) << 40) | (uint64_t)(uu * n + vv);
+    }
+}
+
+__global__ void k_sample_negatives(const uint64_t* __restrict__ keys, const int64_t* __restrict__ starts, int R,
+                                   int64_t E, int64_t n, uint64_t seed, int64_t* __restrict__ out_u,
+                                   int64_t* __restrict__ out_v, int32_t* __restrict__ err) {
+    const uint64_t n2 = (uint64_t)n * (uint64_t)n;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = relation_of(starts, R, e);
+        const int64_t lo0 = starts[r], hi0 = starts[r + 1];
+        uint64_t lin = 0;
+        bool found = false;
+        for (int k = 0; k < kMaxAttempts && !found; ++k) {
+            lin = mix64(mix64(seed ^ (uint64_t)e * 0xD6E8FEB86659FD93ull) + (uint64_t)k) % n2;
+            const uint64_t key = ((uint64_t)r << 40) | lin;
+            int64_t lo = lo0, hi = hi0;                     // is `key` one of this block's positives?
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            found = !(lo < hi0 && keys[lo] == key);
+        }
+        if (!found && err) atomicOr(err, 2);                // the block's positives (nearly) cover all n^2 pairs
+        out_u[e] = (int64_t)(lin / (uint64_t)n);
+        out_v[e] = (int64_t)(lin % (uint64_t)n);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, const int64_t* range_list_host,
+                                     int64_t R, int64_t E, int64_t N, void* stream, gn_negative_sampler** out) {
+    GN_REQUIRE(out != nullptr, "sampler output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(R >= 1 && E >= 0 && N >= 1, "bad size (R=%lld, E=%lld, N=%lld)", (long long)R, (long long)E, (long long)N);
+    GN_REQUIRE(E == 0 || (u && v), "edge pointers are null");
+    GN_REQUIRE(range_list_host != nullptr, "range_list is null");
+    if (N >= (1ll << 20) || R >= (1ll << 23))
+        return gn::fail(GN_ERR_UNSUPPORTED, "sampler keys hold 2^20 nodes and 2^23 relations at most");
+    std::vector<int64_t> starts(R + 1);
+    int64_t cursor = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        if (range_list_host[2 * r] != cursor || range_list_host[2 * r + 1] < cursor)
+            return gn::fail(GN_ERR_INVALID_ARG, "range_list must tile [0,E) in relation order (row %lld)", (long long)r);
+        starts[r] = cursor;
+        cursor = range_list_host[2 * r + 1];
+    }
+    if (cursor != E) return gn::fail(GN_ERR_INVALID_ARG, "range_list covers %lld edges but edge_index has %lld",
+                                     (long long)cursor, (long long)E);
+    starts[R] = E;
+    hipStream_t st = gn::as_stream(stream);
+    gn_negative_sampler* s = new gn_negative_sampler();
+    s->num_edges = E; s->num_nodes = N; s->num_relations = R;
+    auto bail = [&](gn_status code) { gn_negative_sampler_destroy(s); return code; };
+#define GN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(gn::fail(GN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
+    GN_TRY(s->keys.alloc(E));
+    GN_TRY(s->starts.alloc(R + 1));
+    GN_TRY(hipMemcpyAsync(s->starts.p, starts.data(), (R + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    uint64_t* raw = nullptr;
+    int32_t* err = nullptr;
+    void* scratch = nullptr;
+    int32_t bad = 0;
+    if (E > 0) {
+        GN_TRY(hipMalloc(reinterpret_cast<void**>(&raw), E * sizeof(uint64_t)));
+        hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&err), sizeof(int32_t));
+        if (e2 != hipSuccess) { (void)hipFree(raw); return bail(gn::fail(GN_ERR_HIP, "hipMalloc failed")); }
+        (void)hipMemsetAsync(err, 0, sizeof(int32_t), st);
+        k_pair_keys<<<gn::stream_grid(E, 256), 256, 0, st>>>(u, v, s->starts.p, (int)R, E, N, raw, err);
+        size_t bytes = 0;
+        hipError_t e3 = rocprim::radix_sort_keys(nullptr, bytes, raw, s->keys.p, (size_t)E, 0, 64, st);
+        if (e3 == hipSuccess) e3 = hipMalloc(&scratch, bytes ? bytes : 1);
+        if (e3 == hipSuccess) e3 = rocprim::radix_sort_keys(scratch, bytes, raw, s->keys.p, (size_t)E, 0, 64, st);
+        if (e3 == hipSuccess) e3 = hipMemcpyAsync(&bad, err, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
+        (void)hipFree(raw); (void)hipFree(err); if (scratch) (void)hipFree(scratch);
+        if (e3 != hipSuccess) return bail(gn::fail(GN_ERR_HIP, "sampler construction failed: %s", hipGetErrorString(e3)));
+    } else {
+        GN_TRY(hipStreamSynchronize(st));
+    }
+#undef GN_TRY
+    if (bad) return bail(gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld)", (long long)N));
+    *out = s;
+    return GN_OK;
+}
+
+void gn_negative_sampler_destroy(gn_negative_sampler* s) {
+    if (!s) return;
+    s->keys.release();
+    s->starts.release();
+    delete s;
+}
+
+gn_status gn_negative_sampler_sample(const gn_negative_sampler* s, uint64_t seed, int64_t* out_u, int64_t* out_v,
+                                     int32_t* error_flag, void* stream) {
+    GN_REQUIRE(s != nullptr, "sampler is null");
+    if (s->num_edges == 0) return GN_OK;
+    GN_REQUIRE(out_u && out_v, "output pointers are null");
+    k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, gn::as_stream(stream)>>>(
+        s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, error_flag);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // extern "C"

@@ -119,6 +119,13 @@ def typed_negative_sampling(pos_edge_index: torch.Tensor, num_nodes: int, range_
     return torch.cat(parts, dim=1)
 
 
+def device_negative_sampler(pos_edge_index: torch.Tensor, num_nodes: int, range_list=None):
+    """GPU counterpart of `typed_negative_sampling` for a static positive edge list: build once, then
+    ``sampler.sample(seed)`` every epoch (no host round trip, no per-relation Python loop)."""
+    from ._hip import NegativeSampler
+    return NegativeSampler(pos_edge_index, num_nodes, range_list)
+
+
 def profile(fn):
     """No-op stand-in for ``pytorch_memlab.profile`` (reference: GripNet-pose.py:18,112)."""
     return fn

@@ -191,6 +191,21 @@ GN_API gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t 
                                    float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, void* workspace,
                                    size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Typed negative sampling on the device (replaces gripnet/utils.py:98-119 and its per-epoch host round
+ * trip, GripNet-pose.py:131).  The sampler sorts the positive pairs of every relation block once
+ * (range_list on the host, [R,2], must tile [0,E)); gn_negative_sampler_sample then writes, for every
+ * positive edge e of block r, one pair (u, v) drawn uniformly (with replacement) from the n^2 pairs
+ * that are not positives of block r.  Deterministic in `seed`.  Bit 1 of *error_flag (device int32,
+ * may be NULL) is set if a block's positives leave (almost) no pair to draw. */
+typedef struct gn_negative_sampler gn_negative_sampler;
+GN_API gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, const int64_t* range_list_host,
+                                     int64_t num_relations, int64_t num_edges, int64_t num_nodes, void* stream,
+                                     gn_negative_sampler** sampler);
+GN_API void gn_negative_sampler_destroy(gn_negative_sampler* sampler);
+GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
+                                     int64_t* out_v, int32_t* error_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

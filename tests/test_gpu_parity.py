@@ -403,3 +403,36 @@ def test_pose2_syn_properties(gpu):
     plan.finalize(parts[0] + parts[1], x, conv.root, None, True, out)
     close(out, z[:, 48:], TOL)
     _hip.raise_if_index_errors(gpu)
+
+
+# ---- device-side negative sampling ---------------------------------------------------
+def test_device_negative_sampling(gpu):
+    """Same contract as gripnet/utils.py:98-119: one pair per positive edge, drawn from the n^2 pairs of
+    its relation block that are not positives of that block; deterministic per seed, uniform."""
+    from gripnet_amd.utils import device_negative_sampler
+    gen = torch.Generator().manual_seed(71)
+    n, sizes = 40, [600, 0, 1500, 7, 300]                  # block 2 holds almost every pair: many redraws
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    pos = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    sampler = device_negative_sampler(pos.to(gpu), n, rl)
+    neg = sampler.sample(seed=5)
+    assert neg.shape == pos.shape and neg.dtype == torch.int64 and neg.is_cuda
+    assert int(neg.min()) >= 0 and int(neg.max()) < n
+    negc = neg.cpu()
+    for r, (s, e) in enumerate(rl.tolist()):
+        pos_keys = set((pos[0, s:e] * n + pos[1, s:e]).tolist())
+        neg_keys = (negc[0, s:e] * n + negc[1, s:e]).tolist()
+        assert not pos_keys.intersection(neg_keys), "relation {} drew a positive pair".format(r)
+    assert torch.equal(sampler.sample(seed=5), neg)                       # deterministic in the seed
+    assert not torch.equal(sampler.sample(seed=6), neg)
+    _hip.raise_if_index_errors(gpu)
+    # untyped form and uniformity on a sparse positive set: every row / column about equally likely
+    big = torch.randint(0, 500, (2, 200000), generator=gen)
+    s2 = device_negative_sampler(big.to(gpu), 500)
+    draw = s2.sample(seed=1).cpu()
+    for axis in (0, 1):
+        counts = torch.bincount(draw[axis], minlength=500).double()
+        assert counts.min() > 250 and counts.max() < 560                  # mean 400, sigma 20
+    with pytest.raises(IndexError):
+        device_negative_sampler(torch.tensor([[0, 41], [1, 2]], device=gpu), n)
