@@ -46,7 +46,7 @@ SIGNATURES = {
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
-    "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
@@ -431,7 +431,7 @@ def distmult(z, u_v, edge_type, weight, sigmoid, out):
 def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd):
     ei, u, v, e = edge_rows(u_v)
     et = i64_vec(edge_type)
-    need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], e))
+    need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], weight.shape[0], e))
     ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
     _call("gn_distmult_backward_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
           weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), ptr(ws), need, stream_ptr(z.device))

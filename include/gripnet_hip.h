@@ -181,10 +181,10 @@ GN_API gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64_t n
 /* Backward of the DistMult decoder (autograd of decoder.py:19-23 under the loss of GripNet-pose.py:140-146).
  * grad_logit[e] = d loss / d s_e (the caller folds the sigmoid derivative in).  dz [n, F] and dD [R, F]
  * are overwritten:  dz[u_e] += g_e z[v_e] * D[r_e],  dz[v_e] += g_e z[u_e] * D[r_e],  dD[r_e] += g_e z[u_e] * z[v_e].
- * Edges with an id outside its table contribute nothing.  Accumulation uses float atomics: the last
- * bits of the gradients may differ from run to run.  Scratch is caller-provided
- * (gn_distmult_backward_workspace_bytes; 0 when the general path is taken). */
-GN_API size_t gn_distmult_backward_workspace_bytes(int64_t num_nodes, int64_t num_features, int64_t num_edges);
+ * Edges with an id outside its table contribute nothing.  Sort-based segmented reduction: no atomics,
+ * bitwise reproducible.  Scratch is caller-provided (gn_distmult_backward_workspace_bytes). */
+GN_API size_t gn_distmult_backward_workspace_bytes(int64_t num_nodes, int64_t num_features, int64_t num_relations,
+                                            int64_t num_edges);
 GN_API gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
                                    const int64_t* u, const int64_t* v, const int64_t* edge_type, const float* d,
                                    int64_t ld_d, int64_t num_relations, int64_t num_edges, const float* grad_logit,
