@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gripnet_amd.decoder import multiRelaInnerProductDecoder         # reference: from gripnet.decoder import ...
 from gripnet_amd.layers import homoGraph, interGraph                  # reference: from gripnet.layers import ...
 from gripnet_amd.synth import make_pose
-from gripnet_amd.utils import EPS, auprc_auroc_ap, device_negative_sampler
+from gripnet_amd.utils import EPS, device_negative_sampler, relation_metrics
 
 
 class Model(torch.nn.Module):                                         # GripNet-pose.py:73-82
@@ -68,10 +68,10 @@ def main():
         loss = -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()
         loss.backward()
         optimizer.step()
-        score = torch.cat([pos_score, neg_score]).detach()
-        target = torch.cat([torch.ones_like(pos_score), torch.zeros_like(neg_score)])
-        auprc, auroc, ap = auprc_auroc_ap(target, score)
-        return z.detach(), float(loss), auprc, auroc, ap
+        # per-relation AUPRC / AUROC / AP, averaged over relations: the reference loops over the relations
+        # with one scikit-learn call each (GripNet-pose.py:148-160); here one pass on the GPU
+        auprc, auroc, ap = relation_metrics(pos_score, neg_score, data.train_range)
+        return z.detach(), float(loss), float(auprc.nanmean()), float(auroc.nanmean()), float(ap.nanmean())
 
     for epoch in range(args.epochs):
         t0 = time.time()

@@ -51,6 +51,8 @@ SIGNATURES = {
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
+    "gn_link_metrics_workspace_bytes": (_sz, [_i64, _i64]),
+    "gn_link_metrics_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
 }
 
 
@@ -470,6 +472,23 @@ class NegativeSampler:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gn_negative_sampler_destroy(h)
+
+
+def link_metrics(pos_score, neg_score, range_list):
+    """(auprc, auroc, ap), each a float64 [R] tensor on the GPU: scikit-learn's three link-prediction
+    metrics for every relation block at once (reference: one sklearn call per relation and epoch)."""
+    require_gpu(pos_score, neg_score)
+    pos = pos_score.detach().to(torch.float32).contiguous()
+    neg = neg_score.detach().to(torch.float32).contiguous()
+    if pos.numel() != neg.numel():
+        raise ValueError("positive and negative score lists differ in length")
+    rl = torch.as_tensor(range_list).to("cpu", torch.int64).contiguous().view(-1, 2)
+    R, E = int(rl.shape[0]), int(pos.numel())
+    out = torch.empty((3, R), dtype=torch.float64, device=pos.device)
+    need = int(load().gn_link_metrics_workspace_bytes(R, E))
+    ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=pos.device)
+    _call("gn_link_metrics_f32", ptr(pos), ptr(neg), rl.data_ptr(), R, E, ptr(out), ptr(ws), need, stream_ptr(pos.device))
+    return out[0], out[1], out[2]
 
 
 def softmax_rows(x):

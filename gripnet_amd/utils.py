@@ -126,6 +126,13 @@ def device_negative_sampler(pos_edge_index: torch.Tensor, num_nodes: int, range_
     return NegativeSampler(pos_edge_index, num_nodes, range_list)
 
 
+def relation_metrics(pos_score: torch.Tensor, neg_score: torch.Tensor, range_list):
+    """Per-relation (auprc, auroc, ap) on the GPU, float64 [R] each: what the reference's epoch loop computes
+    with one `auprc_auroc_ap` call per relation (GripNet-pose.py:148-160)."""
+    from ._hip import link_metrics
+    return link_metrics(pos_score, neg_score, range_list)
+
+
 def profile(fn):
     """No-op stand-in for ``pytorch_memlab.profile`` (reference: GripNet-pose.py:18,112)."""
     return fn

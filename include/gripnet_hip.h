@@ -206,6 +206,18 @@ GN_API void gn_negative_sampler_destroy(gn_negative_sampler* sampler);
 GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
                                      int64_t* out_v, int32_t* error_flag, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Per-relation evaluation metrics (replaces the R scikit-learn calls and device -> host copies per epoch
+ * of GripNet-pose.py:148-160,188-199 / gripnet/utils.py:28-35).  pos_score / neg_score hold E scores
+ * each, segmented by the same range_list ([R,2] on the host).  out is [3, R] float64 on the device:
+ * row 0 area under the precision-recall curve (trapezoid, with the point recall 0 / precision 1),
+ * row 1 ROC AUC, row 2 average precision, per relation, with scikit-learn's treatment of tied scores;
+ * NaN for a relation without edges.  Synchronises `stream` once. */
+GN_API size_t gn_link_metrics_workspace_bytes(int64_t num_relations, int64_t num_edges);
+GN_API gn_status gn_link_metrics_f32(const float* pos_score, const float* neg_score, const int64_t* range_list_host,
+                              int64_t num_relations, int64_t num_edges, double* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -436,3 +436,29 @@ def test_device_negative_sampling(gpu):
         assert counts.min() > 250 and counts.max() < 560                  # mean 400, sigma 20
     with pytest.raises(IndexError):
         device_negative_sampler(torch.tensor([[0, 41], [1, 2]], device=gpu), n)
+
+
+# ---- per-relation metrics on the device -------------------------------------------------
+def test_relation_metrics_match_sklearn(gpu):
+    """AUPRC / AUROC / AP of every relation block at once against scikit-learn called per block, the way
+    GripNet-pose.py:148-160 does it; heavy ties, a tiny block, an empty block."""
+    from gripnet_amd.utils import auprc_auroc_ap, relation_metrics
+    gen = torch.Generator().manual_seed(83)
+    sizes = [400, 3, 0, 2500, 1, 90]
+    rl = gripnet_amd.utils.get_range_list([torch.zeros(2, s) for s in sizes])
+    E = sum(sizes)
+    pos = torch.sigmoid(torch.randn(E, generator=gen) + 0.7)
+    neg = torch.sigmoid(torch.randn(E, generator=gen) - 0.3)
+    pos[:300] = torch.round(pos[:300] * 8) / 8                       # many tied scores inside relation 0
+    neg[:300] = torch.round(neg[:300] * 8) / 8
+    auprc, auroc, ap = relation_metrics(pos.to(gpu), neg.to(gpu), rl)
+    for r, (s, e) in enumerate(rl.tolist()):
+        if e == s:
+            assert torch.isnan(auprc[r]) and torch.isnan(auroc[r]) and torch.isnan(ap[r])
+            continue
+        score = torch.cat([pos[s:e], neg[s:e]])
+        target = torch.cat([torch.ones(e - s), torch.zeros(e - s)])
+        ref = auprc_auroc_ap(target, score)
+        got = (float(auprc[r]), float(auroc[r]), float(ap[r]))
+        for a, b, name in zip(got, ref, ("auprc", "auroc", "ap")):
+            assert abs(a - b) <= 1e-9, "relation {} {}: {} vs sklearn {}".format(r, name, a, b)
