@@ -462,3 +462,72 @@ def test_relation_metrics_match_sklearn(gpu):
         got = (float(auprc[r]), float(auroc[r]), float(ap[r]))
         for a, b, name in zip(got, ref, ("auprc", "auroc", "ap")):
             assert abs(a - b) <= 1e-9, "relation {} {}: {} vs sklearn {}".format(r, name, a, b)
+
+
+# ---- BASELINE.json configs 2 and 4 at scale: the NC suite, large supervertices, wide features --------------
+def test_aminer_syn_vs_oracle(gpu):
+    """aminer-style model at the `aminer-syn` scale with the reference's own layer widths
+    (GripNet-aminer.py:96-98: [128,64,64] / [64,64] / [128,128,32], 8 classes): 50,000 / 20,000 nodes per
+    supervertex, so nothing is LDS-resident and the wide-row specialisations of the gather run."""
+    from gripnet_amd.synth import make_nc
+    data = make_nc("aminer-syn")
+    torch.manual_seed(1111)
+    model = AminerModel(data.n_p_node, data.n_a_node, data.n_a_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    nodes = torch.arange(0, data.n_a_node, 3)
+    ref = orc.aminer_forward(sd, data.pp_edge_idx, data.pp_edge_weight, data.pa_edge_idx, data.aa_edge_idx,
+                             data.aa_edge_weight, nodes)
+    model = model.to(gpu)
+    with torch.no_grad():
+        z, pred = model(make_nc("aminer-syn").to(gpu), nodes.to(gpu))
+    close(z, ref["z"], TOL)
+    close(pred, ref["score"], TOL)
+
+
+def test_freebase_c_syn_vs_oracle(gpu):
+    """freebase-c/d-style model (three supervertices, two external layers in `add` mode merged with the
+    target embeddings, GripNet-freebase-c.py:102-105,150-165) at the same scale."""
+    from gripnet_amd.synth import make_nc
+    data = make_nc("aminer-syn")
+    torch.manual_seed(1111)
+    model = FreebaseCModel(data.n_p_node, data.n_q_node, data.n_a_node, data.n_a_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    nodes = torch.arange(1, data.n_a_node, 3)
+    ref = orc.freebase_c_forward(sd, data.pp_edge_idx, data.pp_edge_weight, data.pa_edge_idx, data.qq_edge_idx,
+                                 data.qq_edge_weight, data.qa_edge_idx, sd["aa_embeddings"], data.aa_edge_idx,
+                                 data.aa_edge_weight, nodes, data.n_a_node)
+    model = model.to(gpu)
+    with torch.no_grad():
+        z, pred = model(make_nc("aminer-syn").to(gpu), nodes.to(gpu))
+    close(z, ref["z"], TOL)
+    close(pred, ref["score"], TOL)
+
+
+def test_rgcn_improved_baseline_caller(gpu):
+    """The reference's second caller of myRGCN + the DistMult decoder (baselines/LP_baselines/rgcn_pose.py:53-106:
+    embedding -> myRGCN x2 -> decoder on a homogenised graph of ~10^4 nodes): too many nodes for the
+    LDS-resident path, so the general relational kernel and the general decoder carry it."""
+    gen = torch.Generator().manual_seed(97)
+    n, R, B = 6000, 12, 16
+    sizes = [int(s) for s in torch.randint(200, 4000, (R,), generator=gen)]
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    ei = torch.cat([torch.cat([b, b.flip(0)], dim=1) for b in blocks], dim=1)
+    rl = gripnet_amd.utils.get_range_list([torch.zeros(2, 2 * s) for s in sizes])
+    et = torch.cat([torch.full((2 * s,), r, dtype=torch.long) for r, s in enumerate(sizes)])
+    torch.manual_seed(101)
+    emb = torch.randn(n, 64)
+    c1 = gripnet_amd.myRGCN(64, 32, R, B, after_relu=False)
+    c2 = gripnet_amd.myRGCN(32, 32, R, B, after_relu=True)
+    dm = gripnet_amd.multiRelaInnerProductDecoder(32, R)
+    sd1 = {k: v.detach().clone() for k, v in c1.state_dict().items()}
+    sd2 = {k: v.detach().clone() for k, v in c2.state_dict().items()}
+    h = torch.relu(orc.rgcn_forward(emb, ei, rl, sd1["basis"], sd1["att"], sd1["root"]))
+    zr = orc.rgcn_forward(h, ei, rl, sd2["basis"], sd2["att"], sd2["root"])
+    ref = orc.distmult(zr, ei, et, dm.weight.detach())
+    c1, c2, dm = c1.to(gpu), c2.to(gpu), dm.to(gpu)
+    with torch.no_grad():
+        hg = c1(emb.to(gpu), ei.to(gpu), et.to(gpu), rl, _relu=True)
+        zg = c2(hg, ei.to(gpu), et.to(gpu), rl)
+        score = dm(zg, ei.to(gpu), et.to(gpu))
+    close(zg, zr, TOL)
+    close(score, ref, TOL)
