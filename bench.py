@@ -165,7 +165,7 @@ def main():
     achieved = stage_bytes[dom] / (dom_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if world == 1 and os.path.exists(tpath):      # PMC-measured HBM bytes of the same launch (profiles/, N = 1)
         try:
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
         except Exception:
