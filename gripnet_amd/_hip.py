@@ -33,7 +33,8 @@ SIGNATURES = {
     "gn_graph_plan_input_edges": (_i64, [_p]),
     "gn_graph_plan_nnz": (_i64, [_p]),
     "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
-    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
+    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p, _p]),
+    "gn_transform_fusable": (_int, [_i64, _i64]),
     "gn_graph_plan_build_transpose": (_int, [_p, _p]),
     "gn_graph_aggregate_t_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
@@ -104,7 +105,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype, fn.argtypes = res, args
-            if lib.gn_version() < 101:
+            if lib.gn_version() < 102:
                 raise RuntimeError("gripnet_amd: libgripnet_hip.so is older than this package")
             _lib = lib
     return _lib
@@ -208,6 +209,11 @@ def edge_rows(edge_index: torch.Tensor):
     return ei, base, base + 8 * e, e
 
 
+def transform_fusable(fin: int, fout: int, x: torch.Tensor) -> bool:
+    """True when gn_graph_aggregate_f32 can contract with W in its epilogue for this input."""
+    return bool(load().gn_transform_fusable(int(fin), int(fout))) and ld(x) % 4 == 0 and x.data_ptr() % 16 == 0
+
+
 def e_count(edge_index):
     return int(edge_index.shape[1])
 
@@ -309,9 +315,11 @@ class GraphPlan:
     def __iter__(self):          # lets `edge_index, norm = conv.cached_result` keep working
         return iter(self.export())
 
-    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None):
+    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None):
+        """out = act(A_norm xw + b), or with `weight` act((A_norm xw) weight + b) (xw is then the layer input)."""
         sc = side_copy(side)
-        _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(bias), int(bool(relu)),
+        _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
+              0 if weight is None else weight.shape[1], ptr(bias), int(bool(relu)),
               ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
         return out
 

@@ -103,6 +103,97 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     }
 }
 
+// ---- aggregate, then transform: out[i, :] = act( (sum_p coef[p] * X[col[p], :]) @ W + bias ) ----------------
+// A_norm (X W) = (A_norm X) W, so the dense contraction of a GCN-style layer (gripnet/layers.py:73) can run
+// on the aggregated row instead of on every node beforehand: no X W launch, no [N, out] round trip through
+// HBM.  The gather is bound by the number of L2 requests (one per neighbour row), not by their size, so
+// gathering the wider input row costs about the same.  FIN = 4 LPE input features (one float4 per lane of
+// the neighbour's group), FOUT in {16, 32}.  Epilogue: after the butterfly fold every lane holds the
+// aggregated features 4j..4j+3 of its j; lane (c = lane % FOUT, kq = lane / FOUT) multiplies KPL = FIN * FOUT / 64
+// of them (fetched with shuffles) by its register-resident slice W[kq*KPL .. , c] and the 64 / FOUT partial
+// sums are folded with two more shuffles.
+template <int LPE, int FOUT>
+__global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const float* __restrict__ w) {
+    constexpr int FIN = 4 * LPE, S = kWave / LPE, G = kWave / FOUT, KPL = FIN / G;
+    static_assert(KPL % 4 == 0, "K slice per lane must cover whole float4 groups");
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / LPE, j = lane % LPE;
+    const int c = lane % FOUT, kq = lane / FOUT;
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    float wreg[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) wreg[i] = w[(kq * KPL + i) * FOUT + c];
+    const float bias = a.bias ? a.bias[c] : 0.f;
+
+    if (a.side.dst) {                                          // concat slot: streamed up front by the whole grid
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + cc];
+            a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+    for (int row = wave; row < a.rows; row += n_waves) {
+        const int begin = a.rowptr[row], end = a.rowptr[row + 1];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = begin; base < end; base += kWave) {
+            const int mine = base + lane;
+            const uint32_t cl = mine < end ? a.col[mine] : 0u;
+            const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+            const int cnt = min(kWave, end - base);
+            for (int it = 0; it * S < cnt; ++it) {
+                const int idx = it * S + slot;
+                const uint32_t cc = (uint32_t)__shfl((int)cl, idx);
+                const float vv = __shfl(v, idx);
+                if (idx < cnt) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.table + (int64_t)cc * a.ld_table + 4 * j);
+                    acc[0] += vv * t.x; acc[1] += vv * t.y; acc[2] += vv * t.z; acc[3] += vv * t.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LPE; off < kWave; off <<= 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], off);
+        }
+        // every lane now holds aggregated features 4j .. 4j+3; contract with W
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) part += __shfl(acc[i % 4], kq * (KPL / 4) + i / 4) * wreg[i];
+#pragma unroll
+        for (int off = FOUT; off < kWave; off <<= 1) part += __shfl_xor(part, off);
+        if (kq == 0) {
+            float val = part + bias;
+            if (a.relu) val = fmaxf(val, 0.f);
+            a.out[(int64_t)row * a.ld_out + c] = val;
+        }
+    }
+}
+
+// FIN in {16, 32, 64}, FOUT in {16, 32} with at least 4 input features per lane slice
+inline bool transform_fusable(int64_t fin, int64_t fout) {
+    if (fast_paths_disabled()) return false;
+    if (!(fin == 16 || fin == 32 || fin == 64) || !(fout == 16 || fout == 32)) return false;
+    return (fin * fout / 64) % 4 == 0;
+}
+
+inline gn_status launch_aggregate_transform(const AggArgs& a, const float* w, int fout, hipStream_t st) {
+    if (a.rows == 0) return GN_OK;
+    const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), 256 * 8);
+    const int key = a.features * 100 + fout;
+    switch (key) {
+        case 1616: k_aggregate_transform<4, 16><<<grid, 256, 0, st>>>(a, w); break;
+        case 3216: k_aggregate_transform<8, 16><<<grid, 256, 0, st>>>(a, w); break;
+        case 6416: k_aggregate_transform<16, 16><<<grid, 256, 0, st>>>(a, w); break;
+        case 3232: k_aggregate_transform<8, 32><<<grid, 256, 0, st>>>(a, w); break;
+        case 6432: k_aggregate_transform<16, 32><<<grid, 256, 0, st>>>(a, w); break;
+        default: return fail(GN_ERR_UNSUPPORTED, "no fused transform for %d -> %d features", a.features, fout);
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int VEC>

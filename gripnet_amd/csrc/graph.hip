@@ -3,13 +3,15 @@
 #include "aggregate.cuh"
 
 extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw,
-                                            int64_t num_features, const float* bias, int relu, float* out,
-                                            int64_t ld_out, const gn_side_copy* side, void* stream) {
+                                            int64_t num_features, const float* weight, int64_t out_features,
+                                            const float* bias, int relu, float* out, int64_t ld_out,
+                                            const gn_side_copy* side, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(num_features >= 0 && num_features < (1ll << 31), "bad feature count");
     if (plan->rows == 0 || num_features == 0) return GN_OK;
     GN_REQUIRE(xw && out, "feature pointers are null");
-    GN_REQUIRE(ld_xw >= num_features && ld_out >= num_features, "leading dimension smaller than the row length");
+    const int64_t width = weight ? out_features : num_features;
+    GN_REQUIRE(ld_xw >= num_features && ld_out >= width, "leading dimension smaller than the row length");
     gn::AggArgs a;
     a.rowptr = plan->rowptr.p;
     a.col = reinterpret_cast<const uint32_t*>(plan->col.p);
@@ -27,6 +29,12 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.rows = (int)plan->rows;
     gn_status ss = gn::check_side(side, plan->rows, &a.side);
     if (ss != GN_OK) return ss;
+    if (weight) {            // aggregate the input rows, then contract with W in the epilogue
+        if (!gn::transform_fusable(num_features, out_features) || (ld_xw % 4) != 0 || !gn::aligned16(xw))
+            return gn::fail(GN_ERR_UNSUPPORTED, "no fused transform for %lld -> %lld features (or unaligned rows)",
+                            (long long)num_features, (long long)out_features);
+        return gn::launch_aggregate_transform(a, weight, (int)out_features, gn::as_stream(stream));
+    }
     return gn::launch_aggregate(a, gn::as_stream(stream));
 }
 
@@ -56,4 +64,8 @@ extern "C" gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const f
     a.ld_out = ld_out;
     a.rows = (int)plan->table_rows;
     return gn::launch_aggregate(a, gn::as_stream(stream));
+}
+
+extern "C" int gn_transform_fusable(int64_t in_features, int64_t out_features) {
+    return gn::transform_fusable(in_features, out_features) ? 1 : 0;
 }

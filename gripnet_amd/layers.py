@@ -81,10 +81,13 @@ class myGCN(Module):
                 raise RuntimeError("slot-fused outputs are an inference path; autograd builds its own concat")
             return y
         x = _hip.f32_rows(x)
-        xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
-        _hip.gemm(x, self.weight, xw)                                            # layers.py:73
         if out is None:
             out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
+        if _hip.transform_fusable(self.in_channels, self.out_channels, x) and self.weight.is_contiguous():
+            # A_norm (x W) = (A_norm x) W: the contraction of layers.py:73 runs on the aggregated row
+            return plan.aggregate(x, self.bias, relu, out, side, weight=self.weight)
+        xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
+        _hip.gemm(x, self.weight, xw)                                            # layers.py:73
         return plan.aggregate(xw, self.bias, relu, out, side)                    # layers.py:92-100
 
     def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None):

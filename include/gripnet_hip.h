@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 101 /* 0.1.1 */
+#define GN_VERSION 102 /* 0.1.2 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -99,8 +99,15 @@ GN_API gn_status gn_graph_plan_export(const gn_graph_plan* plan, int64_t* edge_i
  * as the reference does (layers.py:73).  bias may be NULL.  `out` may be a column slice of a
  * wider matrix (ld_out), which is how the concat of layers.py:309,376 is written in place. */
 GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw, int64_t num_features,
+                                 const float* weight /* nullable */, int64_t out_features,
                                  const float* bias, int relu, float* out, int64_t ld_out,
                                  const gn_side_copy* side /* nullable */, void* stream);
+/* With weight != NULL ([num_features, out_features], row-major, contiguous) the table is the layer INPUT x
+ * and the call computes act( (A_norm x) W + bias ) = act( A_norm (x W) + bias ): the contraction of
+ * layers.py:73 runs on the aggregated row, so no x W launch is needed.  Supported for num_features in
+ * {16,32,64} and out_features in {16,32} (GN_ERR_UNSUPPORTED otherwise: call gn_gemm_f32 first).
+ * gn_transform_fusable tells without launching. */
+GN_API int gn_transform_fusable(int64_t in_features, int64_t out_features);
 
 /* Backward pass of the GCN-style layers (autograd of GripNet-pose.py:140-146 through layers.py:92-100).
  * gn_graph_plan_build_transpose adds the source-major CSR of the same coefficients to a plan (once;
