@@ -352,28 +352,35 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_t(WtArgs g) {
     // All loads are unconditional (clamped indices, zeroed by select afterwards): a conditional load
     // would be waited for one by one instead of being batched ahead of the MFMA chain.
     const int arow_c = min(arow, g.relations - 1);
-    for (int b0 = 0; b0 < g.bases; b0 += 16) {
-        float av[4], bv[kWtK][4];
+    // two K steps (32 bases) per trip: all of their loads are in flight before the first MFMA
+    for (int b0 = 0; b0 < g.bases; b0 += 32) {
+        float av[2][4], bv[2][kWtK][4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int b = b0 + 4 * q + jj, bc = min(b, g.bases - 1);
-            av[jj] = g.att[(int64_t)arow_c * g.bases + bc];
-            const float* __restrict__ bp = g.basis + ((int64_t)bc * g.fin + k0) * g.fout + col0 + c16;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int t = 0; t < kWtK; ++t) bv[t][jj] = bp[t * g.fout];
-        }
+            for (int jj = 0; jj < 4; ++jj) {
+                const int b = b0 + 16 * h + 4 * q + jj, bc = min(b, g.bases - 1);
+                av[h][jj] = g.att[(int64_t)arow_c * g.bases + bc];
+                const float* __restrict__ bp = g.basis + ((int64_t)bc * g.fin + k0) * g.fout + col0 + c16;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const bool live = (b0 + 4 * q + jj) < g.bases;
-            av[jj] = (live && arow < g.relations) ? av[jj] : 0.f;
+                for (int t = 0; t < kWtK; ++t) bv[h][t][jj] = bp[t * g.fout];
+            }
 #pragma unroll
-            for (int t = 0; t < kWtK; ++t) bv[t][jj] = live ? bv[t][jj] : 0.f;
-        }
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int t = 0; t < kWtK; ++t)
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool live = (b0 + 16 * h + 4 * q + jj) < g.bases;
+                av[h][jj] = (live && arow < g.relations) ? av[h][jj] : 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[t][jj], acc[t], 0, 0, 0);
+                for (int t = 0; t < kWtK; ++t) bv[h][t][jj] = live ? bv[h][t][jj] : 0.f;
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < kWtK; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][jj], bv[h][t][jj], acc[t], 0, 0, 0);
     }
     // lane (c16, q), element i: W[row0 + 4q + i][k0 + t][col0 + c16], t = 0..kWtK-1
 #pragma unroll

@@ -531,3 +531,35 @@ def test_rgcn_improved_baseline_caller(gpu):
         score = dm(zg, ei.to(gpu), et.to(gpu))
     close(zg, zr, TOL)
     close(score, ref, TOL)
+
+
+def test_sharded_forward_on_hip_kernels(gpu):
+    """gripnet_amd.sharded with the product kernels: world_size 1 end to end, and the two ranks of a
+    world_size-2 job run one after the other on this device with the all-reduce done by hand
+    (the RCCL call itself is covered by bench.py --gpus N; its gloo twin by tests/test_sharded_gloo.py)."""
+    from gripnet_amd.sharded import ShardedPoseForward
+    data = make_pose("small").to(gpu)
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    with torch.no_grad():
+        z_ref, score_ref = model(data)
+        z1, s1 = ShardedPoseForward(model, data, 0, 1)()
+        close(z1, z_ref)
+        close(s1, score_ref)
+        ranks = [ShardedPoseForward(model, data, k, 2) for k in range(2)]
+        x = ranks[0].kernels.encode_genes()
+        parts = []
+        for f in ranks:
+            p = torch.empty(data.n_d_node, 32, device=gpu)
+            f.kernels.partial(x, p)
+            parts.append(p)
+        total = parts[0] + parts[1]                               # what all_reduce(SUM) leaves on every rank
+        scores = []
+        for f in ranks:
+            out = torch.empty(data.n_d_node, 80, device=gpu)
+            f.kernels.finalize(total.clone(), x, out[:, 48:], out[:, :48])
+            close(out, z_ref)
+            scores.append(f.kernels.score(out))
+        assert ranks[0].edge_hi == ranks[1].edge_lo
+        close(torch.cat(scores), score_ref)
+    _hip.raise_if_index_errors(gpu)
