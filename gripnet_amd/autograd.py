@@ -79,7 +79,19 @@ class RgcnConvFn(torch.autograd.Function):
             # dx[s] = sum_{e: src=s} gm[dst_e] W_{r(e)}^T: the same relational layer on the reversed graph
             # with the transposed bases, un-normalised (HIP, general path), plus the root term
             dxe = torch.empty((n, fin), dtype=torch.float32, device=x.device)
-            rev.forward(gm, basis.detach().transpose(1, 2).contiguous(), att.detach(), None, None, False, dxe, partial=True)
+            bt = basis.detach().transpose(1, 2)                                  # [B, fout, fin]: W_r^T = sum_b att[r,b] bt[b]
+            if fout == 32 and fin % 32 != 0 and fin > 32:
+                # the LDS-resident kernel produces 32 output features: run it per 32-column block of W_r^T
+                # (the last block zero-padded) instead of falling back to the HBM-table path
+                for c0 in range(0, fin, 32):
+                    w = min(32, fin - c0)
+                    blk = torch.zeros((B, fout, 32), dtype=torch.float32, device=x.device)
+                    blk[:, :, :w] = bt[:, :, c0:c0 + w]
+                    tmp = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+                    rev.forward(gm, blk, att.detach(), None, None, False, tmp, partial=True)
+                    dxe[:, c0:c0 + w] = tmp[:, :w]
+            else:
+                rev.forward(gm, bt.contiguous(), att.detach(), None, None, False, dxe, partial=True)
             dx = dxe + g @ root.detach().t()
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             # dW_r = X^T Q_r,  Q_r[s] = sum_{e in r, src=s} gm[dst_e]   (HIP gather-reduce, (relation, source) rows)
