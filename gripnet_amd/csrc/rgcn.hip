@@ -15,6 +15,11 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
                                const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
                                const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
+bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed);
+gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, const float* x, int64_t ld_x, int64_t fin,
+                                const float* root, const float* bias, int relu, float* out, int64_t ld_out,
+                                const gn_side_copy& side, hipStream_t st);
+
 namespace {
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -139,6 +144,8 @@ gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* summed, in
     gn_side_copy sc;
     gn_status ss = gn::check_side(side, N, &sc);
     if (ss != GN_OK) return ss;
+    if (gn_rgcn_fast_finalize_applicable(fin, fout, ld_summed, summed))
+        return gn_rgcn_fast_finalize(plan, summed, x, ld_x, fin, root, bias, relu, out, ld_out, sc, gn::as_stream(stream));
     gn_status s = gn_gemm_f32(x, ld_x, 0, nullptr, 0, root, fout, 0, out, ld_out, 0, N, fout, fin, 1, bias, 0, stream);
     if (s != GN_OK) return s;
     k_rgcn_finalize<<<gn::stream_grid(N * fout, 256), 256, 0, gn::as_stream(stream)>>>(

@@ -823,6 +823,25 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     return GN_OK;
 }
 
+// Multi-GPU finalisation: the all-reduced [n, 32] sum is one "slab"; mean / root / bias / activation and the
+// concat slot in a single launch (the general path needs a GEMM launch for the root term first).
+bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed) {
+    return !gn::fast_paths_disabled() && fout == kFout && fin >= 1 && fin <= 64 && ld_summed == kFout &&
+           (reinterpret_cast<uintptr_t>(summed) & 15) == 0;
+}
+
+gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, const float* x, int64_t ld_x, int64_t fin,
+                                const float* root, const float* bias, int relu, float* out, int64_t ld_out,
+                                const gn_side_copy& side, hipStream_t st) {
+    FinArgs f;
+    f.slabs = summed; f.groups = 1; f.n = (int)plan->num_nodes; f.indeg = plan->indeg.p; f.x = x; f.ld_x = ld_x;
+    f.fin = (int)fin; f.root = root; f.bias = bias; f.relu = relu; f.partial = 0; f.out = out; f.ld_out = ld_out;
+    f.side = side;
+    k_rgcn_slab_finalize<<<(int)plan->num_nodes, 256, 0, st>>>(f);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 bool gn_rgcn_fast_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     if (!plan->fast_ok || gn::fast_paths_disabled()) return false;
     return fout == kFout && (fin == 16 || fin == 32 || fin == 48 || fin == 64) && bases >= 1;
