@@ -127,5 +127,6 @@ struct gn_rgcn_plan {
     int64_t n_seg = 0;
     int fast_groups = 0, fast_ts = 0, fast_ts_pad = 0;
     size_t fast_lds_bytes = 0;
+    int fast_cols = 32;             // output columns per workgroup of the LDS-resident kernel (32, or 16 = column halves)
     int fast_ok = 0;
 };

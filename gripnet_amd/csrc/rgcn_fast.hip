@@ -36,42 +36,48 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 1024;
-constexpr int kWaves = kThreads / 64;
-constexpr int kFout = 32;                  // the slot layout is built for 8-lane rows (out_features = 32)
-constexpr int kLpr = kFout / 4;            // lanes per feature row (float4 each)
-constexpr int kSlots = 64 / kLpr;          // edges in flight per wave
-constexpr int kNB = kWaves * kSlots;       // destination slots per item
+constexpr int kFout = 32;                  // out_features of the layer this path is built for
+constexpr int kLpr = kFout / 4;            // float4 per full feature row (slab layout, finalisation)
+constexpr int kNB = 128;                   // destination slots per item = edges in flight per workgroup
 constexpr int kGroups = 256;               // persistent workgroups = CUs of an MI355X
 constexpr int kChunk = 4096;               // packed words per work item = LDS edge buffer (16 KB)
 constexpr int kItemEdges = kChunk - 3 * 128; // edges per work item: every slot list is padded to 4 words
-constexpr int kEdgeRegs = kChunk / kThreads;
 constexpr int kItemOverhead = 2048;        // H-tile cost in edge equivalents (LPT balancing)
 constexpr size_t kLdsBudget = 159 * 1024;
+constexpr size_t kLdsHalfBudget = 80 * 1024 - 512;   // two workgroups per CU (allocation granularity left over)
 constexpr int kMaxRowTilesPerWave = 3;
 constexpr uint32_t kEndFlag = 0x80000000u;  // packed word: [31] last edge of its destination run, [30:16] dst, [15:0] src - tile base
 
 struct FastGeom {
     int tiles = 0;      // source tiles
     int ts = 0;         // rows per source tile, a multiple of 16 (MFMA row tile)
+    int cols = 0;       // output columns per workgroup: 32 (one workgroup per CU) or 16 (two, column halves)
     size_t lds_bytes = 0;
 };
 
-constexpr int kDescWin = 64;               // work descriptors cached in LDS (2 KB window)
+constexpr int kDescWin = 32;               // work descriptors cached in LDS (1 KB window)
 
-size_t lds_bytes_for(int64_t n, int64_t ts) {
-    return (size_t)(n + ts) * kFout * sizeof(float) + (size_t)(kChunk + 8) * sizeof(uint32_t) + kDescWin * 32;
+size_t lds_bytes_for(int64_t n, int64_t ts, int cols) {
+    return (size_t)(n + ts) * cols * sizeof(float) + (size_t)(kChunk + 8) * sizeof(uint32_t) + kDescWin * 32;
 }
 
+// Two geometries.  Column halves: a workgroup of 512 threads owns 16 of the 32 output columns (its half of
+// the H tile and of the accumulator), two workgroups share a CU, and while one is in its MFMA phase the
+// other gathers from LDS - the two phases use different units and a single workgroup can only alternate.
+// Needs 2 x LDS <= 160 KB.  Full width (1024 threads, one workgroup per CU) covers the larger node counts.
 FastGeom geometry(int64_t n) {
     FastGeom g;
-    for (int t = 1; t <= 16; ++t) {
-        const int64_t ts = gn::ceil_div(gn::ceil_div(n, t), 16) * 16;
-        if (ts > 16 * kWaves * kMaxRowTilesPerWave) continue;
-        const size_t bytes = lds_bytes_for(n, ts);
-        if (bytes <= kLdsBudget) {
-            g.tiles = (int)gn::ceil_div(n, ts); g.ts = (int)ts; g.lds_bytes = bytes;
-            return g;
+    for (int cols = kFout / 2; cols <= kFout; cols *= 2) {
+        const int waves = kNB / (64 / (cols / 4));
+        const size_t budget = cols == kFout ? kLdsBudget : kLdsHalfBudget;
+        for (int t = 1; t <= 16; ++t) {
+            const int64_t ts = gn::ceil_div(gn::ceil_div(n, t), 16) * 16;
+            if (ts > 16 * waves * kMaxRowTilesPerWave) continue;
+            const size_t bytes = lds_bytes_for(n, ts, cols);
+            if (bytes <= budget) {
+                g.tiles = (int)gn::ceil_div(n, ts); g.ts = (int)ts; g.cols = cols; g.lds_bytes = bytes;
+                return g;
+            }
         }
     }
     return g;
@@ -100,41 +106,51 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Pointer parameters are passed one by one and __restrict__-qualified: the work descriptors are
 // then read with scalar loads, and every prefetch below is unconditional (clamped indices) so that
 // the compiler's vmcnt bookkeeping stays exact and no wait drains more than it needs.
-struct FastDims { int64_t ld_x; int n; int ts; };
+struct FastDims { int64_t ld_x; int n; int ts; int groups; };
 
 #ifdef GN_STAMPS
 // Diagnostic build only (make STAMPS=1): per-workgroup phase times, never part of the product library.
-__device__ unsigned long long g_stamps[kGroups][8];
-__device__ unsigned long long g_wave_stamps[kGroups][kWaves][4];   // per wave: gather, top, trips, mfma
+__device__ unsigned long long g_stamps[2 * kGroups][8];
+__device__ unsigned long long g_wave_stamps[2 * kGroups][16][4];   // per wave: gather, top, trips, mfma
 #define GN_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define GN_STAMP(var)
 #endif
 
-template <int FIN, int RT>
-__global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__ x, const float* __restrict__ wt,
+template <int FIN, int RT, int COLS>
+__global__ __launch_bounds__(32 * COLS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rgcn_lds(const float* __restrict__ x, const float* __restrict__ wt,
                                                         const uint32_t* __restrict__ packed,
                                                         const int32_t* __restrict__ slot_off,
                                                         const WorkDesc* __restrict__ work,
                                                         const int32_t* __restrict__ wg_begin,
                                                         float* __restrict__ slabs, FastDims a) {
     constexpr int KC = FIN / 16;             // 16-deep K chunks
-    constexpr int CT = kFout / 16;           // 16-column tiles
+    constexpr int CT = COLS / 16;            // 16-column tiles of this workgroup's column block
+    constexpr int LPR = COLS / 4;            // lanes per feature row (float4 each)
+    constexpr int SLOTS = 64 / LPR;          // edges in flight per wave
+    constexpr int THREADS = 32 * COLS;       // kNB slots x LPR lanes
+    constexpr int WAVES = THREADS / 64;
+    constexpr int EREGS = kChunk / THREADS;
     extern __shared__ f32x4 lds4[];
-    f32x4* acc4 = lds4;                                          // [n][kLpr]
-    f32x4* h4 = lds4 + (size_t)a.n * kLpr;                       // [ts][kLpr]
+    f32x4* acc4 = lds4;                                          // [n][LPR]
+    f32x4* h4 = lds4 + (size_t)a.n * LPR;                        // [ts][LPR]
     float* hf = reinterpret_cast<float*>(h4);
-    uint32_t* ebuf = reinterpret_cast<uint32_t*>(h4 + (size_t)a.ts * kLpr);   // [kChunk + 8]
+    uint32_t* ebuf = reinterpret_cast<uint32_t*>(h4 + (size_t)a.ts * LPR);    // [kChunk + 8]
     int4* wdesc = reinterpret_cast<int4*>(ebuf + kChunk + 8);                  // [kDescWin][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int slot = lane / kLpr, j = lane % kLpr;
+    const int slot = lane / LPR, j = lane % LPR;
+    // workgroups grp and grp + groups share the work list (and, 256 apart, an XCD's L2 for it)
+    const int grp = blockIdx.x % a.groups, col0 = (blockIdx.x / a.groups) * COLS;
+    // row tiles are dealt to waves in opposite orders by the two column halves: the waves that hold
+    // one row tile more than the rest then sit on different SIMDs of the CU
+    const int wrow = col0 ? WAVES - 1 - wave : wave;
 
-    for (int i = tid; i < a.n * kLpr; i += kThreads) acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < a.n * LPR; i += THREADS) acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (tid < 8) ebuf[kChunk + tid] = 0u;
 
-    int wi = wg_begin[blockIdx.x];
-    const int wend = wg_begin[blockIdx.x + 1];
+    int wi = wg_begin[grp];
+    const int wend = wg_begin[grp + 1];
     f32x4 afrag[RT][KC];                 // X fragments of the current source tile
     f32x4 bfrag[KC][CT];                 // W_rel fragments of the current item
     int a_tile = -1;                     // source tile whose X fragments sit in afrag
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
     auto fill_window = [&](int base) {
         const int cnt = min(kDescWin, wend - base) * 2;
         const int4* __restrict__ src = reinterpret_cast<const int4*>(work + base);
-        for (int i = tid; i < cnt; i += kThreads) wdesc[i] = src[i];
+        for (int i = tid; i < cnt; i += THREADS) wdesc[i] = src[i];
     };
     struct Desc { int rel, tile, start, count, item; };
     auto read_desc = [&](int w) {
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-                b[kc][ct] = *reinterpret_cast<const f32x4*>(wr + (16 * ct + c16) * FIN + 16 * kc);
+                b[kc][ct] = *reinterpret_cast<const f32x4*>(wr + (col0 + 16 * ct + c16) * FIN + 16 * kc);
     };
     if (wi < wend) {
         d = read_desc(wi);
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
             a_tile = d.tile;                             // issued first: the MFMAs wait for these only
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                const int lrow = (wave + r * kWaves) * 16 + c16;
+                const int lrow = (wrow + r * WAVES) * 16 + c16;
                 const int grow = d.tile * a.ts + lrow;
                 const bool valid = lrow < a.ts && grow < a.n;
                 const float* __restrict__ xr = x + (int64_t)(valid ? grow : 0) * a.ld_x + 4 * q;
@@ -204,13 +220,13 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
                 for (int kc = 0; kc < KC; ++kc) afrag[r][kc] = *reinterpret_cast<const f32x4*>(xr + 16 * kc) * keep;
             }
         }
-        uint32_t e[kEdgeRegs];
+        uint32_t e[EREGS];
 #pragma unroll
-        for (int i = 0; i < kEdgeRegs; ++i) {
-            const int idx = tid + i * kThreads;
+        for (int i = 0; i < EREGS; ++i) {
+            const int idx = tid + i * THREADS;
             e[i] = packed[d.start + min(idx, d.count - 1)];      // entries past the item are never read back
         }
-        const int sidx = d.item * kNB + wave * kSlots + slot;
+        const int sidx = d.item * kNB + wave * SLOTS + slot;
         int g4 = (slot_off[sidx] - d.start) >> 2;                // this slot's list, in groups of 4 words
         const int g4end = (slot_off[sidx + 1] - d.start) >> 2;
         f32x4 bnext[KC][CT];
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
             h_rel = d.rel; h_tile = d.tile;
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                const int rt = wave + r * kWaves;
+                const int rt = wrow + r * WAVES;
                 if (rt * 16 < a.ts) {                    // wave-uniform
                     f32x4 acc[CT];
 #pragma unroll
@@ -241,12 +257,12 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) hf[(rt * 16 + 4 * q + i) * kFout + 16 * ct + c16] = acc[ct][i];
+                        for (int i = 0; i < 4; ++i) hf[(rt * 16 + 4 * q + i) * COLS + 16 * ct + c16] = acc[ct][i];
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < kEdgeRegs; ++i) ebuf[tid + i * kThreads] = e[i];
+        for (int i = 0; i < EREGS; ++i) ebuf[tid + i * THREADS] = e[i];
         GN_STAMP(t3);
         lds_barrier();
         GN_STAMP(t4);
@@ -258,34 +274,40 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
         // the accumulator row only there.  The slot is the only owner of its destinations inside
         // an item, so the read-modify-write needs no atomics and the order of adds is fixed.
         const uint4* ebuf4 = reinterpret_cast<const uint4*>(ebuf);
-        auto row = [&](uint32_t w) { return h4[(w & 0xffffu) * kLpr + j]; };
+        const f32x4* hrow = h4 + j;                       // this lane's float4 of an H row / accumulator row
+        f32x4* arow = acc4 + j;
+        auto src_of = [](uint32_t w) { return __builtin_amdgcn_ubfe(w, 0, 16) * LPR; };
+        auto dst_of = [](uint32_t w) { return __builtin_amdgcn_ubfe(w, 16, 15) * LPR; };
+        // sum_k = sum_{k-1} * keep_{k-1} + H[src_k], keep = 0 after the last edge of a run: the run sum restarts
+        // inside the FMA instead of with a reset under a branch (x * 1 + y and x * 0 + y are exact).
         f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float keep = 0.f;
         uint4 W = ebuf4[min(g4, kChunk / 4)];
         while (__any(g4 < g4end)) {
             const uint4 Wn = ebuf4[min(g4 + 1, kChunk / 4)];          // next group, in flight during the adds
-            const f32x4 r0 = row(W.x), r1 = row(W.y), r2 = row(W.z), r3 = row(W.w);
             if (g4 < g4end) {
-                // accumulator rows of the runs that end in this group: read now, with the H rows,
-                // so that the adds below wait for LDS once per group instead of once per run
-                const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
-                const int i0 = ((W.x >> 16) & 0x7fffu) * kLpr + j, i1 = ((W.y >> 16) & 0x7fffu) * kLpr + j;
-                const int i2 = ((W.z >> 16) & 0x7fffu) * kLpr + j, i3 = ((W.w >> 16) & 0x7fffu) * kLpr + j;
-                if (W.x & kEndFlag) a0 = acc4[i0];
-                if (W.y & kEndFlag) a1 = acc4[i1];
-                if (W.z & kEndFlag) a2 = acc4[i2];
-                if (W.w & kEndFlag) a3 = acc4[i3];
-#define GN_EDGE(wk, rk, ak, ik)                                           \
-                sum += rk;                                                \
-                if (wk & kEndFlag) {                                      \
-                    acc4[ik] = ak + sum;                                  \
-                    sum = zero4;                                          \
-                }
-                GN_EDGE(W.x, r0, a0, i0)
-                GN_EDGE(W.y, r1, a1, i1)
-                GN_EDGE(W.z, r2, a2, i2)
-                GN_EDGE(W.w, r3, a3, i3)
-#undef GN_EDGE
+                const f32x4 r0 = hrow[src_of(W.x)], r1 = hrow[src_of(W.y)], r2 = hrow[src_of(W.z)], r3 = hrow[src_of(W.w)];
+                // accumulator rows of the runs that end in this group: read now, with the H rows, so that the
+                // adds below wait for LDS once per group instead of once per run (left undefined otherwise:
+                // they are only consumed under the same flag)
+                const bool e0 = (int32_t)W.x < 0, e1 = (int32_t)W.y < 0, e2 = (int32_t)W.z < 0, e3 = (int32_t)W.w < 0;
+                const int i0 = dst_of(W.x), i1 = dst_of(W.y), i2 = dst_of(W.z), i3 = dst_of(W.w);
+                f32x4 a0, a1, a2, a3;
+                asm volatile("" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3));   // defined-as-anything, no zeroing moves
+                if (e0) a0 = arow[i0];
+                if (e1) a1 = arow[i1];
+                if (e2) a2 = arow[i2];
+                if (e3) a3 = arow[i3];
+                const f32x4 s0 = sum * keep + r0;
+                if (e0) arow[i0] = a0 + s0;
+                const f32x4 s1 = s0 * (e0 ? 0.f : 1.f) + r1;
+                if (e1) arow[i1] = a1 + s1;
+                const f32x4 s2 = s1 * (e1 ? 0.f : 1.f) + r2;
+                if (e2) arow[i2] = a2 + s2;
+                const f32x4 s3 = s2 * (e2 ? 0.f : 1.f) + r3;
+                if (e3) arow[i3] = a3 + s3;
+                sum = s3;
+                keep = e3 ? 0.f : 1.f;
             }
             W = Wn;
             ++g4;
@@ -319,9 +341,9 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_lds(const float* __restrict__
 #endif
     __syncthreads();
     // slabs are destination-major, [n][groups][FOUT]: the reduction reads one contiguous run per row
-    f32x4* slab = reinterpret_cast<f32x4*>(slabs) + (size_t)blockIdx.x * kLpr;
-    for (int i = tid; i < a.n * kLpr; i += kThreads)
-        slab[(size_t)(i / kLpr) * gridDim.x * kLpr + (i % kLpr)] = acc4[i];
+    f32x4* slab = reinterpret_cast<f32x4*>(slabs) + (size_t)grp * kLpr + col0 / 4;
+    for (int i = tid; i < a.n * LPR; i += THREADS)
+        slab[(size_t)(i / LPR) * a.groups * kLpr + (i % LPR)] = acc4[i];
 }
 
 // Wt[r][col * fin + k] = sum_b att[r, b] * basis[b, k, col]       (layers.py:172-173, transposed)
@@ -623,28 +645,35 @@ gn_status sort_keys(Scratch& tmp, const uint64_t* kin, uint64_t* kout, size_t n,
     return GN_OK;
 }
 
-template <int FIN, int RT>
+template <int FIN, int RT, int COLS>
 gn_status launch_main(const FastArgs& a, int groups, size_t lds_bytes, hipStream_t st) {
     static thread_local bool configured = false;
     if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgcn_lds<FIN, RT>),
+        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgcn_lds<FIN, RT, COLS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
     FastDims dm;
-    dm.ld_x = a.ld_x; dm.n = a.n; dm.ts = a.ts;
-    k_rgcn_lds<FIN, RT><<<groups, kThreads, lds_bytes, st>>>(a.x, a.wt, a.packed, a.slot_off, a.work, a.wg_begin, a.slabs, dm);
+    dm.ld_x = a.ld_x; dm.n = a.n; dm.ts = a.ts; dm.groups = groups;
+    k_rgcn_lds<FIN, RT, COLS><<<groups * (kFout / COLS), 32 * COLS, lds_bytes, st>>>(a.x, a.wt, a.packed, a.slot_off, a.work,
+                                                                                    a.wg_begin, a.slabs, dm);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
 
-template <int FIN>
-gn_status launch_main_rt(const FastArgs& a, int rt, int groups, size_t lds_bytes, hipStream_t st) {
-    switch (rt) {
-        case 1: return launch_main<FIN, 1>(a, groups, lds_bytes, st);
-        case 2: return launch_main<FIN, 2>(a, groups, lds_bytes, st);
-        default: return launch_main<FIN, 3>(a, groups, lds_bytes, st);
+template <int FIN, int COLS>
+gn_status launch_main_rt(const FastArgs& a, int groups, size_t lds_bytes, hipStream_t st) {
+    switch ((int)gn::ceil_div(a.ts / 16, COLS / 2)) {          // row tiles per wave; COLS / 2 waves
+        case 1: return launch_main<FIN, 1, COLS>(a, groups, lds_bytes, st);
+        case 2: return launch_main<FIN, 2, COLS>(a, groups, lds_bytes, st);
+        default: return launch_main<FIN, 3, COLS>(a, groups, lds_bytes, st);
     }
+}
+
+template <int FIN>
+gn_status launch_main_cols(const FastArgs& a, int cols, int groups, size_t lds_bytes, hipStream_t st) {
+    return cols == kFout ? launch_main_rt<FIN, kFout>(a, groups, lds_bytes, st)
+                         : launch_main_rt<FIN, kFout / 2>(a, groups, lds_bytes, st);
 }
 
 }  // namespace
@@ -819,6 +848,7 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     plan->fast_ts = g.ts;
     plan->fast_ts_pad = g.ts;
     plan->fast_lds_bytes = g.lds_bytes;
+    plan->fast_cols = g.cols;
     plan->fast_ok = 1;
     return GN_OK;
 }
@@ -874,13 +904,12 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     a.work = reinterpret_cast<const WorkDesc*>(plan->wg_items.p); a.wg_begin = plan->wg_begin.p;
     a.ts = plan->fast_ts; a.slabs = slabs;
     const int groups = plan->fast_groups;
-    const int rt = (int)gn::ceil_div(plan->fast_ts / 16, kWaves);
     gn_status s;
     switch (fin) {
-        case 16: s = launch_main_rt<16>(a, rt, groups, plan->fast_lds_bytes, st); break;
-        case 32: s = launch_main_rt<32>(a, rt, groups, plan->fast_lds_bytes, st); break;
-        case 48: s = launch_main_rt<48>(a, rt, groups, plan->fast_lds_bytes, st); break;
-        default: s = launch_main_rt<64>(a, rt, groups, plan->fast_lds_bytes, st); break;
+        case 16: s = launch_main_cols<16>(a, plan->fast_cols, groups, plan->fast_lds_bytes, st); break;
+        case 32: s = launch_main_cols<32>(a, plan->fast_cols, groups, plan->fast_lds_bytes, st); break;
+        case 48: s = launch_main_cols<48>(a, plan->fast_cols, groups, plan->fast_lds_bytes, st); break;
+        default: s = launch_main_cols<64>(a, plan->fast_cols, groups, plan->fast_lds_bytes, st); break;
     }
     if (s != GN_OK) return s;
     FinArgs f;
@@ -894,9 +923,9 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
 
 #ifdef GN_STAMPS
 extern "C" __attribute__((visibility("default"))) int gn_debug_read_stamps(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * kGroups * 8);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2 * kGroups * 8);
 }
 extern "C" __attribute__((visibility("default"))) int gn_debug_read_wave_stamps(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * kGroups * kWaves * 4);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 2 * kGroups * 16 * 4);
 }
 #endif

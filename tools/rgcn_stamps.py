@@ -39,7 +39,7 @@ def main():
             conv(x, data.train_idx, data.train_et, data.train_range, _out=out, _relu=True)
     torch.cuda.synchronize()
     lib = _hip.load()
-    buf = np.zeros((256, 8), dtype=np.uint64)
+    buf = np.zeros((512, 8), dtype=np.uint64)
     lib.gn_debug_read_stamps.argtypes = [C.c_void_p]
     rc = lib.gn_debug_read_stamps(buf.ctypes.data)
     assert rc == 0, rc
@@ -51,7 +51,7 @@ def main():
         print("{:18s} mean {:9.0f} cyc/wg  ({:5.1f} %)   per item {:7.0f}   min {:8.0f} max {:8.0f}".format(
             n, b[:, k].mean(), 100 * b[:, k].sum() / tot.sum(), b[:, k].sum() / b[:, 5].sum(), b[:, k].min(), b[:, k].max()))
     print("stamped loop cycles per wg: min {:.0f} mean {:.0f} max {:.0f}".format(tot.min(), tot.mean(), tot.max()))
-    wb = np.zeros((256, 16, 4), dtype=np.uint64)
+    wb = np.zeros((512, 16, 4), dtype=np.uint64)
     lib.gn_debug_read_wave_stamps.argtypes = [C.c_void_p]
     assert lib.gn_debug_read_wave_stamps(wb.ctypes.data) == 0
     w = wb.astype(np.float64)
