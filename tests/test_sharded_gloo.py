@@ -83,7 +83,10 @@ def _worker(rank, world, port, q):
             parts[0] = score
             for r in range(1, world):
                 dist.recv(parts[r], src=r)
-            q.put((z, [t for t in zs], torch.cat(parts), sd, lo, hi))
+            # numpy arrays travel by value: a tensor would travel as a shared-memory handle that dies
+            # with this process if the parent has not mapped it yet
+            q.put((z.numpy(), [t.numpy() for t in zs], torch.cat(parts).numpy(),
+                   {k: v.numpy() for k, v in sd.items()}, lo, hi))
         else:
             dist.send(score.contiguous(), dst=0)
     finally:
@@ -108,6 +111,8 @@ def test_two_rank_sharded_forward_equals_single_process():
     for p in procs:
         p.start()
     z, zs, score, sd, lo, hi = q.get(timeout=240)
+    z, zs, score = torch.from_numpy(z), [torch.from_numpy(t) for t in zs], torch.from_numpy(score)
+    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
