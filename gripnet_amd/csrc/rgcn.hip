@@ -15,6 +15,14 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
                                const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
                                const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
+// rgcn_acc.hip
+bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
+                              const float* basis, const float* att, int64_t bases, const float* root,
+                              const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
+                              const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
+
 bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed);
 gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, const float* x, int64_t ld_x, int64_t fin,
                                 const float* root, const float* bias, int relu, float* out, int64_t ld_out,
@@ -64,6 +72,7 @@ extern "C" {
 
 size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     if (!plan || fin <= 0 || fout <= 0) return 0;
+    if (gn_rgcn_acc_applicable(plan, fin, fout, bases)) return gn_rgcn_acc_workspace_bytes(plan, fin, fout, bases);
     if (gn_rgcn_fast_applicable(plan, fin, fout, bases)) return gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases);
     return general_layout(plan, fin, fout).total;
 }
@@ -85,6 +94,9 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     gn_status ss = gn::check_side(side, N, &sc);
     if (ss != GN_OK) return ss;
 
+    if (gn_rgcn_acc_applicable(plan, fin, fout, bases))
+        return gn_rgcn_acc_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, out,
+                                   ld_out, sc, workspace, workspace_bytes, st);
     if (gn_rgcn_fast_applicable(plan, fin, fout, bases))
         return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, out,
                                     ld_out, sc, workspace, workspace_bytes, st);

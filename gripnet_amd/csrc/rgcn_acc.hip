@@ -1,0 +1,703 @@
+// Multi-relational layer for small supervertices, aggregate-then-transform with the sums kept in the
+// matrix-core accumulators (the drug supervertex of PoSE: n_d = 645 nodes, 48 -> 32 features, ~10^3
+// relations, millions of edges).
+//
+//   out[i] = (sum_r (sum_{e in r, dst=i} x[src_e]) W_r) / max(1, indeg_i) + x[i] root (+ bias)
+//          = (sum_{e: dst=i} x[src_e] W_{r(e)}) / ...                     (gripnet/layers.py:165-197)
+//
+// The node table x ([n, in], 124 KB at 645 x 48) lives in every CU's LDS.  A wave owns kTpg tiles
+// of 16 DESTINATION rows for the whole kernel and walks a list of (relation, row group) units:
+//   (1) gather: lane (row = lane % 16, quarter = lane / 16) adds the quarter's in/4 features of
+//       x[src] for every edge (relation, src -> row) from LDS into registers - the 16 x in matrix
+//       A_r of per-destination sums, already laid out as the A operand of v_mfma_f32_16x16x4_f32
+//       (which k a lane supplies is free as long as the B operand agrees, so a lane holds in/4
+//       consecutive features and reads them with 16-byte LDS loads);
+//   (2) transform: acc[tile] += A_r W_r on the matrix cores; the accumulator registers carry the
+//       sum over relations, so nothing is scattered, nothing is read-modify-written and no barrier
+//       sits between a workgroup's prologue and its epilogue.
+// Edge lists reach the waves as one private, contiguous stream per wave of 128-byte blocks: 4
+// "iterations" x 16 rows of uint16 source ids, rows without an edge in an iteration point at a zero
+// row of the LDS table (no branches, no bounds).  The stream is staged through a 1 KB LDS window per
+// wave, refilled from registers that were loaded a window ahead.
+// Workgroups = row groups x slabs: the 16 waves of a workgroup share a row group and split its
+// units (longest-processing-time at plan time); they fold their accumulators through LDS in wave
+// order, and the per-workgroup slabs are summed in slab order by k_rgcn_slab_finalize: fixed
+// summation order, bitwise reproducible.
+//
+// HBM traffic: 2 bytes per edge slot (the stream) + W_r fragments (L2-resident).  Matrix-core time:
+// 2 n in out flops per relation at the fp32 MFMA rate, i.e. 1.9 GFLOP / 157 TFLOP/s = 12 us on
+// pose0-syn, the floor of this formulation.
+#include "common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+// rgcn_fast.hip
+gn_status gn_rgcn_slab_finalize_launch(const gn_rgcn_plan* plan, const float* slabs, int groups, const float* x,
+                                       int64_t ld_x, int64_t fin, const float* root, const float* bias, int relu,
+                                       int partial, float* out, int64_t ld_out, const gn_side_copy& side, hipStream_t st);
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef GN_ACC_TPG
+#define GN_ACC_TPG 3
+#endif
+#ifndef GN_ACC_WAVES
+#define GN_ACC_WAVES 16
+#endif
+constexpr int kTpg = GN_ACC_TPG;            // 16-row tiles per wave = accumulator tiles kept in registers
+constexpr int kWaves = GN_ACC_WAVES;         // waves per workgroup (one workgroup per CU: the node table fills its LDS)
+constexpr int kThreads = kWaves * 64;
+constexpr int kCus = 256;
+constexpr int kIterCap = 32;       // iterations per unit and tile: longer (relation, row) lists are cut into chunks
+constexpr int kStage = 8;          // stream blocks per LDS window of a wave (1 KB)
+constexpr int kFoutAcc = 32;       // out_features (slab layout of k_rgcn_slab_finalize)
+constexpr size_t kLdsBudget = 159 * 1024;
+// cost model of the plan-time balancing, in cycles of the wave's SIMD
+constexpr int kTileCost = 24 * 32; // 24 MFMAs of 32 cycles per non-empty tile
+constexpr int kBlockCost = 200;    // one stream block: 12 LDS reads + adds, every slot padding
+constexpr int kEdgeCost = 6;       // what a real edge adds (bank conflicts grow with the number of distinct rows read)
+
+// Diagnostic builds only (make MODE=n -> libgripnet_hip_mode<n>.so, never the product library):
+// bit 0 = no MFMA phase, bit 1 = no table gather (the stream is still read), bit 2 = conflict-free gather.
+#ifndef GN_ACC_MODE
+#define GN_ACC_MODE 0
+#endif
+
+#ifdef GN_STAMPS
+// Diagnostic build only (make STAMPS=1): per-wave times, never part of the product library.
+__device__ unsigned long long g_acc_stamps[4096][8];
+#endif
+
+struct alignas(16) AccUnit {
+    int32_t rel;
+    uint8_t blocks[4];             // stream blocks (4 iterations each) of the unit's tiles; 0 = tile has no edge
+    int32_t pad0, pad1;
+};
+static_assert(kTpg <= 4, "AccUnit holds four tile block counts");
+
+struct AccDims { int64_t ld_x; int n; int tiles; int q_groups; int slabs; };
+
+// hi = bf16(v), lo = bf16(v - hi) for two floats at a time; returns the packed pairs (element 0 in the low half).
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+
+// SPLIT = false: the transform runs on v_mfma_f32_16x16x4_f32 (exact fp32, the fp32 vector rate).
+// SPLIT = true:  both operands are split into bf16 pairs (v = hi + lo, |v - hi - lo| <= 2^-18 |v|) and the
+//                transform is three v_mfma_f32_16x16x32_bf16 products hi.hi + hi.lo + lo.hi accumulated in fp32
+//                (the dropped lo.lo term and the residuals are ~2^-17 of a product: a few 1e-6 on the layer's
+//                output, against the 1e-4 contract) at 3/16 of the fp32 matrix time.
+template <int FIN, int NT, bool SPLIT>
+__global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__ x, const f32x4* __restrict__ wfrag,
+                                                      const u32x2* __restrict__ stream,
+                                                      const AccUnit* __restrict__ units,
+                                                      const int32_t* __restrict__ wave_units,
+                                                      const uint32_t* __restrict__ wave_stream,
+                                                      float* __restrict__ slabs, AccDims a) {
+    constexpr int KQ = FIN / 4;              // features per lane quarter
+    constexpr int KP = KQ / 4;               // 16-byte pieces of them
+    constexpr int M = (KQ + 7) / 8;          // bf16 MFMAs (8 k per lane) that cover a quarter
+    constexpr int BV = SPLIT ? NT * M * 2 : NT * KP;   // 16-byte W fragments per lane and relation
+    constexpr int XL = FIN / 4;              // float4 per row of x
+    // LDS row stride: one float4 of padding.  Unpadded, a row starts at bank 48 * src mod 64, one of four values
+    // (two at in = 32), and the 8 lanes that share a quarter inside a 16-lane access group of ds_read_b128 pile
+    // onto them; an odd stride in float4 spreads the row starts over all 16 bank quads.
+    constexpr int XS = XL + 1;
+    extern __shared__ f32x4 lds4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int qg = blockIdx.x % a.q_groups, slab = blockIdx.x / a.q_groups;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
+
+#ifdef GN_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_gather = 0, st_mfma = 0, st_blocks = 0;
+#endif
+    // ---- this wave's work list and the head of its stream: in flight while the table is filled ----
+    int u = wave_units[wv];
+    const int u_end = wave_units[wv + 1];
+    // The stream is staged through a private LDS window of kStage blocks per wave: one 16-byte load per lane
+    // brings 8 blocks, the next window waits in registers while the current one is consumed (a register
+    // ring rotated with moves would have to wait for its youngest load on every trip).
+    constexpr int SV = kStage / 8;                                // 16-byte loads per lane and window
+    const u32x4* __restrict__ gp = reinterpret_cast<const u32x4*>(stream) + (size_t)wave_stream[wv] * 8 + lane;
+    u32x4 pre[SV];
+#pragma unroll
+    for (int i = 0; i < SV; ++i) pre[i] = gp[i * 64];             // the stream ends with two spare windows
+    gp += kStage * 8;
+    auto load_b = [&](int rel, f32x4 (&b)[BV]) {
+        const f32x4* __restrict__ wr = wfrag + (size_t)rel * (BV * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < BV; ++i) b[i] = wr[i * 64];
+    };
+    AccUnit d = units[u < u_end ? u : 0];
+    f32x4 bfrag[BV];                         // fp32: [nt][p];  split: [nt][m][hi, lo]
+    load_b(d.rel, bfrag);
+
+    // ---- node table -> LDS, plus the zero row that padded slots point at ----
+    // (eight loads per thread in flight before the first store: a load-store loop would pay one L2 round trip per trip)
+    for (int base = 0; base < a.n * XL; base += 8 * kThreads) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = min(base + k * kThreads + tid, a.n * XL - 1);
+            const int r = i / XL, c = i - r * XL;
+            v[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * a.ld_x + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * kThreads + tid;
+            const int r = i / XL, c = i - r * XL;
+            if (i < a.n * XL) lds4[r * XS + c] = v[k];
+        }
+    }
+    if (tid < XL) lds4[a.n * XS + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4* stage = reinterpret_cast<u32x4*>(lds4 + (a.n + 1) * XS) + wave * (kStage * 8);
+    const u32x2* stage2 = reinterpret_cast<const u32x2*>(stage) + n16;
+    __syncthreads();
+#ifdef GN_STAMPS
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
+    const int st_u0 = u;
+#endif
+
+    f32x4 acc[kTpg][NT];
+#pragma unroll
+    for (int t = 0; t < kTpg; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4* __restrict__ xq = lds4 + kq * KP;               // this lane's quarter of a table row
+    // wnext is the stream word of the next block to consume, read from the window one block ahead (the stream
+    // is contiguous across tiles and units, so the look-ahead never stops); pos is its block in the window.
+    int pos = 0;
+    auto refill = [&]() {                                         // publish the waiting window, fetch the one after
+#pragma unroll
+        for (int i = 0; i < SV; ++i) stage[i * 64 + lane] = pre[i];
+#pragma unroll
+        for (int i = 0; i < SV; ++i) pre[i] = gp[i * 64];
+        gp += kStage * 8;
+        pos = 0;
+    };
+    refill();
+    u32x2 wnext = stage2[0];                                      // LDS is in order per wave: no wait after the stores
+
+    for (; u < u_end; ++u) {
+        const AccUnit dn = units[u + 1 < u_end ? u + 1 : u];     // scalar load, a whole unit ahead
+#pragma unroll
+        for (int t = 0; t < kTpg; ++t) {
+            const int nb = d.blocks[t];                           // wave-uniform
+            if (nb == 0) continue;
+            f32x4 s[KP];
+#pragma unroll
+            for (int p = 0; p < KP; ++p) s[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef GN_STAMPS
+            const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+            st_blocks += nb;
+#endif
+            for (int k = 0; k < nb; ++k) {
+                const u32x2 w = wnext;
+                if (++pos == kStage) refill();
+                wnext = stage2[pos * 16];
+#if GN_ACC_MODE & 4      // every lane reads the same table row: the gather without bank conflicts
+                const uint32_t s0 = pos, s1 = pos + 1, s2 = pos + 2, s3 = pos + 3 + (w.x & w.y & 1u);
+#else
+                const uint32_t s0 = w.x & 0xffffu, s1 = w.x >> 16, s2 = w.y & 0xffffu, s3 = w.y >> 16;
+#endif
+                const f32x4* __restrict__ r0 = xq + s0 * XS;
+                const f32x4* __restrict__ r1 = xq + s1 * XS;
+                const f32x4* __restrict__ r2 = xq + s2 * XS;
+                const f32x4* __restrict__ r3 = xq + s3 * XS;
+#if GN_ACC_MODE & 2
+                s[0][0] += __uint_as_float(s0 + s1 + s2 + s3);
+#else
+#pragma unroll
+                for (int p = 0; p < KP; ++p) s[p] += (r0[p] + r1[p]) + (r2[p] + r3[p]);
+#endif
+            }
+#ifdef GN_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
+#if GN_ACC_MODE & 1
+#pragma unroll
+            for (int p = 0; p < KP; ++p) acc[t][0] += s[p] * bfrag[p];
+#else
+            if constexpr (SPLIT) {
+                // lane (row, kg) supplies A[row][k = 8 kg + j] = s[8 m + j].  A quarter that ends half way through
+                // its last MFMA (in = 16, 48) packs that one as A = {hi, lo} against B = {hi, hi} and B = {lo, 0}:
+                // hi.hi + lo.hi in one instruction, hi.lo in the other.
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const bool half = 8 * m + 4 == KQ;
+                    u32x4 ah, al;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int e = 8 * m + 2 * h;              // flat index into the quarter
+                        uint32_t hi = 0u, lo = 0u;
+                        if (e < KQ) split2(s[e / 4][e % 4], s[e / 4][e % 4 + 1], hi, lo);
+                        ah[h] = hi; al[h] = lo;
+                    }
+                    if (half) { ah[2] = al[0]; ah[3] = al[1]; }
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ah), xl = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bfrag[(nt * M + m) * 2]);
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, bfrag[(nt * M + m) * 2 + 1]);
+                        if (!half) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t][nt], 0, 0, 0);
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t][nt], 0, 0, 0);
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[t][nt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < KP; ++p)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(s[p][jj], bfrag[nt * KP + p][jj], acc[t][nt], 0, 0, 0);
+            }
+#endif
+#ifdef GN_STAMPS
+            asm volatile("s_nop 0" :: "v"(acc[t][0]), "v"(acc[t][NT - 1]) : "memory");   // the chain has retired
+            const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+            st_gather += st_b - st_a; st_mfma += st_c - st_b;
+#endif
+        }
+        d = dn;
+        // W fragments of the next unit: they land during its first gather (vmcnt retires in order, so a second
+        // register set loaded a unit ahead would be waited for at the same place and only cost registers)
+        load_b(d.rel, bfrag);
+    }
+
+#ifdef GN_STAMPS
+    const unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- fold the 16 waves of the workgroup in wave order, leave as one slab ----
+    __syncthreads();                                              // every wave is done with the table
+    float* red = reinterpret_cast<float*>(lds4);                  // [wave][tile][16 rows][NT * 16]
+    constexpr int RW = NT * 16;
+#pragma unroll
+    for (int t = 0; t < kTpg; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)                            // D fragment: lane (n16, kq) holds row 4 kq + i, column n16
+                red[((wave * kTpg + t) * 16 + 4 * kq + i) * RW + nt * 16 + n16] = acc[t][nt][i];
+    __syncthreads();
+    constexpr int OUT4 = kTpg * 16 * (RW / 4);
+    if (tid < OUT4) {
+        const int row = tid / (RW / 4), c4 = tid % (RW / 4);
+        f32x4 v = lds4[tid];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += lds4[w * OUT4 + tid];
+        const int grow = qg * (kTpg * 16) + row;
+        if (grow < a.n) reinterpret_cast<f32x4*>(slabs)[((size_t)grow * a.slabs + slab) * (RW / 4) + c4] = v;
+    }
+#ifdef GN_STAMPS
+    if (lane == 0 && wv < 4096) {
+        unsigned long long* o = g_acc_stamps[wv];
+        o[0] = st_t0; o[1] = st_t1; o[2] = st_t2; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = st_gather; o[5] = st_mfma; o[6] = (unsigned long long)(u_end - st_u0); o[7] = st_blocks;
+    }
+#endif
+}
+
+// Wfrag[r][nt][p][lane = kq * 16 + n16][jj] = W_r[kq * KQ + 4 p + jj][16 nt + n16],  W_r = sum_b att[r, b] basis[b]
+// (layers.py:172-173): the B operand of the transform above, one 16-byte load per lane and (nt, p).
+// One wave = 16 relations x (4 consecutive k) x (16 columns): four MFMA tiles over the bases.
+__global__ __launch_bounds__(256) void k_rgcn_weights_frag(const float* __restrict__ att, const float* __restrict__ basis,
+                                                          f32x4* __restrict__ wfrag, int relations, int bases, int fin,
+                                                          int fout, int tasks, int split) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= tasks) return;
+    const int n16 = lane & 15, q = lane >> 4;
+    const int nts = fout / 16, kgs = fin / 4;
+    const int nt = task % nts, kg = (task / nts) % kgs, rb = task / (nts * kgs);
+    const int r0 = rb * 16, k0 = kg * 4;
+    const int arow = min(r0 + n16, relations - 1);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < bases; b0 += 8) {                       // two K steps per trip, loads first
+        float av[2], bv[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = b0 + 4 * h + q, bc = min(b, bases - 1);
+            av[h] = att[(int64_t)arow * bases + bc];
+            const float* __restrict__ bp = basis + ((int64_t)bc * fin + k0) * fout + nt * 16 + n16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[h][j] = bp[j * fout];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool live = b0 + 4 * h + q < bases;
+            av[h] = live ? av[h] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h], live ? bv[h][j] : 0.f, acc[j], 0, 0, 0);
+        }
+    }
+    const int KQ = fin / 4, KP = KQ / 4;
+    const int kqo = k0 / KQ, p = (k0 % KQ) / 4;
+    if (!split) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 4 * q + i;
+            if (r < relations)
+                wfrag[(((size_t)r * nts + nt) * KP + p) * 64 + kqo * 16 + n16] = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+        }
+        return;
+    }
+    // bf16 pairs for v_mfma_f32_16x16x32_bf16: fragment (r, nt, m, hi | lo), lane kg * 16 + col, element j holds
+    // W_r[kg * KQ + 8 m + j][col] (zero past the quarter).  This lane owns elements j0 .. j0 + 3 of four relations.
+    const int M = (KQ + 7) / 8;
+    const int within = k0 % KQ, m = within / 8, j0 = within % 8;
+    const bool pad_upper = j0 == 0 && within + 4 >= KQ;               // the quarter ends half way through this MFMA
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * q + i;
+        if (r >= relations) continue;
+        uint32_t h0, l0, h1, l1;
+        split2(acc[0][i], acc[1][i], h0, l0);
+        split2(acc[2][i], acc[3][i], h1, l1);
+        uint32_t* base = reinterpret_cast<uint32_t*>(wfrag + ((((size_t)r * nts + nt) * M + m) * 2) * 64 + kqo * 16 + n16);
+        uint32_t* hi = base + j0 / 2;
+        uint32_t* lo = base + 64 * 4 + j0 / 2;
+        if (pad_upper) {                                                  // packed half MFMA: B = {hi, hi} and {lo, 0}
+            *reinterpret_cast<u32x4*>(hi) = (u32x4){h0, h1, h0, h1};
+            *reinterpret_cast<u32x4*>(lo) = (u32x4){l0, l1, 0u, 0u};
+        } else {
+            *reinterpret_cast<u32x2*>(hi) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(lo) = (u32x2){l0, l1};
+        }
+    }
+}
+
+// ---- plan construction ----------------------------------------------------------------------------
+__global__ void k_acc_keys(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                           const int64_t* __restrict__ range_start, int R, int64_t lo, int64_t hi, int64_t N,
+                           uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+    for (int64_t e = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x) {
+        int a = 0, b = R;
+        while (b - a > 1) {
+            int mid = (a + b) >> 1;
+            if (range_start[mid] <= e) a = mid; else b = mid;
+        }
+        key[e - lo] = (uint32_t)((int64_t)a * N + dst[e]);       // ids validated by the general plan builder
+        val[e - lo] = (uint32_t)src[e];
+    }
+}
+
+__global__ void k_acc_rowptr(const uint32_t* __restrict__ sorted, int n, int64_t count, int32_t* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i > count) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (sorted[mid] < (uint32_t)i) lo = mid + 1; else hi = mid;
+    }
+    out[i] = lo;
+}
+
+__global__ void k_acc_fill(uint32_t* __restrict__ stream32, int64_t words, uint32_t v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
+        stream32[i] = v;
+}
+
+// Edge p of the (relation, dst)-sorted list, the j-th of its run: chunk j / cap, iteration j % cap of tile dst / 16.
+__global__ void k_acc_scatter(const uint32_t* __restrict__ key_sorted, const uint32_t* __restrict__ src_sorted,
+                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ chunk_base,
+                              const uint32_t* __restrict__ chunk_off, int n, int N, int tiles,
+                              uint16_t* __restrict__ stream16) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t k = key_sorted[p];
+    const int r = (int)(k / (uint32_t)N), dd = (int)(k - (uint32_t)r * (uint32_t)N);
+    const int j = p - rowptr[k];
+    const int c = j / kIterCap, it = j % kIterCap;
+    const uint32_t blk = chunk_off[chunk_base[r * tiles + dd / 16] + c] + (uint32_t)(it >> 2);
+    stream16[(size_t)blk * 64 + (dd & 15) * 4 + (it & 3)] = (uint16_t)src_sorted[p];
+}
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+};
+
+int bits_for(int64_t n) {
+    int b = 1;
+    while (((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+// GN_ACC_EXACT=1: the transform on the fp32 matrix instruction instead of the three bf16 products.
+bool acc_exact() {
+    const char* e = getenv("GN_ACC_EXACT");
+    return e && e[0] == '1';
+}
+
+// 16-byte W fragments per lane and relation (see k_rgcn_acc)
+size_t acc_w_bytes(int64_t relations, int64_t fin, int64_t fout) {
+    const int64_t kq = fin / 4, m = (kq + 7) / 8;
+    const int64_t frags = std::max<int64_t>((fout / 16) * m * 2, (fout / 16) * (kq / 4));     // either layout fits
+    return ((size_t)relations * frags * 64 * 16 + 255) & ~size_t(255);
+}
+
+bool acc_disabled() {
+    if (gn::fast_paths_disabled()) return true;
+    const char* e = getenv("GN_DISABLE_ACC");
+    return e && e[0] == '1';
+}
+
+template <int FIN, bool SPLIT>
+gn_status launch_acc(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, const f32x4* wfrag, float* slabs,
+                     size_t lds_bytes, hipStream_t st) {
+    static thread_local bool configured = false;
+    if (!configured) {
+        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgcn_acc<FIN, kFoutAcc / 16, SPLIT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    AccDims dm;
+    dm.ld_x = ld_x; dm.n = (int)plan->num_nodes; dm.tiles = plan->acc_tiles; dm.q_groups = plan->acc_q; dm.slabs = plan->acc_g;
+    k_rgcn_acc<FIN, kFoutAcc / 16, SPLIT><<<plan->acc_q * plan->acc_g, kThreads, lds_bytes, st>>>(
+        x, wfrag, reinterpret_cast<const u32x2*>(plan->acc_stream.p), reinterpret_cast<const AccUnit*>(plan->acc_units.p),
+        plan->acc_wave_units.p, plan->acc_wave_stream.p, slabs, dm);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // namespace
+
+// Builds the per-wave unit lists and edge streams of the shard.  Leaves plan->acc_ok = 0 when the graph does
+// not qualify (node ids beyond 16 bits of stream word, nothing to do).
+gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
+                                 const std::vector<int64_t>& ranges, hipStream_t st) {
+    plan->acc_ok = 0;
+    const int64_t N = plan->num_nodes, R = plan->num_relations, E = plan->shard_edges;
+    if (acc_disabled() || N < 1 || N > 2500 || R < 1 || E < 1) return GN_OK;
+    const int tiles = (int)gn::ceil_div(N, 16);
+    const int Q = (int)gn::ceil_div(tiles, kTpg);
+    const int G = std::max(1, kCus / Q);
+    if (R * N >= ((int64_t)1 << 31) || R * tiles >= ((int64_t)1 << 28)) return GN_OK;
+
+    Scratch tmp;
+    int64_t* starts_dev;
+    uint32_t *key, *key_sorted, *val, *val_sorted;
+    int32_t* rowptr;
+    GN_HIP(tmp.get(&starts_dev, R + 1));
+    GN_HIP(tmp.get(&key, E));
+    GN_HIP(tmp.get(&key_sorted, E));
+    GN_HIP(tmp.get(&val, E));
+    GN_HIP(tmp.get(&val_sorted, E));
+    GN_HIP(tmp.get(&rowptr, R * N + 1));
+    std::vector<int64_t> starts(R + 1, plan->input_edges);
+    for (int64_t r = 0; r < R; ++r) starts[r] = ranges[2 * r];
+    GN_HIP(hipMemcpyAsync(starts_dev, starts.data(), (R + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    k_acc_keys<<<gn::stream_grid(E, 256), 256, 0, st>>>(src, dst, starts_dev, (int)R, plan->edge_lo, plan->edge_hi, N, key, val);
+    GN_LAUNCH_CHECK();
+    {
+        size_t bytes = 0;
+        GN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key, key_sorted, val, val_sorted, (size_t)E, 0, bits_for(R * N), st));
+        char* scratch = nullptr;
+        GN_HIP(tmp.get(&scratch, bytes));
+        GN_HIP(rocprim::radix_sort_pairs(scratch, bytes, key, key_sorted, val, val_sorted, (size_t)E, 0, bits_for(R * N), st));
+    }
+    k_acc_rowptr<<<(int)gn::ceil_div(R * N + 1, 256), 256, 0, st>>>(key_sorted, (int)E, R * N, rowptr);
+    GN_LAUNCH_CHECK();
+    std::vector<int32_t> rp(R * N + 1);
+    GN_HIP(hipMemcpyAsync(rp.data(), rowptr, (R * N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+
+    // iterations of every (relation, tile) = its longest (relation, destination) run
+    std::vector<int32_t> iters((size_t)R * tiles, 0);
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t i = 0; i < N; ++i) {
+            const int32_t c = rp[r * N + i + 1] - rp[r * N + i];
+            int32_t& m = iters[r * tiles + i / 16];
+            m = std::max(m, c);
+        }
+    // units = (relation, row group, chunk of <= kIterCap iterations per tile)
+    struct Unit { int32_t rel, chunk; uint8_t blocks[4]; int64_t cost; };
+    std::vector<std::vector<Unit>> per_q(Q);
+    for (int64_t r = 0; r < R; ++r)
+        for (int q = 0; q < Q; ++q) {
+            int32_t longest = 0;
+            for (int t = 0; t < kTpg; ++t) {
+                const int tile = q * kTpg + t;
+                if (tile < tiles) longest = std::max(longest, iters[r * tiles + tile]);
+            }
+            const int64_t row0 = (int64_t)q * kTpg * 16, row1 = std::min<int64_t>(N, row0 + kTpg * 16);
+            for (int c = 0; c * kIterCap < longest; ++c) {
+                Unit un = {(int32_t)r, c, {0, 0, 0, 0}, 0};
+                int64_t edges = 0;
+                for (int64_t i = row0; i < row1; ++i)
+                    edges += std::min(kIterCap, std::max(0, rp[r * N + i + 1] - rp[r * N + i] - c * kIterCap));
+                for (int t = 0; t < kTpg; ++t) {
+                    const int tile = q * kTpg + t;
+                    const int32_t it = tile < tiles ? std::min(kIterCap, std::max(0, iters[r * tiles + tile] - c * kIterCap)) : 0;
+                    un.blocks[t] = (uint8_t)((it + 3) / 4);
+                    if (it > 0) un.cost += kTileCost + (int64_t)un.blocks[t] * kBlockCost;
+                }
+                un.cost += edges * kEdgeCost;
+                per_q[q].push_back(un);
+            }
+        }
+    // Longest-processing-time assignment in two levels: a row group's units to its G workgroups (the LDS is
+    // the shared resource of the gather, so whole workgroups have to carry equal loads), then a workgroup's
+    // units to its waves.  A wave walks its units in relation order (all waves sweep the relations together:
+    // W_r stays L2-resident).
+    const int n_waves = Q * G * kWaves;
+    std::vector<std::vector<Unit>> per_wave(n_waves);
+    auto lpt = [](const std::vector<Unit>& us, int bins, std::vector<std::vector<Unit>>& out) {
+        out.assign(bins, {});
+        std::vector<int> order(us.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return us[x].cost > us[y].cost; });
+        std::vector<std::pair<int64_t, int>> heap;
+        for (int w = 0; w < bins; ++w) heap.emplace_back(0, w);
+        auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (int idx : order) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto& top = heap.back();
+            out[top.second].push_back(us[idx]);
+            top.first += us[idx].cost;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    };
+    for (int q = 0; q < Q; ++q) {
+        std::vector<std::vector<Unit>> per_wg, per_w;
+        lpt(per_q[q], G, per_wg);
+        for (int slab = 0; slab < G; ++slab) {
+            lpt(per_wg[slab], kWaves, per_w);
+            for (int wi = 0; wi < kWaves; ++wi) per_wave[(slab * Q + q) * kWaves + wi] = std::move(per_w[wi]);   // block = slab * Q + q
+        }
+    }
+    std::vector<AccUnit> units;
+    std::vector<int32_t> wave_units(n_waves + 1, 0);
+    std::vector<uint32_t> wave_stream(n_waves, 0);
+    // (relation, tile) -> first entry of its per-chunk block offsets
+    std::vector<int32_t> chunk_base((size_t)R * tiles + 1, 0);
+    for (int64_t k = 0; k < R * tiles; ++k) chunk_base[k + 1] = chunk_base[k] + (int32_t)gn::ceil_div(iters[k], kIterCap);
+    std::vector<uint32_t> chunk_off(chunk_base[R * tiles] + 1, 0);
+    uint64_t blocks_total = 0;
+    for (int w = 0; w < n_waves; ++w) {
+        auto& us = per_wave[w];
+        std::sort(us.begin(), us.end(), [](const Unit& x, const Unit& y) { return x.rel != y.rel ? x.rel < y.rel : x.chunk < y.chunk; });
+        const int q = (w / kWaves) % Q;
+        wave_stream[w] = (uint32_t)blocks_total;
+        for (const Unit& un : us) {
+            AccUnit au = {un.rel, {un.blocks[0], un.blocks[1], un.blocks[2], un.blocks[3]}, 0, 0};
+            units.push_back(au);
+            for (int t = 0; t < kTpg; ++t) {
+                if (un.blocks[t] == 0) continue;
+                const int tile = q * kTpg + t;
+                chunk_off[chunk_base[(int64_t)un.rel * tiles + tile] + un.chunk] = (uint32_t)blocks_total;
+                blocks_total += un.blocks[t];
+            }
+        }
+        wave_units[w + 1] = (int32_t)units.size();
+    }
+    if (blocks_total + 3 * kStage >= ((uint64_t)1 << 26)) return GN_OK;      // 64 B-word index must fit 32 bits
+    if (units.empty()) units.push_back(AccUnit{0, {0, 0, 0, 0}, 0, 0});
+
+    int32_t* chunk_base_dev;
+    uint32_t* chunk_off_dev;
+    GN_HIP(tmp.get(&chunk_base_dev, chunk_base.size()));
+    GN_HIP(tmp.get(&chunk_off_dev, chunk_off.size()));
+    GN_HIP(hipMemcpyAsync(chunk_base_dev, chunk_base.data(), chunk_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(chunk_off_dev, chunk_off.data(), chunk_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    const int64_t words = (int64_t)(blocks_total + 3 * kStage) * 32;         // uint32 words: 16 rows x 2 per block
+    GN_HIP(plan->acc_stream.alloc((size_t)words));
+    GN_HIP(plan->acc_units.alloc(units.size() * (sizeof(AccUnit) / sizeof(int32_t))));
+    GN_HIP(plan->acc_wave_units.alloc(wave_units.size()));
+    GN_HIP(plan->acc_wave_stream.alloc(wave_stream.size()));
+    k_acc_fill<<<gn::stream_grid(words, 256), 256, 0, st>>>(plan->acc_stream.p, words, (uint32_t)N | ((uint32_t)N << 16));
+    GN_LAUNCH_CHECK();
+    k_acc_scatter<<<(int)gn::ceil_div(E, 256), 256, 0, st>>>(key_sorted, val_sorted, rowptr, chunk_base_dev, chunk_off_dev,
+                                                            (int)E, (int)N, tiles,
+                                                            reinterpret_cast<uint16_t*>(plan->acc_stream.p));
+    GN_LAUNCH_CHECK();
+    GN_HIP(hipMemcpyAsync(plan->acc_units.p, units.data(), units.size() * sizeof(AccUnit), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->acc_wave_units.p, wave_units.data(), wave_units.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->acc_wave_stream.p, wave_stream.data(), wave_stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipStreamSynchronize(st));       // host vectors and scratch go out of scope after this
+    plan->acc_tiles = tiles; plan->acc_q = Q; plan->acc_g = G;
+    plan->acc_blocks = (int64_t)blocks_total;
+    plan->acc_ok = 1;
+    return GN_OK;
+}
+
+static size_t acc_lds_bytes(int64_t n, int64_t fin) {
+    const size_t table = (size_t)(n + 1) * (fin + 4) * sizeof(float) + (size_t)kWaves * kStage * 128;
+    const size_t fold = (size_t)kWaves * kTpg * 16 * kFoutAcc * sizeof(float);
+    return std::max(table, fold);
+}
+
+bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
+    if (!plan->acc_ok || acc_disabled()) return false;
+    if (fout != kFoutAcc || !(fin == 16 || fin == 32 || fin == 48) || bases < 1) return false;
+    return acc_lds_bytes(plan->num_nodes, fin) <= kLdsBudget;
+}
+
+size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
+    return acc_w_bytes(plan->num_relations, fin, fout) + (size_t)plan->acc_g * plan->num_nodes * fout * sizeof(float);
+}
+
+gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
+                              const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
+                              int relu, int partial, float* out, int64_t ld_out, const gn_side_copy& side, void* ws,
+                              size_t ws_bytes, hipStream_t st) {
+    GN_REQUIRE(ld_x % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld_x %% 4 == 0");
+    GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
+    const int64_t R = plan->num_relations;
+    f32x4* wfrag = static_cast<f32x4*>(ws);
+    float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + acc_w_bytes(R, fin, fout));
+    const bool split = !acc_exact();
+    const int tasks = (int)(gn::ceil_div(R, 16) * (fin / 4) * (fout / 16));
+    k_rgcn_weights_frag<<<(int)gn::ceil_div(tasks, 4), 256, 0, st>>>(att, basis, wfrag, (int)R, (int)bases, (int)fin,
+                                                                    (int)fout, tasks, split ? 1 : 0);
+    GN_LAUNCH_CHECK();
+    const size_t lds = acc_lds_bytes(plan->num_nodes, fin);
+    gn_status s;
+    switch ((int)fin * 2 + (split ? 1 : 0)) {
+        case 32: s = launch_acc<16, false>(plan, x, ld_x, wfrag, slabs, lds, st); break;
+        case 33: s = launch_acc<16, true>(plan, x, ld_x, wfrag, slabs, lds, st); break;
+        case 64: s = launch_acc<32, false>(plan, x, ld_x, wfrag, slabs, lds, st); break;
+        case 65: s = launch_acc<32, true>(plan, x, ld_x, wfrag, slabs, lds, st); break;
+        case 96: s = launch_acc<48, false>(plan, x, ld_x, wfrag, slabs, lds, st); break;
+        default: s = launch_acc<48, true>(plan, x, ld_x, wfrag, slabs, lds, st); break;
+    }
+    if (s != GN_OK) return s;
+    return gn_rgcn_slab_finalize_launch(plan, slabs, plan->acc_g, x, ld_x, fin, root, bias, relu, partial, out, ld_out, side, st);
+}
+
+#ifdef GN_STAMPS
+extern "C" __attribute__((visibility("default"))) int gn_debug_read_acc_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_acc_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif

@@ -872,6 +872,19 @@ gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, c
     return GN_OK;
 }
 
+// Slab reduction + epilogue for the other relational kernels (rgcn_acc.hip): slabs are [n][groups][32].
+gn_status gn_rgcn_slab_finalize_launch(const gn_rgcn_plan* plan, const float* slabs, int groups, const float* x,
+                                       int64_t ld_x, int64_t fin, const float* root, const float* bias, int relu,
+                                       int partial, float* out, int64_t ld_out, const gn_side_copy& side, hipStream_t st) {
+    FinArgs f;
+    f.slabs = slabs; f.groups = groups; f.n = (int)plan->num_nodes; f.indeg = plan->indeg.p; f.x = x; f.ld_x = ld_x;
+    f.fin = (int)fin; f.root = root; f.bias = bias; f.relu = relu; f.partial = partial; f.out = out; f.ld_out = ld_out;
+    f.side = side;
+    k_rgcn_slab_finalize<<<(int)plan->num_nodes, 256, 0, st>>>(f);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 bool gn_rgcn_fast_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     if (!plan->fast_ok || gn::fast_paths_disabled()) return false;
     return fout == kFout && (fin == 16 || fin == 32 || fin == 48 || fin == 64) && bases >= 1;
