@@ -128,6 +128,15 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_gather = 0, st_mfma = 0, st_blocks = 0;
 #endif
+    // ---- first loads of the table fill: issued before everything else, because vector loads retire in order and
+    //      the stream / W loads below come from further away (HBM / Infinity Cache) than the L2-resident table ----
+    f32x4 fill[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = min(k * kThreads + tid, a.n * XL - 1);
+        const int r = i / XL, c = i - r * XL;
+        fill[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * a.ld_x + 4 * c);
+    }
     // ---- this wave's work list and the head of its stream: in flight while the table is filled ----
     int u = wave_units[wv];
     const int u_end = wave_units[wv + 1];
@@ -150,20 +159,21 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     load_b(d.rel, bfrag);
 
     // ---- node table -> LDS, plus the zero row that padded slots point at ----
-    // (eight loads per thread in flight before the first store: a load-store loop would pay one L2 round trip per trip)
+    // (the first eight loads per thread were issued at the top; a load-store loop would pay one L2 round trip per trip)
     for (int base = 0; base < a.n * XL; base += 8 * kThreads) {
-        f32x4 v[8];
+        if (base > 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = min(base + k * kThreads + tid, a.n * XL - 1);
-            const int r = i / XL, c = i - r * XL;
-            v[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * a.ld_x + 4 * c);
+            for (int k = 0; k < 8; ++k) {
+                const int i = min(base + k * kThreads + tid, a.n * XL - 1);
+                const int r = i / XL, c = i - r * XL;
+                fill[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * a.ld_x + 4 * c);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = base + k * kThreads + tid;
             const int r = i / XL, c = i - r * XL;
-            if (i < a.n * XL) lds4[r * XS + c] = v[k];
+            if (i < a.n * XL) lds4[r * XS + c] = fill[k];
         }
     }
     if (tid < XL) lds4[a.n * XS + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -317,9 +327,12 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
 #endif
 }
 
-// Wfrag[r][nt][p][lane = kq * 16 + n16][jj] = W_r[kq * KQ + 4 p + jj][16 nt + n16],  W_r = sum_b att[r, b] basis[b]
-// (layers.py:172-173): the B operand of the transform above, one 16-byte load per lane and (nt, p).
-// One wave = 16 relations x (4 consecutive k) x (16 columns): four MFMA tiles over the bases.
+// W_r = sum_b att[r, b] basis[b]  (layers.py:172-173), written as the B operand of the transform above:
+//   fp32:  Wfrag[r][nt][p][lane = kg * 16 + col][jj] = W_r[kg * KQ + 4 p + jj][16 nt + col]
+//   split: fragment (r, nt, m, hi | lo), lane kg * 16 + col, bf16 element j = W_r[kg * KQ + 8 m + j][16 nt + col];
+//          a quarter that ends half way through its last MFMA stores {hi, hi} and {lo, 0} (see k_rgcn_acc).
+// One wave = 16 relations x (up to 8 consecutive k of one quarter) x 16 columns: up to eight fp32 MFMA tiles over
+// the bases, and every lane ends up with whole 16-byte fragment elements (16 lanes = one 256-byte run).
 __global__ __launch_bounds__(256) void k_rgcn_weights_frag(const float* __restrict__ att, const float* __restrict__ basis,
                                                           f32x4* __restrict__ wfrag, int relations, int bases, int fin,
                                                           int fout, int tasks, int split) {
@@ -327,63 +340,59 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_frag(const float* __restri
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (task >= tasks) return;
     const int n16 = lane & 15, q = lane >> 4;
-    const int nts = fout / 16, kgs = fin / 4;
-    const int nt = task % nts, kg = (task / nts) % kgs, rb = task / (nts * kgs);
-    const int r0 = rb * 16, k0 = kg * 4;
+    const int nts = fout / 16, KQ = fin / 4, KP = KQ / 4, M = (KQ + 7) / 8;
+    const int nt = task % nts, m = (task / nts) % M, kg = (task / (nts * M)) % 4, rb = task / (nts * M * 4);
+    const int r0 = rb * 16, k0 = kg * KQ + 8 * m;
+    const int nk = min(8, KQ - 8 * m);                                // 8, or 4 when the quarter ends half way (wave-uniform)
     const int arow = min(r0 + n16, relations - 1);
-    f32x4 acc[4];
+    f32x4 acc[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int b0 = 0; b0 < bases; b0 += 8) {                       // two K steps per trip, loads first
-        float av[2], bv[2][4];
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < bases; b0 += 32) {                          // eight K steps per trip: every load is in flight before the first MFMA
+        float av[8], bv[8][8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int b = b0 + 4 * h + q, bc = min(b, bases - 1);
+        for (int h = 0; h < 8; ++h) {
+            const int bc = min(b0 + 4 * h + q, bases - 1);           // unconditional, clamped; zeroed by select below
             av[h] = att[(int64_t)arow * bases + bc];
             const float* __restrict__ bp = basis + ((int64_t)bc * fin + k0) * fout + nt * 16 + n16;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[h][j] = bp[j * fout];
+            for (int j = 0; j < 8; ++j) bv[h][j] = bp[min(j, nk - 1) * fout];
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 8; ++h) {
             const bool live = b0 + 4 * h + q < bases;
-            av[h] = live ? av[h] : 0.f;
+            const float a = live ? av[h] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h], live ? bv[h][j] : 0.f, acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, live ? bv[h][j] : 0.f, acc[j], 0, 0, 0);
+            if (nk == 8) {
+#pragma unroll
+                for (int j = 4; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, live ? bv[h][j] : 0.f, acc[j], 0, 0, 0);
+            }
         }
     }
-    const int KQ = fin / 4, KP = KQ / 4;
-    const int kqo = k0 / KQ, p = (k0 % KQ) / 4;
-    if (!split) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 4 * q + i;
-            if (r < relations)
-                wfrag[(((size_t)r * nts + nt) * KP + p) * 64 + kqo * 16 + n16] = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-        }
-        return;
-    }
-    // bf16 pairs for v_mfma_f32_16x16x32_bf16: fragment (r, nt, m, hi | lo), lane kg * 16 + col, element j holds
-    // W_r[kg * KQ + 8 m + j][col] (zero past the quarter).  This lane owns elements j0 .. j0 + 3 of four relations.
-    const int M = (KQ + 7) / 8;
-    const int within = k0 % KQ, m = within / 8, j0 = within % 8;
-    const bool pad_upper = j0 == 0 && within + 4 >= KQ;               // the quarter ends half way through this MFMA
+    // lane (col, q), register i: W_r[k0 + j][16 nt + col] for relation r0 + 4 q + i, j = 0 .. nk - 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + 4 * q + i;
         if (r >= relations) continue;
-        uint32_t h0, l0, h1, l1;
-        split2(acc[0][i], acc[1][i], h0, l0);
-        split2(acc[2][i], acc[3][i], h1, l1);
-        uint32_t* base = reinterpret_cast<uint32_t*>(wfrag + ((((size_t)r * nts + nt) * M + m) * 2) * 64 + kqo * 16 + n16);
-        uint32_t* hi = base + j0 / 2;
-        uint32_t* lo = base + 64 * 4 + j0 / 2;
-        if (pad_upper) {                                                  // packed half MFMA: B = {hi, hi} and {lo, 0}
-            *reinterpret_cast<u32x4*>(hi) = (u32x4){h0, h1, h0, h1};
-            *reinterpret_cast<u32x4*>(lo) = (u32x4){l0, l1, 0u, 0u};
+        if (!split) {
+            f32x4* o = wfrag + (((size_t)r * nts + nt) * KP + 2 * m) * 64 + kg * 16 + n16;
+            o[0] = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+            if (nk == 8) o[64] = (f32x4){acc[4][i], acc[5][i], acc[6][i], acc[7][i]};
         } else {
-            *reinterpret_cast<u32x2*>(hi) = (u32x2){h0, h1};
-            *reinterpret_cast<u32x2*>(lo) = (u32x2){l0, l1};
+            uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+            split2(acc[0][i], acc[1][i], h0, l0);
+            split2(acc[2][i], acc[3][i], h1, l1);
+            if (nk == 8) {
+                split2(acc[4][i], acc[5][i], h2, l2);
+                split2(acc[6][i], acc[7][i], h3, l3);
+            } else {                                                  // packed half MFMA: B = {hi, hi} and {lo, 0}
+                h2 = h0; h3 = h1; l2 = 0u; l3 = 0u;
+            }
+            const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+            u32x4* o = reinterpret_cast<u32x4*>(wfrag) + ((((size_t)r * nts + nt) * M + m) * 2) * 64 + kg * 16 + n16;
+            o[0] = hi;
+            o[64] = lo;
         }
     }
 }
@@ -678,7 +687,7 @@ gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t 
     f32x4* wfrag = static_cast<f32x4*>(ws);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + acc_w_bytes(R, fin, fout));
     const bool split = !acc_exact();
-    const int tasks = (int)(gn::ceil_div(R, 16) * (fin / 4) * (fout / 16));
+    const int tasks = (int)(gn::ceil_div(R, 16) * 4 * ((fin / 4 + 7) / 8) * (fout / 16));
     k_rgcn_weights_frag<<<(int)gn::ceil_div(tasks, 4), 256, 0, st>>>(att, basis, wfrag, (int)R, (int)bases, (int)fin,
                                                                     (int)fout, tasks, split ? 1 : 0);
     GN_LAUNCH_CHECK();
