@@ -57,9 +57,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graphs", action="store_true",
-                    help="replay the launch-bound stages as hipGraphs (measured slower than eager launches at "
-                         "the current kernel times, so off by default)")
+    ap.add_argument("--eager", dest="graphs", action="store_false",
+                    help="launch every entry point from Python instead of replaying the stages around the dominant "
+                         "entry point as hipGraphs (eager launching is host-bound: ~150 us of Python per step "
+                         "against ~120 us of kernels on pose0-syn)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -121,9 +122,9 @@ def main():
                 eager.step()
             per_call0, breakdown = per_entry_us(eager.step, 5)
             dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
-            # --graphs: the launch-bound stages replay as hipGraphs; the stage that holds the dominant entry
-            # point stays eager between them so that it is bracketed by HIP events in EVERY timed step
-            stages = PoseStages(model, data, graphs=True, eager_stage=CANDIDATES[dom]) if args.graphs else eager
+            # default: every stage replays as a hipGraph; the stage that holds the dominant entry point is a graph
+            # of its own, bracketed by HIP events on its stream in EVERY timed step
+            stages = PoseStages(model, data, graphs=True, timed_entry=dom) if args.graphs else eager
             step = stages.step
         else:
             from gripnet_amd.pipeline import Graphed
@@ -183,7 +184,7 @@ def main():
                    "edges_aggregated_per_step": A, "n_g": data.n_g_node, "n_d": n_d, "relations": data.n_dd_edge_type,
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
-                   "launch": "hipGraph replay of the launch-bound stages; {} eager, HIP-event timed".format(dom) if args.graphs else "eager"},
+                   "launch": "hipGraph replay of the stages; {} HIP-event timed around its own graph".format(dom) if args.graphs else "eager"},
         "roofline": roofline,
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
         "edges_scored_per_sec": (hi - lo) / (per_call0["gn_distmult_forward_f32"] * 1e-6),

@@ -19,6 +19,8 @@ _lib = None
 _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
+GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
+ABI_VERSION = 103                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -44,6 +46,7 @@ SIGNATURES = {
     "gn_rgcn_plan_destroy": (None, [_p]),
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
     "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
+    "gn_rgcn_weights_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
@@ -105,7 +108,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype, fn.argtypes = res, args
-            if lib.gn_version() < 102:
+            if lib.gn_version() < ABI_VERSION:
                 raise RuntimeError("gripnet_amd: libgripnet_hip.so is older than this package")
             _lib = lib
     return _lib
@@ -151,6 +154,28 @@ class KernelTimer:
 _timer = None
 
 
+class bracket:
+    """HIP events around a region of the current stream, reported to the active KernelTimer under `name`
+    (a stage replayed as a hipGraph makes no timed library call of its own).  No-op without a timer."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        t = _timer
+        self.on = t is not None and (t.only is None or self.name in t.only)
+        if self.on:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            stop = torch.cuda.Event(enable_timing=True)
+            stop.record()
+            _timer.add(self.name, self.start, stop)
+
+
 def _call(name, *args, tag=None):
     fn = getattr(load(), name)
     t = _timer
@@ -170,6 +195,17 @@ def require_gpu(*tensors):
             raise RuntimeError(
                 "gripnet_amd runs on an MI355X only: got a {} tensor on {} (no CPU fallback; "
                 "move the model and the data to 'cuda')".format(tuple(t.shape), t.device))
+
+
+_side_streams = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One extra HIP stream per device for work that overlaps the main chain (the relational weights)."""
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 def stream_ptr(device=None) -> int:
@@ -382,11 +418,18 @@ class RgcnPlan:
             self._ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
         return self._ws, need
 
-    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None):
+    def weights(self, basis, att):
+        """W_r = sum_b att[r,b] basis[b] into the plan's workspace, on the current stream (gn_rgcn_weights_f32)."""
+        ws, need = self._workspace(basis.shape[1], basis.shape[2], basis.shape[0])
+        _call("gn_rgcn_weights_f32", self._h, basis.shape[1], ptr(basis), ptr(att), basis.shape[0], basis.shape[2],
+              ptr(ws), need, stream_ptr(basis.device))
+
+    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, weights_ready=False):
         ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0])
         sc = side_copy(side)
+        flags = (GN_RGCN_PARTIAL if partial else 0) | (GN_RGCN_WEIGHTS_READY if weights_ready else 0)
         _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
-              ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), int(bool(partial)),
+              ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), flags,
               ptr(out), ld(out), _ref(sc), ptr(ws), need, stream_ptr(x.device))
         return out
 

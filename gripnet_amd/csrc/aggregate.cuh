@@ -11,6 +11,15 @@
 
 #include "common.h"
 
+// Groups of S neighbour rows a wave requests before it consumes the first one.
+#ifndef GN_AGG_U
+#define GN_AGG_U 2
+#endif
+// Upper bound of the launch grid (blocks of four waves); rows beyond it are taken grid-stride.
+#ifndef GN_AGG_GRID
+#define GN_AGG_GRID (256 * 8)
+#endif
+
 namespace gn {
 
 struct AggArgs {
@@ -62,19 +71,32 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                 const uint32_t c = mine < end ? a.col[mine] : 0u;
                 const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
                 const int cnt = min(kWave, end - base);
-                for (int it = 0; it * S < cnt; ++it) {
-                    const int idx = it * S + slot;
-                    const uint32_t cc = (uint32_t)__shfl((int)c, idx);
-                    const float vv = __shfl(v, idx);
-                    if (idx < cnt && active) {
-                        const float* src = a.table + (int64_t)cc * a.ld_table + fcol;
-                        if constexpr (VEC == 4) {
-                            const float4 t = *reinterpret_cast<const float4*>(src);
-                            acc[0] += vv * t.x; acc[1] += vv * t.y; acc[2] += vv * t.z; acc[3] += vv * t.w;
-                        } else {
-                            acc[0] += vv * src[0];
+                // The neighbour rows of the whole batch are requested before the first one is consumed: a loop
+                // that loads and adds one group of S rows per trip pays an L2 round trip per trip.
+                constexpr int IT = kWave / S, U = IT < GN_AGG_U ? IT : GN_AGG_U;   // groups of S rows per batch, U in flight
+                for (int it0 = 0; it0 * S < cnt; it0 += U) {
+                    float t[U][VEC], vv[U];
+#pragma unroll
+                    for (int it = 0; it < U; ++it) {
+                        const int idx = (it0 + it) * S + slot;
+                        const uint32_t cc = (uint32_t)__shfl((int)c, idx);
+                        vv[it] = __shfl(v, idx);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) t[it][k] = 0.f;
+                        if (idx < cnt && active) {
+                            const float* src = a.table + (int64_t)cc * a.ld_table + fcol;
+                            if constexpr (VEC == 4) {
+                                const float4 r = *reinterpret_cast<const float4*>(src);
+                                t[it][0] = r.x; t[it][1] = r.y; t[it][2] = r.z; t[it][3] = r.w;
+                            } else {
+                                t[it][0] = src[0];
+                            }
                         }
                     }
+#pragma unroll
+                    for (int it = 0; it < U; ++it)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] += vv[it] * t[it][k];
                 }
             }
 #pragma unroll
@@ -142,13 +164,22 @@ __global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const fl
             const uint32_t cl = mine < end ? a.col[mine] : 0u;
             const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
             const int cnt = min(kWave, end - base);
-            for (int it = 0; it * S < cnt; ++it) {
-                const int idx = it * S + slot;
-                const uint32_t cc = (uint32_t)__shfl((int)cl, idx);
-                const float vv = __shfl(v, idx);
-                if (idx < cnt) {
-                    const float4 t = *reinterpret_cast<const float4*>(a.table + (int64_t)cc * a.ld_table + 4 * j);
-                    acc[0] += vv * t.x; acc[1] += vv * t.y; acc[2] += vv * t.z; acc[3] += vv * t.w;
+            // U groups of S neighbour rows are requested before the first one is consumed (see k_aggregate)
+            constexpr int IT = kWave / S, U = IT < GN_AGG_U ? IT : GN_AGG_U;
+            for (int it0 = 0; it0 * S < cnt; it0 += U) {
+                float4 t[U];
+                float vv[U];
+#pragma unroll
+                for (int it = 0; it < U; ++it) {
+                    const int idx = (it0 + it) * S + slot;
+                    const uint32_t cc = (uint32_t)__shfl((int)cl, idx);
+                    vv[it] = __shfl(v, idx);
+                    t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < cnt) t[it] = *reinterpret_cast<const float4*>(a.table + (int64_t)cc * a.ld_table + 4 * j);
+                }
+#pragma unroll
+                for (int it = 0; it < U; ++it) {
+                    acc[0] += vv[it] * t[it].x; acc[1] += vv[it] * t[it].y; acc[2] += vv[it] * t[it].z; acc[3] += vv[it] * t[it].w;
                 }
             }
         }
@@ -180,7 +211,7 @@ inline bool transform_fusable(int64_t fin, int64_t fout) {
 
 inline gn_status launch_aggregate_transform(const AggArgs& a, const float* w, int fout, hipStream_t st) {
     if (a.rows == 0) return GN_OK;
-    const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), 256 * 8);
+    const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), GN_AGG_GRID);
     const int key = a.features * 100 + fout;
     switch (key) {
         case 1616: k_aggregate_transform<4, 16><<<grid, 256, 0, st>>>(a, w); break;
@@ -227,7 +258,7 @@ inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
     const int units = vec ? a.features / 4 : a.features;
     int lpe = 1;
     while (lpe < units && lpe < kWave) lpe <<= 1;
-    const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), 256 * 8);
+    const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), GN_AGG_GRID);
     if (vec) launch_aggregate_lpe<4>(a, lpe, grid, st); else launch_aggregate_lpe<1>(a, lpe, grid, st);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -29,6 +29,7 @@ struct DmFastArgs {
     const float* d; int64_t ld_d; int r;
     int64_t e; int64_t edges_per_wg; int sigmoid; float* out; int32_t* err;
     int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
+    int stride4;           // LDS row stride in float4, the same in every phase (see gn_distmult_fast_forward)
 };
 
 template <int CTRL>
@@ -53,14 +54,14 @@ __device__ __forceinline__ float row_sum16(float x) {
 // otherwise each step gathers its D chunks from L2.
 // W4 > 0: the phase width (in float4 chunks) is a compile-time constant; W4 == 0: runtime w4.
 template <int S, int W4, int CPL, bool UNIFORM_R>
-__device__ __forceinline__ void quad_step(const char* __restrict__ lds, int w4, int l4, int iu, int iv, int ir,
+__device__ __forceinline__ void quad_step(const char* __restrict__ lds, int stride_bytes, int w4, int l4, int iu, int iv, int ir,
                                           const float* __restrict__ dcol, int64_t ld_d, const f32x4 (&dreg)[CPL],
                                           float& result) {
     constexpr int kBcast = S * 0x55;     // quad_perm [S,S,S,S]
     const int uu = dpp_i<kBcast>(iu), vv = dpp_i<kBcast>(iv);
     const int width4 = W4 > 0 ? W4 : w4;
-    const char* pu = lds + __umul24(uu, width4 * 16) + l4 * 16;
-    const char* pv = lds + __umul24(vv, width4 * 16) + l4 * 16;
+    const char* pu = lds + __umul24(uu, stride_bytes) + l4 * 16;
+    const char* pv = lds + __umul24(vv, stride_bytes) + l4 * 16;
     const float* dr = dcol;
     if constexpr (!UNIFORM_R) dr = dcol + (int64_t)dpp_i<kBcast>(ir) * ld_d;
     // all LDS reads (and D gathers) of the step are issued before any of them is consumed
@@ -108,7 +109,7 @@ __device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, i
 }
 
 template <int W4, int CPL>
-__device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, int c0, int w4, bool first, bool last,
+__device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first, bool last,
                                           int64_t wg_lo, int64_t wg_hi, int wave, int lane) {
     const int l4 = lane & 3;
     const float* dcol = a.d + c0 + 4 * l4;
@@ -140,15 +141,15 @@ __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, 
                     dreg[i] = (l4 + 4 * i < w4) ? *reinterpret_cast<const f32x4*>(dcol + (int64_t)r0 * a.ld_d + 16 * i)
                                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            quad_step<0, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
-            quad_step<1, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
-            quad_step<2, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
-            quad_step<3, W4, CPL, true>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<0, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<1, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<2, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<3, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
         } else {
-            quad_step<0, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
-            quad_step<1, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
-            quad_step<2, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
-            quad_step<3, W4, CPL, false>(lds, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<0, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<1, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<2, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<3, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
         }
         if (mine < wg_hi) {
             float total = cur.carried + result;
@@ -175,18 +176,19 @@ __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
     for (int ph = 0; ph < a.n_phases; ++ph) {
         const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
         __syncthreads();                                    // everyone is done with the previous phase's table
-        for (int idx = tid; idx < a.n * w4; idx += kThreads) {
-            const int row = idx / w4, c4 = idx - row * w4;
-            lds4[idx] = *reinterpret_cast<const float4*>(a.z + (int64_t)row * a.ld_z + c0 + 4 * c4);
+        for (int idx = tid; idx < a.n * a.stride4; idx += kThreads) {     // the padding is zeroed: idle lanes read it (x 0)
+            const int row = idx / a.stride4, c4 = idx - row * a.stride4;
+            lds4[idx] = c4 < w4 ? *reinterpret_cast<const float4*>(a.z + (int64_t)row * a.ld_z + c0 + 4 * c4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {                                       // common widths get compile-time addressing
-            case 16: run_phase<16, 4>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 12: run_phase<12, 3>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 8: run_phase<8, 2>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 4: run_phase<4, 1>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            default: run_phase<0, 4>(a, lds, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
         }
     }
 }
@@ -233,7 +235,13 @@ gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int6
     a.n_phases = plan_phases(n, f, a.c0, a.width);
     int max_w = 0;
     for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
-    const size_t lds_bytes = (size_t)n * max_w * sizeof(float);
+    // LDS rows keep one stride for all phases, an odd number of 64-byte slots where there is room: a quad reads
+    // 64 contiguous bytes of a row, and with rows 128 bytes apart (a 32-column phase) the four quads of a
+    // 16-lane access group would share only two of the four 64-byte bank slots.
+    int stride4 = max_w / 4;
+    if ((stride4 / 4) % 2 == 0 && (size_t)n * (stride4 + 4) * 16 <= kLdsBudget + 8 * 1024) stride4 += 4;
+    a.stride4 = stride4;
+    const size_t lds_bytes = (size_t)n * stride4 * 16;
     // one workgroup per CU; every workgroup's range is a multiple of 64 edges
     int64_t groups = std::min<int64_t>(256, gn::ceil_div(e, 64 * (kThreads / 64)));
     if (groups < 1) groups = 1;

@@ -10,18 +10,22 @@
 // rgcn_fast.hip
 bool gn_rgcn_fast_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
 size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+gn_status gn_rgcn_fast_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
+                               int64_t bases, int64_t fout, void* ws, hipStream_t st);
 gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                                const float* basis, const float* att, int64_t bases, const float* root,
-                               const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
-                               const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
+                               const float* bias, int64_t fout, int relu, int partial, int weights_ready, float* out,
+                               int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
 // rgcn_acc.hip
 bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
 size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+gn_status gn_rgcn_acc_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
+                              int64_t bases, int64_t fout, void* ws, hipStream_t st);
 gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                               const float* basis, const float* att, int64_t bases, const float* root,
-                              const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
-                              const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
+                              const float* bias, int64_t fout, int relu, int partial, int weights_ready, float* out,
+                              int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
 bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed);
 gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, const float* x, int64_t ld_x, int64_t fin,
@@ -77,10 +81,28 @@ size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fo
     return general_layout(plan, fin, fout).total;
 }
 
+gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att, int64_t bases,
+                              int64_t fout, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
+    if (plan->num_nodes == 0 || plan->num_relations == 0) return GN_OK;
+    GN_REQUIRE(basis && att, "operand pointer is null");
+    GN_REQUIRE(workspace_bytes >= gn_rgcn_workspace_bytes(plan, fin, fout, bases) && workspace,
+               "workspace too small: need %zu bytes", gn_rgcn_workspace_bytes(plan, fin, fout, bases));
+    hipStream_t st = gn::as_stream(stream);
+    if (gn_rgcn_acc_applicable(plan, fin, fout, bases)) return gn_rgcn_acc_weights(plan, fin, basis, att, bases, fout, workspace, st);
+    if (gn_rgcn_fast_applicable(plan, fin, fout, bases)) return gn_rgcn_fast_weights(plan, fin, basis, att, bases, fout, workspace, st);
+    // general path, K7: W[R, fin*fout] = att[R,B] @ basis[B, fin*fout]   (layers.py:172-173)
+    float* W = reinterpret_cast<float*>(static_cast<char*>(workspace) + general_layout(plan, fin, fout).w_off);
+    return gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, plan->num_relations, fin * fout,
+                       bases, 1, nullptr, 0, stream);
+}
+
 gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                               const float* basis, const float* att, int64_t bases, const float* root,
-                              const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
+                              const float* bias, int64_t fout, int relu, int flags, float* out, int64_t ld_out,
                               const gn_side_copy* side, void* workspace, size_t workspace_bytes, void* stream) {
+    const int partial = flags & GN_RGCN_PARTIAL, weights_ready = (flags & GN_RGCN_WEIGHTS_READY) ? 1 : 0;
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
@@ -95,11 +117,11 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     if (ss != GN_OK) return ss;
 
     if (gn_rgcn_acc_applicable(plan, fin, fout, bases))
-        return gn_rgcn_acc_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, out,
-                                   ld_out, sc, workspace, workspace_bytes, st);
+        return gn_rgcn_acc_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, weights_ready,
+                                   out, ld_out, sc, workspace, workspace_bytes, st);
     if (gn_rgcn_fast_applicable(plan, fin, fout, bases))
-        return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, out,
-                                    ld_out, sc, workspace, workspace_bytes, st);
+        return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, weights_ready,
+                                    out, ld_out, sc, workspace, workspace_bytes, st);
 
     const GeneralWs l = general_layout(plan, fin, fout);
     char* ws = static_cast<char*>(workspace);
@@ -109,8 +131,8 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     gn_status s;
     if (R > 0) {
         // K7: W[R, fin*fout] = att[R,B] @ basis[B, fin*fout]   (layers.py:172-173)
-        s = gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, R, fin * fout, bases, 1,
-                        nullptr, 0, stream);
+        s = weights_ready ? GN_OK : gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, R,
+                                                fin * fout, bases, 1, nullptr, 0, stream);
         if (s != GN_OK) return s;
         // H[r] = X @ W[r] for all relations; grid.z carries the relation, in slabs of 32768
         for (int64_t r0 = 0; r0 < R; r0 += 32768) {

@@ -86,6 +86,7 @@ static_assert(kTpg <= 4, "AccUnit holds four tile block counts");
 
 struct AccDims { int64_t ld_x; int n; int tiles; int q_groups; int slabs; };
 
+
 // hi = bf16(v), lo = bf16(v - hi) for two floats at a time; returns the packed pairs (element 0 in the low half).
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -677,20 +678,31 @@ size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_
     return acc_w_bytes(plan->num_relations, fin, fout) + (size_t)plan->acc_g * plan->num_nodes * fout * sizeof(float);
 }
 
+gn_status gn_rgcn_acc_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
+                              int64_t bases, int64_t fout, void* ws, hipStream_t st) {
+    GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
+    const int64_t R = plan->num_relations;
+    const int tasks = (int)(gn::ceil_div(R, 16) * 4 * ((fin / 4 + 7) / 8) * (fout / 16));
+    k_rgcn_weights_frag<<<(int)gn::ceil_div(tasks, 4), 256, 0, st>>>(att, basis, static_cast<f32x4*>(ws), (int)R, (int)bases,
+                                                                    (int)fin, (int)fout, tasks, acc_exact() ? 0 : 1);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                               const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
-                              int relu, int partial, float* out, int64_t ld_out, const gn_side_copy& side, void* ws,
-                              size_t ws_bytes, hipStream_t st) {
+                              int relu, int partial, int weights_ready, float* out, int64_t ld_out,
+                              const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st) {
     GN_REQUIRE(ld_x % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld_x %% 4 == 0");
     GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
     const int64_t R = plan->num_relations;
     f32x4* wfrag = static_cast<f32x4*>(ws);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + acc_w_bytes(R, fin, fout));
     const bool split = !acc_exact();
-    const int tasks = (int)(gn::ceil_div(R, 16) * 4 * ((fin / 4 + 7) / 8) * (fout / 16));
-    k_rgcn_weights_frag<<<(int)gn::ceil_div(tasks, 4), 256, 0, st>>>(att, basis, wfrag, (int)R, (int)bases, (int)fin,
-                                                                    (int)fout, tasks, split ? 1 : 0);
-    GN_LAUNCH_CHECK();
+    if (!weights_ready) {
+        gn_status ws_status = gn_rgcn_acc_weights(plan, fin, basis, att, bases, fout, ws, st);
+        if (ws_status != GN_OK) return ws_status;
+    }
     const size_t lds = acc_lds_bytes(plan->num_nodes, fin);
     gn_status s;
     switch ((int)fin * 2 + (split ? 1 : 0)) {
@@ -702,6 +714,8 @@ gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t 
         default: s = launch_acc<48, true>(plan, x, ld_x, wfrag, slabs, lds, st); break;
     }
     if (s != GN_OK) return s;
+    // (summing the slabs inside the kernel, by the last workgroup of every row group behind an agent-scope hand-off,
+    // was measured: +8 us on the kernel's tail against the 4.5 us launch it removes)
     return gn_rgcn_slab_finalize_launch(plan, slabs, plan->acc_g, x, ld_x, fin, root, bias, relu, partial, out, ld_out, side, st);
 }
 

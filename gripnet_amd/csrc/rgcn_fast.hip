@@ -895,23 +895,33 @@ size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64
     return w + (size_t)plan->fast_groups * plan->num_nodes * fout * sizeof(float);
 }
 
+gn_status gn_rgcn_fast_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
+                               int64_t bases, int64_t fout, void* ws, hipStream_t st) {
+    GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
+    // K7: W_r = sum_b att[r,b] basis[b], stored transposed per relation   (layers.py:172-173)
+    WtArgs wa;
+    wa.att = att; wa.basis = basis; wa.wt = static_cast<float*>(ws); wa.relations = (int)plan->num_relations;
+    wa.bases = (int)bases; wa.fin = (int)fin; wa.fout = (int)fout;
+    dim3 wgrid((unsigned)gn::ceil_div(plan->num_relations, 16), (unsigned)((fin / 16) * (fout / 16)));
+    k_rgcn_weights_t<<<wgrid, 256, 0, st>>>(wa);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                                const float* basis, const float* att, int64_t bases, const float* root,
-                               const float* bias, int64_t fout, int relu, int partial, float* out, int64_t ld_out,
-                               const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st) {
+                               const float* bias, int64_t fout, int relu, int partial, int weights_ready, float* out,
+                               int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st) {
     GN_REQUIRE(ld_x % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld_x %% 4 == 0");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
     GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
     float* Wt = static_cast<float*>(ws);
     const size_t w_bytes = ((size_t)R * fin * fout * sizeof(float) + 255) & ~size_t(255);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + w_bytes);
-    // K7: W_r = sum_b att[r,b] basis[b], stored transposed per relation   (layers.py:172-173)
-    WtArgs wa;
-    wa.att = att; wa.basis = basis; wa.wt = Wt; wa.relations = (int)R; wa.bases = (int)bases; wa.fin = (int)fin;
-    wa.fout = (int)fout;
-    dim3 wgrid((unsigned)gn::ceil_div(R, 16), (unsigned)((fin / 16) * (fout / 16)));
-    k_rgcn_weights_t<<<wgrid, 256, 0, st>>>(wa);
-    GN_LAUNCH_CHECK();
+    if (!weights_ready) {
+        gn_status ws_status = gn_rgcn_fast_weights(plan, fin, basis, att, bases, fout, ws, st);
+        if (ws_status != GN_OK) return ws_status;
+    }
     FastArgs a;
     a.x = x; a.ld_x = ld_x; a.n = (int)N; a.wt = Wt; a.packed = plan->packed.p; a.slot_off = plan->seg_begin.p;
     a.work = reinterpret_cast<const WorkDesc*>(plan->wg_items.p); a.wg_begin = plan->wg_begin.p;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 102 /* 0.1.2 */
+#define GN_VERSION 103 /* 0.1.3 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -158,13 +158,24 @@ GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
 GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features,
                                int64_t num_bases);
 
-/* partial == 0:  out[i,:] = act( (sum_{e: dst=i} x[src_e] W_{r(e)}) / max(1, indeg_i) + x[i] root + bias )
- * partial == 1:  out[i,:] = sum_{e in [edge_lo,edge_hi): dst=i} x[src_e] W_{r(e)}   (un-normalised
- *                shard contribution; all-reduce it, then call gn_rgcn_finalize_f32)
+/* W_r = sum_b att[r,b] basis[b] for every relation (layers.py:172-173), written into `workspace` in the layout the
+ * forward kernels read.  Optional: gn_rgcn_forward_f32 computes it itself unless GN_RGCN_WEIGHTS_READY is set.
+ * The weights depend on the parameters only, so a caller can launch this on a second stream while the layers
+ * that produce x are still running, and order the forward behind it with an event. */
+GN_API gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t in_features, const float* basis, const float* att,
+                              int64_t num_bases, int64_t out_features, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+#define GN_RGCN_PARTIAL 1        /* flags of gn_rgcn_forward_f32 */
+#define GN_RGCN_WEIGHTS_READY 2  /* `workspace` already holds the output of gn_rgcn_weights_f32 for these parameters */
+
+/* flags & GN_RGCN_PARTIAL == 0:  out[i,:] = act( (sum_{e: dst=i} x[src_e] W_{r(e)}) / max(1, indeg_i) + x[i] root + bias )
+ * flags & GN_RGCN_PARTIAL:       out[i,:] = sum_{e in [edge_lo,edge_hi): dst=i} x[src_e] W_{r(e)}   (un-normalised
+ *                                shard contribution; all-reduce it, then call gn_rgcn_finalize_f32)
  * with W_r = sum_b att[r,b] basis[b]  (layers.py:172-173).  bias may be NULL. */
 GN_API gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t in_features,
                               const float* basis, const float* att, int64_t num_bases, const float* root,
-                              const float* bias, int64_t out_features, int relu, int partial, float* out,
+                              const float* bias, int64_t out_features, int relu, int flags, float* out,
                               int64_t ld_out, const gn_side_copy* side /* nullable */, void* workspace,
                               size_t workspace_bytes, void* stream);
 
