@@ -114,14 +114,15 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     constexpr int M = (KQ + 7) / 8;          // bf16 MFMAs (8 k per lane) that cover a quarter
     constexpr int BV = SPLIT ? NT * M * 2 : NT * KP;   // 16-byte W fragments per lane and relation
     constexpr int XL = FIN / 4;              // float4 per row of x
-    // LDS row stride: one float4 of padding.  Unpadded, a row starts at bank 48 * src mod 64, one of four values
-    // (two at in = 32), and the 8 lanes that share a quarter inside a 16-lane access group of ds_read_b128 pile
-    // onto them; an odd stride in float4 spreads the row starts over all 16 bank quads.
-    constexpr int XS = XL + 1;
+    // LDS rows are whole 64-byte bank slots, an odd number of them per row: the four lanes that gather one edge
+    // read one slot (see below), and the plan orders every row's edges so that the four edges a 16-lane access
+    // group of ds_read_b128 works on sit in four different slots wherever the graph allows it.
+    constexpr int XS = 4 * ((FIN / 16) | 1);
     extern __shared__ f32x4 lds4[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n16 = lane & 15, kq = lane >> 4;
+    const int n16 = lane & 15, kq = lane >> 4;       // MFMA layout: row lane % 16, k group lane / 16
+    const int grow = lane >> 2, gq = lane & 3;        // gather layout: row lane / 4, quarter lane % 4
     const int qg = blockIdx.x % a.q_groups, slab = blockIdx.x / a.q_groups;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
 
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
             if (i < a.n * XL) lds4[r * XS + c] = fill[k];
         }
     }
-    if (tid < XL) lds4[a.n * XS + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4* stage = reinterpret_cast<u32x4*>(lds4 + (a.n + 1) * XS) + wave * (kStage * 8);
-    const u32x2* stage2 = reinterpret_cast<const u32x2*>(stage) + n16;
+    if (tid < 4 * XS) lds4[a.n * XS + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};   // four zero rows, one per bank slot, for padded edge slots
+    u32x4* stage = reinterpret_cast<u32x4*>(lds4 + (a.n + 4) * XS) + wave * (kStage * 8);
+    const u32x2* stage2 = reinterpret_cast<const u32x2*>(stage) + grow;
     __syncthreads();
 #ifdef GN_STAMPS
     const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
@@ -191,7 +192,12 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     for (int t = 0; t < kTpg; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4* __restrict__ xq = lds4 + kq * KP;               // this lane's quarter of a table row
+    // Gather layout: the four lanes 4 r .. 4 r + 3 work on the edge of row r and read the four consecutive 16-byte
+    // pieces 4 p + gq of x[src] (one 64-byte bank slot per instruction and edge, so a 16-lane access group touches
+    // four slots); lane (r, gq) therefore sums features 16 p + 4 gq + c.  The sums are moved to the MFMA layout
+    // once per tile (ds_bpermute), not once per edge.
+    const f32x4* __restrict__ xq = lds4 + gq;
+    const int from_lane4 = 4 * (4 * n16 + kq);                    // MFMA lane (row n16, k group kq) takes gather lane 4 n16 + kq
     // wnext is the stream word of the next block to consume, read from the window one block ahead (the stream
     // is contiguous across tiles and units, so the look-ahead never stops); pos is its block in the window.
     int pos = 0;
@@ -236,19 +242,25 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
                 s[0][0] += __uint_as_float(s0 + s1 + s2 + s3);
 #else
 #pragma unroll
-                for (int p = 0; p < KP; ++p) s[p] += (r0[p] + r1[p]) + (r2[p] + r3[p]);
+                for (int p = 0; p < KP; ++p) s[p] += (r0[4 * p] + r1[4 * p]) + (r2[4 * p] + r3[4 * p]);
 #endif
             }
 #ifdef GN_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long st_b = __builtin_amdgcn_s_memtime();
 #endif
+#pragma unroll
+            for (int p = 0; p < KP; ++p)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    s[p][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(from_lane4, __float_as_int(s[p][c])));
 #if GN_ACC_MODE & 1
 #pragma unroll
             for (int p = 0; p < KP; ++p) acc[t][0] += s[p] * bfrag[p];
 #else
             if constexpr (SPLIT) {
-                // lane (row, kg) supplies A[row][k = 8 kg + j] = s[8 m + j].  A quarter that ends half way through
+                // lane (row, kg) supplies A[row][k = 8 kg + j] = s[8 m + j] = feature 16 ((8 m + j) / 4) + 4 kg + (8 m + j) % 4.
+                // A quarter that ends half way through
                 // its last MFMA (in = 16, 48) packs that one as A = {hi, lo} against B = {hi, hi} and B = {lo, 0}:
                 // hi.hi + lo.hi in one instruction, hi.lo in the other.
 #pragma unroll
@@ -329,8 +341,9 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
 }
 
 // W_r = sum_b att[r, b] basis[b]  (layers.py:172-173), written as the B operand of the transform above:
-//   fp32:  Wfrag[r][nt][p][lane = kg * 16 + col][jj] = W_r[kg * KQ + 4 p + jj][16 nt + col]
-//   split: fragment (r, nt, m, hi | lo), lane kg * 16 + col, bf16 element j = W_r[kg * KQ + 8 m + j][16 nt + col];
+// (k group kg, e-th value of the group) is feature f(kg, e) = 16 (e / 4) + 4 kg + e % 4 (the gather layout of k_rgcn_acc)
+//   fp32:  Wfrag[r][nt][p][lane = kg * 16 + col][jj] = W_r[f(kg, 4 p + jj)][16 nt + col]
+//   split: fragment (r, nt, m, hi | lo), lane kg * 16 + col, bf16 element j = W_r[f(kg, 8 m + j)][16 nt + col];
 //          a quarter that ends half way through its last MFMA stores {hi, hi} and {lo, 0} (see k_rgcn_acc).
 // One wave = 16 relations x (up to 8 consecutive k of one quarter) x 16 columns: up to eight fp32 MFMA tiles over
 // the bases, and every lane ends up with whole 16-byte fragment elements (16 lanes = one 256-byte run).
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_frag(const float* __restri
     const int n16 = lane & 15, q = lane >> 4;
     const int nts = fout / 16, KQ = fin / 4, KP = KQ / 4, M = (KQ + 7) / 8;
     const int nt = task % nts, m = (task / nts) % M, kg = (task / (nts * M)) % 4, rb = task / (nts * M * 4);
-    const int r0 = rb * 16, k0 = kg * KQ + 8 * m;
+    const int r0 = rb * 16;
     const int nk = min(8, KQ - 8 * m);                                // 8, or 4 when the quarter ends half way (wave-uniform)
     const int arow = min(r0 + n16, relations - 1);
     f32x4 acc[8];
@@ -355,9 +368,12 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_frag(const float* __restri
         for (int h = 0; h < 8; ++h) {
             const int bc = min(b0 + 4 * h + q, bases - 1);           // unconditional, clamped; zeroed by select below
             av[h] = att[(int64_t)arow * bases + bc];
-            const float* __restrict__ bp = basis + ((int64_t)bc * fin + k0) * fout + nt * 16 + n16;
+            const float* __restrict__ bp = basis + (int64_t)bc * fin * fout + nt * 16 + n16;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bv[h][j] = bp[min(j, nk - 1) * fout];
+            for (int j = 0; j < 8; ++j) {
+                const int e = 8 * m + min(j, nk - 1);
+                bv[h][j] = bp[(16 * (e / 4) + 4 * kg + e % 4) * fout];
+            }
         }
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256) void k_rgcn_weights_frag(const float* __restri
             }
         }
     }
-    // lane (col, q), register i: W_r[k0 + j][16 nt + col] for relation r0 + 4 q + i, j = 0 .. nk - 1
+    // lane (col, q), register i: W_r[f(kg, 8 m + j)][16 nt + col] for relation r0 + 4 q + i, j = 0 .. nk - 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + 4 * q + i;
@@ -422,26 +438,6 @@ __global__ void k_acc_rowptr(const uint32_t* __restrict__ sorted, int n, int64_t
         if (sorted[mid] < (uint32_t)i) lo = mid + 1; else hi = mid;
     }
     out[i] = lo;
-}
-
-__global__ void k_acc_fill(uint32_t* __restrict__ stream32, int64_t words, uint32_t v) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
-        stream32[i] = v;
-}
-
-// Edge p of the (relation, dst)-sorted list, the j-th of its run: chunk j / cap, iteration j % cap of tile dst / 16.
-__global__ void k_acc_scatter(const uint32_t* __restrict__ key_sorted, const uint32_t* __restrict__ src_sorted,
-                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ chunk_base,
-                              const uint32_t* __restrict__ chunk_off, int n, int N, int tiles,
-                              uint16_t* __restrict__ stream16) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t k = key_sorted[p];
-    const int r = (int)(k / (uint32_t)N), dd = (int)(k - (uint32_t)r * (uint32_t)N);
-    const int j = p - rowptr[k];
-    const int c = j / kIterCap, it = j % kIterCap;
-    const uint32_t blk = chunk_off[chunk_base[r * tiles + dd / 16] + c] + (uint32_t)(it >> 2);
-    stream16[(size_t)blk * 64 + (dd & 15) * 4 + (it & 3)] = (uint16_t)src_sorted[p];
 }
 
 struct Scratch {
@@ -539,7 +535,9 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     k_acc_rowptr<<<(int)gn::ceil_div(R * N + 1, 256), 256, 0, st>>>(key_sorted, (int)E, R * N, rowptr);
     GN_LAUNCH_CHECK();
     std::vector<int32_t> rp(R * N + 1);
+    std::vector<uint32_t> srcs(E);                                    // sources in (relation, destination) order
     GN_HIP(hipMemcpyAsync(rp.data(), rowptr, (R * N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipMemcpyAsync(srcs.data(), val_sorted, (size_t)E * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
 
     // iterations of every (relation, tile) = its longest (relation, destination) run
@@ -635,23 +633,93 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     if (blocks_total + 3 * kStage >= ((uint64_t)1 << 26)) return GN_OK;      // 64 B-word index must fit 32 bits
     if (units.empty()) units.push_back(AccUnit{0, {0, 0, 0, 0}, 0, 0});
 
-    int32_t* chunk_base_dev;
-    uint32_t* chunk_off_dev;
-    GN_HIP(tmp.get(&chunk_base_dev, chunk_base.size()));
-    GN_HIP(tmp.get(&chunk_off_dev, chunk_off.size()));
-    GN_HIP(hipMemcpyAsync(chunk_base_dev, chunk_base.data(), chunk_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(chunk_off_dev, chunk_off.data(), chunk_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    // ---- the edge streams.  Which edge of a row goes into which iteration is free (the order of a sum), so it is
+    //      chosen for the LDS: in the gather layout of k_rgcn_acc the four lanes of a row read one 64-byte bank
+    //      slot of x[src] per instruction, slot = (src * odd) mod 4, and ds_read_b128 serves the wave in four
+    //      access groups of four rows each.  Per iteration and access group the rows pick edges whose sources
+    //      fall into different slots where they can; rows with edges to spare sit an iteration out (their slot
+    //      then points at a zero row in a free slot) rather than collide. ----
     const int64_t words = (int64_t)(blocks_total + 3 * kStage) * 32;         // uint32 words: 16 rows x 2 per block
+    std::vector<uint16_t> stream16((size_t)words * 2);
+    static const int kGroupRows[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};   // rows = lanes / 4 of the b128 access groups
+    int pos_in_group[16];
+    for (int g = 0; g < 4; ++g)
+        for (int k = 0; k < 4; ++k) pos_in_group[kGroupRows[g][k]] = k;
+    for (size_t i = 0; i < stream16.size(); ++i) stream16[i] = (uint16_t)(N + pos_in_group[(i >> 2) & 15]);   // padding: four zero rows, one per slot
+    {
+        std::vector<uint16_t> byclass;                       // one row's sources, grouped by slot class
+        int cur[16][4], end[16][4], rem[16];
+        std::vector<uint16_t> rowbuf[16];
+        for (int64_t r = 0; r < R; ++r)
+            for (int tile = 0; tile < tiles; ++tile) {
+                const int32_t L = iters[r * tiles + tile];
+                if (L == 0) continue;
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t d = (int64_t)tile * 16 + i;
+                    rowbuf[i].clear();
+                    rem[i] = 0;
+                    for (int c = 0; c < 4; ++c) cur[i][c] = end[i][c] = 0;
+                    if (d >= N) continue;
+                    const int32_t b0 = rp[r * N + d], b1 = rp[r * N + d + 1];
+                    rem[i] = b1 - b0;
+                    int cnt[4] = {0, 0, 0, 0};
+                    for (int32_t p = b0; p < b1; ++p) ++cnt[srcs[p] & 3];
+                    int off = 0;
+                    for (int c = 0; c < 4; ++c) { cur[i][c] = off; off += cnt[c]; end[i][c] = off; }
+                    rowbuf[i].resize(rem[i]);
+                    int fillp[4] = {cur[i][0], cur[i][1], cur[i][2], cur[i][3]};
+                    for (int32_t p = b0; p < b1; ++p) rowbuf[i][fillp[srcs[p] & 3]++] = (uint16_t)srcs[p];
+                }
+                const int32_t cb = chunk_base[r * tiles + tile];
+                for (int32_t it = 0; it < L; ++it) {
+                    const int32_t left = L - it;             // iterations left, this one included
+                    const size_t blk = (size_t)chunk_off[cb + it / kIterCap] + (size_t)((it % kIterCap) >> 2);
+                    uint16_t* out = stream16.data() + blk * 64 + (it & 3);         // + row * 4
+                    for (int g = 0; g < 4; ++g) {
+                        int order[4] = {kGroupRows[g][0], kGroupRows[g][1], kGroupRows[g][2], kGroupRows[g][3]};
+                        // rows that cannot sit out first, then the fuller ones
+                        std::sort(order, order + 4, [&](int x, int y) {
+                            const bool mx = rem[x] >= left, my = rem[y] >= left;
+                            return mx != my ? mx : rem[x] > rem[y];
+                        });
+                        unsigned used = 0;
+                        bool idle[4] = {false, false, false, false};
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = order[k];
+                            if (rem[i] == 0) { idle[k] = true; continue; }
+                            int best = -1, bestcnt = 0;
+                            for (int c = 0; c < 4; ++c) {
+                                const int n_c = end[i][c] - cur[i][c];
+                                if (n_c > bestcnt && !((used >> c) & 1)) { best = c; bestcnt = n_c; }
+                            }
+                            if (best < 0) {
+                                if (rem[i] < left) { idle[k] = true; continue; }      // can wait for a free slot
+                                for (int c = 0; c < 4; ++c) {
+                                    const int n_c = end[i][c] - cur[i][c];
+                                    if (n_c > bestcnt) { best = c; bestcnt = n_c; }
+                                }
+                            }
+                            out[i * 4] = rowbuf[i][cur[i][best]++];
+                            --rem[i];
+                            used |= 1u << best;
+                        }
+                        for (int k = 0; k < 4; ++k) {        // rows that sit out: a zero row in a slot nobody reads
+                            if (!idle[k]) continue;
+                            const int i = order[k];
+                            for (int z = 0; z < 4; ++z) {
+                                const unsigned c = (unsigned)(N + z) & 3u;
+                                if (!((used >> c) & 1)) { out[i * 4] = (uint16_t)(N + z); used |= 1u << c; break; }
+                            }
+                        }
+                    }
+                }
+            }
+    }
     GN_HIP(plan->acc_stream.alloc((size_t)words));
     GN_HIP(plan->acc_units.alloc(units.size() * (sizeof(AccUnit) / sizeof(int32_t))));
     GN_HIP(plan->acc_wave_units.alloc(wave_units.size()));
     GN_HIP(plan->acc_wave_stream.alloc(wave_stream.size()));
-    k_acc_fill<<<gn::stream_grid(words, 256), 256, 0, st>>>(plan->acc_stream.p, words, (uint32_t)N | ((uint32_t)N << 16));
-    GN_LAUNCH_CHECK();
-    k_acc_scatter<<<(int)gn::ceil_div(E, 256), 256, 0, st>>>(key_sorted, val_sorted, rowptr, chunk_base_dev, chunk_off_dev,
-                                                            (int)E, (int)N, tiles,
-                                                            reinterpret_cast<uint16_t*>(plan->acc_stream.p));
-    GN_LAUNCH_CHECK();
+    GN_HIP(hipMemcpyAsync(plan->acc_stream.p, stream16.data(), (size_t)words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->acc_units.p, units.data(), units.size() * sizeof(AccUnit), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->acc_wave_units.p, wave_units.data(), wave_units.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->acc_wave_stream.p, wave_stream.data(), wave_stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -663,7 +731,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
 }
 
 static size_t acc_lds_bytes(int64_t n, int64_t fin) {
-    const size_t table = (size_t)(n + 1) * (fin + 4) * sizeof(float) + (size_t)kWaves * kStage * 128;
+    const size_t table = (size_t)(n + 4) * 16 * ((fin / 16) | 1) * sizeof(float) + (size_t)kWaves * kStage * 128;
     const size_t fold = (size_t)kWaves * kTpg * 16 * kFoutAcc * sizeof(float);
     return std::max(table, fold);
 }
