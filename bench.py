@@ -57,10 +57,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", dest="graphs", action="store_false",
-                    help="launch every entry point from Python instead of replaying the stages around the dominant "
-                         "entry point as hipGraphs (eager launching is host-bound: ~150 us of Python per step "
-                         "against ~120 us of kernels on pose0-syn)")
+    ap.add_argument("--launch", choices=("auto", "eager", "graphs"), default="auto",
+                    help="eager: every entry point launched from Python (~100-150 us of host work per step, depending "
+                         "on the box, against ~120 us of kernels on pose0-syn); graphs: the stages replayed as hipGraphs "
+                         "(the dominant entry point's stage is a graph of its own, bracketed by HIP events); auto: "
+                         "whichever of the two runs the step faster on this box, measured before the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -99,7 +100,8 @@ def main():
     E_dd = int(data.train_idx.shape[1])
     lo, hi = shard_edge_ranges(E_dd, world)[rank]
     n_d = data.n_d_node
-    CANDIDATES = {"gn_rgcn_forward_f32": "drugs", "gn_distmult_forward_f32": "decode"}
+    CANDIDATES = {"gn_rgcn_forward_f32": "drugs", "gn_distmult_forward_f32": "decode",
+                  "gn_distmult_plan_forward_f32": "decode"}     # the decoder scores the static positive list through its plan
 
     def fence():
         if dist is not None:
@@ -122,10 +124,23 @@ def main():
                 eager.step()
             per_call0, breakdown = per_entry_us(eager.step, 5)
             dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
-            # default: every stage replays as a hipGraph; the stage that holds the dominant entry point is a graph
-            # of its own, bracketed by HIP events on its stream in EVERY timed step
-            stages = PoseStages(model, data, graphs=True, timed_entry=dom) if args.graphs else eager
-            step = stages.step
+            # graphs: every stage replays as a hipGraph; the stage that holds the dominant entry point is a graph of
+            # its own, bracketed by HIP events on its stream in EVERY timed step.  eager: the events sit around the
+            # dominant entry point's launches themselves (_hip._call).
+            def quick(fn, n=20):
+                for _ in range(5):
+                    fn()
+                fence()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                fence()
+                return (time.perf_counter() - t) / n
+            launch = args.launch
+            graphed = PoseStages(model, data, graphs=True, timed_entry=dom) if launch != "eager" else None
+            if launch == "auto":
+                launch = "graphs" if quick(graphed.step) < quick(eager.step) else "eager"
+            step = graphed.step if launch == "graphs" else eager.step
         else:
             from gripnet_amd.pipeline import Graphed
             from gripnet_amd.sharded import ShardedPoseForward
@@ -134,7 +149,8 @@ def main():
                 fwd()
             per_call0, breakdown = per_entry_us(fwd, 5)
             dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
-            if args.graphs:                           # replicated gene layers as one graph; the collective is never captured
+            launch = "eager" if args.launch == "eager" else "graphs"
+            if launch == "graphs":                    # replicated gene layers as one graph; the collective is never captured
                 fwd.kernels.encode_genes = Graphed(fwd.kernels.encode_genes).capture()
             step = fwd
 
@@ -160,7 +176,8 @@ def main():
 
     # ---- roofline of the dominant entry point (HIP events on its stream, inside the timed region) ----
     alg = algorithmic_bytes(data, hi - lo, E_dd)
-    stage_bytes = {"gn_distmult_forward_f32": alg["dmt"], "gn_rgcn_forward_f32": alg["dd"]}
+    stage_bytes = {"gn_distmult_forward_f32": alg["dmt"], "gn_distmult_plan_forward_f32": alg["dmt"],
+                   "gn_rgcn_forward_f32": alg["dd"]}
     calls, total_ms = timer.summary()[dom]
     dom_us = 1e3 * total_ms / calls
     achieved = stage_bytes[dom] / (dom_us * 1e-6) / 1e9
@@ -184,10 +201,12 @@ def main():
                    "edges_aggregated_per_step": A, "n_g": data.n_g_node, "n_d": n_d, "relations": data.n_dd_edge_type,
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
-                   "launch": "hipGraph replay of the stages; {} HIP-event timed around its own graph".format(dom) if args.graphs else "eager"},
+                   "launch": ("hipGraph replay of the stages; {} HIP-event timed around its own graph".format(dom)
+                              if launch == "graphs" else "eager; {} HIP-event timed around every launch".format(dom))},
         "roofline": roofline,
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
-        "edges_scored_per_sec": (hi - lo) / (per_call0["gn_distmult_forward_f32"] * 1e-6),
+        "edges_scored_per_sec": (hi - lo) / (per_call0.get("gn_distmult_plan_forward_f32",
+                                                           per_call0.get("gn_distmult_forward_f32", float("nan"))) * 1e-6),
     }
 
     # ---- CPU baseline + parity in the same run (rank 0, N = 1) ---------------------------------

@@ -20,7 +20,7 @@ _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
-ABI_VERSION = 103                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 104                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -50,6 +50,10 @@ SIGNATURES = {
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
+    "gn_distmult_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_distmult_plan_destroy": (None, [_p]),
+    "gn_distmult_plan_edges": (_i64, [_p]),
+    "gn_distmult_plan_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _int, _p, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
@@ -479,6 +483,35 @@ def distmult(z, u_v, edge_type, weight, sigmoid, out):
           ld(weight), weight.shape[0], e, int(bool(sigmoid)), ptr(out),
           ptr(error_flag(z.device)), stream_ptr(z.device))
     return out
+
+
+class DistMultPlan:
+    """Owner of a gn_distmult_plan handle: one static (edge_index, edge_type) list, validated, packed and ordered
+    for the LDS-resident decoder kernel (the positive edges a training loop scores every epoch)."""
+
+    def __init__(self, u_v, edge_type, num_nodes, num_relations):
+        lib = load()
+        require_gpu(u_v, edge_type)
+        ei, u, v, e = edge_rows(u_v)
+        et = i64_vec(edge_type)
+        if et.numel() != e:
+            raise ValueError("edge_type has {} entries for {} edges".format(et.numel(), e))
+        h = _p()
+        with torch.cuda.device(ei.device):
+            check(lib.gn_distmult_plan_create(u, v, ptr(et), e, int(num_nodes), int(num_relations),
+                                              stream_ptr(ei.device), C.byref(h)))
+        self._h, self.device, self.num_edges = h, ei.device, e
+        self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)
+
+    def forward(self, z, weight, sigmoid, out):
+        _call("gn_distmult_plan_forward_f32", self._h, ptr(z), ld(z), z.shape[1], ptr(weight), ld(weight),
+              int(bool(sigmoid)), ptr(out), stream_ptr(z.device))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gn_distmult_plan_destroy(h)
 
 
 def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd):

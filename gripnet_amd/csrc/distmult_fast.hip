@@ -12,16 +12,11 @@
 // ds_read_b128 (16 edges in flight per wave step), the relation row D[r] stays in registers
 // while r does not change (type-sorted positives), and the quad's partial products are folded
 // with two DPP adds.
-#include "common.h"
+#include "distmult_quad.cuh"
 
 namespace {
 
-constexpr int kMaxPhases = 8;
-constexpr int kThreads = 1024;
-constexpr size_t kLdsBudget = 150 * 1024;   // of 160 KB; the rest is left to the runtime
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace gn_dm;
 
 struct DmFastArgs {
     const float* z; int64_t ld_z; int n; int features;
@@ -31,66 +26,6 @@ struct DmFastArgs {
     int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
     int stride4;           // LDS row stride in float4, the same in every phase (see gn_distmult_fast_forward)
 };
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {
-    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
-}
-// sum over the 16 lanes of a DPP row, result in every lane
-__device__ __forceinline__ float row_sum16(float x) {
-    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
-    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
-    x = dpp_add<0x141>(x);   // row_half_mirror
-    x = dpp_add<0x140>(x);   // row_mirror
-    return x;
-}
-
-// One edge per QUAD (4 lanes), 16 edges per wave step.  Lane l4 of the quad covers the 16-byte
-// chunks l4, l4+4, ... of the phase's columns, so a 48-column phase is 3 x (2 ds_read_b128 + a
-// few FMAs) per lane and the per-edge fold is two DPP adds.
-// UNIFORM_R: the whole 64-edge batch has one relation whose D chunks already sit in `dreg`;
-// otherwise each step gathers its D chunks from L2.
-// W4 > 0: the phase width (in float4 chunks) is a compile-time constant; W4 == 0: runtime w4.
-template <int S, int W4, int CPL, bool UNIFORM_R>
-__device__ __forceinline__ void quad_step(const char* __restrict__ lds, int stride_bytes, int w4, int l4, int iu, int iv, int ir,
-                                          const float* __restrict__ dcol, int64_t ld_d, const f32x4 (&dreg)[CPL],
-                                          float& result) {
-    constexpr int kBcast = S * 0x55;     // quad_perm [S,S,S,S]
-    const int uu = dpp_i<kBcast>(iu), vv = dpp_i<kBcast>(iv);
-    const int width4 = W4 > 0 ? W4 : w4;
-    const char* pu = lds + __umul24(uu, stride_bytes) + l4 * 16;
-    const char* pv = lds + __umul24(vv, stride_bytes) + l4 * 16;
-    const float* dr = dcol;
-    if constexpr (!UNIFORM_R) dr = dcol + (int64_t)dpp_i<kBcast>(ir) * ld_d;
-    // all LDS reads (and D gathers) of the step are issued before any of them is consumed
-    f32x4 P[CPL], Q[CPL], D[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const bool present = W4 > 0 ? (4 * i < W4) : (4 * i < w4);
-        const bool ragged = W4 > 0 ? (4 * i + 3 >= W4) : true;   // only the last chunk group can be partial
-        const bool live = present && (!ragged || (l4 + 4 * i < width4));
-        const int off = live ? 64 * i : 0;
-        if (W4 > 0 && !present) continue;
-        P[i] = *reinterpret_cast<const f32x4*>(pu + off);
-        Q[i] = *reinterpret_cast<const f32x4*>(pv + off);
-        if constexpr (UNIFORM_R) D[i] = dreg[i]; else D[i] = *reinterpret_cast<const f32x4*>(dr + off / 4);
-        if (!live) D[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    f32x2 acc2 = {0.f, 0.f};             // two running sums -> v_pk_mul_f32 / v_pk_fma_f32
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        if (W4 > 0 && 4 * i >= W4) continue;
-        const f32x2 lo = P[i].xy * Q[i].xy, hi = P[i].zw * Q[i].zw;
-        acc2 = lo * D[i].xy + acc2;
-        acc2 = hi * D[i].zw + acc2;
-    }
-    float acc = acc2.x + acc2.y;
-    acc = dpp_add<0xB1>(acc);            // quad_perm [1,0,3,2]
-    acc = dpp_add<0x4E>(acc);            // quad_perm [2,3,0,1]
-    if (l4 == S) result = acc;
-}
 
 struct Batch {            // one lane's edge of a 64-edge batch
     int64_t u, v, r;
@@ -154,7 +89,7 @@ __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, 
         if (mine < wg_hi) {
             float total = cur.carried + result;
             if (last) {
-                if (a.sigmoid) total = 1.0f / (1.0f + expf(-total));
+                if (a.sigmoid) total = sigmoid_f32(total);
                 if (!ok) {
                     total = __builtin_nanf("");
                     if (a.err) atomicOr(a.err, 1);
@@ -176,11 +111,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
     for (int ph = 0; ph < a.n_phases; ++ph) {
         const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
         __syncthreads();                                    // everyone is done with the previous phase's table
-        for (int idx = tid; idx < a.n * a.stride4; idx += kThreads) {     // the padding is zeroed: idle lanes read it (x 0)
-            const int row = idx / a.stride4, c4 = idx - row * a.stride4;
-            lds4[idx] = c4 < w4 ? *reinterpret_cast<const float4*>(a.z + (int64_t)row * a.ld_z + c0 + 4 * c4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        fill_table(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid);
         __syncthreads();
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {                                       // common widths get compile-time addressing
@@ -191,27 +122,6 @@ __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
             default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
         }
     }
-}
-
-// Column phases: as few as possible; each at most 64 columns (4 lanes x 4 chunks x float4) with
-// n x width x 4 B inside the LDS budget; widths are multiples of 16 columns except the last.
-int plan_phases(int64_t n, int64_t f, int* c0, int* width) {
-    if (n <= 0 || f <= 0 || f % 4 != 0) return 0;
-    int64_t max_w = (int64_t)(kLdsBudget / (n * 4)) / 16 * 16;
-    if (max_w > 64) max_w = 64;
-    if (max_w < 16) return 0;
-    const int64_t phases = gn::ceil_div(f, max_w);
-    if (phases > kMaxPhases) return 0;
-    int64_t c = 0;
-    int k = 0;
-    while (c < f) {
-        const int64_t w = std::min(max_w, f - c);
-        c0[k] = (int)c;
-        width[k] = (int)w;
-        c += w;
-        ++k;
-    }
-    return k;
 }
 
 }  // namespace
@@ -235,11 +145,7 @@ gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int6
     a.n_phases = plan_phases(n, f, a.c0, a.width);
     int max_w = 0;
     for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
-    // LDS rows keep one stride for all phases, an odd number of 64-byte slots where there is room: a quad reads
-    // 64 contiguous bytes of a row, and with rows 128 bytes apart (a 32-column phase) the four quads of a
-    // 16-lane access group would share only two of the four 64-byte bank slots.
-    int stride4 = max_w / 4;
-    if ((stride4 / 4) % 2 == 0 && (size_t)n * (stride4 + 4) * 16 <= kLdsBudget + 8 * 1024) stride4 += 4;
+    const int stride4 = lds_stride4(n, max_w);
     a.stride4 = stride4;
     const size_t lds_bytes = (size_t)n * stride4 * 16;
     // one workgroup per CU; every workgroup's range is a multiple of 64 edges

@@ -1,0 +1,296 @@
+// DistMult decoder on a cached, re-encoded STATIC edge list (the positive edges of GripNet-pose.py:137,185:
+// the same train_idx / train_et tensors every epoch; negative samples change per epoch and keep going
+// through gn_distmult_forward_f32).
+//
+//   out[e] = sigma?( sum_k z[u_e,k] * z[v_e,k] * D[r_e,k] )                          (decoder.py:19-23)
+//
+// What the plan buys over streaming the raw int64 triples every call (distmult_fast.hip):
+//   - HBM: one 32-bit word per edge (u : 13 | v : 13 | position in its 64-edge batch : 6) and one relation word per
+//     batch, instead of 24 bytes per edge and column phase;
+//   - LDS: inside a batch the edges are dealt to the (wave step, access group) cells so that the four edges a
+//     16-lane ds_read_b128 access group works on have their u rows - and their v rows - in four different
+//     64-byte bank slots wherever the batch allows it (a batch is 64 consecutive edges of the caller's list, so the
+//     score of an edge still lands in its own 256-byte window of `out`);
+//   - VALU: no int64 arithmetic, no range checks (validated once, at plan time), the batch's relation is a
+//     scalar.
+// Same column phases and quad-per-edge arithmetic as the plan-less kernel: results are bitwise the same.
+#include "distmult_quad.cuh"
+
+#include <algorithm>
+#include <vector>
+
+struct gn_distmult_plan {
+    int64_t num_edges = 0, num_nodes = 0, num_relations = 0, batches = 0;
+    gn::DevBuf<uint32_t> packed;     // [batches * 64]
+    gn::DevBuf<int32_t> batch_rel;   // [batches] relation of the batch, or -1 when it holds more than one
+    gn::DevBuf<uint16_t> rel16;      // [batches * 64] relation of every slot (read for mixed batches only)
+};
+
+namespace {
+
+using namespace gn_dm;
+
+constexpr int kNodeBits = 13;
+constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
+
+struct DmPlanArgs {
+    const float* z; int64_t ld_z; int n;
+    const uint32_t* packed; const int32_t* batch_rel; const uint16_t* rel16;
+    const float* d; int64_t ld_d;
+    int64_t e; int64_t batches; int64_t batches_per_wg; int sigmoid; float* out;
+    int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
+    int stride4;
+};
+
+// All indices are 32-bit here (E < 2^31 is a plan invariant) and everything that depends on the batch only is scalar.
+template <int W4, int CPL>
+__device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first,
+                                          bool last, uint32_t b_lo, uint32_t b_hi, int wave, int lane) {
+    const int l4 = lane & 3;
+    const float* __restrict__ dcol = a.d + c0 + 4 * l4;
+    const uint32_t* __restrict__ pk = a.packed + lane;
+    const int32_t* __restrict__ brel = a.batch_rel;
+    const uint32_t e32 = (uint32_t)a.e;
+    int cur_r = -1;                                         // relation whose chunks sit in dreg
+    f32x4 dreg[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) dreg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr uint32_t kWavesPerWg = kThreads / 64;
+
+    uint32_t b = b_lo + (uint32_t)wave;
+    if (b >= b_hi) return;
+    uint32_t wn = pk[b * 64u];
+    int reln = brel[b];
+    for (; b < b_hi; b += kWavesPerWg) {
+        const uint32_t w = wn;
+        const int rel = reln;
+        const uint32_t bn = b + kWavesPerWg < b_hi ? b + kWavesPerWg : b;
+        wn = pk[bn * 64u];                                    // next batch in flight while this one computes
+        reln = brel[bn];
+        const int iu = (int)(w & kNodeMask), iv = (int)((w >> kNodeBits) & kNodeMask);
+        const uint32_t mine = b * 64u + (w >> (2 * kNodeBits));
+        const bool valid = mine < e32;
+        const float carried = (!first && valid) ? a.out[mine] : 0.f;
+        float result = 0.f;
+        if (rel >= 0) {                                       // wave-uniform
+            if (rel != cur_r) {
+                cur_r = rel;
+#pragma unroll
+                for (int i = 0; i < CPL; ++i)
+                    dreg[i] = (l4 + 4 * i < w4) ? *reinterpret_cast<const f32x4*>(dcol + (int64_t)rel * a.ld_d + 16 * i)
+                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            quad_step<0, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, 0, dcol, a.ld_d, dreg, result);
+            quad_step<1, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, 0, dcol, a.ld_d, dreg, result);
+            quad_step<2, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, 0, dcol, a.ld_d, dreg, result);
+            quad_step<3, W4, CPL, true>(lds, stride_bytes, w4, l4, iu, iv, 0, dcol, a.ld_d, dreg, result);
+        } else {
+            const int ir = (int)a.rel16[b * 64u + (uint32_t)lane];
+            quad_step<0, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<1, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<2, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+            quad_step<3, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
+        }
+        if (valid) {
+            float total = carried + result;
+            if (last && a.sigmoid) total = sigmoid_f32(total);
+            a.out[mine] = total;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
+    extern __shared__ float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t b_lo = (uint32_t)(blockIdx.x * a.batches_per_wg);
+    const uint32_t b_hi = (uint32_t)min(a.batches, (int64_t)b_lo + a.batches_per_wg);
+    const char* lds = reinterpret_cast<const char*>(lds4);
+
+    for (int ph = 0; ph < a.n_phases; ++ph) {
+        const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
+        __syncthreads();                                    // everyone is done with the previous phase's table
+        fill_table(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid);
+        __syncthreads();
+        const bool first = ph == 0, last = ph == a.n_phases - 1;
+        switch (w4) {
+            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
+            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
+            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
+            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
+            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
+        }
+    }
+}
+
+// Deals the (up to) 64 edges of a batch to its slots.  Lane l of the wave holds slot l; wave step S works on the
+// slots 4 q + S of the 16 quads q, and ds_read_b128 serves the quads in four access groups.  A cell = (step,
+// access group) = four slots that hit the LDS together: its edges should have four different u % 4 and four
+// different v % 4 (the bank slot of a row is (row * odd stride) % 4).
+void deal_batch(const int64_t* u, const int64_t* v, int count, int* slot_of_edge) {
+    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+    static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
+                                      {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
+                                      {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
+                                      {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
+    std::vector<int> bucket[4][4];                         // edges by (u % 4, v % 4)
+    for (int e = 0; e < count; ++e) bucket[u[e] & 3][v[e] & 3].push_back(e);
+    int left = count;
+    for (int cell = 0; cell < 16; ++cell) {
+        const int S = cell & 3, g = cell >> 2;
+        int chosen[4] = {-1, -1, -1, -1};
+        if (left > 0) {
+            // a full cell: one edge from each (c, sigma(c)) for the permutation whose scarcest bucket is fullest
+            int best = -1, best_min = 0;
+            for (int p = 0; p < 24; ++p) {
+                int mn = 1 << 30;
+                for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
+                if (mn > best_min) { best_min = mn; best = p; }
+            }
+            if (best >= 0) {
+                for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
+            } else {
+                // no conflict-free quadruple left: take edges one by one, preferring unused u and v classes
+                unsigned used_u = 0, used_v = 0;
+                for (int k = 0; k < 4; ++k) {
+                    int bc = -1, bd = -1, bscore = -1;
+                    for (int c = 0; c < 4; ++c)
+                        for (int dd = 0; dd < 4; ++dd) {
+                            if (bucket[c][dd].empty()) continue;
+                            const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
+                            if (score > bscore) { bscore = score; bc = c; bd = dd; }
+                        }
+                    if (bc < 0) break;
+                    chosen[k] = bucket[bc][bd].back();
+                    bucket[bc][bd].pop_back();
+                    used_u |= 1u << bc; used_v |= 1u << bd;
+                }
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            if (chosen[k] >= 0) { slot_of_edge[chosen[k]] = 4 * kGroupQuads[g][k] + S; --left; }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
+                                  int64_t num_nodes, int64_t num_relations, void* stream, gn_distmult_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_relations >= 0, "negative size");
+    GN_REQUIRE(num_edges == 0 || (u && v && edge_type), "edge pointers are null");
+    if (num_nodes > (int64_t)kNodeMask + 1 || num_relations > 65535 || num_edges >= ((int64_t)1 << 31))
+        return gn::fail(GN_ERR_UNSUPPORTED, "edge list too large for the packed plan encoding (nodes <= %u, relations <= 65535)",
+                        kNodeMask + 1);
+    hipStream_t st = gn::as_stream(stream);
+    const int64_t E = num_edges, B = gn::ceil_div(E, 64);
+    std::vector<int64_t> hu(E), hv(E), hr(E);
+    if (E > 0) {
+        GN_HIP(hipMemcpyAsync(hu.data(), u, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(hv.data(), v, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(hr.data(), edge_type, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipStreamSynchronize(st));
+    }
+    for (int64_t e = 0; e < E; ++e)
+        if ((uint64_t)hu[e] >= (uint64_t)num_nodes || (uint64_t)hv[e] >= (uint64_t)num_nodes ||
+            (uint64_t)hr[e] >= (uint64_t)num_relations)
+            return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
+                            (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
+                            (long long)num_nodes, (long long)num_relations);
+    // an unused slot scores node 0 against node 0 under relation 0 (or the batch's) and is never written
+    std::vector<uint32_t> packed((size_t)B * 64, (uint32_t)63 << (2 * kNodeBits));
+    std::vector<int32_t> batch_rel((size_t)B, 0);
+    std::vector<uint16_t> rel16((size_t)B * 64, 0);
+    int slot_of_edge[64];
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t e0 = b * 64;
+        const int count = (int)std::min<int64_t>(64, E - e0);
+        deal_batch(hu.data() + e0, hv.data() + e0, count, slot_of_edge);
+        bool uniform = true;
+        for (int k = 1; k < count; ++k) uniform = uniform && hr[e0 + k] == hr[e0];
+        batch_rel[b] = uniform ? (int32_t)hr[e0] : -1;
+        bool taken[64] = {false};
+        for (int k = 0; k < count; ++k) {
+            const int s = slot_of_edge[k];
+            taken[s] = true;
+            packed[e0 + s] = (uint32_t)hu[e0 + k] | ((uint32_t)hv[e0 + k] << kNodeBits) | ((uint32_t)k << (2 * kNodeBits));
+            rel16[e0 + s] = (uint16_t)hr[e0 + k];
+        }
+        // unused slots of the last batch: position = an index past the end of the edge list
+        int spare = count;
+        for (int s = 0; s < 64; ++s)
+            if (!taken[s]) {
+                packed[e0 + s] = (uint32_t)std::min(spare, 63) << (2 * kNodeBits);
+                rel16[e0 + s] = (uint16_t)(count > 0 ? hr[e0] : 0);
+                ++spare;
+            }
+    }
+    gn_distmult_plan* p = new gn_distmult_plan();
+    p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = B;
+    auto bail = [&](hipError_t e) {
+        gn_distmult_plan_destroy(p);
+        return gn::fail(GN_ERR_HIP, "DistMult plan upload failed: %s", hipGetErrorString(e));
+    };
+    hipError_t he;
+    if ((he = p->packed.alloc((size_t)B * 64)) != hipSuccess) return bail(he);
+    if ((he = p->batch_rel.alloc((size_t)B)) != hipSuccess) return bail(he);
+    if ((he = p->rel16.alloc((size_t)B * 64)) != hipSuccess) return bail(he);
+    if (B > 0) {
+        if ((he = hipMemcpyAsync(p->packed.p, packed.data(), (size_t)B * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipMemcpyAsync(p->batch_rel.p, batch_rel.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipMemcpyAsync(p->rel16.p, rel16.data(), (size_t)B * 64 * sizeof(uint16_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);     // host vectors go out of scope after this
+    }
+    *out = p;
+    return GN_OK;
+}
+
+void gn_distmult_plan_destroy(gn_distmult_plan* p) {
+    if (!p) return;
+    p->packed.release();
+    p->batch_rel.release();
+    p->rel16.release();
+    delete p;
+}
+
+int64_t gn_distmult_plan_edges(const gn_distmult_plan* plan) { return plan ? plan->num_edges : -1; }
+
+gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
+                                       const float* d, int64_t ld_d, int apply_sigmoid, float* out, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    if (plan->num_edges == 0) return GN_OK;
+    GN_REQUIRE(z && d && out, "operand pointer is null");
+    GN_REQUIRE(num_features > 0 && ld_z >= num_features && ld_d >= num_features, "feature count / leading dimension mismatch");
+    const int64_t n = plan->num_nodes, f = num_features;
+    DmPlanArgs a;
+    a.n_phases = (f % 4 == 0 && ld_z % 4 == 0 && ld_d % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0)
+                     ? plan_phases(n, f, a.c0, a.width) : 0;
+    if (gn::fast_paths_disabled() || a.n_phases < 1 || a.n_phases > 4)
+        return gn::fail(GN_ERR_UNSUPPORTED, "the planned decoder needs a node table that fits the LDS in at most four column "
+                                            "phases (n = %lld, features = %lld): use gn_distmult_forward_f32", (long long)n, (long long)f);
+    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.packed = plan->packed.p; a.batch_rel = plan->batch_rel.p; a.rel16 = plan->rel16.p;
+    a.d = d; a.ld_d = ld_d; a.e = plan->num_edges; a.batches = plan->batches; a.sigmoid = apply_sigmoid; a.out = out;
+    int max_w = 0;
+    for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
+    a.stride4 = lds_stride4(n, max_w);
+    const size_t lds_bytes = (size_t)n * a.stride4 * 16;
+    int64_t groups = std::min<int64_t>(256, gn::ceil_div(plan->batches, kThreads / 64));
+    if (groups < 1) groups = 1;
+    a.batches_per_wg = gn::ceil_div(plan->batches, groups);
+    groups = gn::ceil_div(plan->batches, a.batches_per_wg);
+    static thread_local bool configured = false;
+    if (!configured) {
+        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_plan),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    k_distmult_plan<<<(unsigned)groups, kThreads, lds_bytes, gn::as_stream(stream)>>>(a);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // extern "C"

@@ -20,7 +20,27 @@ class multiRelaInnerProductDecoder(Module):
         super().__init__()
         self.num_et, self.in_dim = num_et, in_dim
         self.weight = Parameter(torch.empty(num_et, in_dim))
+        self._seen = []                      # recently scored edge lists: [edge_index, edge_type, versions, plan]
         self.reset_parameters()
+
+    def plan_for(self, z, edge_index, edge_type):
+        """Cached plan of a STATIC edge list, or None.  A list is taken to be static the second time the very same
+        tensors (same storage, unchanged in place) are scored: the positive edges of a training loop
+        (GripNet-pose.py:137,185), not the negative samples, which are new tensors every epoch.  The cache holds
+        the tensors, so their storage cannot be handed to another tensor while an entry is alive."""
+        key = (edge_index._version, edge_type._version)
+        for k, entry in enumerate(self._seen):
+            if entry[0] is edge_index and entry[1] is edge_type and entry[2] == key:
+                if entry[3] is None:
+                    try:
+                        entry[3] = _hip.DistMultPlan(edge_index, edge_type, z.shape[0], self.num_et)
+                    except _hip.GripNetHipError:          # too many nodes / relations for the packed encoding
+                        entry[3] = False
+                self._seen.insert(0, self._seen.pop(k))
+                return entry[3] or None
+        self._seen.insert(0, [edge_index, edge_type, key, None])
+        del self._seen[2:]
+        return None
 
     def forward(self, z, edge_index, edge_type, sigmoid=True):
         _hip.require_gpu(z, edge_index, edge_type, self.weight)
@@ -30,6 +50,14 @@ class multiRelaInnerProductDecoder(Module):
         if z.shape[1] != self.in_dim:
             raise ValueError("expected {} features, got {}".format(self.in_dim, z.shape[1]))
         out = torch.empty((edge_index.shape[1],), dtype=torch.float32, device=z.device)
+        plan = self.plan_for(z, edge_index, edge_type)
+        if plan is not None and plan.num_nodes == z.shape[0]:
+            try:
+                return plan.forward(z, self.weight, sigmoid, out)
+            except _hip.GripNetHipError as err:                    # node table too large for the LDS: the general kernels
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+                self._seen[0][3] = False
         return _hip.distmult(z, edge_index, edge_type, self.weight, sigmoid, out)
 
     def reset_parameters(self):

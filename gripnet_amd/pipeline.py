@@ -139,7 +139,7 @@ class PoseStages:
 
     def __init__(self, model: PoseModel, data, graphs: bool = True, edge_index=None, edge_type=None,
                  timed_entry: Optional[str] = None):
-        """`timed_entry` ("gn_rgcn_forward_f32" or "gn_distmult_forward_f32"): with graphs, the stage that holds
+        """`timed_entry` ("gn_rgcn_forward_f32" or "gn_distmult[_plan]_forward_f32"): with graphs, the stage that holds
         that entry point is replayed as a graph of its own, bracketed by HIP events whenever a
         _hip.KernelTimer is active (the graph replay makes no timed library call itself)."""
         self.model, self.data = model, data
@@ -205,7 +205,7 @@ class PoseStages:
                     self.drugs()
             else:
                 self.drugs()
-        if timed == "gn_distmult_forward_f32":
+        if timed in ("gn_distmult_forward_f32", "gn_distmult_plan_forward_f32"):
             with _hip.bracket(timed):
                 return self.z, self.decode()
         return self.z, self.decode()

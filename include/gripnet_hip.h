@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 103 /* 0.1.3 */
+#define GN_VERSION 104 /* 0.1.4 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -195,6 +195,21 @@ GN_API gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64_t n
                                   const int64_t* u, const int64_t* v, const int64_t* edge_type,
                                   const float* d, int64_t ld_d, int64_t num_relations, int64_t num_edges,
                                   int apply_sigmoid, float* out, int32_t* error_flag, void* stream);
+
+/* The same decoder on a cached, re-encoded STATIC edge list: the positive edges, which the reference scores with the
+ * same train_idx / train_et tensors every epoch (GripNet-pose.py:137,185).  The plan validates the triples once
+ * (GN_ERR_INDEX_RANGE), packs them into one 32-bit word per edge and orders the edges inside every 64-edge batch for
+ * conflict-free LDS gathers; scores come out in the caller's edge order, bitwise equal to gn_distmult_forward_f32.
+ * Plan creation copies the triples to the host and synchronises `stream`.  GN_ERR_UNSUPPORTED: more than 8192 nodes
+ * or 65535 relations (create), or a node table that does not fit the LDS in four column phases (forward) - use
+ * gn_distmult_forward_f32 then. */
+typedef struct gn_distmult_plan gn_distmult_plan;
+GN_API gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
+                                  int64_t num_nodes, int64_t num_relations, void* stream, gn_distmult_plan** plan);
+GN_API void gn_distmult_plan_destroy(gn_distmult_plan* plan);
+GN_API int64_t gn_distmult_plan_edges(const gn_distmult_plan* plan);
+GN_API gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
+                                       const float* d, int64_t ld_d, int apply_sigmoid, float* out, void* stream);
 
 /* Backward of the DistMult decoder (autograd of decoder.py:19-23 under the loss of GripNet-pose.py:140-146).
  * grad_logit[e] = d loss / d s_e (the caller folds the sigmoid derivative in).  dz [n, F] and dD [R, F]

@@ -568,3 +568,46 @@ def test_sharded_forward_on_hip_kernels(gpu):
         assert ranks[0].edge_hi == ranks[1].edge_lo
         close(torch.cat(scores), score_ref)
     _hip.raise_if_index_errors(gpu)
+
+
+# ---- the decoder's plan for static edge lists ---------------------------------------------------
+def test_decoder_plan_matches_planless_scores_bitwise(gpu):
+    """Second sighting of the same (edge_index, edge_type) tensors builds a plan (packed, batch-ordered edges);
+    its scores are the plan-less kernel's, bit for bit, in the caller's edge order: ragged last batch, batches
+    that straddle relations, repeated edges, u == v, sigmoid on and off.  New tensors never get a plan."""
+    gen = torch.Generator().manual_seed(11)
+    n, f, R = 300, 80, 7
+    sizes = [1000, 0, 37, 5000, 64, 1, 129]
+    ei = torch.cat([torch.randint(0, n, (2, s), generator=gen) for s in sizes], dim=1)
+    ei[1, :50] = ei[0, :50]                                           # u == v
+    ei[:, 100:164] = ei[:, 200:201]                                   # one edge 64 times
+    et = torch.cat([torch.full((s,), r, dtype=torch.int64) for r, s in enumerate(sizes)])
+    z = torch.randn(n, f, generator=gen).to(gpu)
+    dec = gripnet_amd.multiRelaInnerProductDecoder(f, R).to(gpu)
+    ei_g, et_g = ei.to(gpu), et.to(gpu)
+    with torch.no_grad():
+        for sig in (True, False):
+            first = dec(z, ei_g, et_g, sigmoid=sig)                   # plan-less (first sighting) or planned
+            again = dec(z, ei_g, et_g, sigmoid=sig)
+            assert torch.equal(first, again)
+            close(again, orc.distmult(z.cpu(), ei, et, dec.weight.detach().cpu(), sigmoid=sig))
+        assert dec._seen[0][3] not in (None, False)                   # the plan exists and was used
+        fresh = dec(z, ei_g.clone(), et_g.clone())                    # same values, new tensors: plan-less path
+        assert torch.equal(fresh, dec(z, ei_g, et_g))
+        ei_g[0, 0] = (ei_g[0, 0] + 1) % n                             # in-place change: the cached plan is stale
+        changed = dec(z, ei_g, et_g)
+        ei2 = ei.clone(); ei2[0, 0] = (ei2[0, 0] + 1) % n
+        close(changed, orc.distmult(z.cpu(), ei2, et, dec.weight.detach().cpu()))
+
+
+def test_decoder_plan_rejects_out_of_range_edges(gpu):
+    dec = gripnet_amd.multiRelaInnerProductDecoder(16, 3).to(gpu)
+    z = torch.randn(10, 16, device=gpu)
+    ei = torch.tensor([[0, 1, 2], [3, 4, 10]], device=gpu)           # node 10 does not exist
+    et = torch.tensor([0, 1, 2], device=gpu)
+    with torch.no_grad():
+        dec(z, ei, et)                                                # first sighting: NaN + lazy error flag, as before
+        with pytest.raises(IndexError):
+            _hip.raise_if_index_errors(gpu)
+        with pytest.raises(IndexError):
+            dec(z, ei, et)                                            # second sighting validates at plan time

@@ -19,6 +19,7 @@ import re
 ENTRY = {
     "gn_rgcn_forward_f32": ("k_rgcn_weights_t", "k_rgcn_weights_frag", "k_rgcn_lds", "k_rgcn_acc", "k_rgcn_slab_finalize"),
     "gn_distmult_forward_f32": ("k_distmult_lds", "k_distmult<"),
+    "gn_distmult_plan_forward_f32": ("k_distmult_plan",),
     "gn_graph_aggregate_f32": ("k_aggregate",),
     "gn_gemm_f32": ("k_gemm_f32",),
 }
