@@ -7,26 +7,33 @@
 //
 // The node table x ([n, in], 124 KB at 645 x 48) lives in every CU's LDS.  A wave owns kTpg tiles
 // of 16 DESTINATION rows for the whole kernel and walks a list of (relation, row group) units:
-//   (1) gather: lane (row = lane % 16, quarter = lane / 16) adds the quarter's in/4 features of
-//       x[src] for every edge (relation, src -> row) from LDS into registers - the 16 x in matrix
-//       A_r of per-destination sums, already laid out as the A operand of v_mfma_f32_16x16x4_f32
-//       (which k a lane supplies is free as long as the B operand agrees, so a lane holds in/4
-//       consecutive features and reads them with 16-byte LDS loads);
-//   (2) transform: acc[tile] += A_r W_r on the matrix cores; the accumulator registers carry the
-//       sum over relations, so nothing is scattered, nothing is read-modify-written and no barrier
-//       sits between a workgroup's prologue and its epilogue.
+//   (1) gather: the four lanes 4 r .. 4 r + 3 add x[src] for every edge (relation, src -> row r of
+//       the tile) from LDS into registers, 16 rows at a time; one ds_read_b128 per lane and 64
+//       features of a row, the four lanes of a row covering one 64-byte bank slot;
+//   (2) the 16 x in matrix A_r of per-destination sums is moved to the A-operand layout of the
+//       matrix instruction once per tile (ds_bpermute) and transformed: acc[tile] += A_r W_r.  The
+//       accumulator registers carry the sum over relations, so nothing is scattered, nothing is
+//       read-modify-written and no barrier sits between a workgroup's prologue and its epilogue.
+//       The product runs as three bf16 MFMAs on split operands (hi.hi + hi.lo + lo.hi, fp32
+//       accumulate; GN_ACC_EXACT=1 selects the fp32 matrix instruction): the fp32 MFMA runs at the
+//       fp32 vector rate and shares the SIMD's issue with the gather's adds.
 // Edge lists reach the waves as one private, contiguous stream per wave of 128-byte blocks: 4
-// "iterations" x 16 rows of uint16 source ids, rows without an edge in an iteration point at a zero
-// row of the LDS table (no branches, no bounds).  The stream is staged through a 1 KB LDS window per
-// wave, refilled from registers that were loaded a window ahead.
-// Workgroups = row groups x slabs: the 16 waves of a workgroup share a row group and split its
-// units (longest-processing-time at plan time); they fold their accumulators through LDS in wave
-// order, and the per-workgroup slabs are summed in slab order by k_rgcn_slab_finalize: fixed
-// summation order, bitwise reproducible.
+// "iterations" x 16 rows of uint16 source ids; rows without an edge in an iteration point at one of
+// four zero rows of the LDS table (no branches, no bounds).  Which edge of a row goes into which
+// iteration is decided at plan time for the LDS: per iteration, the four rows of a ds_read_b128
+// access group read four different bank slots wherever the graph allows it (conflict cycles are
+// ~16 % of the LDS cycles on pose0-syn; a random order gives ~3x the conflict-free time).  The
+// stream is staged through a 1 KB LDS window per wave, refilled from registers that were loaded a
+// window ahead.
+// Workgroups = row groups x slabs: the waves of a workgroup share a row group and split its units
+// (longest-processing-time in two levels at plan time); they fold their accumulators through LDS
+// in wave order, and the per-workgroup slabs are summed in slab order by k_rgcn_slab_finalize:
+// fixed summation order, bitwise reproducible.
 //
-// HBM traffic: 2 bytes per edge slot (the stream) + W_r fragments (L2-resident).  Matrix-core time:
-// 2 n in out flops per relation at the fp32 MFMA rate, i.e. 1.9 GFLOP / 157 TFLOP/s = 12 us on
-// pose0-syn, the floor of this formulation.
+// HBM traffic: 2 bytes per edge slot (the stream) + the W_r fragments, which every XCD's L2 fetches
+// once.  Matrix-core time of the fp32 form: 2 n in out flops per relation = 1.9 GFLOP / 157 TFLOP/s
+// = 12 us on pose0-syn; of the split form 3/16 of that.  What bounds the kernel now is the LDS
+// bandwidth of the gather (192 bytes per edge slot, ~2.4 slots per edge after padding).
 #include "common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -51,7 +58,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define GN_ACC_TPG 3
 #endif
 #ifndef GN_ACC_WAVES
-#define GN_ACC_WAVES 16
+#define GN_ACC_WAVES 12
 #endif
 constexpr int kTpg = GN_ACC_TPG;            // 16-row tiles per wave = accumulator tiles kept in registers
 constexpr int kWaves = GN_ACC_WAVES;         // waves per workgroup (one workgroup per CU: the node table fills its LDS)
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
 #ifdef GN_STAMPS
     const unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- fold the 16 waves of the workgroup in wave order, leave as one slab ----
+    // ---- fold the waves of the workgroup in wave order, leave as one slab ----
     __syncthreads();                                              // every wave is done with the table
     float* red = reinterpret_cast<float*>(lds4);                  // [wave][tile][16 rows][NT * 16]
     constexpr int RW = NT * 16;
