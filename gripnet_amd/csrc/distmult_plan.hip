@@ -59,18 +59,29 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
 
     uint32_t b = b_lo + (uint32_t)wave;
     if (b >= b_hi) return;
-    uint32_t wn = pk[b * 64u];
-    int reln = brel[b];
+    // Between two launches of the forward nothing of the edge stream stays in L2, and a wave has one batch of
+    // work (a few hundred cycles) between loads: the packed words run three batches ahead of the arithmetic, the
+    // relation word two, the partial sum of the previous phase one.
+    auto clampb = [&](uint32_t x) { return x < b_hi ? x : b; };
+    uint32_t w0 = pk[b * 64u], w1 = pk[clampb(b + kWavesPerWg) * 64u], w2 = pk[clampb(b + 2 * kWavesPerWg) * 64u];
+    int r0 = brel[b], r1 = brel[clampb(b + kWavesPerWg)];
+    auto position = [&](uint32_t bb, uint32_t ww) { return bb * 64u + (ww >> (2 * kNodeBits)); };
+    float cnext = (!first && position(b, w0) < e32) ? a.out[position(b, w0)] : 0.f;
     for (; b < b_hi; b += kWavesPerWg) {
-        const uint32_t w = wn;
-        const int rel = reln;
-        const uint32_t bn = b + kWavesPerWg < b_hi ? b + kWavesPerWg : b;
-        wn = pk[bn * 64u];                                    // next batch in flight while this one computes
-        reln = brel[bn];
+        const uint32_t w = w0;
+        const int rel = r0;
+        const float carried = cnext;
+        const uint32_t bn = clampb(b + kWavesPerWg);
+        w0 = w1; w1 = w2; r0 = r1;
+        w2 = pk[clampb(b + 3 * kWavesPerWg) * 64u];
+        r1 = brel[clampb(b + 2 * kWavesPerWg)];
+        {
+            const uint32_t next = position(bn, w0);
+            cnext = (!first && next < e32) ? a.out[next] : 0.f;
+        }
         const int iu = (int)(w & kNodeMask), iv = (int)((w >> kNodeBits) & kNodeMask);
-        const uint32_t mine = b * 64u + (w >> (2 * kNodeBits));
+        const uint32_t mine = position(b, w);
         const bool valid = mine < e32;
-        const float carried = (!first && valid) ? a.out[mine] : 0.f;
         float result = 0.f;
         if (rel >= 0) {                                       // wave-uniform
             if (rel != cur_r) {

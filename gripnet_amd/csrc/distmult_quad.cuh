@@ -43,9 +43,14 @@ __device__ __forceinline__ void fill_table(float4* lds4, const float* __restrict
     if (c4 >= stride4) return;
     const bool live = c4 < w4;
     const float* __restrict__ src = z + c0 + 4 * (live ? c4 : 0);
-    for (int row = tid >> 5; row < n; row += kThreads / 32)
+    // every workgroup reads the same table at the same time: each starts at a different row, so that they do not
+    // all queue on the same L2 channel
+    const int rot = (int)((blockIdx.x * 53u) % (unsigned)n);
+    for (int k = tid >> 5; k < n; k += kThreads / 32) {
+        const int row = k + rot < n ? k + rot : k + rot - n;
         lds4[row * stride4 + c4] = live ? *reinterpret_cast<const float4*>(src + (int64_t)row * ld_z)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // One edge per QUAD (4 lanes), 16 edges per wave step.  Lane l4 of the quad covers the 16-byte

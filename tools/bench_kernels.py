@@ -40,12 +40,23 @@ def main():
     ap.add_argument("--what", default="distmult,rgcn,gcn,full")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--shuffle-types", action="store_true", help="DistMult on a shuffled edge list (unsorted relation ids)")
+    ap.add_argument("--flush", type=int, default=0, help="MB of unrelated data streamed between launches (cold L2, as inside the forward)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     data = make_pose(args.workload).to(dev)
     torch.manual_seed(1111)
     model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
     what = set(args.what.split(","))
+    if args.flush:
+        junk = torch.empty(args.flush << 18, dtype=torch.float32, device=dev)
+        global timed
+        plain_timed = timed
+
+        def timed(fn, iters, warm=3):                      # time fn alone, with the flush between launches
+            def both():
+                junk.add_(1.0)
+                fn()
+            return plain_timed(both, iters, warm) - plain_timed(lambda: junk.add_(1.0), iters, warm)
     E = data.train_idx.shape[1]
     n_d, R = data.n_d_node, data.n_dd_edge_type
     with torch.no_grad():
