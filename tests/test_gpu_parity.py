@@ -611,3 +611,25 @@ def test_decoder_plan_rejects_out_of_range_edges(gpu):
             _hip.raise_if_index_errors(gpu)
         with pytest.raises(IndexError):
             dec(z, ei, et)                                            # second sighting validates at plan time
+
+
+def test_rgcn_weights_prefetched_on_a_second_stream(gpu):
+    """gn_rgcn_weights_f32 + GN_RGCN_WEIGHTS_READY: W_r computed ahead of the forward on another stream gives the
+    forward's own result bit for bit; a parameter update between prefetch and forward drops the prefetched weights."""
+    data = make_pose("small").to(gpu)
+    n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
+    conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
+    x = torch.randn(n, fin, device=gpu)
+    with torch.no_grad():
+        assert conv.prefetch_weights() is False                         # no plan before the first forward
+        base = conv(x, data.train_idx, None, data.train_range, _relu=True)
+        assert conv.prefetch_weights() is True
+        again = conv(x, data.train_idx, None, data.train_range, _relu=True)
+        assert torch.equal(base, again)
+        assert conv.prefetch_weights() is True
+        conv.att.mul_(2.0)                                              # stale: the forward recomputes W_r in line
+        changed = conv(x, data.train_idx, None, data.train_range, _relu=True)
+        sd = {k: v.detach().cpu() for k, v in conv.state_dict().items()}
+        ref = torch.relu(orc.rgcn_forward(x.cpu(), data.train_idx.cpu(), data.train_range.cpu(), sd["basis"], sd["att"],
+                                          sd["root"], sd.get("bias")))
+        close(changed, ref)
