@@ -69,9 +69,14 @@ constexpr int kStage = 8;          // stream blocks per LDS window of a wave (1 
 constexpr int kFoutAcc = 32;       // out_features (slab layout of k_rgcn_slab_finalize)
 constexpr size_t kLdsBudget = 159 * 1024;
 // cost model of the plan-time balancing, in cycles of the wave's SIMD
-constexpr int kTileCost = 24 * 32; // 24 MFMAs of 32 cycles per non-empty tile
-constexpr int kBlockCost = 200;    // one stream block: 12 LDS reads + adds, every slot padding
-constexpr int kEdgeCost = 6;       // what a real edge adds (bank conflicts grow with the number of distinct rows read)
+#ifndef GN_ACC_TILE_COST
+#define GN_ACC_TILE_COST 550
+#define GN_ACC_BLOCK_COST 1000
+#define GN_ACC_EDGE_COST 0
+#endif
+constexpr int kTileCost = GN_ACC_TILE_COST;    // move to the MFMA layout, split, 10 bf16 MFMAs (measured, tools/acc_stamps.py)
+constexpr int kBlockCost = GN_ACC_BLOCK_COST;  // one stream block: 12 LDS reads + adds, with the workgroup's other waves on the LDS
+constexpr int kEdgeCost = GN_ACC_EDGE_COST;    // what a real edge adds to its block (nothing since the plan orders edges for the LDS)
 
 // Diagnostic builds only (make MODE=n -> libgripnet_hip_mode<n>.so, never the product library):
 // bit 0 = no MFMA phase, bit 1 = no table gather (the stream is still read), bit 2 = conflict-free gather.
@@ -139,10 +144,15 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
 #endif
     // ---- first loads of the table fill: issued before everything else, because vector loads retire in order and
     //      the stream / W loads below come from further away (HBM / Infinity Cache) than the L2-resident table ----
-    f32x4 fill[8];
+    // (every workgroup reads the same table at the same time: each starts at its own offset, so that they do not all
+    // queue on the same L2 channel)
+    constexpr int FILL = 12;
+    const int fill_total = a.n * XL, fill_rot = (int)((blockIdx.x * 977u) % (unsigned)fill_total);
+    auto fill_index = [&](int i) { i += fill_rot; return i < fill_total ? i : i - fill_total; };
+    f32x4 fill[FILL];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = min(k * kThreads + tid, a.n * XL - 1);
+    for (int k = 0; k < FILL; ++k) {
+        const int i = fill_index(min(k * kThreads + tid, fill_total - 1));
         const int r = i / XL, c = i - r * XL;
         fill[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * a.ld_x + 4 * c);
     }
@@ -168,21 +178,23 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     load_b(d.rel, bfrag);
 
     // ---- node table -> LDS, plus the zero row that padded slots point at ----
-    // (the first eight loads per thread were issued at the top; a load-store loop would pay one L2 round trip per trip)
-    for (int base = 0; base < a.n * XL; base += 8 * kThreads) {
+    // (the first FILL loads per thread were issued at the top - the whole table at n = 645; a load-store loop would
+    // pay one L2 round trip per trip)
+    for (int base = 0; base < fill_total; base += FILL * kThreads) {
         if (base > 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = min(base + k * kThreads + tid, a.n * XL - 1);
+            for (int k = 0; k < FILL; ++k) {
+                const int i = fill_index(min(base + k * kThreads + tid, fill_total - 1));
                 const int r = i / XL, c = i - r * XL;
                 fill[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * a.ld_x + 4 * c);
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = base + k * kThreads + tid;
+        for (int k = 0; k < FILL; ++k) {
+            const int j = base + k * kThreads + tid;
+            const int i = fill_index(min(j, fill_total - 1));
             const int r = i / XL, c = i - r * XL;
-            if (i < a.n * XL) lds4[r * XS + c] = fill[k];
+            if (j < fill_total) lds4[r * XS + c] = fill[k];
         }
     }
     if (tid < 4 * XS) lds4[a.n * XS + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};   // four zero rows, one per bank slot, for padded edge slots
