@@ -202,6 +202,96 @@ __global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const fl
     }
 }
 
+
+// ---- aggregate, then transform, for narrow rows (16 or 32 input features): quads instead of shuffles ----------
+// Same job and same wave-per-destination-row mapping as k_aggregate_transform, but a neighbour row is gathered
+// by a QUAD (lane j: features 4 j .. 4 j + 3, and 16 + 4 j .. for 32 features), so that the 64 (neighbour,
+// coefficient) pairs of a batch are handed out with DPP quad broadcasts (the four pairs a quad works through sit in
+// its own four lanes: no LDS-pipe shuffle per group of neighbours) and 16 neighbours are gathered per step.  All
+// four steps' gathers are in flight before the first is consumed.  The 16 partial sums of the quads are folded with
+// a butterfly (fixed order), after which every quad holds the aggregated row; quad q then computes output column q:
+// lane (q, j) multiplies the features it holds by its slice of W and the quad folds with two DPP adds.
+template <int CTRL>
+__device__ __forceinline__ int agg_dpp(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float agg_dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void k_aggregate_transform_q(AggArgs a, const float* __restrict__ w) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int FOUT = 16;
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 2, j = lane & 3;
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    f32x4 wreg[VPL];                                          // W[16 v + 4 j + c][q]
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wreg[v][c] = w[(16 * v + 4 * j + c) * FOUT + q];
+    const float bias = a.bias ? a.bias[q] : 0.f;
+
+    if (a.side.dst) {                                          // concat slot: streamed up front by the whole grid
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + cc];
+            a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+    const float* __restrict__ tab = a.table + 4 * j;
+    for (int row = wave; row < a.rows; row += n_waves) {
+        const int begin = a.rowptr[row], end = a.rowptr[row + 1];
+        f32x4 s[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) s[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int base = begin; base < end; base += kWave) {
+            const int mine = base + lane;
+            const int c = mine < end ? (int)a.col[mine] : 0;
+            const float cf = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+            const int left = end - base - 4 * q;                 // pairs of this quad that exist (may be <= 0)
+            int cc[4], ff[4];
+            cc[0] = agg_dpp<0x00>(c); cc[1] = agg_dpp<0x55>(c); cc[2] = agg_dpp<0xAA>(c); cc[3] = agg_dpp<0xFF>(c);
+            const int fi = __float_as_int(cf);
+            ff[0] = agg_dpp<0x00>(fi); ff[1] = agg_dpp<0x55>(fi); ff[2] = agg_dpp<0xAA>(fi); ff[3] = agg_dpp<0xFF>(fi);
+            f32x4 t[4][VPL];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    t[k][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (left > k) t[k][v] = *reinterpret_cast<const f32x4*>(tab + (int64_t)cc[k] * a.ld_table + 16 * v);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) s[v] += __int_as_float(ff[k]) * t[k][v];
+        }
+        // fold the 16 quads (lanes with equal j): butterfly over lane bits 2 .. 5, every lane ends with the total
+#pragma unroll
+        for (int off = 4; off < kWave; off <<= 1)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[v][c] += __shfl_xor(s[v][c], off);
+        // output column q: this lane's slice of the contraction, then the quad
+        float part = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part += s[v][c] * wreg[v][c];
+        part = agg_dpp_add<0xB1>(part);                          // quad_perm [1,0,3,2]
+        part = agg_dpp_add<0x4E>(part);                          // quad_perm [2,3,0,1]
+        if (j == 0) {
+            float val = part + bias;
+            if (a.relu) val = fmaxf(val, 0.f);
+            a.out[(int64_t)row * a.ld_out + q] = val;
+        }
+    }
+}
+
 // FIN in {16, 32, 64}, FOUT in {16, 32} with at least 4 input features per lane slice
 inline bool transform_fusable(int64_t fin, int64_t fout) {
     if (fast_paths_disabled()) return false;
@@ -209,10 +299,25 @@ inline bool transform_fusable(int64_t fin, int64_t fout) {
     return (fin * fout / 64) % 4 == 0;
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// GN_DISABLE_QUAD=1: the shuffle-based kernel for 16- and 32-wide rows as well (parity tests cover both)
+inline bool quad_gather_disabled() {
+    const char* e = getenv("GN_DISABLE_QUAD");
+    return e && e[0] == '1';
+}
+
 inline gn_status launch_aggregate_transform(const AggArgs& a, const float* w, int fout, hipStream_t st) {
     if (a.rows == 0) return GN_OK;
     const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), GN_AGG_GRID);
     const int key = a.features * 100 + fout;
+    // 16-wide rows: quad gathers (14.8 vs 16.4 us on the second gene layer of pose0-syn); 32-wide rows are faster
+    // with one 16-byte load per lane and neighbour (k_aggregate_transform<8, 16> 19.2 us, the quad form 21.5)
+    if (key == 1616 && a.ld_table % 4 == 0 && aligned16(a.table) && !quad_gather_disabled()) {
+        k_aggregate_transform_q<1><<<grid, 256, 0, st>>>(a, w);
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     switch (key) {
         case 1616: k_aggregate_transform<4, 16><<<grid, 256, 0, st>>>(a, w); break;
         case 3216: k_aggregate_transform<8, 16><<<grid, 256, 0, st>>>(a, w); break;
@@ -225,7 +330,6 @@ inline gn_status launch_aggregate_transform(const AggArgs& a, const float* w, in
     return GN_OK;
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int VEC>
 inline void launch_aggregate_lpe(const AggArgs& a, int lpe, int grid, hipStream_t st) {

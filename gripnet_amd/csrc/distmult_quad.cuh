@@ -44,12 +44,22 @@ __device__ __forceinline__ void fill_table(float4* lds4, const float* __restrict
     const bool live = c4 < w4;
     const float* __restrict__ src = z + c0 + 4 * (live ? c4 : 0);
     // every workgroup reads the same table at the same time: each starts at a different row, so that they do not
-    // all queue on the same L2 channel
+    // all queue on the same L2 channel; eight loads are in flight per thread before the first store (the table was
+    // written by the previous kernel: these are Infinity Cache / HBM round trips, not L2 hits)
     const int rot = (int)((blockIdx.x * 53u) % (unsigned)n);
-    for (int k = tid >> 5; k < n; k += kThreads / 32) {
-        const int row = k + rot < n ? k + rot : k + rot - n;
-        lds4[row * stride4 + c4] = live ? *reinterpret_cast<const float4*>(src + (int64_t)row * ld_z)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int kRowsPerPass = kThreads / 32;
+    for (int k0 = tid >> 5; k0 < n; k0 += 8 * kRowsPerPass) {
+        float4 v[8];
+        int rows[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = min(k0 + i * kRowsPerPass, n - 1);
+            rows[i] = k + rot < n ? k + rot : k + rot - n;
+            v[i] = live ? *reinterpret_cast<const float4*>(src + (int64_t)rows[i] * ld_z) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (k0 + i * kRowsPerPass < n) lds4[rows[i] * stride4 + c4] = v[i];
     }
 }
 

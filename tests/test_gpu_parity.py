@@ -181,9 +181,11 @@ def test_nc_pipelines_vs_reference(gpu, golden):
 
 @pytest.fixture(params=["acc", "lds", "general"])
 def kernel_path(request, monkeypatch):
-    """Run a test once per relational kernel: register-accumulated (default), LDS-resident accumulator, general."""
+    """Run a test once per relational kernel: register-accumulated (default), LDS-resident accumulator, general;
+    the last two also take the shuffle-based form of the 16-wide GCN gather instead of the quad form."""
     monkeypatch.setenv("GN_DISABLE_FAST", "1" if request.param == "general" else "0")
     monkeypatch.setenv("GN_DISABLE_ACC", "1" if request.param == "lds" else "0")
+    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param == "acc" else "1")
     return request.param
 
 
