@@ -117,7 +117,8 @@ def main():
                {k: 1e3 * tot / n for k, (calls, tot) in t.summary().items()}
 
     with torch.no_grad():
-        if world == 1:
+        sharded = None
+        if world == 1 and os.environ.get("GN_BENCH_SHARDED_PATH") != "1":   # (the variable rehearses the N > 1 code path on one GPU)
             from gripnet_amd.pipeline import PoseStages
             eager = PoseStages(model, data, graphs=False)
             for _ in range(3):                        # builds the plans
@@ -144,7 +145,7 @@ def main():
         else:
             from gripnet_amd.pipeline import Graphed
             from gripnet_amd.sharded import ShardedPoseForward
-            fwd = ShardedPoseForward(model, data, rank, world)
+            fwd = sharded = ShardedPoseForward(model, data, rank, world)
             for _ in range(3):
                 fwd()
             per_call0, breakdown = per_entry_us(fwd, 5)
@@ -201,8 +202,9 @@ def main():
                    "edges_aggregated_per_step": A, "n_g": data.n_g_node, "n_d": n_d, "relations": data.n_dd_edge_type,
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
-                   "launch": ("hipGraph replay of the stages; {} HIP-event timed around its own graph".format(dom)
-                              if launch == "graphs" else "eager; {} HIP-event timed around every launch".format(dom))},
+                   "launch": ("eager; {} HIP-event timed around every launch".format(dom) if launch == "eager" else
+                              "hipGraph replay of the stages; {} HIP-event timed around its own graph".format(dom) if sharded is None else
+                              "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
         "roofline": roofline,
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
         "edges_scored_per_sec": (hi - lo) / (per_call0.get("gn_distmult_plan_forward_f32",
