@@ -111,7 +111,12 @@ __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
     for (int ph = 0; ph < a.n_phases; ++ph) {
         const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
         __syncthreads();                                    // everyone is done with the previous phase's table
-        fill_table(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid);
+        switch (w4) {                                       // compile-time row width where it is a common one
+            case 16: fill_table<16>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            case 12: fill_table<12>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            case 8: fill_table<8>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            default: fill_table<0>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+        }
         __syncthreads();
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {                                       // common widths get compile-time addressing

@@ -110,6 +110,14 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
     }
 }
 
+#ifdef GN_STAMPS
+// Diagnostic build only (make STAMPS=1): 100 MHz timestamps of wave 0 of every workgroup, never in the product library.
+__device__ unsigned long long g_dm_stamps[256][12];
+#define GN_DM_STAMP(k) if (tid == 0 && blockIdx.x < 256) g_dm_stamps[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define GN_DM_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
     extern __shared__ float4 lds4[];
     const int tid = threadIdx.x;
@@ -118,11 +126,19 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
     const uint32_t b_hi = (uint32_t)min(a.batches, (int64_t)b_lo + a.batches_per_wg);
     const char* lds = reinterpret_cast<const char*>(lds4);
 
+    GN_DM_STAMP(0);
     for (int ph = 0; ph < a.n_phases; ++ph) {
         const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
         __syncthreads();                                    // everyone is done with the previous phase's table
-        fill_table(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid);
+        GN_DM_STAMP(1 + 3 * ph);
+        switch (w4) {                                       // compile-time row width where it is a common one
+            case 16: fill_table<16>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            case 12: fill_table<12>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            case 8: fill_table<8>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            default: fill_table<0>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+        }
         __syncthreads();
+        GN_DM_STAMP(2 + 3 * ph);
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {
             case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
@@ -131,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
             case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
             default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
         }
+        GN_DM_STAMP(3 + 3 * ph);
     }
 }
 
@@ -305,3 +322,9 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
 }
 
 }  // extern "C"
+
+#ifdef GN_STAMPS
+extern "C" __attribute__((visibility("default"))) int gn_debug_read_dm_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dm_stamps), sizeof(unsigned long long) * 256 * 12);
+}
+#endif

@@ -36,30 +36,36 @@ __device__ __forceinline__ float row_sum16(float x) {
 __device__ __forceinline__ float sigmoid_f32(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // One column phase of the node table into LDS: rows of `stride4` float4, the first w4 of them columns c0 .. c0 + 4 w4 of
-// z, the rest zero (idle lanes of a ragged chunk group read the padding, x 0).  32 lanes per row, no division.
-__device__ __forceinline__ void fill_table(float4* lds4, const float* __restrict__ z, int64_t ld_z, int n, int c0, int w4,
+// z, the rest zero (idle lanes of a ragged chunk group read the padding, x 0).  Every lane carries a float4 (a flat
+// index over the n x w4 elements; W4 > 0 makes the division a compile-time one), eight loads in flight per thread
+// before the first store: the table was written by the previous kernel, so these are Infinity Cache / HBM round
+// trips, and every workgroup reads the same table at the same time - each starts at its own offset so that they do
+// not all queue on the same L2 channel.
+template <int W4>
+__device__ __forceinline__ void fill_table(float4* lds4, const float* __restrict__ z, int64_t ld_z, int n, int c0, int w4rt,
                                            int stride4, int tid) {
-    const int c4 = tid & 31;
-    if (c4 >= stride4) return;
-    const bool live = c4 < w4;
-    const float* __restrict__ src = z + c0 + 4 * (live ? c4 : 0);
-    // every workgroup reads the same table at the same time: each starts at a different row, so that they do not
-    // all queue on the same L2 channel; eight loads are in flight per thread before the first store (the table was
-    // written by the previous kernel: these are Infinity Cache / HBM round trips, not L2 hits)
-    const int rot = (int)((blockIdx.x * 53u) % (unsigned)n);
-    constexpr int kRowsPerPass = kThreads / 32;
-    for (int k0 = tid >> 5; k0 < n; k0 += 8 * kRowsPerPass) {
+    const int w4 = W4 > 0 ? W4 : w4rt;
+    const int total = n * w4;
+    const int rot = (int)((blockIdx.x * 977u) % (unsigned)total);
+    for (int base = 0; base < total; base += 8 * kThreads) {
         float4 v[8];
-        int rows[8];
+        int at[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = min(k0 + i * kRowsPerPass, n - 1);
-            rows[i] = k + rot < n ? k + rot : k + rot - n;
-            v[i] = live ? *reinterpret_cast<const float4*>(src + (int64_t)rows[i] * ld_z) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 8; ++k) {
+            int i = min(base + k * kThreads + tid, total - 1) + rot;
+            i = i < total ? i : i - total;
+            const int row = i / w4, c4 = i - row * w4;
+            at[k] = row * stride4 + c4;
+            v[k] = *reinterpret_cast<const float4*>(z + (int64_t)row * ld_z + c0 + 4 * c4);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (k0 + i * kRowsPerPass < n) lds4[rows[i] * stride4 + c4] = v[i];
+        for (int k = 0; k < 8; ++k)
+            if (base + k * kThreads + tid < total) lds4[at[k]] = v[k];
+    }
+    const int pad = stride4 - w4;                                  // zero the row padding
+    for (int i = tid; i < n * pad; i += kThreads) {
+        const int row = i / pad;
+        lds4[row * stride4 + w4 + (i - row * pad)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
