@@ -20,7 +20,7 @@ _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
-ABI_VERSION = 104                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 105                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -47,6 +47,8 @@ SIGNATURES = {
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
     "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
     "gn_rgcn_weights_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "gn_graph_aggregate_with_rgcn_weights_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p,
+                                                         _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
@@ -365,9 +367,19 @@ class GraphPlan:
     def __iter__(self):          # lets `edge_index, norm = conv.cached_result` keep working
         return iter(self.export())
 
-    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None):
-        """out = act(A_norm xw + b), or with `weight` act((A_norm xw) weight + b) (xw is then the layer input)."""
+    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None, cowork=None):
+        """out = act(A_norm xw + b), or with `weight` act((A_norm xw) weight + b) (xw is then the layer input).
+        `cowork` = (RgcnPlan, basis, att): the relational weights of a later layer are computed by the same launch
+        (gn_graph_aggregate_with_rgcn_weights_f32)."""
         sc = side_copy(side)
+        if cowork is not None and weight is not None:
+            rplan, basis, att = cowork
+            ws, need = rplan._workspace(basis.shape[1], basis.shape[2], basis.shape[0])
+            _call("gn_graph_aggregate_with_rgcn_weights_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
+                  weight.shape[1], ptr(bias), int(bool(relu)), ptr(out), ld(out), _ref(sc),
+                  rplan._h, basis.shape[1], ptr(basis), ptr(att), basis.shape[0], basis.shape[2], ptr(ws), need,
+                  stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}+weights]".format(self.kind))
+            return out
         _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
               0 if weight is None else weight.shape[1], ptr(bias), int(bool(relu)),
               ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))

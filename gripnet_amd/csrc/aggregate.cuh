@@ -134,15 +134,17 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
 // aggregated features 4j..4j+3 of its j; lane (c = lane % FOUT, kq = lane / FOUT) multiplies KPL = FIN * FOUT / 64
 // of them (fetched with shuffles) by its register-resident slice W[kq*KPL .. , c] and the 64 / FOUT partial
 // sums are folded with two more shuffles.
+// (the body takes its block index and block count as arguments: gn_graph_aggregate_with_rgcn_weights_f32 runs it on
+// the first blocks of a launch whose other blocks do something else)
 template <int LPE, int FOUT>
-__global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const float* __restrict__ w) {
+__device__ __forceinline__ void aggregate_transform_body(const AggArgs& a, const float* __restrict__ w, int block, int n_blocks) {
     constexpr int FIN = 4 * LPE, S = kWave / LPE, G = kWave / FOUT, KPL = FIN / G;
     static_assert(KPL % 4 == 0, "K slice per lane must cover whole float4 groups");
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPE, j = lane % LPE;
     const int c = lane % FOUT, kq = lane / FOUT;
-    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
-    const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    const int wave = (int)((block * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)(((int64_t)n_blocks * blockDim.x) >> 6);
     float wreg[KPL];
 #pragma unroll
     for (int i = 0; i < KPL; ++i) wreg[i] = w[(kq * KPL + i) * FOUT + c];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const fl
 
     if (a.side.dst) {                                          // concat slot: streamed up front by the whole grid
         const int64_t total = a.side.rows * a.side.cols;
-        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t t = block * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)n_blocks * blockDim.x) {
             const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
             const float v = a.side.src[i * a.side.ld_src + cc];
             a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
@@ -200,6 +202,11 @@ __global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const fl
             a.out[(int64_t)row * a.ld_out + c] = val;
         }
     }
+}
+
+template <int LPE, int FOUT>
+__global__ __launch_bounds__(256) void k_aggregate_transform(AggArgs a, const float* __restrict__ w) {
+    aggregate_transform_body<LPE, FOUT>(a, w, (int)blockIdx.x, (int)gridDim.x);
 }
 
 

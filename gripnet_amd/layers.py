@@ -74,7 +74,7 @@ class myGCN(Module):
             self.cached_result = build()
         return self.cached_result
 
-    def _run(self, plan, x, n_out, out, relu, side):
+    def _run(self, plan, x, n_out, out, relu, side, cowork=None):
         if recording(x, self.weight, self.bias):                                 # training: autograd path
             y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu)
             if side is not None or out is not None:
@@ -85,7 +85,11 @@ class myGCN(Module):
             out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
         if _hip.transform_fusable(self.in_channels, self.out_channels, x) and self.weight.is_contiguous():
             # A_norm (x W) = (A_norm x) W: the contraction of layers.py:73 runs on the aggregated row
-            return plan.aggregate(x, self.bias, relu, out, side, weight=self.weight)
+            done = cowork.cowork_request() if cowork is not None else None      # W_r of a later relational layer, same launch
+            y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, cowork=done)
+            if done is not None:
+                cowork.cowork_done()
+            return y
         xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
         _hip.gemm(x, self.weight, xw)                                            # layers.py:73
         return plan.aggregate(xw, self.bias, relu, out, side)                    # layers.py:92-100
@@ -96,13 +100,14 @@ class myGCN(Module):
         plan = self._plan(edge_index, lambda: _hip.GraphPlan.gcn(edge_index, n, edge_weight, self.improved))
         return self._run(plan, x, n, _out, _relu, _side)
 
-    def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None):
+    def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None,
+                          _cowork=None):
         """The conv as interGraph uses it (layers.py:363-368), in closed form: rows are targets."""
         _hip.require_gpu(x, inter_edge_index, edge_weight, self.weight)
         n_src = x.size(0)
         plan = self._plan(inter_edge_index,
                           lambda: _hip.GraphPlan.bipartite(inter_edge_index, n_src, n_target, edge_weight))
-        return self._run(plan, x, n_target, _out, _relu, _side)
+        return self._run(plan, x, n_target, _out, _relu, _side, _cowork)
 
     def __repr__(self):
         return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
@@ -144,6 +149,17 @@ class myRGCN(Module):
             self._plan_key = key
         return self._plan
 
+    def cowork_request(self):
+        """(plan, basis, att) for a launch that is asked to compute this layer's W_r on the side, or None (no plan
+        yet, or autograd is recording)."""
+        if self._plan is None or recording(self.basis, self.att):
+            return None
+        return (self._plan, self.basis, self.att)
+
+    def cowork_done(self):
+        """The launch has been queued on the current stream: the next forward on this plan skips its weights kernel."""
+        self._prefetched = (None, self._plan, self.basis._version, self.att._version)
+
     def prefetch_weights(self):
         """Start W_r = sum_b att[r,b] basis[b] (layers.py:172-173) on a second HIP stream; the next inference
         forward on the same plan waits for it with an event instead of computing it in line.  The weights
@@ -180,7 +196,8 @@ class myRGCN(Module):
                                                         device=x.device)
         ready, pre, self._prefetched = False, getattr(self, "_prefetched", None), None
         if pre is not None and pre[1] is plan and pre[2:] == (self.basis._version, self.att._version):
-            torch.cuda.current_stream(x.device).wait_event(pre[0])
+            if pre[0] is not None:                       # computed on another stream (prefetch_weights)
+                torch.cuda.current_stream(x.device).wait_event(pre[0])
             ready = True
         return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, weights_ready=ready)
 
@@ -275,7 +292,8 @@ class interGraph(Module):
     def reset_parameters(self):
         self.target_feat.data.normal_()
 
-    def forward(self, x, inter_edge_index, edge_weight=None, if_relu=True, mod="cat"):
+    def forward(self, x, inter_edge_index, edge_weight=None, if_relu=True, mod="cat", *, _cowork=None):
+        # _cowork: a myRGCN whose weights W_r = att . basis are computed by this layer's launch (inference path)
         _hip.require_gpu(x, inter_edge_index)
         dev = x.device
         if recording(x, *self.parameters()):                                     # training: autograd-tracked glue
@@ -292,7 +310,8 @@ class interGraph(Module):
         if mod == "cat":                                                         # layers.py:375-376
             out, (y, tf) = _cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
             self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu,
-                                        _side=(self.target_feat, tf, 1))     # |target_feat| slot, same launch
+                                        _side=(self.target_feat, tf, 1),     # |target_feat| slot, same launch
+                                        _cowork=_cowork)
             return out
         y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if y.shape[1] == self.target_feat.shape[1]:                              # layers.py:378-379

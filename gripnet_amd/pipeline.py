@@ -34,7 +34,8 @@ class PoseModel(Module):
 
     def encode(self, data):
         z = self.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)    # pose.py:117-119
-        z = self.gd(z, data.gd_edge_index, mod="cat", if_relu=True)                            # pose.py:120
+        z = self.gd(z, data.gd_edge_index, mod="cat", if_relu=True,                            # pose.py:120
+                    _cowork=self.dd.conv_list[0])        # + W_r of the relational layer below, in the same launch
         return self.dd(z, data.train_idx, edge_type=data.train_et, range_list=data.train_range,
                        if_catout=True)                                                         # pose.py:121-127
 
@@ -172,7 +173,7 @@ class PoseStages:
     def _genes_eager(self):
         d = self.data
         z = self.model.gg(None, d.gg_edge_index, edge_weight=d.edge_weight, if_catout=True)
-        return self.model.gd(z, d.gd_edge_index, mod="cat", if_relu=True)
+        return self.model.gd(z, d.gd_edge_index, mod="cat", if_relu=True, _cowork=self.conv)
 
     def _decode_eager(self):
         return self.model.dmt(self.z, self.idx, self.et)
@@ -187,6 +188,10 @@ class PoseStages:
     def _drugs_eager(self):
         fin = self.conv.in_channels
         d = self.data
+        if self.conv.cowork_request() is not None:
+            # the genes stage always runs first and its last launch computes W_r (see _genes_eager); when the two
+            # stages are separate hipGraphs the hand-over flag set while genes was captured is gone by now
+            self.conv.cowork_done()
         self.conv(self.x, d.train_idx, d.train_et, d.train_range, _out=self.z[:, fin:], _relu=True,
                   _side=(self.x, self.z[:, :fin], 0))
         return self.z

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 104 /* 0.1.4 */
+#define GN_VERSION 105 /* 0.1.5 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -165,6 +165,17 @@ GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_featu
 GN_API gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t in_features, const float* basis, const float* att,
                               int64_t num_bases, int64_t out_features, void* workspace, size_t workspace_bytes,
                               void* stream);
+
+/* gn_graph_aggregate_f32 (first eleven arguments, `weight` required) and gn_rgcn_weights_f32 (the rest) as ONE launch:
+ * the external layer's aggregation (gripnet/layers.py:363-370) and the weights of the relational layer that follows it
+ * (layers.py:172-173) are independent, short and latency-bound, so the launch takes the longer of the two instead of
+ * their sum.  Follow it with gn_rgcn_forward_f32(..., GN_RGCN_WEIGHTS_READY, ...).  Shapes the combined launch does not
+ * cover run as the two entry points, one after the other. */
+GN_API gn_status gn_graph_aggregate_with_rgcn_weights_f32(
+    const gn_graph_plan* plan, const float* x, int64_t ld_x, int64_t num_features, const float* weight, int64_t out_features,
+    const float* bias, int relu, float* out, int64_t ld_out, const gn_side_copy* side /* nullable */,
+    const gn_rgcn_plan* rgcn_plan, int64_t rgcn_in_features, const float* basis, const float* att, int64_t num_bases,
+    int64_t rgcn_out_features, void* rgcn_workspace, size_t rgcn_workspace_bytes, void* stream);
 
 #define GN_RGCN_PARTIAL 1        /* flags of gn_rgcn_forward_f32 */
 #define GN_RGCN_WEIGHTS_READY 2  /* `workspace` already holds the output of gn_rgcn_weights_f32 for these parameters */

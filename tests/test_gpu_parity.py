@@ -635,3 +635,24 @@ def test_rgcn_weights_prefetched_on_a_second_stream(gpu):
         ref = torch.relu(orc.rgcn_forward(x.cpu(), data.train_idx.cpu(), data.train_range.cpu(), sd["basis"], sd["att"],
                                           sd["root"], sd.get("bias")))
         close(changed, ref)
+
+
+def test_external_layer_computes_relational_weights_in_its_launch(gpu):
+    """gn_graph_aggregate_with_rgcn_weights_f32 (interGraph(..., _cowork=conv)): the external layer's output and the
+    relational layer that then skips its weights kernel both equal the separate launches, bit for bit."""
+    data = make_pose("small").to(gpu)
+    torch.manual_seed(5)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    conv = model.dd.conv_list[0]
+    with torch.no_grad():
+        z_gg = model.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)
+        x_sep = model.gd(z_gg, data.gd_edge_index, mod="cat", if_relu=True)
+        z_sep = model.dd(x_sep, data.train_idx, edge_type=data.train_et, range_list=data.train_range, if_catout=True)
+        assert getattr(conv, "_prefetched", None) is None
+        x_fused = model.gd(z_gg, data.gd_edge_index, mod="cat", if_relu=True, _cowork=conv)
+        assert conv._prefetched is not None and conv._prefetched[0] is None
+        z_fused = model.dd(x_fused, data.train_idx, edge_type=data.train_et, range_list=data.train_range, if_catout=True)
+        assert conv._prefetched is None
+        assert torch.equal(x_sep, x_fused) and torch.equal(z_sep, z_fused)
+        z_all, _ = model(data)                                            # PoseModel.encode uses the combined launch
+        assert torch.equal(z_all, z_sep)
