@@ -159,7 +159,8 @@ def main():
         for _ in range(max(args.warmup, 1)):
             z, score = step()
         fence()
-        timer = _hip.KernelTimer(only=(dom,))
+        timer = _hip.KernelTimer(only=(dom,), pool=2 * args.steps + 8)
+        fence()
         t0 = time.perf_counter()
         with timer:
             for _ in range(args.steps):

@@ -135,9 +135,17 @@ class KernelTimer:
     """Optional per-entry-point device timing: while active, every launch made through this
     module is bracketed by HIP events on the launching stream (used by bench.py's roofline)."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, pool=0):
+        """`pool`: events created (and recorded once, which is when HIP allocates them) up front, so that a timed
+        region pays two event records per bracketed launch and nothing else."""
         self.events = {}
         self.only = None if only is None else set(only)
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
+        for e in self._pool:
+            e.record()
+
+    def event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         global _timer
@@ -171,13 +179,13 @@ class bracket:
         t = _timer
         self.on = t is not None and (t.only is None or self.name in t.only)
         if self.on:
-            self.start = torch.cuda.Event(enable_timing=True)
+            self.start = t.event()
             self.start.record()
         return self
 
     def __exit__(self, *exc):
         if self.on:
-            stop = torch.cuda.Event(enable_timing=True)
+            stop = _timer.event()
             stop.record()
             _timer.add(self.name, self.start, stop)
 
@@ -187,7 +195,7 @@ def _call(name, *args, tag=None):
     t = _timer
     if t is None or (t.only is not None and name not in t.only):
         return check(fn(*args))
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start, stop = t.event(), t.event()
     start.record()
     status = fn(*args)
     stop.record()

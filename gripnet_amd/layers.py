@@ -241,7 +241,7 @@ class homoGraph(Module):
             assert edge_type is not None
             assert range_list is not None
         _hip.require_gpu(x, homo_edge_index)
-        if recording(x, *self.parameters()):                                     # training: plain concat, autograd-tracked
+        if torch.is_grad_enabled() and recording(x, *self.parameters()):                                     # training: plain concat, autograd-tracked
             outs, h = [x], x
             for net in self.conv_list:
                 if self.multi_relational:
@@ -296,7 +296,7 @@ class interGraph(Module):
         # _cowork: a myRGCN whose weights W_r = att . basis are computed by this layer's launch (inference path)
         _hip.require_gpu(x, inter_edge_index)
         dev = x.device
-        if recording(x, *self.parameters()):                                     # training: autograd-tracked glue
+        if torch.is_grad_enabled() and recording(x, *self.parameters()):                                     # training: autograd-tracked glue
             y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
             if not self.if_one_external:
                 return y
