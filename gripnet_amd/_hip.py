@@ -20,7 +20,7 @@ _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
-ABI_VERSION = 105                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 106                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -47,6 +47,8 @@ SIGNATURES = {
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
     "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
     "gn_rgcn_weights_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "gn_cast_bf16": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "gn_graph_aggregate_bf16": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
     "gn_graph_aggregate_with_rgcn_weights_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p,
                                                          _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
@@ -391,6 +393,16 @@ class GraphPlan:
         _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
               0 if weight is None else weight.shape[1], ptr(bias), int(bool(relu)),
               ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
+        return out
+
+    def aggregate_bf16(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None):
+        """out = act(A_norm bf16(xw) + b): the gathered table is rounded to bf16 once and read at half the bytes;
+        sums, bias, activation and `out` are fp32 (gn_cast_bf16 + gn_graph_aggregate_bf16)."""
+        table = torch.empty(xw.shape, dtype=torch.bfloat16, device=xw.device)
+        _call("gn_cast_bf16", ptr(xw), ld(xw), ptr(table), ld(table), xw.shape[0], xw.shape[1], stream_ptr(xw.device))
+        sc = side_copy(side)
+        _call("gn_graph_aggregate_bf16", self._h, ptr(table), ld(table), xw.shape[1], ptr(bias), int(bool(relu)),
+              ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_bf16[{}]".format(self.kind))
         return out
 
     def aggregate_t(self, g: torch.Tensor, out: torch.Tensor):

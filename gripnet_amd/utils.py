@@ -133,6 +133,20 @@ def relation_metrics(pos_score: torch.Tensor, neg_score: torch.Tensor, range_lis
     return link_metrics(pos_score, neg_score, range_list)
 
 
+def set_table_storage(module, storage: str = "bf16"):
+    """Switch every GCN-style layer under `module` to "bf16" (or back to "fp32") storage of its gathered table:
+    x W is rounded to bf16 once per forward and read at half the bytes; sums, bias, activation, outputs and every
+    parameter stay fp32 (inference path; training is unchanged).  The reference has no reduced precision; this is
+    the build's own variant for the node-classification suite.  Returns the layers touched."""
+    from .layers import myGCN
+    if storage not in ("fp32", "bf16"):
+        raise ValueError("storage must be 'fp32' or 'bf16', got {!r}".format(storage))
+    touched = [m for m in module.modules() if isinstance(m, myGCN)]
+    for m in touched:
+        m.table_storage = storage
+    return touched
+
+
 def profile(fn):
     """No-op stand-in for ``pytorch_memlab.profile`` (reference: GripNet-pose.py:18,112)."""
     return fn

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 105 /* 0.1.5 */
+#define GN_VERSION 106 /* 0.1.6 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -108,6 +108,17 @@ GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* 
  * {16,32,64} and out_features in {16,32} (GN_ERR_UNSUPPORTED otherwise: call gn_gemm_f32 first).
  * gn_transform_fusable tells without launching. */
 GN_API int gn_transform_fusable(int64_t in_features, int64_t out_features);
+
+/* bf16 STORAGE of the gathered table (the reference is fp32 throughout, this is the build's own
+ * reduced-traffic variant for the node-classification suite): gn_cast_bf16 rounds x W to bf16 once,
+ * gn_graph_aggregate_bf16 computes out[i,:] = act( sum_e coef_e * table[src(e),:] + bias ) from it with fp32 sums and an
+ * fp32 result.  num_features % 8 == 0, 16-byte aligned rows.  Error against the fp32 layer: one bf16 rounding (2^-9
+ * relative) of every gathered element; exact against the same sum over the rounded table. */
+GN_API gn_status gn_cast_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                       void* stream);
+GN_API gn_status gn_graph_aggregate_bf16(const gn_graph_plan* plan, const uint16_t* table, int64_t ld_table, int64_t num_features,
+                                  const float* bias, int relu, float* out, int64_t ld_out,
+                                  const gn_side_copy* side /* nullable */, void* stream);
 
 /* Backward pass of the GCN-style layers (autograd of GripNet-pose.py:140-146 through layers.py:92-100).
  * gn_graph_plan_build_transpose adds the source-major CSR of the same coefficients to a plan (once;

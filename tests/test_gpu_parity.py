@@ -656,3 +656,51 @@ def test_external_layer_computes_relational_weights_in_its_launch(gpu):
         assert torch.equal(x_sep, x_fused) and torch.equal(z_sep, z_fused)
         z_all, _ = model(data)                                            # PoseModel.encode uses the combined launch
         assert torch.equal(z_all, z_sep)
+
+
+# ---- bf16 storage of the gathered table -----------------------------------
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("fout", [8, 24, 64, 200])
+def test_gcn_bf16_table_is_exact_against_the_rounded_table(gpu, fout):
+    """gn_cast_bf16 + gn_graph_aggregate_bf16: with x W rounded to bf16 the layer equals the fp32 oracle run on the
+    same rounded table to the usual tolerance (fp32 sums), and stays within one bf16 rounding of the fp32 layer."""
+    gen = torch.Generator().manual_seed(fout)
+    n, fin, e = 700, 40, 9000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[1, :400] = 5                                                   # one hub row, isolated nodes elsewhere
+    w = torch.rand(e, generator=gen) + 0.5
+    x = torch.randn(n, fin, generator=gen)
+    conv = gripnet_amd.myGCN(fin, fout, cached=True).to(gpu)
+    conv.bias.data.normal_()
+    with torch.no_grad():
+        y32 = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True)
+        gripnet_amd.utils.set_table_storage(conv, "bf16")
+        y16 = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True)
+        gripnet_amd.utils.set_table_storage(conv, "fp32")
+        assert torch.equal(y32, conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True))
+    wt, b = conv.weight.detach().cpu(), conv.bias.detach().cpu()
+    ei2, norm = orc.gcn_norm(ei, n, w)
+    xw16 = _bf16_round(x @ wt)
+    ref16 = torch.relu(torch.zeros(n, fout).index_add_(0, ei2[1], norm.view(-1, 1) * xw16.index_select(0, ei2[0])) + b)
+    close(y16, ref16)
+    scale = float(y32.abs().max())
+    assert float((y16 - y32).abs().max()) <= 2.0 ** -8 * max(scale, 1.0)          # stated tolerance of the bf16 variant
+
+
+def test_nc_pipeline_with_bf16_tables(gpu, golden):
+    """The aminer pipeline of the golden fixtures with bf16 tables in every GCN-style layer: class probabilities within
+    5e-3 of the reference's fp32 result (three stacked layers of rounded tables), argmax unchanged on >= 99 % of nodes."""
+    g = golden("aminer_tiny")
+    m = load_into(AminerModel(g.meta["n_p"], g.meta["n_a"], g.meta["n_class"], pp_nhids=g.meta["pp_nhids"],
+                              pa_out=g.meta["pa_out"], aa_hidden=g.meta["aa_nhids"][1:]), g.state("", strip=False), gpu)
+    data = Data(**{k: g.t(k, gpu) for k in ("pp_edge_idx", "pa_edge_idx", "aa_edge_idx", "pp_edge_weight", "aa_edge_weight")})
+    touched = gripnet_amd.utils.set_table_storage(m, "bf16")
+    assert len(touched) >= 5
+    with torch.no_grad():
+        z, score = m(data, g.t("node_list", gpu))
+    ref = g.t("out.score")
+    assert float((score.cpu() - ref).abs().max()) <= 5e-3
+    assert float((score.cpu().argmax(1) == ref.argmax(1)).float().mean()) >= 0.99

@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="aminer")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--storage", default="fp32", choices=("fp32", "bf16"), help="storage of the gathered tables")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     data = make_nc("aminer-syn").to(dev)
@@ -27,6 +28,8 @@ def main():
         model = AminerModel(data.n_p_node, data.n_a_node, data.n_a_type).to(dev)
     else:
         model = FreebaseCModel(data.n_p_node, data.n_q_node, data.n_a_node, data.n_a_type).to(dev)
+    from gripnet_amd.utils import set_table_storage
+    set_table_storage(model, args.storage)
     nodes = torch.arange(0, data.n_a_node, 2, device=dev)
     with torch.no_grad():
         for _ in range(3):
@@ -40,7 +43,7 @@ def main():
         torch.cuda.synchronize()
     edges = 2 * (data.pp_edge_idx.shape[1] + data.n_p_node) + data.pa_edge_idx.shape[1] + 2 * (data.aa_edge_idx.shape[1] + data.n_a_node)
     us = 1e3 * a.elapsed_time(b) / args.iters
-    print("{} forward on aminer-syn: {:.1f} us  ({:.3e} edges aggregated/s)".format(args.model, us, edges / us * 1e6))
+    print("{} forward on aminer-syn, {} tables: {:.1f} us  ({:.3e} edges aggregated/s)".format(args.model, args.storage, us, edges / us * 1e6))
 
 
 if __name__ == "__main__":
