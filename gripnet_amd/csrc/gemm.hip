@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < g.k; k0 += 16) {
+    // K chunks of 16, software-pipelined: the loads of chunk k + 1 are in flight while the 16 MFMAs of chunk k run
+    // (a load - wait - MFMA loop pays an L2 round trip per chunk: 25 us instead of ~10 on [50000 x 128] @ [128 x 64]).
+    auto load_chunk = [&](int k0, float (&av)[4], float (&bv)[kColTiles][4]) {
         const int kb = k0 + 4 * q;
-        float av[4], bv[kColTiles][4];
         if (g.a_vec_ok && k0 + 16 <= g.k) {                                 // wave-uniform
             const float4 t = *reinterpret_cast<const float4*>(arow_ptr + kb);
             av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
@@ -68,6 +69,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[t][j] = B[(int64_t)min(kb + j, g.k - 1) * g.ldb + col];
         }
+    };
+    float av[4], bv[kColTiles][4];
+    load_chunk(0, av, bv);
+    for (int k0 = 0; k0 < g.k; k0 += 16) {
+        const int kb = k0 + 4 * q;
+        float an[4], bn[kColTiles][4];
+        load_chunk(k0 + 16 < g.k ? k0 + 16 : k0, an, bn);                   // the last trip re-reads its own chunk (unused)
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[j] = (a_ok && kb + j < g.k) ? av[j] : 0.f;
 #pragma unroll
@@ -78,6 +86,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
             for (int j = 0; j < 4; ++j)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], (col_ok && kb + j < g.k) ? bv[t][j] : 0.f, acc[t], 0, 0, 0);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = an[j];
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[t][j] = bn[t][j];
     }
 #pragma unroll
     for (int t = 0; t < kColTiles; ++t) {
@@ -91,6 +105,86 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                 float v = acc[t][i] + bias;
                 if (g.relu) v = fmaxf(v, 0.f);
                 C[(int64_t)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// Tall-skinny form (one shared B of at most 64 KB per 64-column block: every layer's x @ W): B is laid out ONCE per
+// workgroup in LDS as MFMA B fragments ([16-deep K chunk][column tile][lane] float4), so that a chunk costs one
+// 16-byte global load (A) and kColTiles ds_read_b128 per lane instead of 16 four-byte global loads whose issue - not
+// the MFMAs - bounded k_gemm_f32 (17 load instructions of 16 cycles per 16 MFMAs of 8 cycles of the CU).  Workgroups
+// are persistent over the row tiles; A is read one chunk ahead.
+__global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles) {
+    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int col0 = blockIdx.y * (16 * kColTiles);
+    const int chunks = (g.k + 15) / 16;
+    const int n_tiles = min(kColTiles, (g.n - col0 + 15) / 16);
+    for (int idx = threadIdx.x; idx < chunks * kColTiles * 64; idx += 256) {
+        const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
+        const int col = col0 + 16 * t + (l & 15), kb = 16 * ch + 4 * (l >> 4);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (col < g.n && kb + j < g.k) ? g.b[(int64_t)(kb + j) * g.ldb + col] : 0.f;
+        bfrag[idx] = v;
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x * 4 + wave; tile < row_tiles; tile += gridDim.x * 4) {
+        const int row0 = tile * 16;
+        const int arow = row0 + r;
+        int64_t a_src_row = min(arow, g.m - 1);
+        bool a_ok = arow < g.m;
+        if (g.a_rows) {
+            a_src_row = g.a_rows[a_src_row];
+            a_ok = a_ok && (uint64_t)a_src_row < (uint64_t)g.a_table_rows;      // out of table -> zeros
+            if (!a_ok) a_src_row = 0;
+        }
+        const float* __restrict__ arow_ptr = g.a + a_src_row * g.lda;
+        auto load_a = [&](int ch) {
+            const int kb = 16 * ch + 4 * q;
+            f32x4 v;
+            if (g.a_vec_ok && 16 * ch + 16 <= g.k) {
+                v = *reinterpret_cast<const f32x4*>(arow_ptr + kb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = arow_ptr[min(kb + j, g.k - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = kb + j < g.k ? v[j] : 0.f;
+            }
+            return a_ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        f32x4 acc[kColTiles];
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 av = load_a(0);
+        for (int ch = 0; ch < chunks; ++ch) {
+            const f32x4 an = load_a(ch + 1 < chunks ? ch + 1 : ch);
+            const f32x4* __restrict__ bp = bfrag + (size_t)ch * kColTiles * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < kColTiles; ++t) {
+                if (t >= n_tiles) break;
+                const f32x4 bv = bp[t * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[t], 0, 0, 0);
+            }
+            av = an;
+        }
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) {
+            const int col = col0 + 16 * t + r;
+            if (col >= g.n) continue;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * q + i;
+                if (row < g.m) {
+                    float v = acc[t][i] + bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.c[(int64_t)row * g.ldc + col] = v;
+                }
             }
         }
     }
@@ -154,6 +248,14 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     g.c = c; g.ldc = ldc; g.stride_c = stride_c;
     g.m = (int)m; g.n = (int)n; g.k = (int)k; g.bias = bias; g.relu = relu;
     g.a_vec_ok = ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
+    const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
+    if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny, one shared B
+        const int row_tiles = (int)gn::ceil_div(m, 16);
+        dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
+        k_gemm_f32_lds<<<lgrid, 256, lds_bytes, gn::as_stream(stream)>>>(g, row_tiles);
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     dim3 grid((unsigned)gn::ceil_div(m, 64), (unsigned)gn::ceil_div(n, 16 * kColTiles), (unsigned)batch);
     k_gemm_f32<<<grid, 256, 0, gn::as_stream(stream)>>>(g);
     GN_LAUNCH_CHECK();
