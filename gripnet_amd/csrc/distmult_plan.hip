@@ -45,7 +45,7 @@ struct DmPlanArgs {
 // All indices are 32-bit here (E < 2^31 is a plan invariant) and everything that depends on the batch only is scalar.
 template <int W4, int CPL>
 __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first,
-                                          bool last, uint32_t b_lo, uint32_t b_hi, int wave, int lane) {
+                                          bool last, uint32_t b_lo, uint32_t b_hi, uint32_t step, int wave, int lane) {
     const int l4 = lane & 3;
     const float* __restrict__ dcol = a.d + c0 + 4 * l4;
     const uint32_t* __restrict__ pk = a.packed + lane;
@@ -55,7 +55,7 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
     f32x4 dreg[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) dreg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr uint32_t kWavesPerWg = kThreads / 64;
+    const uint32_t kWavesPerWg = step;                      // distance between two batches of this wave
 
     uint32_t b = b_lo + (uint32_t)wave;
     if (b >= b_hi) return;
@@ -122,8 +122,10 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
     extern __shared__ float4 lds4[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t b_lo = (uint32_t)(blockIdx.x * a.batches_per_wg);
-    const uint32_t b_hi = (uint32_t)min(a.batches, (int64_t)b_lo + a.batches_per_wg);
+    // batches are dealt to the workgroups round-robin in groups of one per wave: workgroups that own one contiguous
+    // range each finish a phase 6-8 us apart
+    const uint32_t b_lo = (uint32_t)blockIdx.x * (kThreads / 64), b_hi = (uint32_t)a.batches;
+    const uint32_t step = gridDim.x * (kThreads / 64);
     const char* lds = reinterpret_cast<const char*>(lds4);
 
     GN_DM_STAMP(0);
@@ -141,11 +143,11 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
         GN_DM_STAMP(2 + 3 * ph);
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {
-            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
-            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
-            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
-            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
-            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, wave, lane); break;
+            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
+            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
+            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
+            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
+            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
         }
         GN_DM_STAMP(3 + 3 * ph);
     }
