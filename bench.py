@@ -59,8 +59,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch", choices=("auto", "eager", "graphs"), default="auto",
                     help="eager: every entry point launched from Python (~100-150 us of host work per step, depending "
-                         "on the box, against ~120 us of kernels on pose0-syn); graphs: the stages replayed as hipGraphs "
-                         "(the dominant entry point's stage is a graph of its own, bracketed by HIP events); auto: "
+                         "on the box, against ~110 us of kernels on pose0-syn); graphs: the stages replayed as hipGraphs, "
+                         "except the dominant entry point, which stays a Python launch between HIP events; auto: "
                          "whichever of the two runs the step faster on this box, measured before the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -125,9 +125,8 @@ def main():
                 eager.step()
             per_call0, breakdown = per_entry_us(eager.step, 5)
             dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
-            # graphs: every stage replays as a hipGraph; the stage that holds the dominant entry point is a graph of
-            # its own, bracketed by HIP events on its stream in EVERY timed step.  eager: the events sit around the
-            # dominant entry point's launches themselves (_hip._call).
+            # graphs: every stage but the one that holds the dominant entry point replays as a hipGraph; that entry
+            # point is launched from Python in both modes, with HIP events around it on its stream in EVERY timed step.
             def quick(fn, n=20):                      # under the same event timing as the timed region
                 with _hip.KernelTimer(only=(dom,)):
                     for _ in range(5):
@@ -205,7 +204,7 @@ def main():
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
                    "launch": ("eager; {} HIP-event timed around every launch".format(dom) if launch == "eager" else
-                              "hipGraph replay of the stages; {} HIP-event timed around its own graph".format(dom) if sharded is None else
+                              "hipGraph replay of every stage but {}, which is launched and HIP-event timed from Python".format(dom) if sharded is None else
                               "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
         "roofline": roofline,
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},

@@ -170,28 +170,6 @@ class KernelTimer:
 _timer = None
 
 
-class bracket:
-    """HIP events around a region of the current stream, reported to the active KernelTimer under `name`
-    (a stage replayed as a hipGraph makes no timed library call of its own).  No-op without a timer."""
-
-    def __init__(self, name):
-        self.name = name
-
-    def __enter__(self):
-        t = _timer
-        self.on = t is not None and (t.only is None or self.name in t.only)
-        if self.on:
-            self.start = t.event()
-            self.start.record()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            stop = _timer.event()
-            stop.record()
-            _timer.add(self.name, self.start, stop)
-
-
 def _call(name, *args, tag=None):
     fn = getattr(load(), name)
     t = _timer
