@@ -161,6 +161,9 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     for (int i = 0; i < SV; ++i) pre[i] = gp[i * 64];             // the stream ends with two spare windows
     gp += kStage * 8;
     auto load_b = [&](int rel, f32x4 (&b)[BV]) {
+#if GN_ACC_MODE & 32     // diagnostic: every unit reads one of eight W_r (all of them L2-resident)
+        rel &= 7;
+#endif
         const f32x4* __restrict__ wr = wfrag + (size_t)rel * (BV * 64) + lane;
 #pragma unroll
         for (int i = 0; i < BV; ++i) b[i] = wr[i * 64];
