@@ -40,12 +40,13 @@ struct DmPlanArgs {
     int64_t e; int64_t batches; int64_t batches_per_wg; int sigmoid; float* out;
     int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
     int stride4;
+    int keep_n;                // batches per wave whose partial sums stay in LDS between the phases
 };
 
 // All indices are 32-bit here (E < 2^31 is a plan invariant) and everything that depends on the batch only is scalar.
 template <int W4, int CPL>
 __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first,
-                                          bool last, uint32_t b_lo, uint32_t b_hi, uint32_t step, int wave, int lane) {
+                                          bool last, uint32_t b_lo, uint32_t b_hi, uint32_t step, int wave, int lane, float* keep, int keep_n) {
     const int l4 = lane & 3;
     const float* __restrict__ dcol = a.d + c0 + 4 * l4;
     const uint32_t* __restrict__ pk = a.packed + lane;
@@ -66,18 +67,23 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
     uint32_t w0 = pk[b * 64u], w1 = pk[clampb(b + kWavesPerWg) * 64u], w2 = pk[clampb(b + 2 * kWavesPerWg) * 64u];
     int r0 = brel[b], r1 = brel[clampb(b + kWavesPerWg)];
     auto position = [&](uint32_t bb, uint32_t ww) { return bb * 64u + (ww >> (2 * kNodeBits)); };
-    float cnext = (!first && position(b, w0) < e32) ? a.out[position(b, w0)] : 0.f;
-    for (; b < b_hi; b += kWavesPerWg) {
+    // The partial sums of a wave's first keep_n batches wait for the next phase in LDS (`keep`: 256 bytes per batch,
+    // beside the table) - the same wave works on the same batches in every phase; only batches beyond that go
+    // through `out`.
+    float cnext = (!first && keep_n < 1 && position(b, w0) < e32) ? a.out[position(b, w0)] : 0.f;
+    int nb = 0;                                             // batch number of this wave (wave-uniform)
+    for (; b < b_hi; b += kWavesPerWg, ++nb) {
         const uint32_t w = w0;
         const int rel = r0;
-        const float carried = cnext;
+        const bool kept = nb < keep_n;
+        const float carried = first ? 0.f : (kept ? keep[nb * 64] : cnext);
         const uint32_t bn = clampb(b + kWavesPerWg);
         w0 = w1; w1 = w2; r0 = r1;
         w2 = pk[clampb(b + 3 * kWavesPerWg) * 64u];
         r1 = brel[clampb(b + 2 * kWavesPerWg)];
         {
             const uint32_t next = position(bn, w0);
-            cnext = (!first && next < e32) ? a.out[next] : 0.f;
+            cnext = (!first && nb + 1 >= keep_n && next < e32) ? a.out[next] : 0.f;
         }
         const int iu = (int)(w & kNodeMask), iv = (int)((w >> kNodeBits) & kNodeMask);
         const uint32_t mine = position(b, w);
@@ -102,9 +108,13 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
             quad_step<2, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
             quad_step<3, W4, CPL, false>(lds, stride_bytes, w4, l4, iu, iv, ir, dcol, a.ld_d, dreg, result);
         }
-        if (valid) {
-            float total = carried + result;
-            if (last && a.sigmoid) total = sigmoid_f32(total);
+        float total = carried + result;
+        if (last) {
+            if (a.sigmoid) total = sigmoid_f32(total);
+            if (valid) a.out[mine] = total;
+        } else if (kept) {
+            keep[nb * 64] = total;
+        } else if (valid) {
             a.out[mine] = total;
         }
     }
@@ -126,6 +136,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
     // range each finish a phase 6-8 us apart
     const uint32_t b_lo = (uint32_t)blockIdx.x * (kThreads / 64), b_hi = (uint32_t)a.batches;
     const uint32_t step = gridDim.x * (kThreads / 64);
+    float* keep = reinterpret_cast<float*>(lds4 + (size_t)a.n * a.stride4) + (size_t)wave * a.keep_n * 64 + lane;
     const char* lds = reinterpret_cast<const char*>(lds4);
 
     GN_DM_STAMP(0);
@@ -143,11 +154,11 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
         GN_DM_STAMP(2 + 3 * ph);
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {
-            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
-            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
-            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
-            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
-            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane); break;
+            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
+            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
+            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
+            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
+            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
         }
         GN_DM_STAMP(3 + 3 * ph);
     }
@@ -307,11 +318,16 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
     int max_w = 0;
     for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
     a.stride4 = lds_stride4(n, max_w);
-    const size_t lds_bytes = (size_t)n * a.stride4 * 16;
+    const size_t table_bytes = (size_t)n * a.stride4 * 16;
     int64_t groups = std::min<int64_t>(256, gn::ceil_div(plan->batches, kThreads / 64));
     if (groups < 1) groups = 1;
     a.batches_per_wg = gn::ceil_div(plan->batches, groups);
     groups = gn::ceil_div(plan->batches, a.batches_per_wg);
+    // partial sums between phases: as many batches per wave as the LDS left over by the table holds (4 KB each per workgroup)
+    const int64_t per_wave = gn::ceil_div(plan->batches, groups * (kThreads / 64));
+    const int64_t room = ((int64_t)160 * 1024 - 1024 - (int64_t)table_bytes) / ((kThreads / 64) * 256);
+    a.keep_n = a.n_phases > 1 ? (int)std::max<int64_t>(0, std::min(per_wave, room)) : 0;
+    const size_t lds_bytes = table_bytes + (size_t)a.keep_n * (kThreads / 64) * 256;
     static thread_local bool configured = false;
     if (!configured) {
         GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_plan),

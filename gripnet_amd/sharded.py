@@ -6,8 +6,8 @@ linear in edge subsets, so:
 
   * the type-sorted dd edge list is cut into ``world_size`` contiguous edge ranges balanced by edge
     count (= relation-id sharding with load balancing for skewed relation sizes);
-  * every rank runs the small gene layers (gg, gd) itself: they are <10 % of the work, and replicating
-    them avoids a second collective;
+  * every rank runs the gene layers (gg, gd) itself: 45 of the step's ~110 us on pose0-syn; sharding them by
+    destination rows would need two 1.2 MB all-gathers per forward, which cost more than they save at this size;
   * every rank computes the UN-normalised partial ``P_k[n_d, out]`` of its edge range;
   * ONE ``all_reduce(SUM)`` of ``P_k`` (82,560 B at n_d = 645: latency-bound over xGMI);
   * every rank finalises (global mean, root, bias, ReLU; the in-degree is over the full graph) and
@@ -26,6 +26,21 @@ import torch
 from .utils import shard_edge_ranges
 
 
+class _ShardWeights:
+    """Hands the shard's relational plan to the external layer's launch, which computes W_r = att . basis on the side
+    (gn_graph_aggregate_with_rgcn_weights_f32).  encode_genes always runs before partial, also when it is replayed
+    as a hipGraph, so once the combined launch has been used the weights are known to be in the workspace."""
+
+    def __init__(self, plan, conv):
+        self.plan, self.conv, self.ready = plan, conv, False
+
+    def cowork_request(self):
+        return (self.plan, self.conv.basis, self.conv.att)
+
+    def cowork_done(self):
+        self.ready = True
+
+
 class HipShardKernels:
     """The product arithmetic: HIP kernels behind the C ABI (no CPU fallback)."""
 
@@ -34,16 +49,18 @@ class HipShardKernels:
         self._hip, self.model, self.data = _hip, model, data
         self.conv = model.dd.conv_list[0]
         self.plan = _hip.RgcnPlan(data.train_idx, data.train_range, data.n_d_node, lo, hi)
+        self.weights = _ShardWeights(self.plan, self.conv)
         self.idx = data.train_idx[:, lo:hi].contiguous()
         self.et = data.train_et[lo:hi].contiguous()
 
     def encode_genes(self):
         z = self.model.gg(None, self.data.gg_edge_index, edge_weight=self.data.edge_weight, if_catout=True)
-        return self.model.gd(z, self.data.gd_edge_index, mod="cat", if_relu=True)
+        return self.model.gd(z, self.data.gd_edge_index, mod="cat", if_relu=True, _cowork=self.weights)
 
     def partial(self, x, out):
         c = self.conv
-        return self.plan.forward(x, c.basis, c.att, None, None, False, out, partial=True)
+        return self.plan.forward(x, c.basis, c.att, None, None, False, out, partial=True,
+                                 weights_ready=self.weights.ready)
 
     def finalize(self, summed, x, out, slot0):
         c = self.conv                                           # concat slot 0 is copied by the same launch
