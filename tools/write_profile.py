@@ -33,8 +33,8 @@ Per step: `k_aggregate_transform<8,16>` (gene layer 1), `k_aggregate_transform_q
 Algorithmic bytes of the same launches (SURVEY.md 8d): gn_rgcn_forward_f32 32.5 MB, gn_distmult[_plan]_forward_f32 56.4 MB, GCN layer 31.4 MB.
 The relational kernel moves 74 MB: the 7.7 MB of split W_r fragments (written by the external layer's launch) are fetched by
 every one of the eight XCD L2s (62 MB; partitioning the relations by XCD is the open item), 9.4 MB of edge stream, 1.5 MB of slabs.
-The planned decoder moves 30 MB (4 bytes per edge and phase, the partial sums once through `out`); the plan-less kernel,
-which negative samples and the first sighting of a list still take, 127-155 MB.
+The planned decoder moves {dm_plan:.0f} MB (4 bytes per edge and phase, the scores once; the partial sums wait in LDS between
+the phases); the plan-less kernel, which negative samples and the first sighting of a list still take, 127-155 MB.
 
 ## bench.py line of the profiled run (slower than an un-profiled run: host-side launch gaps under the profiler)
 
@@ -47,7 +47,8 @@ which negative samples and the first sighting of a list still take, 127-155 MB.
 ```
 {final}
 ```
-""".format(tag_short=tag[-1], stats="\n".join(keep), traffic=traffic, bench=bench, final=final)
+""".format(tag_short=tag[-1], stats="\n".join(keep), traffic=traffic, bench=bench, final=final,
+           dm_plan=json.load(open("gpurun_out/traffic_{}.json".format(tag)))["pose0-syn"].get("gn_distmult_plan_forward_f32", 0) / 1e6)
 open("profiles/{}_pose0_rocprof.md".format(tag), "w").write(md)
 t = json.load(open("gpurun_out/traffic_{}.json".format(tag)))
 json.dump(t, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
