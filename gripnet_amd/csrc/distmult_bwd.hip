@@ -12,6 +12,17 @@
 // (a, b, g) by key (rocPRIM radix sort, stable), and one workgroup per output row streams its records
 // with coalesced loads, gathers the two factor rows from L2, sums in registers and folds the 16 edge
 // lanes in a fixed order: no atomics, bitwise reproducible gradients.  dz is the sum of two passes.
+//
+// That general path gathers both factor rows of every record from L2 (2.5 GB per call at 2 M edges x 80
+// features) behind three radix sorts.  When the tables are small - the drug supervertex: a few hundred nodes,
+// ~10^3 relations - the LDS path below is used instead:
+//   * dz: ONE stable sort of 2 E half-edge records (key = the node that receives, payload = the other endpoint,
+//     the relation and g) - dz[i] = sum over the records of i of g z[other] * D[r];
+//   * dD: when the caller says edge_type is sorted (GN_DM_TYPES_SORTED; it is in the reference's layout,
+//     utils.py:168-198) the records stay in edge order and the row offsets come from a binary search;
+//   * k_seg_lds: a workgroup keeps a 16-column block of both tables in LDS, a wave owns a task (<= 512 records of
+//     one key), four lanes per record as in the forward kernel, per-lane sums over the task, one fold across the
+//     16 quads, partial per task; k_seg_lds_combine adds the tasks of a key in order.  Still no atomics.
 #include "common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -172,6 +183,166 @@ __global__ __launch_bounds__(256) void k_seg_reduce_scalar(const int32_t* __rest
     }
 }
 
+
+// ---- LDS path --------------------------------------------------------------------------------------
+constexpr int kTaskRecs = 512;                 // records per wave task
+constexpr int kLdsThreads = 1024;
+constexpr size_t kLdsTableBudget = 150 * 1024;
+
+__device__ __forceinline__ uint64_t pack_rec(uint32_t a, uint32_t b, float g) {
+    return (uint64_t)(a | (b << 16)) | ((uint64_t)__float_as_uint(g) << 32);
+}
+
+// two half-edge records per edge, in edge order (the sort is stable, so the records of a node stay in edge order)
+__global__ void k_half_recs(const int64_t* __restrict__ u, const int64_t* __restrict__ v, const int64_t* __restrict__ et,
+                            const float* __restrict__ gs, int64_t E, int64_t n, int64_t R, uint32_t* __restrict__ keys,
+                            uint64_t* __restrict__ recs) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t uu = u[e], vv = v[e], rr = et[e];
+        const bool ok = (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
+        const float g = ok ? gs[e] : 0.f;
+        reinterpret_cast<uint2*>(keys)[e] = ok ? make_uint2((uint32_t)uu, (uint32_t)vv) : make_uint2((uint32_t)n, (uint32_t)n);
+        recs[2 * e] = ok ? pack_rec((uint32_t)vv, (uint32_t)rr, g) : 0ull;
+        recs[2 * e + 1] = ok ? pack_rec((uint32_t)uu, (uint32_t)rr, g) : 0ull;
+    }
+}
+
+// one record per edge for dD: (u, v, g); keys only when a sort follows
+__global__ void k_pair_recs(const int64_t* __restrict__ u, const int64_t* __restrict__ v, const int64_t* __restrict__ et,
+                            const float* __restrict__ gs, int64_t E, int64_t n, int64_t R, uint32_t* __restrict__ keys,
+                            uint64_t* __restrict__ recs) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t uu = u[e], vv = v[e], rr = et[e];
+        const bool ok = (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
+        recs[e] = ok ? pack_rec((uint32_t)uu, (uint32_t)vv, gs[e]) : 0ull;
+        if (keys) keys[e] = ok ? (uint32_t)rr : (uint32_t)R;
+    }
+}
+
+// rowptr[i] = first position whose (sorted, int64) key is >= i
+__global__ void k_key_offsets64(const int64_t* __restrict__ sorted, int64_t n, int rows, int32_t* __restrict__ rowptr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > rows) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < (int64_t)i) lo = mid + 1; else hi = mid;
+    }
+    rowptr[i] = (int32_t)lo;
+}
+
+// taskptr[k] = number of tasks of the keys before k (a task = up to kTaskRecs records of one key); one workgroup
+__global__ __launch_bounds__(1024) void k_task_ptr(const int32_t* __restrict__ rowptr, int keys, int32_t* __restrict__ taskptr) {
+    __shared__ int32_t sums[1024];
+    const int tid = threadIdx.x;
+    const int strip = (keys + 1023) / 1024;
+    const int k0 = min(tid * strip, keys), k1 = min(k0 + strip, keys);
+    int32_t mine = 0;
+    for (int k = k0; k < k1; ++k) mine += (rowptr[k + 1] - rowptr[k] + kTaskRecs - 1) / kTaskRecs;
+    sums[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                 // inclusive scan
+        const int32_t add = tid >= d ? sums[tid - d] : 0;
+        __syncthreads();
+        sums[tid] += add;
+        __syncthreads();
+    }
+    int32_t run = sums[tid] - mine;
+    for (int k = k0; k < k1; ++k) {
+        taskptr[k] = run;
+        run += (rowptr[k + 1] - rowptr[k] + kTaskRecs - 1) / kTaskRecs;
+    }
+    if (tid == 1023) taskptr[keys] = sums[1023];
+}
+
+struct SegLdsArgs {
+    const uint64_t* recs;        // sorted by key: a | b << 16 | g << 32
+    const int32_t* rowptr;       // [keys + 1]
+    const int32_t* taskptr;      // [keys + 1]
+    int keys;
+    const float* A; int64_t ld_a; int rows_a;
+    const float* B; int64_t ld_b; int rows_b;       // B == A: one table serves both factors
+    int f, col_blocks, workers;
+    float* partial;              // [tasks][f]
+};
+
+// Workgroup = (column block of 16, worker); the blocks of both tables sit in LDS, 64 bytes per row.  Wave tasks are
+// dealt round-robin.  Lane l of a wave loads record l of a 64-record batch; in step S the quad q works on record
+// 4 q + S (quad_perm broadcast) and lane l4 of the quad covers columns 4 l4 .. 4 l4 + 3 of the block.
+__global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
+    extern __shared__ float4 seg_lds4[];
+    const int tid = threadIdx.x, lane = tid & 63, l4 = lane & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = blockIdx.x % a.col_blocks, worker = blockIdx.x / a.col_blocks;
+    const int c0 = cb * 16, w4 = min(4, (a.f - c0) / 4);
+    const bool same = a.B == a.A;
+    {
+        const int total = (a.rows_a + (same ? 0 : a.rows_b)) * 4;
+        for (int i = tid; i < total; i += kLdsThreads) {
+            const int row = i >> 2, c4 = i & 3;
+            const float* src = row < a.rows_a ? a.A + (int64_t)row * a.ld_a : a.B + (int64_t)(row - a.rows_a) * a.ld_b;
+            seg_lds4[i] = c4 < w4 ? *reinterpret_cast<const float4*>(src + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const char* ta = reinterpret_cast<const char*>(seg_lds4) + l4 * 16;
+    const char* tb = same ? ta : ta + (size_t)a.rows_a * 64;
+    const int tasks = a.taskptr[a.keys];
+    for (int t = worker * (kLdsThreads / 64) + wave; t < tasks; t += a.workers * (kLdsThreads / 64)) {
+        int lo = 0, hi = a.keys;                          // the key of task t: last k with taskptr[k] <= t
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.taskptr[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const int begin = a.rowptr[lo] + (t - a.taskptr[lo]) * kTaskRecs;
+        const int end = min(a.rowptr[lo + 1], begin + kTaskRecs);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        uint64_t next = begin + lane < end ? a.recs[begin + lane] : 0ull;
+        for (int base = begin; base < end; base += 64) {
+            const uint64_t rec = next;
+            const int nidx = base + 64 + lane;
+            next = nidx < end ? a.recs[nidx] : 0ull;      // a batch ahead
+            const int ab = (int)(uint32_t)rec, gb = (int)(uint32_t)(rec >> 32);
+            f32x4 va[4], vb[4];
+            float gs[4];
+#define GN_SEG_STEP(S)                                                                                    \
+            {                                                                                             \
+                const uint32_t x = (uint32_t)__builtin_amdgcn_mov_dpp(ab, (S) * 0x55, 0xf, 0xf, true);    \
+                gs[S] = __int_as_float(__builtin_amdgcn_mov_dpp(gb, (S) * 0x55, 0xf, 0xf, true));         \
+                va[S] = *reinterpret_cast<const f32x4*>(ta + ((x & 0xffffu) << 6));                       \
+                vb[S] = *reinterpret_cast<const f32x4*>(tb + ((x >> 16) << 6));                           \
+            }
+            GN_SEG_STEP(0) GN_SEG_STEP(1) GN_SEG_STEP(2) GN_SEG_STEP(3)
+#undef GN_SEG_STEP
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc += gs[s] * (va[s] * vb[s]);
+        }
+        // the 16 quads of the wave, in a fixed order: inside the rows of 16 lanes, then across the four rows
+        // (ds_bpermute: once per task; hipcc folds the four DPP row rotations of a float4 into one, wrongly)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = acc[c];
+            x += __shfl_xor(x, 4);
+            x += __shfl_xor(x, 8);
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            acc[c] = x;
+        }
+        if (lane < w4) *reinterpret_cast<f32x4*>(a.partial + (size_t)t * a.f + c0 + 4 * lane) = acc;
+    }
+}
+
+// out[key, c] = the key's task partials, added in task order
+__global__ void k_seg_lds_combine(const int32_t* __restrict__ taskptr, const float* __restrict__ partial, int keys, int f,
+                                  float* __restrict__ out, int64_t ld_out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)keys * f) return;
+    const int key = (int)(i / f), c = (int)(i - (int64_t)key * f);
+    float s = 0.f;
+    for (int t = taskptr[key]; t < taskptr[key + 1]; ++t) s += partial[(size_t)t * f + c];
+    out[(int64_t)key * ld_out + c] = s;
+}
+
 struct WsLayout { size_t keys, keys_sorted, recs, recs_sorted, rowptr, partial, sort_tmp, total; };
 
 WsLayout ws_layout(int64_t e, int64_t max_rows) {
@@ -190,18 +361,73 @@ WsLayout ws_layout(int64_t e, int64_t max_rows) {
     return l;
 }
 
+struct LdsLayout { size_t keys, keys_sorted, recs, recs_sorted, rowptr, taskptr, partial, sort_tmp, total; };
+
+int64_t lds_max_tasks(int64_t records, int64_t keys) { return records / kTaskRecs + keys + 1; }
+
+LdsLayout lds_layout(int64_t e, int64_t n, int64_t r, int64_t f) {
+    LdsLayout l;
+    size_t sort_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr,
+                                    (uint64_t*)nullptr, (size_t)(2 * e), 0, 32, (hipStream_t)0);
+    const int64_t rows = std::max(n, r);
+    const int64_t tasks = std::max(lds_max_tasks(2 * e, n), lds_max_tasks(e, r));
+    l.keys = 0;
+    l.keys_sorted = l.keys + align_up(2 * e * sizeof(uint32_t));
+    l.recs = l.keys_sorted + align_up(2 * e * sizeof(uint32_t));
+    l.recs_sorted = l.recs + align_up(2 * e * sizeof(uint64_t));
+    l.rowptr = l.recs_sorted + align_up(2 * e * sizeof(uint64_t));
+    l.taskptr = l.rowptr + align_up((rows + 2) * sizeof(int32_t));
+    l.partial = l.taskptr + align_up((rows + 2) * sizeof(int32_t));
+    l.sort_tmp = l.partial + align_up((size_t)tasks * f * sizeof(float));
+    l.total = l.sort_tmp + align_up(sort_bytes);
+    return l;
+}
+
+// what the LDS path takes: 16-bit ids in the packed record, float4 columns, the table blocks inside the LDS
+bool lds_path_shapes(int64_t n, int64_t f, int64_t r) {
+    return !gn::fast_paths_disabled() && n <= 65535 && r <= 65535 && f % 4 == 0 && f >= 4;
+}
+bool lds_dz_fits(int64_t n, int64_t r) { return (size_t)(n + r) * 64 <= kLdsTableBudget; }
+bool lds_dd_fits(int64_t n) { return (size_t)n * 64 <= kLdsTableBudget; }
+
+gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int32_t* taskptr, int64_t keys, const float* A, int64_t ld_a,
+                         int64_t rows_a, const float* B, int64_t ld_b, int64_t rows_b, int64_t f, float* partial, float* out,
+                         int64_t ld_out, hipStream_t st) {
+    static thread_local bool configured = false;
+    if (!configured) {
+        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    k_task_ptr<<<1, 1024, 0, st>>>(rowptr, (int)keys, taskptr);
+    GN_LAUNCH_CHECK();
+    SegLdsArgs a;
+    a.recs = recs; a.rowptr = rowptr; a.taskptr = taskptr; a.keys = (int)keys;
+    a.A = A; a.ld_a = ld_a; a.rows_a = (int)rows_a; a.B = B; a.ld_b = ld_b; a.rows_b = (int)rows_b;
+    a.f = (int)f; a.col_blocks = (int)gn::ceil_div(f, 16);
+    const size_t lds_bytes = (size_t)(rows_a + (B == A ? 0 : rows_b)) * 64;
+    const int per_cu = lds_bytes * 2 <= 156 * 1024 ? 2 : 1;           // 1024-thread workgroups: two per CU at most
+    a.workers = std::max(1, 256 * per_cu / a.col_blocks);
+    a.partial = partial;
+    k_seg_lds<<<a.col_blocks * a.workers, kLdsThreads, lds_bytes, st>>>(a);
+    GN_LAUNCH_CHECK();
+    k_seg_lds_combine<<<(unsigned)gn::ceil_div(keys * f, 256), 256, 0, st>>>(taskptr, partial, (int)keys, (int)f, out, ld_out);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 }  // namespace
 
 extern "C" size_t gn_distmult_backward_workspace_bytes(int64_t n, int64_t f, int64_t r, int64_t e) {
     if (n <= 0 || f <= 0 || r <= 0 || e <= 0) return 0;
-    return ws_layout(e, std::max(n, r)).total;
+    return std::max(ws_layout(e, std::max(n, r)).total, lds_layout(e, n, r, f).total);
 }
 
-extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
-                                              const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
-                                              int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
-                                              float* dd, int64_t ld_dd, void* workspace, size_t workspace_bytes,
-                                              void* stream) {
+extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
+                                                 const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
+                                                 int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
+                                                 float* dd, int64_t ld_dd, int flags, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
     GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
     GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31) && e < (1ll << 31), "table or edge list too large");
     GN_REQUIRE((n == 0 || f == 0 || dz) && (r == 0 || f == 0 || dd), "gradient output pointer is null");
@@ -216,7 +442,9 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
     GN_REQUIRE(z && u && v && et && d && grad_logit, "operand pointer is null");
     GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
     const WsLayout l = ws_layout(e, std::max(n, r));
-    GN_REQUIRE(workspace && workspace_bytes >= l.total, "workspace too small: need %zu bytes", l.total);
+    const LdsLayout ll = lds_layout(e, n, r, f);
+    GN_REQUIRE(workspace && workspace_bytes >= std::max(l.total, ll.total), "workspace too small: need %zu bytes",
+               std::max(l.total, ll.total));
     char* ws = static_cast<char*>(workspace);
     uint32_t* keys = reinterpret_cast<uint32_t*>(ws + l.keys);
     uint32_t* keys_sorted = reinterpret_cast<uint32_t*>(ws + l.keys_sorted);
@@ -230,7 +458,46 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
                      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) |
                        reinterpret_cast<uintptr_t>(dd)) & 15) == 0;
 
+    const bool lds_shapes = lds_path_shapes(n, f, r) && (ld_z % 4 == 0) && (ld_d % 4 == 0) &&
+                            ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+    const bool lds_dz = lds_shapes && lds_dz_fits(n, r), lds_dd = lds_shapes && lds_dd_fits(n);
+    if (lds_dz || lds_dd) {
+        uint32_t* k2 = reinterpret_cast<uint32_t*>(ws + ll.keys);
+        uint32_t* k2s = reinterpret_cast<uint32_t*>(ws + ll.keys_sorted);
+        uint64_t* r2 = reinterpret_cast<uint64_t*>(ws + ll.recs);
+        uint64_t* r2s = reinterpret_cast<uint64_t*>(ws + ll.recs_sorted);
+        int32_t* rp = reinterpret_cast<int32_t*>(ws + ll.rowptr);
+        int32_t* tp = reinterpret_cast<int32_t*>(ws + ll.taskptr);
+        float* part = reinterpret_cast<float*>(ws + ll.partial);
+        size_t sort2 = ll.total - ll.sort_tmp;
+        if (lds_dz) {
+            k_half_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, k2, r2);
+            GN_LAUNCH_CHECK();
+            GN_HIP(rocprim::radix_sort_pairs(ws + ll.sort_tmp, sort2, k2, k2s, r2, r2s, (size_t)(2 * e), 0, bits_for(n + 1), st));
+            k_key_offsets<<<(int)gn::ceil_div(n + 1, 256), 256, 0, st>>>(k2s, 2 * e, (int)n, rp);
+            GN_LAUNCH_CHECK();
+            const gn_status rc = launch_seg_lds(r2s, rp, tp, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
+            if (rc != GN_OK) return rc;
+        }
+        if (lds_dd) {
+            const bool sorted = (flags & GN_DM_TYPES_SORTED) != 0;
+            k_pair_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, sorted ? nullptr : k2, r2);
+            GN_LAUNCH_CHECK();
+            const uint64_t* recs_dd = r2;
+            if (sorted) {
+                k_key_offsets64<<<(int)gn::ceil_div(r + 1, 256), 256, 0, st>>>(et, e, (int)r, rp);
+            } else {
+                GN_HIP(rocprim::radix_sort_pairs(ws + ll.sort_tmp, sort2, k2, k2s, r2, r2s, (size_t)e, 0, bits_for(r + 1), st));
+                k_key_offsets<<<(int)gn::ceil_div(r + 1, 256), 256, 0, st>>>(k2s, e, (int)r, rp);
+                recs_dd = r2s;
+            }
+            GN_LAUNCH_CHECK();
+            const gn_status rc = launch_seg_lds(recs_dd, rp, tp, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st);
+            if (rc != GN_OK) return rc;
+        }
+    }
     for (int mode = 0; mode < 3; ++mode) {
+        if (mode == 2 ? lds_dd : lds_dz) continue;       // done above
         const int64_t rows = mode == 2 ? r : n;
         const float* A = z;                              // a is always a node id
         const int64_t ld_a = ld_z;
@@ -268,4 +535,13 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
         }
     }
     return GN_OK;
+}
+
+extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
+                                              const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
+                                              int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
+                                              float* dd, int64_t ld_dd, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+    return gn_distmult_backward_ex_f32(z, ld_z, n, f, u, v, et, d, ld_d, r, e, grad_logit, dz, ld_dz, dd, ld_dd, 0, workspace,
+                                       workspace_bytes, stream);
 }

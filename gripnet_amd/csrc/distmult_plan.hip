@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
     GN_DM_STAMP(0);
     for (int ph = 0; ph < a.n_phases; ++ph) {
         const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
-        __syncthreads();                                    // everyone is done with the previous phase's table
+        if (ph > 0) __syncthreads();                        // everyone is done with the previous phase's table
         GN_DM_STAMP(1 + 3 * ph);
         switch (w4) {                                       // compile-time row width where it is a common one
             case 16: fill_table<16>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;

@@ -66,7 +66,10 @@ constexpr int kTpg = GN_ACC_TPG;            // 16-row tiles per wave = accumulat
 constexpr int kWaves = GN_ACC_WAVES;         // waves per workgroup (one workgroup per CU: the node table fills its LDS)
 constexpr int kThreads = kWaves * 64;
 constexpr int kCus = 256;
-constexpr int kIterCap = 32;       // iterations per unit and tile: longer (relation, row) lists are cut into chunks
+#ifndef GN_ACC_ITER_CAP
+#define GN_ACC_ITER_CAP 32
+#endif
+constexpr int kIterCap = GN_ACC_ITER_CAP;       // iterations per unit and tile: longer (relation, row) lists are cut into chunks
 constexpr int kStage = 8;          // stream blocks per LDS window of a wave (1 KB)
 constexpr int kFoutAcc = 32;       // out_features (slab layout of k_rgcn_slab_finalize)
 constexpr size_t kLdsBudget = 159 * 1024;

@@ -101,9 +101,14 @@ def test_homo_graph_gcn_gradients(gpu):
         close(p.grad, sd["h." + k].grad, 1e-4, what=k)
 
 
+@pytest.mark.parametrize("tables", ["lds", "l2"])
 @pytest.mark.parametrize("sigmoid", [True, False])
 @pytest.mark.parametrize("n,f,shuffle", [(100, 80, False), (645, 80, False), (37, 20, True), (3000, 24, True)])
-def test_distmult_gradients(gpu, sigmoid, n, f, shuffle):
+def test_distmult_gradients(gpu, sigmoid, n, f, shuffle, tables, monkeypatch):
+    """Both reductions: factor tables in LDS (small supervertex; (3000, 24) does not fit and takes the other one
+    anyway) and gathered from L2 behind three sorts; relation ids sorted (no sort for dD) and shuffled."""
+    if tables == "l2":
+        monkeypatch.setenv("GN_DISABLE_FAST", "1")
     gen = torch.Generator().manual_seed(23 + n)
     R, e = 7, 5000
     ei = torch.randint(0, n, (2, e), generator=gen)

@@ -53,6 +53,26 @@ def main():
     print("units per wave mean {:.2f} max {:.0f}; blocks per wave mean {:.1f} max {:.0f}".format(b[:, 6].mean(), b[:, 6].max(), b[:, 7].mean(), b[:, 7].max()))
     print("gather cycles per wave mean {:.0f} (per block {:.0f}); mfma cycles per wave mean {:.0f} (per non-empty tile ~{:.0f})".format(
         b[:, 4].mean(), b[:, 4].sum() / max(b[:, 7].sum(), 1), b[:, 5].mean(), b[:, 5].sum() / max(b[:, 6].sum() * 3, 1)))
+    full = buf[: (len(buf[buf[:, 0] > 0]) // 12) * 12].astype(np.float64)
+    if len(full) == len(b):                                      # 12 waves per workgroup, in launch order
+        wg = us(full[:, 2] - full[:, 1]).reshape(-1, 12)
+        fill = us(full[:, 1] - t0).reshape(-1, 12)[:, 0]
+        blocks = full[:, 7].reshape(-1, 12)
+        tiles = full[:, 6].reshape(-1, 12) * 3
+        print("per workgroup: loop mean over waves min {:.1f} mean {:.1f} max {:.1f}; spread inside a workgroup (max - mean) mean {:.1f} max {:.1f}".format(
+            wg.mean(1).min(), wg.mean(1).mean(), wg.mean(1).max(), (wg.max(1) - wg.mean(1)).mean(), (wg.max(1) - wg.mean(1)).max()))
+        print("fill done per workgroup: min {:.1f} mean {:.1f} max {:.1f}".format(fill.min(), fill.mean(), fill.max()))
+        A = np.stack([blocks.ravel(), tiles.ravel(), np.ones(blocks.size)], 1)
+        coef, *_ = np.linalg.lstsq(A, wg.ravel(), rcond=None)
+        res = wg.ravel() - A @ coef
+        print("fit loop_us = {:.4f} * blocks + {:.4f} * tiles + {:.2f}; residual rms {:.2f} us, max {:.2f}".format(coef[0], coef[1], coef[2], np.sqrt((res ** 2).mean()), np.abs(res).max()))
+        resw = res.reshape(-1, 12).mean(1)
+        print("residual by workgroup: rms {:.2f}, worst {:.2f} us; by eight-way interleave (XCD) mean {}".format(
+            np.sqrt((resw ** 2).mean()), resw.max(), np.round([resw[i::8].mean() for i in range(8)], 2)))
+        order = np.argsort(-wg.max(1))[:8]
+        for o in order:
+            print("  wg {:3d}: loop max {:.1f} mean {:.1f} blocks/wave {:.0f}..{:.0f} tiles {:.0f}..{:.0f} fill {:.1f}".format(
+                o, wg[o].max(), wg[o].mean(), blocks[o].min(), blocks[o].max(), tiles[o].min(), tiles[o].max(), fill[o]))
     cyc = b[:, 4] + b[:, 5]
     print("stamped cycles / loop time: implied clock x share = {:.2f} GHz-equivalent".format((cyc.sum() / (loop.sum() * 1e3))))
 
