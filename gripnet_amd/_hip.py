@@ -59,6 +59,8 @@ SIGNATURES = {
     "gn_distmult_plan_destroy": (None, [_p]),
     "gn_distmult_plan_edges": (_i64, [_p]),
     "gn_distmult_plan_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _int, _p, _p]),
+    "gn_xtg_workspace_bytes": (_sz, [_i64, _i64]),
+    "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _sz, _p]),
@@ -274,6 +276,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
                           ptr(b), ld(b) if ldb is None else ldb, stride_b,
                           ptr(out), ld(out) if ldc is None else ldc, stride_c,
           m, n, k, batch, ptr(bias), int(bool(relu)), stream_ptr(a.device))
+    return out
+
+
+def xtg(x: torch.Tensor, g: torch.Tensor):
+    """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients); torch.matmul beyond 4096 outputs."""
+    k1, k2 = x.shape[1], g.shape[1]
+    if k1 * k2 > 4096 or k1 * k2 == 0:
+        return x.t() @ g
+    out = torch.empty((k1, k2), dtype=torch.float32, device=x.device)
+    need = int(load().gn_xtg_workspace_bytes(k1, k2))
+    ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+    _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need, stream_ptr(x.device))
     return out
 
 

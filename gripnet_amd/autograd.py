@@ -4,8 +4,8 @@ The reference trains full-batch: every epoch calls ``loss.backward()`` through t
 (GripNet-pose.py:140-146).  When autograd is recording, the modules in layers.py / decoder.py route
 through the ``torch.autograd.Function``s below instead of the slot-fused inference path.  The sparse
 parts of every gradient run in HIP kernels behind the C ABI (transposed normalised adjacency,
-DistMult scatter); the small dense contractions of the backward pass (dW = x^T g, dx = g W^T) are plain
-library GEMMs (torch.matmul -> rocBLAS / hipBLASLt).
+DistMult scatter) and so do the tall-skinny weight gradients dW = x^T g (gn_xtg_f32); the remaining small dense
+contractions (dx = g W^T, the basis / attention gradients) are plain library GEMMs (torch.matmul).
 """
 from __future__ import annotations
 
@@ -45,7 +45,7 @@ class GcnConvFn(torch.autograd.Function):
         gxw = torch.empty((ctx.plan.n_table, g.shape[1]), dtype=torch.float32, device=g.device)
         ctx.plan.aggregate_t(g, gxw)                           # A_norm^T g  (HIP, source-major CSR)
         dx = gxw @ w.t() if ctx.needs_input_grad[0] else None
-        dw = x.t() @ gxw if ctx.needs_input_grad[1] else None
+        dw = _hip.xtg(x, gxw) if ctx.needs_input_grad[1] else None
         db = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None
 
@@ -103,7 +103,7 @@ class RgcnConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 datt = dw @ basis.detach().reshape(B, fin * fout).t()
         if ctx.needs_input_grad[3]:
-            droot = x.t() @ g
+            droot = _hip.xtg(x, g)
         if ctx.needs_input_grad[4]:
             dbias = g.sum(dim=0)
         return dx, dbasis, datt, droot, dbias, None, None

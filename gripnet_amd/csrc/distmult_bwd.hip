@@ -332,15 +332,40 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
     }
 }
 
-// out[key, c] = the key's task partials, added in task order
-__global__ void k_seg_lds_combine(const int32_t* __restrict__ taskptr, const float* __restrict__ partial, int keys, int f,
-                                  float* __restrict__ out, int64_t ld_out) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= (int64_t)keys * f) return;
-    const int key = (int)(i / f), c = (int)(i - (int64_t)key * f);
-    float s = 0.f;
-    for (int t = taskptr[key]; t < taskptr[key + 1]; ++t) s += partial[(size_t)t * f + c];
-    out[(int64_t)key * ld_out + c] = s;
+// out[key, :] = the key's task partials.  One workgroup per key: eight slices take every eighth task each (four
+// loads in flight), then the slices are added in slice order - a fixed order, whatever the number of tasks (a hub
+// relation has hundreds).
+__global__ __launch_bounds__(256) void k_seg_lds_combine(const int32_t* __restrict__ taskptr, const float* __restrict__ partial,
+                                                         int f, float* __restrict__ out, int64_t ld_out) {
+    __shared__ f32x4 fold[8][32];
+    const int key = blockIdx.x, slice = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int t0 = taskptr[key], t1 = taskptr[key + 1];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < f; c0 += 128) {                 // 32 float4 lanes per pass
+        const bool col_ok = c0 + 4 * j < f;
+        f32x4 s = zero4;
+        if (col_ok) {
+            const float* p = partial + c0 + 4 * j;
+            int t = t0 + slice;
+            for (; t + 24 < t1; t += 32) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p + (size_t)t * f);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 8) * f);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 16) * f);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 24) * f);
+                s += a; s += b; s += c; s += d;
+            }
+            for (; t < t1; t += 8) s += *reinterpret_cast<const f32x4*>(p + (size_t)t * f);
+        }
+        __syncthreads();
+        fold[slice][j] = s;
+        __syncthreads();
+        if (slice == 0 && col_ok) {
+            f32x4 r = fold[0][j];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) r += fold[k][j];
+            *reinterpret_cast<f32x4*>(out + (int64_t)key * ld_out + c0 + 4 * j) = r;
+        }
+    }
 }
 
 struct WsLayout { size_t keys, keys_sorted, recs, recs_sorted, rowptr, partial, sort_tmp, total; };
@@ -411,7 +436,7 @@ gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int32_t* t
     a.partial = partial;
     k_seg_lds<<<a.col_blocks * a.workers, kLdsThreads, lds_bytes, st>>>(a);
     GN_LAUNCH_CHECK();
-    k_seg_lds_combine<<<(unsigned)gn::ceil_div(keys * f, 256), 256, 0, st>>>(taskptr, partial, (int)keys, (int)f, out, ld_out);
+    k_seg_lds_combine<<<(unsigned)keys, 256, 0, st>>>(taskptr, partial, (int)f, out, ld_out);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -458,8 +483,9 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) |
                        reinterpret_cast<uintptr_t>(dd)) & 15) == 0;
 
-    const bool lds_shapes = lds_path_shapes(n, f, r) && (ld_z % 4 == 0) && (ld_d % 4 == 0) &&
-                            ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+    const bool lds_shapes = lds_path_shapes(n, f, r) && (ld_z % 4 == 0) && (ld_d % 4 == 0) && (ld_dz % 4 == 0) && (ld_dd % 4 == 0) &&
+                            ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) |
+                              reinterpret_cast<uintptr_t>(dd)) & 15) == 0;
     const bool lds_dz = lds_shapes && lds_dz_fits(n, r), lds_dd = lds_shapes && lds_dd_fits(n);
     if (lds_dz || lds_dd) {
         uint32_t* k2 = reinterpret_cast<uint32_t*>(ws + ll.keys);

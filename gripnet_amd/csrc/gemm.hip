@@ -232,6 +232,63 @@ __global__ void k_softmax_rows(float* __restrict__ x, int64_t ld, int64_t rows, 
 
 }  // namespace
 
+
+// ---- out[k1, k2] = x^T g over m rows (weight gradients of the GCN-style layers: dW = x^T (A^T g)) -----------------
+// Tall and skinny: m is the gene supervertex (~2e4 rows), k1 x k2 a weight matrix (<= 64 x 32).  Every workgroup
+// takes a slice of rows into LDS and leaves its k1 x k2 partial; k_xtg_fold adds the slices in slice order
+// (bitwise reproducible; a library GEMM without split-K spends 60-100 us on these shapes).
+constexpr int kXtgSlices = 256;
+constexpr int kXtgMaxRows = 128;       // rows of a slice held in LDS at a time
+
+__global__ __launch_bounds__(256) void k_xtg_partial(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ g,
+                                                     int64_t ld_g, int64_t m, int k1, int k2, float* __restrict__ partial) {
+    extern __shared__ float xtg_lds[];
+    float* xs = xtg_lds;                                  // [rows][k1 + 1]
+    float* gs = xtg_lds + (size_t)kXtgMaxRows * (k1 + 1); // [rows][k2]
+    const int tid = threadIdx.x;
+    const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = blockIdx.x * per, r1 = min(m, r0 + per);
+    const int outs = k1 * k2;
+    float acc[16];                                        // outputs tid, tid + 256, ... (k1 k2 <= 4096)
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int64_t base = r0; base < r1; base += kXtgMaxRows) {
+        const int rows = (int)min<int64_t>(kXtgMaxRows, r1 - base);
+        __syncthreads();
+        for (int i = tid; i < rows * k1; i += 256) {
+            const int r = i / k1, c = i - r * k1;
+            xs[r * (k1 + 1) + c] = x[(base + r) * ld_x + c];
+        }
+        for (int i = tid; i < rows * k2; i += 256) {
+            const int r = i / k2, c = i - r * k2;
+            gs[r * k2 + c] = g[(base + r) * ld_g + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const int idx = tid + o * 256;
+            if (idx >= outs) break;
+            const int i = idx / k2, j = idx - i * k2;
+            float a = acc[o];
+            for (int r = 0; r < rows; ++r) a = fmaf(xs[r * (k1 + 1) + i], gs[r * k2 + j], a);
+            acc[o] = a;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        const int idx = tid + o * 256;
+        if (idx < outs) partial[(size_t)blockIdx.x * outs + idx] = acc[o];
+    }
+}
+
+__global__ void k_xtg_fold(const float* __restrict__ partial, int slices, int outs, int k2, float* __restrict__ out, int64_t ld_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= outs) return;
+    float s = 0.f;
+    for (int b = 0; b < slices; ++b) s += partial[(size_t)b * outs + idx];
+    out[(int64_t)(idx / k2) * ld_out + idx % k2] = s;
+}
+
 extern "C" {
 
 gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
@@ -283,4 +340,35 @@ gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, 
     return GN_OK;
 }
 
+size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2) {
+    if (k1 <= 0 || k2 <= 0) return 0;
+    return (size_t)kXtgSlices * k1 * k2 * sizeof(float);
+}
+
+gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int64_t k1, int64_t k2, float* out,
+                     int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(m >= 0 && k1 >= 0 && k2 >= 0, "negative size");
+    if (k1 == 0 || k2 == 0) return GN_OK;
+    if (k1 * k2 > 4096) return gn::fail(GN_ERR_UNSUPPORTED, "x^T g: %lld x %lld outputs (at most 4096)", (long long)k1, (long long)k2);
+    GN_REQUIRE(out && ld_out >= k2, "output pointer is null or its leading dimension too small");
+    GN_REQUIRE(m == 0 || (x && g && ld_x >= k1 && ld_g >= k2), "operand pointer is null or a leading dimension too small");
+    GN_REQUIRE(workspace && workspace_bytes >= gn_xtg_workspace_bytes(k1, k2), "workspace too small: need %zu bytes",
+               gn_xtg_workspace_bytes(k1, k2));
+    hipStream_t st = gn::as_stream(stream);
+    const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kXtgSlices, gn::ceil_div(m, 16)));
+    const size_t lds = (size_t)kXtgMaxRows * (k1 + 1 + k2) * sizeof(float);
+    static thread_local bool configured = false;
+    if (!configured) {
+        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xtg_partial), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    k_xtg_partial<<<slices, 256, lds, st>>>(x, ld_x, g, ld_g, m, (int)k1, (int)k2, static_cast<float*>(workspace));
+    GN_LAUNCH_CHECK();
+    k_xtg_fold<<<(unsigned)gn::ceil_div(k1 * k2, 256), 256, 0, st>>>(static_cast<const float*>(workspace), slices, (int)(k1 * k2), (int)k2,
+                                                                  out, ld_out);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 }  // extern "C"
+

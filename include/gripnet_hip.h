@@ -138,6 +138,13 @@ GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, cons
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
                       int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int relu, void* stream);
 
+/* out[k1, k2] = x^T g over m rows (x [m, k1], g [m, k2]; k1 * k2 <= 4096): the weight gradients dW = x^T (A_norm^T g)
+ * of the GCN-style layers and d root = x^T g of the relational one (autograd of layers.py:73,193).  Row slices are
+ * reduced in a fixed order: bitwise reproducible.  Scratch is caller-provided. */
+GN_API size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2);
+GN_API gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int64_t k1, int64_t k2,
+                     float* out, int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Element-wise merges of the external layer (gripnet/layers.py:375-384) and slot copies of the
  * concat outputs:  mode 0: dst = src;  1: dst = |src|;  2: dst = (dst + |src|) / 2;
  * 3: dst = (dst + relu(src)) / 2;  4: dst = (dst + src + src2) / 3 (freebase-c merge,

@@ -284,3 +284,16 @@ def test_pose_training_step_gradients(gpu, scale):
         opt.step()
         losses.append(float(l2))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("m,k1,k2", [(19081, 64, 16), (645, 48, 32), (100, 7, 5), (1, 16, 16), (3000, 64, 64)])
+def test_weight_gradient_contraction(gpu, m, k1, k2):
+    """x^T g of the tall-skinny weight gradients (gn_xtg_f32) against float64; column slices as operands."""
+    from gripnet_amd import _hip
+    gen = torch.Generator().manual_seed(41 + m)
+    wide = torch.randn(m, k1 + 3, generator=gen).to(gpu)
+    x, g = wide[:, 3:], torch.randn(m, k2, generator=gen).to(gpu)
+    got = _hip.xtg(x, g)
+    want = (x.double().t() @ g.double()).float()
+    close(got, want, 1e-4 * max(1.0, want.abs().max().item()), what="x^T g")
+    assert torch.equal(got, _hip.xtg(x, g))                  # fixed summation order
