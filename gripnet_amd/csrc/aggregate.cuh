@@ -38,6 +38,7 @@ struct AggArgs {
     int64_t ld_out;
     int rows;
     gn_side_copy side = {nullptr, 0, nullptr, 0, 0, 0, 0};   // optional fused row copy (dst == nullptr: none)
+    int64_t nnz = -1;      // stored coefficients, when the caller knows them (picks the short-row kernel)
 };
 
 template <int VEC, int LPE>
@@ -121,6 +122,57 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                     dst[0] = acc[0];
                 }
             }
+        }
+    }
+}
+
+// Rows of a few neighbours each (the (relation, source) rows of the relational layer's weight gradient: 6 x 10^5 rows
+// of ~3 edges): a wave per row spends its time on row bookkeeping.  Here LPE lanes own a row - 64 / LPE rows per wave
+// side by side, every lane sums its own four columns over the row's neighbours, two loads in flight - and nothing
+// is folded across lanes.
+template <int LPE>
+__global__ __launch_bounds__(256) void k_aggregate_short(AggArgs a) {
+    constexpr int S = kWave / LPE;
+    const int lane = threadIdx.x & 63, slot = lane / LPE, j = lane % LPE;
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    const int fcol = 4 * j;
+    const bool active = fcol < a.features;
+    if (a.side.dst) {
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, c = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + c];
+            a.side.dst[i * a.side.ld_dst + c] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+    for (int row0 = wave * S; row0 < a.rows; row0 += n_waves * S) {
+        const int row = row0 + slot;
+        const bool live = row < a.rows && active;
+        const int begin = live ? a.rowptr[row] : 0, end = live ? a.rowptr[row + 1] : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = begin; __any(p < end); p += 2) {
+            const bool h0 = p < end, h1 = p + 1 < end;
+            const uint32_t c0 = h0 ? a.col[p] : 0u, c1 = h1 ? a.col[p + 1] : 0u;
+            const float v0 = h0 ? (a.coef ? a.coef[p] : 1.0f) : 0.f, v1 = h1 ? (a.coef ? a.coef[p + 1] : 1.0f) : 0.f;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+            if (h0) r0 = *reinterpret_cast<const float4*>(a.table + (int64_t)c0 * a.ld_table + fcol);
+            if (h1) r1 = *reinterpret_cast<const float4*>(a.table + (int64_t)c1 * a.ld_table + fcol);
+            acc.x += v0 * r0.x; acc.y += v0 * r0.y; acc.z += v0 * r0.z; acc.w += v0 * r0.w;
+            acc.x += v1 * r1.x; acc.y += v1 * r1.y; acc.z += v1 * r1.z; acc.w += v1 * r1.w;
+        }
+        if (live) {
+            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+            const float div = a.rowdiv ? fmaxf(a.rowdiv[row], 1.0f) : 1.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float val = a.rowdiv ? o[t] / div : o[t];
+                if (a.addend) val += a.addend[(int64_t)row * a.ld_addend + fcol + t];
+                if (a.bias) val += a.bias[fcol + t];
+                if (a.relu) val = fmaxf(val, 0.f);
+                o[t] = val;
+            }
+            *reinterpret_cast<float4*>(a.out + (int64_t)row * a.ld_out + fcol) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -370,6 +422,18 @@ inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
     int lpe = 1;
     while (lpe < units && lpe < kWave) lpe <<= 1;
     const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), GN_AGG_GRID);
+    if (vec && lpe <= 16 && a.nnz >= 0 && a.nnz < 8 * (int64_t)a.rows && !fast_paths_disabled()) {
+        const int sgrid = (int)std::min<int64_t>(ceil_div((int64_t)a.rows * lpe, 256), GN_AGG_GRID);
+        switch (lpe) {
+            case 1: k_aggregate_short<1><<<sgrid, 256, 0, st>>>(a); break;
+            case 2: k_aggregate_short<2><<<sgrid, 256, 0, st>>>(a); break;
+            case 4: k_aggregate_short<4><<<sgrid, 256, 0, st>>>(a); break;
+            case 8: k_aggregate_short<8><<<sgrid, 256, 0, st>>>(a); break;
+            default: k_aggregate_short<16><<<sgrid, 256, 0, st>>>(a); break;
+        }
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     if (vec) launch_aggregate_lpe<4>(a, lpe, grid, st); else launch_aggregate_lpe<1>(a, lpe, grid, st);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -281,12 +281,30 @@ __global__ __launch_bounds__(256) void k_xtg_partial(const float* __restrict__ x
     }
 }
 
-__global__ void k_xtg_fold(const float* __restrict__ partial, int slices, int outs, int k2, float* __restrict__ out, int64_t ld_out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= outs) return;
+// 16 outputs per workgroup: 16 groups of threads add 16 slices each (independent loads), then the groups are added
+// in group order.
+__global__ __launch_bounds__(256) void k_xtg_fold(const float* __restrict__ partial, int slices, int outs, int k2,
+                                                  float* __restrict__ out, int64_t ld_out) {
+    __shared__ float fold[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + o;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int b = grp * 16 + k;
+        v[k] = (b < slices && idx < outs) ? partial[(size_t)b * outs + idx] : 0.f;
+    }
     float s = 0.f;
-    for (int b = 0; b < slices; ++b) s += partial[(size_t)b * outs + idx];
-    out[(int64_t)(idx / k2) * ld_out + idx % k2] = s;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+    fold[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && idx < outs) {
+        float r = fold[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) r += fold[k][o];
+        out[(int64_t)(idx / k2) * ld_out + idx % k2] = r;
+    }
 }
 
 extern "C" {
@@ -364,7 +382,7 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
     }
     k_xtg_partial<<<slices, 256, lds, st>>>(x, ld_x, g, ld_g, m, (int)k1, (int)k2, static_cast<float*>(workspace));
     GN_LAUNCH_CHECK();
-    k_xtg_fold<<<(unsigned)gn::ceil_div(k1 * k2, 256), 256, 0, st>>>(static_cast<const float*>(workspace), slices, (int)(k1 * k2), (int)k2,
+    k_xtg_fold<<<(unsigned)gn::ceil_div(k1 * k2, 16), 256, 0, st>>>(static_cast<const float*>(workspace), slices, (int)(k1 * k2), (int)k2,
                                                                   out, ld_out);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -27,6 +27,7 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.out = out;
     a.ld_out = ld_out;
     a.rows = (int)plan->rows;
+    a.nnz = plan->nnz;
     gn_status ss = gn::check_side(side, plan->rows, &a.side);
     if (ss != GN_OK) return ss;
     if (weight) {            // aggregate the input rows, then contract with W in the epilogue
@@ -63,6 +64,7 @@ extern "C" gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const f
     a.out = out;
     a.ld_out = ld_out;
     a.rows = (int)plan->table_rows;
+    a.nnz = plan->nnz;
     return gn::launch_aggregate(a, gn::as_stream(stream));
 }
 
