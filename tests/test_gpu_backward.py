@@ -128,8 +128,14 @@ def test_distmult_gradients(gpu, sigmoid, n, f, shuffle, tables, monkeypatch):
     sr = orc.distmult(zr, ei, et, wr, sigmoid=sigmoid)
     (sr * proj).sum().backward()
     close(s, sr, what="forward")
-    close(zg.grad, zr.grad, 1e-4, what="dz")                  # hundreds of atomics per row, order varies
+    close(zg.grad, zr.grad, 1e-4, what="dz")
     close(dm.weight.grad, wr.grad, 1e-4, what="dD")
+    first = (zg.grad.clone(), dm.weight.grad.clone())         # no atomics on floats: the same bits every time
+    zg.grad = None
+    dm.weight.grad = None
+    s = dm(zg, ei.to(gpu), et.to(gpu), sigmoid=sigmoid)
+    (s * proj.to(gpu)).sum().backward()
+    assert torch.equal(zg.grad, first[0]) and torch.equal(dm.weight.grad, first[1])
 
 
 def test_multiclass_decoder_gradients(gpu):
