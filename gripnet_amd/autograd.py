@@ -113,11 +113,20 @@ class DistMultFn(torch.autograd.Function):
     """``sigma?(sum_k z[u,k] z[v,k] D[r,k])`` (decoder.py:19-23) with the scatter gradients in HIP."""
 
     @staticmethod
-    def forward(ctx, z, weight, edge_index, edge_type, sigmoid):
+    def forward(ctx, z, weight, edge_index, edge_type, sigmoid, plan=None):
         zc = _hip.f32_rows(z.detach())
         w = weight.detach()
         out = torch.empty((edge_index.shape[1],), dtype=torch.float32, device=zc.device)
-        _hip.distmult(zc, edge_index, edge_type, w, sigmoid, out)
+        done = False
+        if plan is not None:                                   # a static edge list (the positives): same bits, fewer bytes
+            try:
+                plan.forward(zc, w, sigmoid, out)
+                done = True
+            except _hip.GripNetHipError as err:                # node table too large for the LDS: the general kernels
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+        if not done:
+            _hip.distmult(zc, edge_index, edge_type, w, sigmoid, out)
         ctx.sigmoid = bool(sigmoid)
         ctx.save_for_backward(zc, w, edge_index, edge_type, out if sigmoid else None)
         return out
@@ -131,7 +140,7 @@ class DistMultFn(torch.autograd.Function):
         dz = torch.empty_like(z)
         dd = torch.empty_like(w)
         _hip.distmult_backward(z, ei, et, w, g, dz, dd)
-        return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None
+        return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 class ClassLogitsFn(torch.autograd.Function):

@@ -263,9 +263,9 @@ __global__ __launch_bounds__(1024) void k_task_ptr(const int32_t* __restrict__ r
 // the same slice again and places every record with a returning LDS add on the wave's private offsets.  Nothing is
 // shared between waves, so the place of a record does not depend on timing: reproducible like the radix sort, at a
 // third of its cost (one pass over the edges instead of two over 12-byte pairs, no separate record / offset kernels).
-constexpr int kSortWavesPerWg = 4;
+constexpr int kSortWavesPerWg = 8;
 constexpr int kSortWaves = 256 * kSortWavesPerWg;
-constexpr int64_t kSortMaxKeys = 8192;        // 4 waves x 32 KB of histogram
+constexpr int64_t kSortMaxKeys = 4096;        // 8 waves x 16 KB of histogram
 
 template <bool SCATTER>
 __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
@@ -280,22 +280,41 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
     __builtin_amdgcn_wave_barrier();
     const int64_t per = (E + kSortWaves - 1) / kSortWaves;
     const int64_t e0 = w * per, e1 = min(E, e0 + per);
+    // the triples of the next step are requested before this step's are placed (a step is one round trip otherwise)
+    // (unconditional loads at a clamped index: hipcc waits for a conditional load on its own)
+    if (e0 >= e1) {
+        if (!SCATTER) {
+            for (int b = lane; b < n; b += 64) counts[(size_t)b * kSortWaves + w] = 0;
+            if (w == 0 && lane == 0) counts[(size_t)n * kSortWaves] = 0;
+        }
+        return;
+    }
+    const size_t dump = (size_t)2 * E;                   // 64 spare records behind the 2 E real ones
+    int64_t at = min(e0 + lane, e1 - 1);
+    int64_t nu = u[at], nv = v[at], nr = et[at];
+    float ng = SCATTER ? gs[at] : 0.f;
     for (int64_t base = e0; base < e1; base += 64) {
-        const int64_t e = base + lane;
-        if (e < e1) {
-            const int64_t uu = u[e], vv = v[e], rr = et[e];
-            if ((uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R) {
-                if (SCATTER) {
-                    const float g = gs[e];
-                    const int pu = atomicAdd(&mine[uu], 1);
-                    recs[pu] = pack_rec((uint32_t)vv, (uint32_t)rr, g);
-                    const int pv = atomicAdd(&mine[vv], 1);
-                    recs[pv] = pack_rec((uint32_t)uu, (uint32_t)rr, g);
-                } else {
-                    atomicAdd(&mine[uu], 1);
-                    atomicAdd(&mine[vv], 1);
-                }
+        const int64_t uu = nu, vv = nv, rr = nr;
+        const float g = ng;
+        const bool have = base + lane < e1;
+        at = min(base + 64 + lane, e1 - 1);
+        nu = u[at]; nv = v[at]; nr = et[at];
+        if (SCATTER) ng = gs[at];
+        const bool ok = have && (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
+        if (SCATTER) {
+            // The stores are unconditional (edges that are dropped write to a spare slot past the last record): vector
+            // memory retires in order, and behind a conditional store hipcc has to drain the queue - stores included -
+            // before it may touch the triples requested above.
+            size_t pu = dump + lane, pv = dump + lane;
+            if (ok) {
+                pu = (size_t)atomicAdd(&mine[uu], 1);
+                pv = (size_t)atomicAdd(&mine[vv], 1);
             }
+            recs[pu] = pack_rec((uint32_t)vv, (uint32_t)rr, g);
+            recs[pv] = pack_rec((uint32_t)uu, (uint32_t)rr, g);
+        } else if (ok) {
+            atomicAdd(&mine[uu], 1);
+            atomicAdd(&mine[vv], 1);
         }
     }
     if (!SCATTER) {
@@ -457,7 +476,7 @@ LdsLayout lds_layout(int64_t e, int64_t n, int64_t r, int64_t f) {
     l.keys_sorted = l.keys + align_up(2 * e * sizeof(uint32_t));
     l.recs = l.keys_sorted + align_up(2 * e * sizeof(uint32_t));
     l.recs_sorted = l.recs + align_up(2 * e * sizeof(uint64_t));
-    l.rowptr = l.recs_sorted + align_up(2 * e * sizeof(uint64_t));
+    l.rowptr = l.recs_sorted + align_up((2 * e + 64) * sizeof(uint64_t));
     l.taskptr = l.rowptr + align_up((rows + 2) * sizeof(int32_t));
     l.partial = l.taskptr + align_up((rows + 2) * sizeof(int32_t));
     l.counts = l.partial + align_up((size_t)tasks * f * sizeof(float));

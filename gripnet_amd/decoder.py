@@ -44,11 +44,14 @@ class multiRelaInnerProductDecoder(Module):
 
     def forward(self, z, edge_index, edge_type, sigmoid=True):
         _hip.require_gpu(z, edge_index, edge_type, self.weight)
-        if recording(z, self.weight):
-            return DistMultFn.apply(z, self.weight, edge_index, edge_type, sigmoid)
-        z = _hip.f32_rows(z)
         if z.shape[1] != self.in_dim:
             raise ValueError("expected {} features, got {}".format(self.in_dim, z.shape[1]))
+        if recording(z, self.weight):
+            plan = self.plan_for(z, edge_index, edge_type)
+            if plan is not None and plan.num_nodes != z.shape[0]:
+                plan = None
+            return DistMultFn.apply(z, self.weight, edge_index, edge_type, sigmoid, plan)
+        z = _hip.f32_rows(z)
         out = torch.empty((edge_index.shape[1],), dtype=torch.float32, device=z.device)
         plan = self.plan_for(z, edge_index, edge_type)
         if plan is not None and plan.num_nodes == z.shape[0]:

@@ -4,10 +4,8 @@
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
-# steady state = the last 60 % of the trace by time
-t0, t1 = rows[0][0], rows[-1][1]
-cut = t0 + (t1 - t0) * 0.4
-sel = [r for r in rows if r[0] >= cut]
+# steady state = the last 60 % of the launches
+sel = rows[int(len(rows) * 0.4):]
 busy = sum(e - s for s, e, _ in sel)
 span = sel[-1][1] - sel[0][0]
 print("steady-state window {:.2f} ms, kernels {:d}, device busy {:.2f} ms ({:.0f} %)".format(span / 1e6, len(sel), busy / 1e6, 100.0 * busy / span))
