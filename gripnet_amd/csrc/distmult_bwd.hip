@@ -232,14 +232,17 @@ __global__ void k_key_offsets64(const int64_t* __restrict__ sorted, int64_t n, i
     rowptr[i] = (int32_t)lo;
 }
 
-// taskptr[k] = number of tasks of the keys before k (a task = up to kTaskRecs records of one key); one workgroup
-__global__ __launch_bounds__(1024) void k_task_ptr(const int32_t* __restrict__ rowptr, int keys, int32_t* __restrict__ taskptr) {
+// taskptr[k] = number of tasks of the keys before k (a task = up to kTaskRecs records of one key), and the tasks
+// themselves as (key, first record, end) descriptors; one workgroup.  The row offsets are read `stride` apart (the
+// scanned (node, wave) counts of the counting sort are the offsets of wave 0).
+__global__ __launch_bounds__(1024) void k_task_ptr(const int32_t* __restrict__ rowptr, int64_t stride, int keys,
+                                                   int32_t* __restrict__ taskptr, int4* __restrict__ tasks) {
     __shared__ int32_t sums[1024];
     const int tid = threadIdx.x;
     const int strip = (keys + 1023) / 1024;
     const int k0 = min(tid * strip, keys), k1 = min(k0 + strip, keys);
     int32_t mine = 0;
-    for (int k = k0; k < k1; ++k) mine += (rowptr[k + 1] - rowptr[k] + kTaskRecs - 1) / kTaskRecs;
+    for (int k = k0; k < k1; ++k) mine += (rowptr[(k + 1) * stride] - rowptr[k * stride] + kTaskRecs - 1) / kTaskRecs;
     sums[tid] = mine;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {                 // inclusive scan
@@ -249,11 +252,34 @@ __global__ __launch_bounds__(1024) void k_task_ptr(const int32_t* __restrict__ r
         __syncthreads();
     }
     int32_t run = sums[tid] - mine;
+    constexpr int kInLds = 4096;                          // keys whose offsets fit the LDS: descriptors written task-parallel
+    __shared__ int32_t tp_l[kInLds + 1], rp_l[kInLds + 1];
+    const bool par = keys <= kInLds;
     for (int k = k0; k < k1; ++k) {
         taskptr[k] = run;
-        run += (rowptr[k + 1] - rowptr[k] + kTaskRecs - 1) / kTaskRecs;
+        const int32_t b = rowptr[k * stride], e = rowptr[(k + 1) * stride];
+        if (par) {
+            tp_l[k] = run; rp_l[k] = b;
+            if (k == keys - 1) rp_l[keys] = e;
+            run += (e - b + kTaskRecs - 1) / kTaskRecs;
+        } else {
+            for (int32_t p = b; p < e; p += kTaskRecs) tasks[run++] = make_int4(k, p, min(e, p + kTaskRecs), 0);
+        }
     }
-    if (tid == 1023) taskptr[keys] = sums[1023];
+    const int32_t total = sums[1023];
+    if (tid == 1023) taskptr[keys] = total;
+    if (!par) return;
+    if (tid == 0) tp_l[keys] = total;
+    __syncthreads();
+    for (int t = tid; t < total; t += 1024) {             // a hub key has hundreds of tasks: one thread per task
+        int lo = 0, hi = keys;                            // last k with tp_l[k] <= t (keys without tasks repeat a value)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tp_l[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const int32_t b = rp_l[lo] + (t - tp_l[lo]) * kTaskRecs;
+        tasks[t] = make_int4(lo, b, min(rp_l[lo + 1], b + kTaskRecs), 0);
+    }
 }
 
 
@@ -263,15 +289,16 @@ __global__ __launch_bounds__(1024) void k_task_ptr(const int32_t* __restrict__ r
 // the same slice again and places every record with a returning LDS add on the wave's private offsets.  Nothing is
 // shared between waves, so the place of a record does not depend on timing: reproducible like the radix sort, at a
 // third of its cost (one pass over the edges instead of two over 12-byte pairs, no separate record / offset kernels).
-constexpr int kSortWavesPerWg = 8;
-constexpr int kSortWaves = 256 * kSortWavesPerWg;
-constexpr int64_t kSortMaxKeys = 4096;        // 8 waves x 16 KB of histogram
+constexpr int kSortWavesPerWg = 4;
+constexpr int kSortWaves = 2048;
+static_assert(kSortWavesPerWg == 4, "k_he_scatter_staged reads the four wave offsets of a node as one int4");
+constexpr int64_t kSortMaxKeys = 4096;        // 4 waves x 16 KB of histogram
 
 template <bool SCATTER>
 __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
                                                                    const int64_t* __restrict__ et, const float* __restrict__ gs,
                                                                    int64_t E, int n, int64_t R, int32_t* __restrict__ counts,
-                                                                   uint64_t* __restrict__ recs) {
+                                                                   uint64_t* __restrict__ recs, uint64_t* __restrict__ pair_recs) {
     extern __shared__ int32_t he_hist[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = blockIdx.x * kSortWavesPerWg + wave;
@@ -282,15 +309,9 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
     const int64_t e0 = w * per, e1 = min(E, e0 + per);
     // the triples of the next step are requested before this step's are placed (a step is one round trip otherwise)
     // (unconditional loads at a clamped index: hipcc waits for a conditional load on its own)
-    if (e0 >= e1) {
-        if (!SCATTER) {
-            for (int b = lane; b < n; b += 64) counts[(size_t)b * kSortWaves + w] = 0;
-            if (w == 0 && lane == 0) counts[(size_t)n * kSortWaves] = 0;
-        }
-        return;
-    }
+    if (SCATTER && e0 >= e1) return;
     const size_t dump = (size_t)2 * E;                   // 64 spare records behind the 2 E real ones
-    int64_t at = min(e0 + lane, e1 - 1);
+    int64_t at = max<int64_t>(0, min(e0 + lane, e1 - 1));
     int64_t nu = u[at], nv = v[at], nr = et[at];
     float ng = SCATTER ? gs[at] : 0.f;
     for (int64_t base = e0; base < e1; base += 64) {
@@ -312,29 +333,116 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
             }
             recs[pu] = pack_rec((uint32_t)vv, (uint32_t)rr, g);
             recs[pv] = pack_rec((uint32_t)uu, (uint32_t)rr, g);
+            // the (u, v, g) record of the dD pass, in edge order, while the triple is in registers
+            if (pair_recs) pair_recs[have ? base + lane : dump + lane] = ok ? pack_rec((uint32_t)uu, (uint32_t)vv, g) : 0ull;
         } else if (ok) {
             atomicAdd(&mine[uu], 1);
             atomicAdd(&mine[vv], 1);
         }
     }
     if (!SCATTER) {
-        __builtin_amdgcn_wave_barrier();
-        for (int b = lane; b < n; b += 64) counts[(size_t)b * kSortWaves + w] = mine[b];
+        // the four waves' counts of a node are adjacent words of the (node, wave) array: one 16-byte store
+        __syncthreads();
+        const int w0 = blockIdx.x * kSortWavesPerWg;
+        for (int b = threadIdx.x; b < n; b += kSortWavesPerWg * 64)
+            *reinterpret_cast<int4*>(counts + (size_t)b * kSortWaves + w0) =
+                make_int4(he_hist[b], he_hist[n + b], he_hist[2 * n + b], he_hist[3 * n + b]);
         if (w == 0 && lane == 0) counts[(size_t)n * kSortWaves] = 0;       // the cell whose scan is the record count
     }
 }
 
-// rowptr[k] = offset of node k's first record (= its offset in wave 0); rowptr[n] = all records
-__global__ void k_he_rowptr(const int32_t* __restrict__ offsets, int n, int32_t* __restrict__ rowptr) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k <= n) rowptr[k] = offsets[(size_t)k * kSortWaves];
+
+// The scatter pass with the workgroup's records staged in LDS.  Placed directly (k_he_sort<true>), the 64 lanes of a
+// store hit 64 different cache lines with 8 bytes each: the pass was bound by those partial-line writes (63 us, 18 us
+// without them).  Here the waves of a workgroup own adjacent slices, so for every node the workgroup's records form
+// one contiguous run of the output; they are placed in an LDS copy of that layout first (same wave-private offsets,
+// shifted to the workgroup's base) and then copied out in order: consecutive lanes write consecutive records.
+__global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_scatter_staged(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
+                                                                             const int64_t* __restrict__ et, const float* __restrict__ gs,
+                                                                             int64_t E, int n, int64_t R, const int32_t* __restrict__ offsets,
+                                                                             uint64_t* __restrict__ recs, uint64_t* __restrict__ pair_recs,
+                                                                             int stage_cap) {
+    extern __shared__ int32_t he_hist[];
+    constexpr int T = kSortWavesPerWg * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = blockIdx.x * kSortWavesPerWg, w = w0 + wave;
+    int32_t* loff = he_hist;                                   // [waves][n]
+    int32_t* lbase = he_hist + (size_t)kSortWavesPerWg * n;    // [n + 1]: where a node's run starts in the stage
+    int32_t* gbase = lbase + n + 1;                            // [n]: where it starts in the output
+    uint64_t* stage = reinterpret_cast<uint64_t*>(gbase + n + 1);   // 6 n + 2 words in: 8-byte aligned
+    __shared__ int32_t strip_sum[T];
+    // Offsets of this workgroup's four waves and of the wave after them, per node: five adjacent words.  Run lengths of
+    // the workgroup per node, their exclusive scan = where a node's run starts in the stage.
+    const int strip = (n + T - 1) / T;
+    const int b0 = min(tid * strip, n), b1 = min(b0 + strip, n);
+    int32_t mine_sum = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int32_t* o = offsets + (size_t)b * kSortWaves + w0;
+        const int4 q = *reinterpret_cast<const int4*>(o);     // w0 is a multiple of four, the array 256-byte aligned
+        const int32_t g1 = o[kSortWavesPerWg];
+        gbase[b] = q.x;
+        loff[b] = 0; loff[n + b] = q.y - q.x; loff[2 * n + b] = q.z - q.x; loff[3 * n + b] = q.w - q.x;
+        lbase[b] = g1 - q.x;                                   // run length, replaced by the scan below
+        mine_sum += g1 - q.x;
+    }
+    strip_sum[tid] = mine_sum;
+    __syncthreads();
+    for (int d = 1; d < T; d <<= 1) {
+        const int32_t add = tid >= d ? strip_sum[tid - d] : 0;
+        __syncthreads();
+        strip_sum[tid] += add;
+        __syncthreads();
+    }
+    int32_t run = strip_sum[tid] - mine_sum;
+    for (int b = b0; b < b1; ++b) {
+        const int32_t len = lbase[b];
+        lbase[b] = run;
+#pragma unroll
+        for (int j = 0; j < kSortWavesPerWg; ++j) loff[j * n + b] += run;
+        run += len;
+    }
+    if (tid == T - 1) lbase[n] = strip_sum[T - 1];
+    __syncthreads();
+    const int total = lbase[n];
+    if (total <= stage_cap) {                                  // (always: the host sized the stage for a full slice)
+        int32_t* mine = loff + (size_t)wave * n;
+        const int64_t per = (E + kSortWaves - 1) / kSortWaves;
+        const int64_t e0 = w * per, e1 = min(E, e0 + per);
+        const size_t dump = (size_t)2 * E;
+        if (e0 < e1) {
+            int64_t at = min(e0 + lane, e1 - 1);
+            int64_t nu = u[at], nv = v[at], nr = et[at];
+            float ng = gs[at];
+            for (int64_t base = e0; base < e1; base += 64) {
+                const int64_t uu = nu, vv = nv, rr = nr;
+                const float g = ng;
+                const bool have = base + lane < e1;
+                at = min(base + 64 + lane, e1 - 1);
+                nu = u[at]; nv = v[at]; nr = et[at]; ng = gs[at];
+                const bool ok = have && (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
+                if (ok) {
+                    const int pu = atomicAdd(&mine[uu], 1);
+                    stage[pu] = pack_rec((uint32_t)vv, (uint32_t)rr, g);
+                    const int pv = atomicAdd(&mine[vv], 1);
+                    stage[pv] = pack_rec((uint32_t)uu, (uint32_t)rr, g);
+                }
+                if (pair_recs) pair_recs[have ? base + lane : dump + lane] = ok ? pack_rec((uint32_t)uu, (uint32_t)vv, g) : 0ull;
+            }
+        }
+        __syncthreads();
+        // copy-out: sixteen lanes per node run (a run of the workgroup is ~12 records on pose0-syn)
+        for (int b = tid >> 4; b < n; b += T / 16) {
+            const int s0 = lbase[b], s1 = lbase[b + 1];
+            uint64_t* dst = recs + (size_t)gbase[b] - s0;
+            for (int i = s0 + (tid & 15); i < s1; i += 16) dst[i] = stage[i];
+        }
+    }
 }
 
 struct SegLdsArgs {
     const uint64_t* recs;        // sorted by key: a | b << 16 | g << 32
-    const int32_t* rowptr;       // [keys + 1]
-    const int32_t* taskptr;      // [keys + 1]
-    int keys;
+    const int4* tasks;           // (key, first record, end) per task
+    const int32_t* n_tasks;      // device scalar
     const float* A; int64_t ld_a; int rows_a;
     const float* B; int64_t ld_b; int rows_b;       // B == A: one table serves both factors
     int f, col_blocks, workers;
@@ -362,15 +470,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
     __syncthreads();
     const char* ta = reinterpret_cast<const char*>(seg_lds4) + l4 * 16;
     const char* tb = same ? ta : ta + (size_t)a.rows_a * 64;
-    const int tasks = a.taskptr[a.keys];
-    for (int t = worker * (kLdsThreads / 64) + wave; t < tasks; t += a.workers * (kLdsThreads / 64)) {
-        int lo = 0, hi = a.keys;                          // the key of task t: last k with taskptr[k] <= t
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (a.taskptr[mid] <= t) lo = mid; else hi = mid - 1;
-        }
-        const int begin = a.rowptr[lo] + (t - a.taskptr[lo]) * kTaskRecs;
-        const int end = min(a.rowptr[lo + 1], begin + kTaskRecs);
+    const int tasks = *a.n_tasks;
+    const int t_step = a.workers * (kLdsThreads / 64);
+    int t = worker * (kLdsThreads / 64) + wave;
+    int4 desc = a.tasks[t < tasks ? t : 0];
+    for (; t < tasks; t += t_step) {
+        const int begin = desc.y, end = desc.z;
+        desc = a.tasks[t + t_step < tasks ? t + t_step : 0];        // the next task's descriptor: a task ahead
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         uint64_t next = begin + lane < end ? a.recs[begin + lane] : 0ull;
         for (int base = begin; base < end; base += 64) {
@@ -461,7 +567,7 @@ WsLayout ws_layout(int64_t e, int64_t max_rows) {
     return l;
 }
 
-struct LdsLayout { size_t keys, keys_sorted, recs, recs_sorted, rowptr, taskptr, partial, counts, sort_tmp, sort_tmp_bytes, total; };
+struct LdsLayout { size_t keys, keys_sorted, recs, recs_sorted, rowptr, taskptr, tasks, partial, counts, sort_tmp, sort_tmp_bytes, total; };
 
 int64_t lds_max_tasks(int64_t records, int64_t keys) { return records / kTaskRecs + keys + 1; }
 
@@ -475,10 +581,11 @@ LdsLayout lds_layout(int64_t e, int64_t n, int64_t r, int64_t f) {
     l.keys = 0;
     l.keys_sorted = l.keys + align_up(2 * e * sizeof(uint32_t));
     l.recs = l.keys_sorted + align_up(2 * e * sizeof(uint32_t));
-    l.recs_sorted = l.recs + align_up(2 * e * sizeof(uint64_t));
+    l.recs_sorted = l.recs + align_up((2 * e + 64) * sizeof(uint64_t));
     l.rowptr = l.recs_sorted + align_up((2 * e + 64) * sizeof(uint64_t));
     l.taskptr = l.rowptr + align_up((rows + 2) * sizeof(int32_t));
-    l.partial = l.taskptr + align_up((rows + 2) * sizeof(int32_t));
+    l.tasks = l.taskptr + align_up((rows + 2) * sizeof(int32_t));
+    l.partial = l.tasks + align_up((size_t)tasks * sizeof(int4));
     l.counts = l.partial + align_up((size_t)tasks * f * sizeof(float));
     const size_t cells = n <= kSortMaxKeys ? (size_t)n * kSortWaves + 1 : 1;
     size_t scan_bytes = 0;
@@ -497,7 +604,8 @@ bool lds_path_shapes(int64_t n, int64_t f, int64_t r) {
 bool lds_dz_fits(int64_t n, int64_t r) { return (size_t)(n + r) * 64 <= kLdsTableBudget; }
 bool lds_dd_fits(int64_t n) { return (size_t)n * 64 <= kLdsTableBudget; }
 
-gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int32_t* taskptr, int64_t keys, const float* A, int64_t ld_a,
+gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int64_t rowptr_stride, int32_t* taskptr, int4* tasks, int64_t keys,
+                         const float* A, int64_t ld_a,
                          int64_t rows_a, const float* B, int64_t ld_b, int64_t rows_b, int64_t f, float* partial, float* out,
                          int64_t ld_out, hipStream_t st) {
     static thread_local bool configured = false;
@@ -505,10 +613,10 @@ gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int32_t* t
         GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    k_task_ptr<<<1, 1024, 0, st>>>(rowptr, (int)keys, taskptr);
+    k_task_ptr<<<1, 1024, 0, st>>>(rowptr, rowptr_stride, (int)keys, taskptr, tasks);
     GN_LAUNCH_CHECK();
     SegLdsArgs a;
-    a.recs = recs; a.rowptr = rowptr; a.taskptr = taskptr; a.keys = (int)keys;
+    a.recs = recs; a.tasks = tasks; a.n_tasks = taskptr + keys;
     a.A = A; a.ld_a = ld_a; a.rows_a = (int)rows_a; a.B = B; a.ld_b = ld_b; a.rows_b = (int)rows_b;
     a.f = (int)f; a.col_blocks = (int)gn::ceil_div(f, 16);
     const size_t lds_bytes = (size_t)(rows_a + (B == A ? 0 : rows_b)) * 64;
@@ -575,6 +683,9 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
         uint64_t* r2s = reinterpret_cast<uint64_t*>(ws + ll.recs_sorted);
         int32_t* rp = reinterpret_cast<int32_t*>(ws + ll.rowptr);
         int32_t* tp = reinterpret_cast<int32_t*>(ws + ll.taskptr);
+        int4* tk = reinterpret_cast<int4*>(ws + ll.tasks);
+        const bool sorted_types = (flags & GN_DM_TYPES_SORTED) != 0;
+        bool pairs_done = false;
         float* part = reinterpret_cast<float*>(ws + ll.partial);
         size_t sort2 = ll.sort_tmp_bytes;
         if (lds_dz && n <= kSortMaxKeys) {
@@ -582,20 +693,28 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             if (!sort_configured) {
                 GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 sort_configured = true;
             }
             int32_t* counts = reinterpret_cast<int32_t*>(ws + ll.counts);
             const size_t cells = (size_t)n * kSortWaves + 1, hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
             k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad_logit, e, (int)n, r,
-                                                                                                   counts, nullptr);
+                                                                                                   counts, nullptr, nullptr);
             GN_LAUNCH_CHECK();
             GN_HIP(rocprim::exclusive_scan(ws + ll.sort_tmp, sort2, counts, counts, 0, cells, rocprim::plus<int32_t>(), st));
-            k_he_rowptr<<<(int)gn::ceil_div(n + 1, 256), 256, 0, st>>>(counts, (int)n, rp);
+            pairs_done = lds_dd && sorted_types;               // the dD records come out of the same pass
+            const int64_t per_wave = gn::ceil_div(e, kSortWaves);
+            const size_t stage_cap = (size_t)2 * per_wave * kSortWavesPerWg;
+            const size_t staged_bytes = hist_bytes + (2 * (size_t)n + 2 + 1) * sizeof(int32_t) + stage_cap * sizeof(uint64_t);
+            if (staged_bytes <= 127 * 1024) {                  // (78 KB on pose0-syn: two workgroups per CU)
+                k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(
+                    u, v, et, grad_logit, e, (int)n, r, counts, r2s, pairs_done ? r2 : nullptr, (int)stage_cap);
+            } else {
+                k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad_logit, e, (int)n, r,
+                                                                                                      counts, r2s, pairs_done ? r2 : nullptr);
+            }
             GN_LAUNCH_CHECK();
-            k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad_logit, e, (int)n, r,
-                                                                                                  counts, r2s);
-            GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(r2s, rp, tp, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
+            const gn_status rc = launch_seg_lds(r2s, counts, kSortWaves, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
             if (rc != GN_OK) return rc;
         } else if (lds_dz) {
             k_half_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, k2, r2);
@@ -603,13 +722,15 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             GN_HIP(rocprim::radix_sort_pairs(ws + ll.sort_tmp, sort2, k2, k2s, r2, r2s, (size_t)(2 * e), 0, bits_for(n + 1), st));
             k_key_offsets<<<(int)gn::ceil_div(n + 1, 256), 256, 0, st>>>(k2s, 2 * e, (int)n, rp);
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(r2s, rp, tp, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
+            const gn_status rc = launch_seg_lds(r2s, rp, 1, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
             if (rc != GN_OK) return rc;
         }
         if (lds_dd) {
-            const bool sorted = (flags & GN_DM_TYPES_SORTED) != 0;
-            k_pair_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, sorted ? nullptr : k2, r2);
-            GN_LAUNCH_CHECK();
+            const bool sorted = sorted_types;
+            if (!pairs_done) {
+                k_pair_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, sorted ? nullptr : k2, r2);
+                GN_LAUNCH_CHECK();
+            }
             const uint64_t* recs_dd = r2;
             if (sorted) {
                 k_key_offsets64<<<(int)gn::ceil_div(r + 1, 256), 256, 0, st>>>(et, e, (int)r, rp);
@@ -619,7 +740,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                 recs_dd = r2s;
             }
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(recs_dd, rp, tp, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st);
+            const gn_status rc = launch_seg_lds(recs_dd, rp, 1, tp, tk, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st);
             if (rc != GN_OK) return rc;
         }
     }
