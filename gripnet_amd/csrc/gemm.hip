@@ -7,6 +7,7 @@
 // element j  <->  k = 4q + j) identically for A and B, which lets A be read with one 16-byte
 // load per lane instead of four strided dwords.
 #include "common.h"
+#include "rgcn_weights.cuh"
 
 namespace {
 
@@ -190,6 +191,115 @@ __global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles)
     }
 }
 
+
+// The same tall-skinny product on the bf16 matrix instruction: every fp32 operand is split into bf16 hi + lo and the
+// product is hi.hi + hi.lo + lo.hi in fp32 accumulators (error <= 2^-17 per product, as in k_rgcn_acc; the contract of
+// the path is 1e-4).  v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate - 20+ us of matrix time on
+// [50000 x 128] @ [128 x 64] - the three v_mfma_f32_16x16x32_bf16 take 3/16 of that and the product becomes a stream
+// over A.  B sits in LDS as hi / lo fragments (16 bytes per lane: eight consecutive k of one column); A is read one
+// 32-deep chunk ahead (two 16-byte loads per lane) and split in registers.  GN_GEMM_EXACT=1 keeps the fp32 instruction.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CH>   // chunks of 32 k known at compile time (all of A's row tile requested up front), 0: any number, one ahead
+__global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tiles) {
+    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][hi, lo][64] as 16-byte words
+    u32x4* bsplit = reinterpret_cast<u32x4*>(bfrag);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int col0 = blockIdx.y * (16 * kColTiles);
+    const int chunks = CH > 0 ? CH : g.k / 32;                // k is a multiple of 32 here
+    const int n_tiles = min(kColTiles, (g.n - col0 + 15) / 16);
+    for (int idx = threadIdx.x; idx < chunks * kColTiles * 64; idx += 512) {
+        const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
+        const int col = col0 + 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = col < g.n ? g.b[(int64_t)(kb + j) * g.ldb + col] : 0.f;
+        u32x4 hi, lo;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            uint32_t a, b;
+            gn_rw::split2(v[2 * h], v[2 * h + 1], a, b);
+            hi[h] = a; lo[h] = b;
+        }
+        u32x4* o = bsplit + ((size_t)(ch * kColTiles + t) * 2) * 64 + l;
+        o[0] = hi;
+        o[64] = lo;
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x * 8 + wave; tile < row_tiles; tile += gridDim.x * 8) {
+        const int row0 = tile * 16;
+        const int arow = row0 + r;
+        const bool a_ok = arow < g.m;
+        const float* __restrict__ arow_ptr = g.a + (int64_t)min(arow, g.m - 1) * g.lda + 8 * q;
+        f32x4 acc[kColTiles];
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto step = [&](int ch, const f32x4& a0, const f32x4& a1) {
+            u32x4 ah, al;
+            {
+                uint32_t h, l;
+                gn_rw::split2(a0[0], a0[1], h, l); ah[0] = h; al[0] = l;
+                gn_rw::split2(a0[2], a0[3], h, l); ah[1] = h; al[1] = l;
+                gn_rw::split2(a1[0], a1[1], h, l); ah[2] = h; al[2] = l;
+                gn_rw::split2(a1[2], a1[3], h, l); ah[3] = h; al[3] = l;
+            }
+            if (!a_ok) { ah = (u32x4){0u, 0u, 0u, 0u}; al = ah; }
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah), xl = __builtin_bit_cast(bf16x8, al);
+            const u32x4* __restrict__ bp = bsplit + (size_t)ch * kColTiles * 2 * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < kColTiles; ++t) {
+                if (t >= n_tiles) break;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[(2 * t) * 64]), bl = __builtin_bit_cast(bf16x8, bp[(2 * t + 1) * 64]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[t], 0, 0, 0);
+            }
+        };
+        if constexpr (CH > 0) {
+            // (requesting the first tile's A before B is prepared was slower: the B loads queue behind it, 19.6 -> 27.7 us)
+            f32x4 av[CH][2];
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                av[ch][0] = *reinterpret_cast<const f32x4*>(arow_ptr + 32 * ch);
+                av[ch][1] = *reinterpret_cast<const f32x4*>(arow_ptr + 32 * ch + 4);
+            }
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) step(ch, av[ch][0], av[ch][1]);
+        } else {
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(arow_ptr), a1 = *reinterpret_cast<const f32x4*>(arow_ptr + 4);
+            for (int ch = 0; ch < chunks; ++ch) {
+                const int nx = (ch + 1 < chunks ? ch + 1 : ch) * 32;
+                const f32x4 n0 = *reinterpret_cast<const f32x4*>(arow_ptr + nx), n1 = *reinterpret_cast<const f32x4*>(arow_ptr + nx + 4);
+                step(ch, a0, a1);
+                a0 = n0; a1 = n1;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) {
+            const int col = col0 + 16 * t + r;
+            if (col >= g.n) continue;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * q + i;
+                if (row < g.m) {
+                    float v = acc[t][i] + bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.c[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+bool gemm_exact() {
+    const char* e = getenv("GN_GEMM_EXACT");
+    return e && e[0] == '1';
+}
+
 __global__ void k_merge(float* __restrict__ dst, int64_t ld_dst, const float* __restrict__ src, int64_t ld_src,
                         const float* __restrict__ src2, int64_t ld_src2, int64_t rows, int cols, int mode) {
     const int64_t total = rows * cols;
@@ -326,6 +436,21 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
     if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny, one shared B
         const int row_tiles = (int)gn::ceil_div(m, 16);
+        if (!a_rows && k % 32 == 0 && g.a_vec_ok && !gemm_exact()) {                           // bf16 x 3 on split operands
+            const size_t split_bytes = (size_t)(k / 32) * kColTiles * 2 * 64 * sizeof(f32x4);   // = lds_bytes: 4 bytes per element of B
+            // eight waves per workgroup (two workgroups per CU at k = 256): one row tile per wave on the NC shapes
+            dim3 sgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 8), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
+            hipStream_t st = gn::as_stream(stream);
+            switch (k / 32) {
+                case 1: k_gemm_split_lds<1><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
+                case 2: k_gemm_split_lds<2><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
+                case 4: k_gemm_split_lds<4><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
+                case 8: k_gemm_split_lds<8><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
+                default: k_gemm_split_lds<0><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
+            }
+            GN_LAUNCH_CHECK();
+            return GN_OK;
+        }
         dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
         k_gemm_f32_lds<<<lgrid, 256, lds_bytes, gn::as_stream(stream)>>>(g, row_tiles);
         GN_LAUNCH_CHECK();
