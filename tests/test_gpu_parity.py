@@ -472,11 +472,15 @@ def test_relation_metrics_match_sklearn(gpu):
 
 
 # ---- BASELINE.json configs 2 and 4 at scale: the NC suite, large supervertices, wide features --------------
-def test_aminer_syn_vs_oracle(gpu):
+@pytest.mark.parametrize("matrix_instruction", ["bf16x3", "fp32"])
+def test_aminer_syn_vs_oracle(gpu, matrix_instruction, monkeypatch):
     """aminer-style model at the `aminer-syn` scale with the reference's own layer widths
     (GripNet-aminer.py:96-98: [128,64,64] / [64,64] / [128,128,32], 8 classes): 50,000 / 20,000 nodes per
-    supervertex, so nothing is LDS-resident and the wide-row specialisations of the gather run."""
+    supervertex, so nothing is LDS-resident and the wide-row specialisations of the gather run.  The tall-skinny
+    x W products run on split bf16 operands by default and on the fp32 matrix instruction with GN_GEMM_EXACT=1."""
     from gripnet_amd.synth import make_nc
+    if matrix_instruction == "fp32":
+        monkeypatch.setenv("GN_GEMM_EXACT", "1")
     data = make_nc("aminer-syn")
     torch.manual_seed(1111)
     model = AminerModel(data.n_p_node, data.n_a_node, data.n_a_type)
