@@ -672,7 +672,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) |
                        reinterpret_cast<uintptr_t>(dd)) & 15) == 0;
 
-    const bool lds_shapes = lds_path_shapes(n, f, r) && (ld_z % 4 == 0) && (ld_d % 4 == 0) && (ld_dz % 4 == 0) && (ld_dd % 4 == 0) &&
+    const bool lds_shapes = lds_path_shapes(n, f, r) && 2 * e + 64 < (1ll << 31) && (ld_z % 4 == 0) && (ld_d % 4 == 0) && (ld_dz % 4 == 0) && (ld_dd % 4 == 0) &&
                             ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) |
                               reinterpret_cast<uintptr_t>(dd)) & 15) == 0;
     const bool lds_dz = lds_shapes && lds_dz_fits(n, r), lds_dd = lds_shapes && lds_dd_fits(n);
