@@ -303,3 +303,51 @@ def test_weight_gradient_contraction(gpu, m, k1, k2):
     want = (x.double().t() @ g.double()).float()
     close(got, want, 1e-4 * max(1.0, want.abs().max().item()), what="x^T g")
     assert torch.equal(got, _hip.xtg(x, g))                  # fixed summation order
+
+
+def test_training_step_replays_as_one_graph(gpu):
+    """Once the plans exist, a whole training step (encoder, both decoder calls, loss, backward, Adam) is a fixed
+    sequence of launches on fixed buffers: captured in one hipGraph and replayed, it follows the same loss curve as
+    the eager loop from the same initial state."""
+    import copy
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.synth import make_pose
+    from gripnet_amd.utils import EPS
+    dg = make_pose("small").to(gpu)
+    torch.manual_seed(67)
+    base = PoseModel(dg.n_g_node, dg.n_d_node, dg.n_dd_edge_type).to(gpu)
+    neg = torch.randint(0, dg.n_d_node, tuple(dg.train_idx.shape), device=gpu)
+
+    def make(model, capturable):
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=capturable)
+
+        def step():
+            opt.zero_grad()
+            z = model.encode(dg)
+            loss = -torch.log(model.dmt(z, dg.train_idx, dg.train_et) + EPS).mean() \
+                   - torch.log(1 - model.dmt(z, neg, dg.train_et) + EPS).mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+
+    eager = make(copy.deepcopy(base), False)
+    eager_losses = [float(eager()) for _ in range(6)]
+    graphed_model = copy.deepcopy(base)
+    step = make(graphed_model, True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        warm = [float(step()) for _ in range(3)]              # plans, relation-order check, optimizer state
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = step()
+    replayed = []
+    for _ in range(3):
+        graph.replay()
+        replayed.append(float(static_loss))
+    got = warm + replayed                                     # the capture itself does not run the step
+    for a, b in zip(got, eager_losses):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (got, eager_losses)
+    assert got[-1] < got[0]
