@@ -21,7 +21,7 @@ _lock = threading.Lock()
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 107                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 108                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -63,7 +63,7 @@ SIGNATURES = {
     "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
-    "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _sz, _p]),
+    "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
@@ -565,14 +565,16 @@ def types_sorted(et):
     return ans
 
 
-def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd):
+def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd, probs=None):
+    """`probs`: the sigmoid scores of the forward; grad_logit is then the gradient with respect to them."""
     ei, u, v, e = edge_rows(u_v)
     et = i64_vec(edge_type)
     flags = GN_DM_TYPES_SORTED if types_sorted(edge_type) else 0
     need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], weight.shape[0], e))
     ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
     _call("gn_distmult_backward_ex_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
-          weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), flags, ptr(ws), need, stream_ptr(z.device))
+          weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), flags, ptr(probs), ptr(ws), need,
+          stream_ptr(z.device))
     return dz, dd
 
 

@@ -135,11 +135,10 @@ class DistMultFn(torch.autograd.Function):
     def backward(ctx, g):
         z, w, ei, et, out = ctx.saved_tensors
         g = g.contiguous().to(torch.float32)
-        if ctx.sigmoid:
-            g = g * out * (1.0 - out)                          # d sigma(s) / d s
         dz = torch.empty_like(z)
         dd = torch.empty_like(w)
-        _hip.distmult_backward(z, ei, et, w, g, dz, dd)
+        # d sigma(s) / d s = p (1 - p) is applied inside, where the edge records are built
+        _hip.distmult_backward(z, ei, et, w, g, dz, dd, probs=out if ctx.sigmoid else None)
         return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None
 
 

@@ -32,6 +32,19 @@ namespace {
 
 struct Rec { uint32_t a, b; float g; };       // 12 bytes: factor rows and the edge's upstream gradient
 
+// d loss / d logit of an edge: the caller's gradient, times sigma'(s) = p (1 - p) when the forward returned
+// probabilities p (decoder.py:23) and the caller hands them over instead of folding the factor in itself
+struct GradSrc {
+    const float* g;
+    const float* p;            // nullable
+    __device__ __forceinline__ float at(int64_t e) const {
+        const float v = g[e];
+        if (!p) return v;
+        const float q = p[e];
+        return v * q * (1.0f - q);
+    }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -45,7 +58,7 @@ int bits_for(int64_t n) {
 // mode 0: key = u, a = v, b = r;   mode 1: key = v, a = u, b = r;   mode 2: key = r, a = u, b = v.
 // Edges with an id outside its table get key = num_keys (sorted past the last row, never read).
 __global__ void k_make_recs(int mode, const int64_t* __restrict__ u, const int64_t* __restrict__ v,
-                            const int64_t* __restrict__ et, const float* __restrict__ gs, int64_t E, int64_t n,
+                            const int64_t* __restrict__ et, GradSrc gs, int64_t E, int64_t n,
                             int64_t R, uint32_t num_keys, uint32_t* __restrict__ keys, Rec* __restrict__ recs) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t uu = u[e], vv = v[e], rr = et[e];
@@ -55,7 +68,7 @@ __global__ void k_make_recs(int mode, const int64_t* __restrict__ u, const int64
         if (mode == 0) { key = (uint32_t)uu; rec.a = (uint32_t)vv; rec.b = (uint32_t)rr; }
         else if (mode == 1) { key = (uint32_t)vv; rec.a = (uint32_t)uu; rec.b = (uint32_t)rr; }
         else { key = (uint32_t)rr; rec.a = (uint32_t)uu; rec.b = (uint32_t)vv; }
-        rec.g = ok ? gs[e] : 0.f;
+        rec.g = ok ? gs.at(e) : 0.f;
         if (!ok) { key = num_keys; rec.a = 0; rec.b = 0; }
         keys[e] = key;
         recs[e] = rec;
@@ -196,12 +209,12 @@ __device__ __forceinline__ uint64_t pack_rec(uint32_t a, uint32_t b, float g) {
 
 // two half-edge records per edge, in edge order (the sort is stable, so the records of a node stay in edge order)
 __global__ void k_half_recs(const int64_t* __restrict__ u, const int64_t* __restrict__ v, const int64_t* __restrict__ et,
-                            const float* __restrict__ gs, int64_t E, int64_t n, int64_t R, uint32_t* __restrict__ keys,
+                            GradSrc gs, int64_t E, int64_t n, int64_t R, uint32_t* __restrict__ keys,
                             uint64_t* __restrict__ recs) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t uu = u[e], vv = v[e], rr = et[e];
         const bool ok = (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
-        const float g = ok ? gs[e] : 0.f;
+        const float g = ok ? gs.at(e) : 0.f;
         reinterpret_cast<uint2*>(keys)[e] = ok ? make_uint2((uint32_t)uu, (uint32_t)vv) : make_uint2((uint32_t)n, (uint32_t)n);
         recs[2 * e] = ok ? pack_rec((uint32_t)vv, (uint32_t)rr, g) : 0ull;
         recs[2 * e + 1] = ok ? pack_rec((uint32_t)uu, (uint32_t)rr, g) : 0ull;
@@ -210,12 +223,12 @@ __global__ void k_half_recs(const int64_t* __restrict__ u, const int64_t* __rest
 
 // one record per edge for dD: (u, v, g); keys only when a sort follows
 __global__ void k_pair_recs(const int64_t* __restrict__ u, const int64_t* __restrict__ v, const int64_t* __restrict__ et,
-                            const float* __restrict__ gs, int64_t E, int64_t n, int64_t R, uint32_t* __restrict__ keys,
+                            GradSrc gs, int64_t E, int64_t n, int64_t R, uint32_t* __restrict__ keys,
                             uint64_t* __restrict__ recs) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t uu = u[e], vv = v[e], rr = et[e];
         const bool ok = (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
-        recs[e] = ok ? pack_rec((uint32_t)uu, (uint32_t)vv, gs[e]) : 0ull;
+        recs[e] = ok ? pack_rec((uint32_t)uu, (uint32_t)vv, gs.at(e)) : 0ull;
         if (keys) keys[e] = ok ? (uint32_t)rr : (uint32_t)R;
     }
 }
@@ -296,7 +309,7 @@ constexpr int64_t kSortMaxKeys = 4096;        // 4 waves x 16 KB of histogram
 
 template <bool SCATTER>
 __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
-                                                                   const int64_t* __restrict__ et, const float* __restrict__ gs,
+                                                                   const int64_t* __restrict__ et, GradSrc gs,
                                                                    int64_t E, int n, int64_t R, int32_t* __restrict__ counts,
                                                                    uint64_t* __restrict__ recs, uint64_t* __restrict__ pair_recs) {
     extern __shared__ int32_t he_hist[];
@@ -313,14 +326,14 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
     const size_t dump = (size_t)2 * E;                   // 64 spare records behind the 2 E real ones
     int64_t at = max<int64_t>(0, min(e0 + lane, e1 - 1));
     int64_t nu = u[at], nv = v[at], nr = et[at];
-    float ng = SCATTER ? gs[at] : 0.f;
+    float ng = SCATTER ? gs.at(at) : 0.f;
     for (int64_t base = e0; base < e1; base += 64) {
         const int64_t uu = nu, vv = nv, rr = nr;
         const float g = ng;
         const bool have = base + lane < e1;
         at = min(base + 64 + lane, e1 - 1);
         nu = u[at]; nv = v[at]; nr = et[at];
-        if (SCATTER) ng = gs[at];
+        if (SCATTER) ng = gs.at(at);
         const bool ok = have && (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
         if (SCATTER) {
             // The stores are unconditional (edges that are dropped write to a spare slot past the last record): vector
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
 // one contiguous run of the output; they are placed in an LDS copy of that layout first (same wave-private offsets,
 // shifted to the workgroup's base) and then copied out in order: consecutive lanes write consecutive records.
 __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_scatter_staged(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
-                                                                             const int64_t* __restrict__ et, const float* __restrict__ gs,
+                                                                             const int64_t* __restrict__ et, GradSrc gs,
                                                                              int64_t E, int n, int64_t R, const int32_t* __restrict__ offsets,
                                                                              uint64_t* __restrict__ recs, uint64_t* __restrict__ pair_recs,
                                                                              int stage_cap) {
@@ -412,13 +425,13 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_scatter_staged(cons
         if (e0 < e1) {
             int64_t at = min(e0 + lane, e1 - 1);
             int64_t nu = u[at], nv = v[at], nr = et[at];
-            float ng = gs[at];
+            float ng = gs.at(at);
             for (int64_t base = e0; base < e1; base += 64) {
                 const int64_t uu = nu, vv = nv, rr = nr;
                 const float g = ng;
                 const bool have = base + lane < e1;
                 at = min(base + 64 + lane, e1 - 1);
-                nu = u[at]; nv = v[at]; nr = et[at]; ng = gs[at];
+                nu = u[at]; nv = v[at]; nr = et[at]; ng = gs.at(at);
                 const bool ok = have && (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
                 if (ok) {
                     const int pu = atomicAdd(&mine[uu], 1);
@@ -640,8 +653,8 @@ extern "C" size_t gn_distmult_backward_workspace_bytes(int64_t n, int64_t f, int
 extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
                                                  const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
                                                  int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
-                                                 float* dd, int64_t ld_dd, int flags, void* workspace,
-                                                 size_t workspace_bytes, void* stream) {
+                                                 float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
+                                                 void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
     GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31) && e < (1ll << 31), "table or edge list too large");
     GN_REQUIRE((n == 0 || f == 0 || dz) && (r == 0 || f == 0 || dd), "gradient output pointer is null");
@@ -654,6 +667,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
         return GN_OK;
     }
     GN_REQUIRE(z && u && v && et && d && grad_logit, "operand pointer is null");
+    const GradSrc grad = {grad_logit, sigmoid_scores};
     GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
     const WsLayout l = ws_layout(e, std::max(n, r));
     const LdsLayout ll = lds_layout(e, n, r, f);
@@ -698,7 +712,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             }
             int32_t* counts = reinterpret_cast<int32_t*>(ws + ll.counts);
             const size_t cells = (size_t)n * kSortWaves + 1, hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
-            k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad_logit, e, (int)n, r,
+            k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad, e, (int)n, r,
                                                                                                    counts, nullptr, nullptr);
             GN_LAUNCH_CHECK();
             GN_HIP(rocprim::exclusive_scan(ws + ll.sort_tmp, sort2, counts, counts, 0, cells, rocprim::plus<int32_t>(), st));
@@ -708,16 +722,16 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             const size_t staged_bytes = hist_bytes + (2 * (size_t)n + 2 + 1) * sizeof(int32_t) + stage_cap * sizeof(uint64_t);
             if (staged_bytes <= 127 * 1024) {                  // (78 KB on pose0-syn: two workgroups per CU)
                 k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(
-                    u, v, et, grad_logit, e, (int)n, r, counts, r2s, pairs_done ? r2 : nullptr, (int)stage_cap);
+                    u, v, et, grad, e, (int)n, r, counts, r2s, pairs_done ? r2 : nullptr, (int)stage_cap);
             } else {
-                k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad_logit, e, (int)n, r,
+                k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad, e, (int)n, r,
                                                                                                       counts, r2s, pairs_done ? r2 : nullptr);
             }
             GN_LAUNCH_CHECK();
             const gn_status rc = launch_seg_lds(r2s, counts, kSortWaves, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
             if (rc != GN_OK) return rc;
         } else if (lds_dz) {
-            k_half_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, k2, r2);
+            k_half_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad, e, n, r, k2, r2);
             GN_LAUNCH_CHECK();
             GN_HIP(rocprim::radix_sort_pairs(ws + ll.sort_tmp, sort2, k2, k2s, r2, r2s, (size_t)(2 * e), 0, bits_for(n + 1), st));
             k_key_offsets<<<(int)gn::ceil_div(n + 1, 256), 256, 0, st>>>(k2s, 2 * e, (int)n, rp);
@@ -728,7 +742,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
         if (lds_dd) {
             const bool sorted = sorted_types;
             if (!pairs_done) {
-                k_pair_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad_logit, e, n, r, sorted ? nullptr : k2, r2);
+                k_pair_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad, e, n, r, sorted ? nullptr : k2, r2);
                 GN_LAUNCH_CHECK();
             }
             const uint64_t* recs_dd = r2;
@@ -754,7 +768,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
         float* out = mode == 2 ? dd : dz;
         const int64_t ld_out = mode == 2 ? ld_dd : ld_dz;
         const int accumulate = mode == 1;                // dz = u-side pass, then + v-side pass
-        k_make_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(mode, u, v, et, grad_logit, e, n, r, (uint32_t)rows, keys, recs);
+        k_make_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(mode, u, v, et, grad, e, n, r, (uint32_t)rows, keys, recs);
         GN_LAUNCH_CHECK();
         GN_HIP(rocprim::radix_sort_pairs(ws + l.sort_tmp, sort_bytes, keys, keys_sorted, recs, recs_sorted, (size_t)e, 0,
                                          bits_for(rows + 1), st));
@@ -790,6 +804,6 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
                                               int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
                                               float* dd, int64_t ld_dd, void* workspace, size_t workspace_bytes,
                                               void* stream) {
-    return gn_distmult_backward_ex_f32(z, ld_z, n, f, u, v, et, d, ld_d, r, e, grad_logit, dz, ld_dz, dd, ld_dd, 0, workspace,
+    return gn_distmult_backward_ex_f32(z, ld_z, n, f, u, v, et, d, ld_d, r, e, grad_logit, dz, ld_dz, dd, ld_dd, 0, nullptr, workspace,
                                        workspace_bytes, stream);
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 107 /* 0.1.7 */
+#define GN_VERSION 108 /* 0.1.8 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -246,7 +246,9 @@ GN_API gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, cons
  * Edges with an id outside its table contribute nothing.  Sort-based segmented reduction: no atomics,
  * bitwise reproducible.  Scratch is caller-provided (gn_distmult_backward_workspace_bytes).
  * gn_distmult_backward_ex_f32 takes flags: GN_DM_TYPES_SORTED promises that edge_type is non-decreasing (the
- * reference's layout, utils.py:168-198), which saves the sort of the dD pass.  Node and relation tables that fit
+ * reference's layout, utils.py:168-198), which saves the sort of the dD pass.  sigmoid_scores (the probabilities the
+ * forward returned, decoder.py:23) makes grad_logit the gradient with respect to those: the factor p (1 - p) is
+ * applied where the records are built.  Node and relation tables that fit
  * the LDS in 16-column blocks ((n + R) * 64 B <= 150 KB) are reduced from there; larger ones from L2. */
 #define GN_DM_TYPES_SORTED 1
 GN_API size_t gn_distmult_backward_workspace_bytes(int64_t num_nodes, int64_t num_features, int64_t num_relations,
@@ -259,7 +261,8 @@ GN_API gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t 
 GN_API gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
                                       const int64_t* u, const int64_t* v, const int64_t* edge_type, const float* d,
                                       int64_t ld_d, int64_t num_relations, int64_t num_edges, const float* grad_logit,
-                                      float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, int flags, void* workspace,
+                                      float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, int flags,
+                                      const float* sigmoid_scores /* nullable */, void* workspace,
                                       size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
