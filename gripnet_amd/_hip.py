@@ -63,7 +63,7 @@ SIGNATURES = {
     "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
-    "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _sz, _p]),
+    "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
@@ -550,31 +550,36 @@ class DistMultPlan:
             _lib.gn_distmult_plan_destroy(h)
 
 
-_sorted_types = []          # (tensor, _version, answer) of the last few edge_type tensors asked about
+_sorted_types = []          # (tensor, _version, relations, offsets or None) of the last few edge_type tensors asked about
 
 
-def types_sorted(et):
-    """Is this edge_type tensor non-decreasing?  One device reduction and host read per tensor (and version): the
-    reference passes the same `train_et` with the positive and the negative edges of every epoch."""
-    for t, ver, ans in _sorted_types:
-        if t is et and ver == et._version:
-            return ans
-    ans = bool(et.numel() < 2 or bool((et[1:] >= et[:-1]).all()))
-    _sorted_types.append((et, et._version, ans))
+def type_offsets(et, num_relations):
+    """[R + 1] int32 offsets of the relations in a non-decreasing edge_type tensor, or None if it is not sorted.  One
+    device reduction and host read per tensor (and version): the reference passes the same `train_et` with the
+    positive and the negative edges of every epoch."""
+    for t, ver, r, off in _sorted_types:
+        if t is et and ver == et._version and r == num_relations:
+            return off
+    off = None
+    if et.numel() < 2 or bool((et[1:] >= et[:-1]).all()):
+        bounds = torch.arange(num_relations + 1, device=et.device, dtype=et.dtype)
+        off = torch.searchsorted(et.contiguous(), bounds).to(torch.int32)
+    _sorted_types.append((et, et._version, num_relations, off))
     del _sorted_types[:-4]
-    return ans
+    return off
 
 
 def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd, probs=None):
     """`probs`: the sigmoid scores of the forward; grad_logit is then the gradient with respect to them."""
     ei, u, v, e = edge_rows(u_v)
     et = i64_vec(edge_type)
-    flags = GN_DM_TYPES_SORTED if types_sorted(edge_type) else 0
+    offsets = type_offsets(edge_type, weight.shape[0])
+    flags = GN_DM_TYPES_SORTED if offsets is not None else 0
     need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], weight.shape[0], e))
     ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
     _call("gn_distmult_backward_ex_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
-          weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), flags, ptr(probs), ptr(ws), need,
-          stream_ptr(z.device))
+          weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), flags, ptr(probs), ptr(offsets), ptr(ws),
+          need, stream_ptr(z.device))
     return dz, dd
 
 

@@ -654,7 +654,8 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                                                  const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
                                                  int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
                                                  float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
-                                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                                 const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
+                                                 void* stream) {
     GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
     GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31) && e < (1ll << 31), "table or edge list too large");
     GN_REQUIRE((n == 0 || f == 0 || dz) && (r == 0 || f == 0 || dd), "gradient output pointer is null");
@@ -746,7 +747,10 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                 GN_LAUNCH_CHECK();
             }
             const uint64_t* recs_dd = r2;
-            if (sorted) {
+            const int32_t* rp_dd = rp;
+            if (sorted && type_offsets) {
+                rp_dd = type_offsets;                          // the caller keeps them with its static edge_type
+            } else if (sorted) {
                 k_key_offsets64<<<(int)gn::ceil_div(r + 1, 256), 256, 0, st>>>(et, e, (int)r, rp);
             } else {
                 GN_HIP(rocprim::radix_sort_pairs(ws + ll.sort_tmp, sort2, k2, k2s, r2, r2s, (size_t)e, 0, bits_for(r + 1), st));
@@ -754,7 +758,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                 recs_dd = r2s;
             }
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(recs_dd, rp, 1, tp, tk, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st);
+            const gn_status rc = launch_seg_lds(recs_dd, rp_dd, 1, tp, tk, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st);
             if (rc != GN_OK) return rc;
         }
     }
@@ -804,6 +808,6 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
                                               int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
                                               float* dd, int64_t ld_dd, void* workspace, size_t workspace_bytes,
                                               void* stream) {
-    return gn_distmult_backward_ex_f32(z, ld_z, n, f, u, v, et, d, ld_d, r, e, grad_logit, dz, ld_dz, dd, ld_dd, 0, nullptr, workspace,
+    return gn_distmult_backward_ex_f32(z, ld_z, n, f, u, v, et, d, ld_d, r, e, grad_logit, dz, ld_dz, dd, ld_dd, 0, nullptr, nullptr, workspace,
                                        workspace_bytes, stream);
 }

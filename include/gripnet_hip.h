@@ -248,7 +248,8 @@ GN_API gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, cons
  * gn_distmult_backward_ex_f32 takes flags: GN_DM_TYPES_SORTED promises that edge_type is non-decreasing (the
  * reference's layout, utils.py:168-198), which saves the sort of the dD pass.  sigmoid_scores (the probabilities the
  * forward returned, decoder.py:23) makes grad_logit the gradient with respect to those: the factor p (1 - p) is
- * applied where the records are built.  Node and relation tables that fit
+ * applied where the records are built.  type_offsets ([R + 1] int32 on the device, with GN_DM_TYPES_SORTED): the first
+ * edge of every relation, for callers that keep it with a static edge_type instead of having it searched per call.  Node and relation tables that fit
  * the LDS in 16-column blocks ((n + R) * 64 B <= 150 KB) are reduced from there; larger ones from L2. */
 #define GN_DM_TYPES_SORTED 1
 GN_API size_t gn_distmult_backward_workspace_bytes(int64_t num_nodes, int64_t num_features, int64_t num_relations,
@@ -262,7 +263,8 @@ GN_API gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64
                                       const int64_t* u, const int64_t* v, const int64_t* edge_type, const float* d,
                                       int64_t ld_d, int64_t num_relations, int64_t num_edges, const float* grad_logit,
                                       float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, int flags,
-                                      const float* sigmoid_scores /* nullable */, void* workspace,
+                                      const float* sigmoid_scores /* nullable */,
+                                      const int32_t* type_offsets /* nullable */, void* workspace,
                                       size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
