@@ -101,6 +101,28 @@ struct alignas(16) AccUnit {
 };
 static_assert(kTpg <= 4, "AccUnit holds four tile block counts");
 
+// Workgroup index -> (row group, slab).  Workgroups go to the eight XCDs round-robin (XCD = index % 8) and every XCD has
+// its own L2: slab s < 8 (G / 8) sits on XCD s % 8, so the plan can keep a relation's units on the slabs of one XCD
+// and its W_r fragments are fetched into one L2 instead of eight (62 of the 85 MB the entry point moved).  The
+// G % 8 slabs that are left take what does not fit.
+__host__ __device__ inline void acc_block_to_group(int block, int Q, int G, int& qg, int& slab) {
+    const int g8 = (G / 8) * 8, main_blocks = Q * g8;
+    if (block < main_blocks) {
+        const int x = block & 7, t = block >> 3;
+        qg = t % Q;
+        slab = (t / Q) * 8 + x;
+    } else {
+        const int r = block - main_blocks;
+        qg = r % Q;
+        slab = g8 + r / Q;
+    }
+}
+__host__ inline int acc_group_to_block(int qg, int slab, int Q, int G) {
+    const int g8 = (G / 8) * 8;
+    if (slab < g8) return (((slab >> 3) * Q + qg) << 3) + (slab & 7);
+    return Q * g8 + (slab - g8) * Q + qg;
+}
+
 struct AccDims { int64_t ld_x; int n; int tiles; int q_groups; int slabs; };
 
 
@@ -130,7 +152,8 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kq = lane >> 4;       // MFMA layout: row lane % 16, k group lane / 16
     const int grow = lane >> 2, gq = lane & 3;        // gather layout: row lane / 4, quarter lane % 4
-    const int qg = blockIdx.x % a.q_groups, slab = blockIdx.x / a.q_groups;
+    int qg, slab;
+    acc_block_to_group((int)blockIdx.x, a.q_groups, a.slabs, qg, slab);
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
 
 #ifdef GN_STAMPS
@@ -542,12 +565,50 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
     };
+    // Relations are dealt to eight classes (one per XCD) by their total cost, once for all row groups; a unit may go
+    // to the slabs of its relation's class (slab % 8 = class, slab < 8 (G / 8)) or to one of the G % 8 spare slabs,
+    // whichever is least loaded.  With fewer than eight slabs there are no classes.
+    const int g8 = (G / 8) * 8;
+    std::vector<int> rel_class(R, 0);
+    if (g8 > 0) {
+        std::vector<int64_t> rel_cost(R, 0);
+        for (int q = 0; q < Q; ++q)
+            for (const Unit& un : per_q[q]) rel_cost[un.rel] += un.cost;
+        std::vector<int> order(R);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rel_cost[x] > rel_cost[y]; });
+        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r : order) {
+            const int c = (int)(std::min_element(load, load + 8) - load);
+            rel_class[r] = c;
+            load[c] += rel_cost[r];
+        }
+    }
     for (int q = 0; q < Q; ++q) {
-        std::vector<std::vector<Unit>> per_wg, per_w;
-        lpt(per_q[q], G, per_wg);
+        std::vector<std::vector<Unit>> per_wg(G), per_w;
+        if (g8 == 0) {
+            lpt(per_q[q], G, per_wg);
+        } else {
+            const std::vector<Unit>& us = per_q[q];
+            std::vector<int> order(us.size());
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return us[x].cost > us[y].cost; });
+            std::vector<int64_t> load(G, 0);
+            for (int idx : order) {
+                const int c = rel_class[us[idx].rel];
+                int best = c;
+                for (int sl = c + 8; sl < g8; sl += 8)
+                    if (load[sl] < load[best]) best = sl;
+                for (int sl = g8; sl < G; ++sl)
+                    if (load[sl] < load[best]) best = sl;
+                per_wg[best].push_back(us[idx]);
+                load[best] += us[idx].cost;
+            }
+        }
         for (int slab = 0; slab < G; ++slab) {
             lpt(per_wg[slab], kWaves, per_w);
-            for (int wi = 0; wi < kWaves; ++wi) per_wave[(slab * Q + q) * kWaves + wi] = std::move(per_w[wi]);   // block = slab * Q + q
+            const int block = acc_group_to_block(q, slab, Q, G);
+            for (int wi = 0; wi < kWaves; ++wi) per_wave[block * kWaves + wi] = std::move(per_w[wi]);
         }
     }
     std::vector<AccUnit> units;
@@ -561,7 +622,8 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     for (int w = 0; w < n_waves; ++w) {
         auto& us = per_wave[w];
         std::sort(us.begin(), us.end(), [](const Unit& x, const Unit& y) { return x.rel != y.rel ? x.rel < y.rel : x.chunk < y.chunk; });
-        const int q = (w / kWaves) % Q;
+        int q, slab_of_w;
+        acc_block_to_group(w / kWaves, Q, G, q, slab_of_w);
         wave_stream[w] = (uint32_t)blocks_total;
         for (const Unit& un : us) {
             AccUnit au = {un.rel, {un.blocks[0], un.blocks[1], un.blocks[2], un.blocks[3]}, 0, 0};

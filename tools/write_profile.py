@@ -31,8 +31,9 @@ Per step: `k_aggregate_transform<8,16>` (gene layer 1), `k_aggregate_transform_q
 {traffic}
 
 Algorithmic bytes of the same launches (SURVEY.md 8d): gn_rgcn_forward_f32 32.5 MB, gn_distmult[_plan]_forward_f32 56.4 MB, GCN layer 31.4 MB.
-The relational kernel moves 74 MB: the 7.7 MB of split W_r fragments (written by the external layer's launch) are fetched by
-every one of the eight XCD L2s (62 MB; partitioning the relations by XCD is the open item), 9.4 MB of edge stream, 1.5 MB of slabs.
+The relational kernel moves 31 MB: 9.4 MB of edge stream, the 7.7 MB of split W_r fragments (written by the external layer's
+launch) once or twice - the plan keeps a relation's units on the slabs of one XCD, so its fragments go into one L2 instead of
+eight (72 MB before that) -, the node table of 256 workgroups where it misses the L2s, 1.5 MB of slabs.
 The planned decoder moves {dm_plan:.0f} MB (4 bytes per edge and phase, the scores once; the partial sums wait in LDS between
 the phases); the plan-less kernel, which negative samples and the first sighting of a list still take, 127-155 MB.
 
