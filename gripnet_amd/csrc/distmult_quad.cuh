@@ -8,7 +8,10 @@
 namespace gn_dm {
 
 constexpr int kMaxPhases = 8;
-constexpr int kThreads = 1024;
+#ifndef GN_DM_THREADS
+#define GN_DM_THREADS 1024
+#endif
+constexpr int kThreads = GN_DM_THREADS;
 constexpr size_t kLdsBudget = 150 * 1024;   // of 160 KB; the rest is left to the runtime
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
