@@ -128,6 +128,7 @@ class DistMultFn(torch.autograd.Function):
         if not done:
             _hip.distmult(zc, edge_index, edge_type, w, sigmoid, out)
         ctx.sigmoid = bool(sigmoid)
+        ctx.plan = plan                                        # a static list: its backward plan hangs on the forward one
         ctx.save_for_backward(zc, w, edge_index, edge_type, out if sigmoid else None)
         return out
 
@@ -138,7 +139,28 @@ class DistMultFn(torch.autograd.Function):
         dz = torch.empty_like(z)
         dd = torch.empty_like(w)
         # d sigma(s) / d s = p (1 - p) is applied inside, where the edge records are built
-        _hip.distmult_backward(z, ei, et, w, g, dz, dd, probs=out if ctx.sigmoid else None)
+        probs = out if ctx.sigmoid else None
+        bwd = None
+        if ctx.plan is not None:                               # sort once per static edge list, not once per step
+            bwd = getattr(ctx.plan, "bwd", None)
+            if bwd is None:
+                try:
+                    bwd = _hip.DistMultBwdPlan(ei, et, z.shape[0], w.shape[0])
+                except _hip.GripNetHipError as err:            # tables too large for the LDS path
+                    if err.status != _hip.GN_ERR_UNSUPPORTED:
+                        raise
+                    bwd = False
+                ctx.plan.bwd = bwd
+        done = False
+        if bwd:
+            try:
+                bwd.backward(z, ei, et, w, g, dz, dd, probs)
+                done = True
+            except _hip.GripNetHipError as err:                # unaligned rows: the general entry point
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+        if not done:
+            _hip.distmult_backward(z, ei, et, w, g, dz, dd, probs=probs)
         return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None
 
 

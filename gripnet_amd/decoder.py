@@ -27,7 +27,10 @@ class multiRelaInnerProductDecoder(Module):
         """Cached plan of a STATIC edge list, or None.  A list is taken to be static the second time the very same
         tensors (same storage, unchanged in place) are scored: the positive edges of a training loop
         (GripNet-pose.py:137,185), not the negative samples, which are new tensors every epoch.  The cache holds
-        the tensors, so their storage cannot be handed to another tensor while an entry is alive."""
+        the tensors, so their storage cannot be handed to another tensor while an entry is alive.
+        (The decision is taken here, in Python, per call: a step captured in a hipGraph replays whatever was decided
+        when it was captured.  A buffer that is refilled in place between replays - negative samples - must also be
+        refilled between the warm-up calls, or it is taken for static and its plan is replayed on new contents.)"""
         key = (edge_index._version, edge_type._version)
         for k, entry in enumerate(self._seen):
             if entry[0] is edge_index and entry[1] is edge_type and entry[2] == key:

@@ -351,3 +351,35 @@ def test_training_step_replays_as_one_graph(gpu):
     for a, b in zip(got, eager_losses):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (got, eager_losses)
     assert got[-1] < got[0]
+
+
+def test_decoder_backward_plan_matches_planless_bitwise(gpu):
+    """A static edge list gets the offsets of its sort and its task lists once (gn_distmult_bwd_plan): the gradients
+    are the very bits of the plan-less call; an edge list with an id outside its table, or with unsorted relation ids,
+    is refused when the plan is built."""
+    shuffle = False
+    from gripnet_amd import _hip
+    gen = torch.Generator().manual_seed(71)
+    n, f, R, e = 300, 80, 11, 20000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    et = torch.sort(torch.randint(0, R, (e,), generator=gen)).values
+    if shuffle:
+        et = et[torch.randperm(e, generator=gen)]
+    z = (torch.randn(n, f, generator=gen) * 0.5).to(gpu)
+    w = (torch.randn(R, f, generator=gen) * 0.5).to(gpu)
+    g = torch.randn(e, generator=gen).to(gpu)
+    probs = torch.rand(e, generator=gen).to(gpu)
+    ei, et = ei.to(gpu), et.to(gpu)
+    plan = _hip.DistMultBwdPlan(ei, et, n, R)
+    for p in (None, probs):
+        dz0, dd0 = torch.empty_like(z), torch.empty_like(w)
+        _hip.distmult_backward(z, ei, et, w, g, dz0, dd0, probs=p)
+        dz1, dd1 = torch.full_like(z, 7.0), torch.full_like(w, 7.0)
+        plan.backward(z, ei, et, w, g, dz1, dd1, probs=p)
+        assert torch.equal(dz0, dz1) and torch.equal(dd0, dd1)
+    bad = ei.clone()
+    bad[1, 5] = n
+    with pytest.raises(IndexError):
+        _hip.DistMultBwdPlan(bad, et, n, R)
+    with pytest.raises(_hip.GripNetHipError):
+        _hip.DistMultBwdPlan(ei, et[torch.randperm(e, generator=gen).to(gpu)], n, R)

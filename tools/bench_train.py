@@ -31,6 +31,16 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=args.graph)
     neg = torch.randint(0, data.n_d_node, tuple(data.train_idx.shape), device=dev)
 
+    # new negative pairs every step, as the reference draws them every epoch (GripNet-pose.py:131): only the positive
+    # edge list is static, and only it gets the decoder's forward / backward plans.  (Copied into the buffer the
+    # step reads, outside a captured step.)
+    pool = [torch.randint(0, data.n_d_node, tuple(data.train_idx.shape), device=dev) for _ in range(4)]
+    drawn = [0]
+
+    def resample():
+        neg.copy_(pool[drawn[0] % len(pool)])
+        drawn[0] += 1
+
     def step():
         opt.zero_grad()
         z = model.encode(data)
@@ -48,10 +58,12 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                step()
+                resample()            # (a buffer that stayed the same would be taken for a static list and get plans,
+                step()                #  and a captured step would replay them on new contents)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
+        resample()
         with torch.cuda.graph(graph):
             static_loss = step()
         eager_step = step
@@ -59,6 +71,11 @@ def main():
         def step():
             graph.replay()
             return static_loss
+    train_step = step
+
+    def step():
+        resample()
+        return train_step()
     for _ in range(3):
         loss = step()
     torch.cuda.synchronize()
