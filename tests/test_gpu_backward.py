@@ -5,6 +5,8 @@ Same seeded inputs and weights on both sides; the loss is a fixed random project
 that every output element carries a different gradient.  Bar: 1e-4 abs on every gradient (the
 reference's own tolerance for fp32); checks use 2e-5 unless stated.
 """
+import os
+
 import pytest
 import torch
 
@@ -14,6 +16,8 @@ from gripnet_amd.synth import make_nc
 from oracle import gripnet_oracle as orc
 
 pytestmark = pytest.mark.gpu
+needs_fast_paths = pytest.mark.skipif(os.environ.get("GN_DISABLE_FAST") == "1",
+                                      reason="exercises a fast path that GN_DISABLE_FAST=1 turns off")
 TIGHT = 2e-5
 
 
@@ -353,6 +357,7 @@ def test_training_step_replays_as_one_graph(gpu):
     assert got[-1] < got[0]
 
 
+@needs_fast_paths
 def test_decoder_backward_plan_matches_planless_bitwise(gpu):
     """A static edge list gets the offsets of its sort and its task lists once (gn_distmult_bwd_plan): the gradients
     are the very bits of the plan-less call; an edge list with an id outside its table, or with unsorted relation ids,

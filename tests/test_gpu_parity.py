@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): index outputs bit-exact; fp32 outputs within 1e-
 reference.  Most checks are held to a tighter 2e-5 so that regressions show early.
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -14,6 +16,8 @@ from gripnet_amd.synth import Data, make_pose
 from oracle import gripnet_oracle as orc
 
 pytestmark = pytest.mark.gpu
+needs_fast_paths = pytest.mark.skipif(os.environ.get("GN_DISABLE_FAST") == "1",
+                                      reason="exercises a fast path that GN_DISABLE_FAST=1 turns off")
 
 TOL = 1e-4      # the contract
 TIGHT = 2e-5    # what we actually expect
@@ -577,6 +581,7 @@ def test_sharded_forward_on_hip_kernels(gpu):
 
 
 # ---- the decoder's plan for static edge lists ---------------------------------------------------
+@needs_fast_paths
 def test_decoder_plan_matches_planless_scores_bitwise(gpu):
     """Second sighting of the same (edge_index, edge_type) tensors builds a plan (packed, batch-ordered edges);
     its scores are the plan-less kernel's, bit for bit, in the caller's edge order: ragged last batch, batches
@@ -641,6 +646,7 @@ def test_rgcn_weights_prefetched_on_a_second_stream(gpu):
         close(changed, ref)
 
 
+@needs_fast_paths
 def test_external_layer_computes_relational_weights_in_its_launch(gpu):
     """gn_graph_aggregate_with_rgcn_weights_f32 (interGraph(..., _cowork=conv)): the external layer's output and the
     relational layer that then skips its weights kernel both equal the separate launches, bit for bit."""
@@ -677,9 +683,14 @@ def test_gcn_bf16_table_is_exact_against_the_rounded_table(gpu, fout):
     ei[1, :400] = 5                                                   # one hub row, isolated nodes elsewhere
     w = torch.rand(e, generator=gen) + 0.5
     x = torch.randn(n, fin, generator=gen)
+    torch.manual_seed(1000 + fout)
     conv = gripnet_amd.myGCN(fin, fout, cached=True).to(gpu)
     conv.bias.data.normal_()
     with torch.no_grad():
+        # the table that gets rounded is the GPU's own fp32 product: a host product differs from it in the last bit
+        # here and there, and where that flips a bf16 rounding the two tables differ by 2^-8 of the entry
+        xw_gpu = torch.empty(n, fout, device=gpu)
+        _hip.gemm(x.to(gpu), conv.weight.detach(), xw_gpu)
         y32 = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True)
         gripnet_amd.utils.set_table_storage(conv, "bf16")
         y16 = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True)
@@ -687,7 +698,7 @@ def test_gcn_bf16_table_is_exact_against_the_rounded_table(gpu, fout):
         assert torch.equal(y32, conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True))
     wt, b = conv.weight.detach().cpu(), conv.bias.detach().cpu()
     ei2, norm = orc.gcn_norm(ei, n, w)
-    xw16 = _bf16_round(x @ wt)
+    xw16 = _bf16_round(xw_gpu.cpu())
     ref16 = torch.relu(torch.zeros(n, fout).index_add_(0, ei2[1], norm.view(-1, 1) * xw16.index_select(0, ei2[0])) + b)
     close(y16, ref16)
     scale = float(y32.abs().max())
