@@ -28,10 +28,14 @@ class GcnConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, plan, n_out, relu):
         x = _hip.f32_rows(x.detach())
         w = weight.detach()
-        xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
-        _hip.gemm(x, w, xw)
         out = torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=x.device)
-        plan.aggregate(xw, None if bias is None else bias.detach(), relu, out)
+        b = None if bias is None else bias.detach()
+        if _hip.transform_fusable(w.shape[0], w.shape[1], x) and w.is_contiguous():
+            plan.aggregate(x, b, relu, out, weight=w)          # (A_norm x) W in one launch, as the inference path
+        else:
+            xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
+            _hip.gemm(x, w, xw)
+            plan.aggregate(xw, b, relu, out)
         ctx.plan, ctx.relu, ctx.has_bias = plan, bool(relu), bias is not None
         ctx.save_for_backward(x, w, out if relu else None)
         return out
