@@ -210,7 +210,10 @@ def main():
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
                    "launch": ("eager; {} HIP-event timed around every launch".format(dom) if launch == "eager" else
-                              "hipGraph replay of every stage but {}, which is launched and HIP-event timed from Python".format(dom) if sharded is None else
+                              ("gene and external layers replayed as one hipGraph; {} launched and HIP-event timed from Python, the "
+                               "decoder (one kernel) launched from Python as well".format(dom) if dom == "gn_rgcn_forward_f32" else
+                               "hipGraph replay of every stage but {}, which is launched and HIP-event timed from Python".format(dom))
+                              if sharded is None else
                               "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
         "roofline": roofline,
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},

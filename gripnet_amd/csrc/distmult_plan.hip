@@ -17,6 +17,7 @@
 #include "distmult_quad.cuh"
 
 #include <algorithm>
+#include <unordered_map>
 #include <vector>
 
 struct gn_distmult_plan {
@@ -24,6 +25,8 @@ struct gn_distmult_plan {
     gn::DevBuf<uint32_t> packed;     // [batches * 64]
     gn::DevBuf<int32_t> batch_rel;   // [batches] relation of the batch, or -1 when it holds more than one
     gn::DevBuf<uint16_t> rel16;      // [batches * 64] relation of every slot (read for mixed batches only)
+    gn::DevBuf<uint32_t> own;        // [batches * 64] position of the slot's edge in the caller's list
+    gn::DevBuf<uint32_t> mirror;     // [batches * 64] second position that takes the slot's score, or kNoMirror
 };
 
 namespace {
@@ -32,15 +35,17 @@ using namespace gn_dm;
 
 constexpr int kNodeBits = 13;
 constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
+constexpr uint32_t kNoMirror = 0xffffffffu;
 
 struct DmPlanArgs {
     const float* z; int64_t ld_z; int n;
-    const uint32_t* packed; const int32_t* batch_rel; const uint16_t* rel16;
+    const uint32_t* packed; const int32_t* batch_rel; const uint16_t* rel16; const uint32_t* own; const uint32_t* mirror;
     const float* d; int64_t ld_d;
     int64_t e; int64_t batches; int64_t batches_per_wg; int sigmoid; float* out;
     int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
     int stride4;
     int keep_n;                // batches per wave whose partial sums stay in LDS between the phases
+    int all_kept;              // no wave has more batches than that
 };
 
 // All indices are 32-bit here (E < 2^31 is a plan invariant) and everything that depends on the batch only is scalar.
@@ -66,11 +71,18 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
     auto clampb = [&](uint32_t x) { return x < b_hi ? x : b; };
     uint32_t w0 = pk[b * 64u], w1 = pk[clampb(b + kWavesPerWg) * 64u], w2 = pk[clampb(b + 2 * kWavesPerWg) * 64u];
     int r0 = brel[b], r1 = brel[clampb(b + kWavesPerWg)];
-    auto position = [&](uint32_t bb, uint32_t ww) { return bb * 64u + (ww >> (2 * kNodeBits)); };
+    // a batch = 64 consecutive SCORED edges of the caller's list (the others are mirrors, below): positions are explicit
+    const uint32_t* __restrict__ own = a.own + lane;
+    // (positions are read where they are used: in the last phase, and in the others by waves that have more batches than
+    // partial sums fit the LDS; the mirror positions in the last phase only)
+    const bool need_own = last || !a.all_kept, need_mir = last;
+    uint32_t o0 = need_own ? own[b * 64u] : 0u, o1 = need_own ? own[clampb(b + kWavesPerWg) * 64u] : 0u;
+    const uint32_t* __restrict__ mir = a.mirror + lane;
+    uint32_t mnext = need_mir ? mir[b * 64u] : kNoMirror;
     // The partial sums of a wave's first keep_n batches wait for the next phase in LDS (`keep`: 256 bytes per batch,
     // beside the table) - the same wave works on the same batches in every phase; only batches beyond that go
     // through `out`.
-    float cnext = (!first && keep_n < 1 && position(b, w0) < e32) ? a.out[position(b, w0)] : 0.f;
+    float cnext = (!first && keep_n < 1 && o0 < e32) ? a.out[o0] : 0.f;
     int nb = 0;                                             // batch number of this wave (wave-uniform)
     for (; b < b_hi; b += kWavesPerWg, ++nb) {
         const uint32_t w = w0;
@@ -78,15 +90,14 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
         const bool kept = nb < keep_n;
         const float carried = first ? 0.f : (kept ? keep[nb * 64] : cnext);
         const uint32_t bn = clampb(b + kWavesPerWg);
-        w0 = w1; w1 = w2; r0 = r1;
+        const uint32_t mine = o0, mcur = mnext;
+        w0 = w1; w1 = w2; r0 = r1; o0 = o1;
         w2 = pk[clampb(b + 3 * kWavesPerWg) * 64u];
         r1 = brel[clampb(b + 2 * kWavesPerWg)];
-        {
-            const uint32_t next = position(bn, w0);
-            cnext = (!first && nb + 1 >= keep_n && next < e32) ? a.out[next] : 0.f;
-        }
+        if (need_own) o1 = own[clampb(b + 2 * kWavesPerWg) * 64u];
+        if (need_mir) mnext = mir[bn * 64u];
+        cnext = (!first && nb + 1 >= keep_n && o0 < e32) ? a.out[o0] : 0.f;
         const int iu = (int)(w & kNodeMask), iv = (int)((w >> kNodeBits) & kNodeMask);
-        const uint32_t mine = position(b, w);
         const bool valid = mine < e32;
         float result = 0.f;
         if (rel >= 0) {                                       // wave-uniform
@@ -112,6 +123,9 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
         if (last) {
             if (a.sigmoid) total = sigmoid_f32(total);
             if (valid) a.out[mine] = total;
+            // the same unordered node pair under the same relation elsewhere in the list (the reversed copy of a
+            // bidirectional edge, utils.py:132-138): z_u z_v is commutative, so that score is this one, bit for bit
+            if (mcur != kNoMirror) a.out[mcur] = total;
         } else if (kept) {
             keep[nb * 64] = total;
         } else if (valid) {
@@ -227,7 +241,7 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         return gn::fail(GN_ERR_UNSUPPORTED, "edge list too large for the packed plan encoding (nodes <= %u, relations <= 65535)",
                         kNodeMask + 1);
     hipStream_t st = gn::as_stream(stream);
-    const int64_t E = num_edges, B = gn::ceil_div(E, 64);
+    const int64_t E = num_edges;
     std::vector<int64_t> hu(E), hv(E), hr(E);
     if (E > 0) {
         GN_HIP(hipMemcpyAsync(hu.data(), u, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -241,48 +255,76 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
             return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
                             (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
                             (long long)num_nodes, (long long)num_relations);
-    // an unused slot scores node 0 against node 0 under relation 0 (or the batch's) and is never written
-    std::vector<uint32_t> packed((size_t)B * 64, (uint32_t)63 << (2 * kNodeBits));
-    std::vector<int32_t> batch_rel((size_t)B, 0);
-    std::vector<uint16_t> rel16((size_t)B * 64, 0);
-    int slot_of_edge[64];
-    for (int64_t b = 0; b < B; ++b) {
-        const int64_t e0 = b * 64;
-        const int count = (int)std::min<int64_t>(64, E - e0);
-        deal_batch(hu.data() + e0, hv.data() + e0, count, slot_of_edge);
-        bool uniform = true;
-        for (int k = 1; k < count; ++k) uniform = uniform && hr[e0 + k] == hr[e0];
-        batch_rel[b] = uniform ? (int32_t)hr[e0] : -1;
-        bool taken[64] = {false};
-        for (int k = 0; k < count; ++k) {
-            const int s = slot_of_edge[k];
-            taken[s] = true;
-            packed[e0 + s] = (uint32_t)hu[e0 + k] | ((uint32_t)hv[e0 + k] << kNodeBits) | ((uint32_t)k << (2 * kNodeBits));
-            rel16[e0 + s] = (uint16_t)hr[e0 + k];
-        }
-        // unused slots of the last batch: position = an index past the end of the edge list
-        int spare = count;
-        for (int s = 0; s < 64; ++s)
-            if (!taken[s]) {
-                packed[e0 + s] = (uint32_t)std::min(spare, 63) << (2 * kNodeBits);
-                rel16[e0 + s] = (uint16_t)(count > 0 ? hr[e0] : 0);
-                ++spare;
+    // Triples with the same unordered node pair and relation have the same score (the reference's positive list holds
+    // every edge in both directions): they are paired up, the first of a pair is scored and writes both positions.
+    std::vector<int64_t> mirror_of(E, -1);
+    std::vector<char> covered(E, 0);
+    {
+        std::unordered_map<uint64_t, int64_t> open;
+        open.reserve((size_t)E);
+        for (int64_t e = 0; e < E; ++e) {
+            const uint64_t lo = (uint64_t)std::min(hu[e], hv[e]), hi = (uint64_t)std::max(hu[e], hv[e]);
+            const uint64_t key = ((uint64_t)hr[e] << (2 * kNodeBits)) | (lo << kNodeBits) | hi;
+            auto it = open.find(key);
+            if (it != open.end()) {
+                mirror_of[it->second] = e;
+                covered[e] = 1;
+                open.erase(it);
+            } else {
+                open.emplace(key, e);
             }
+        }
     }
+    // batches: 64 consecutive scored edges each, in list order
+    std::vector<uint32_t> packed, own, mirror;
+    std::vector<int32_t> batch_rel;
+    std::vector<uint16_t> rel16;
+    int slot_of_edge[64];
+    int64_t cu[64], cv[64], ce[64];
+    int64_t scan = 0;
+    while (scan < E) {
+        int count = 0;
+        for (; scan < E && count < 64; ++scan)
+            if (!covered[scan]) { cu[count] = hu[scan]; cv[count] = hv[scan]; ce[count] = scan; ++count; }
+        if (count == 0) break;
+        deal_batch(cu, cv, count, slot_of_edge);
+        bool uniform = true;
+        for (int k = 1; k < count; ++k) uniform = uniform && hr[ce[k]] == hr[ce[0]];
+        const size_t s0 = packed.size();
+        packed.resize(s0 + 64); own.resize(s0 + 64); mirror.resize(s0 + 64); rel16.resize(s0 + 64);
+        batch_rel.push_back(uniform ? (int32_t)hr[ce[0]] : -1);
+        bool taken[64] = {false};
+        auto fill = [&](int s, int k) {
+            const int64_t e = ce[k];
+            packed[s0 + s] = (uint32_t)hu[e] | ((uint32_t)hv[e] << kNodeBits);
+            own[s0 + s] = (uint32_t)e;
+            rel16[s0 + s] = (uint16_t)hr[e];
+            mirror[s0 + s] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
+        };
+        for (int k = 0; k < count; ++k) { taken[slot_of_edge[k]] = true; fill(slot_of_edge[k], k); }
+        // a slot without an edge repeats the batch's first one: the same score into the same positions
+        for (int s = 0; s < 64; ++s)
+            if (!taken[s]) fill(s, 0);
+    }
+    const int64_t NB = (int64_t)batch_rel.size();
     gn_distmult_plan* p = new gn_distmult_plan();
-    p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = B;
+    p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = NB;
     auto bail = [&](hipError_t e) {
         gn_distmult_plan_destroy(p);
         return gn::fail(GN_ERR_HIP, "DistMult plan upload failed: %s", hipGetErrorString(e));
     };
     hipError_t he;
-    if ((he = p->packed.alloc((size_t)B * 64)) != hipSuccess) return bail(he);
-    if ((he = p->batch_rel.alloc((size_t)B)) != hipSuccess) return bail(he);
-    if ((he = p->rel16.alloc((size_t)B * 64)) != hipSuccess) return bail(he);
-    if (B > 0) {
-        if ((he = hipMemcpyAsync(p->packed.p, packed.data(), (size_t)B * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-        if ((he = hipMemcpyAsync(p->batch_rel.p, batch_rel.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-        if ((he = hipMemcpyAsync(p->rel16.p, rel16.data(), (size_t)B * 64 * sizeof(uint16_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+    if ((he = p->packed.alloc((size_t)NB * 64)) != hipSuccess) return bail(he);
+    if ((he = p->batch_rel.alloc((size_t)NB)) != hipSuccess) return bail(he);
+    if ((he = p->rel16.alloc((size_t)NB * 64)) != hipSuccess) return bail(he);
+    if ((he = p->mirror.alloc((size_t)NB * 64)) != hipSuccess) return bail(he);
+    if ((he = p->own.alloc((size_t)NB * 64)) != hipSuccess) return bail(he);
+    if (NB > 0) {
+        if ((he = hipMemcpyAsync(p->packed.p, packed.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipMemcpyAsync(p->batch_rel.p, batch_rel.data(), (size_t)NB * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipMemcpyAsync(p->rel16.p, rel16.data(), (size_t)NB * 64 * sizeof(uint16_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipMemcpyAsync(p->mirror.p, mirror.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+        if ((he = hipMemcpyAsync(p->own.p, own.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
         if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);     // host vectors go out of scope after this
     }
     *out = p;
@@ -294,6 +336,8 @@ void gn_distmult_plan_destroy(gn_distmult_plan* p) {
     p->packed.release();
     p->batch_rel.release();
     p->rel16.release();
+    p->mirror.release();
+    p->own.release();
     delete p;
 }
 
@@ -313,7 +357,7 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
     if (gn::fast_paths_disabled() || a.n_phases < 1 || a.n_phases > 4)
         return gn::fail(GN_ERR_UNSUPPORTED, "the planned decoder needs a node table that fits the LDS in at most four column "
                                             "phases (n = %lld, features = %lld): use gn_distmult_forward_f32", (long long)n, (long long)f);
-    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.packed = plan->packed.p; a.batch_rel = plan->batch_rel.p; a.rel16 = plan->rel16.p;
+    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.packed = plan->packed.p; a.batch_rel = plan->batch_rel.p; a.rel16 = plan->rel16.p; a.own = plan->own.p; a.mirror = plan->mirror.p;
     a.d = d; a.ld_d = ld_d; a.e = plan->num_edges; a.batches = plan->batches; a.sigmoid = apply_sigmoid; a.out = out;
     int max_w = 0;
     for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
@@ -327,6 +371,7 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
     const int64_t per_wave = gn::ceil_div(plan->batches, groups * (kThreads / 64));
     const int64_t room = ((int64_t)160 * 1024 - 1024 - (int64_t)table_bytes) / ((kThreads / 64) * 256);
     a.keep_n = a.n_phases > 1 ? (int)std::max<int64_t>(0, std::min(per_wave, room)) : 0;
+    a.all_kept = a.n_phases > 1 && a.keep_n >= per_wave;
     const size_t lds_bytes = table_bytes + (size_t)a.keep_n * (kThreads / 64) * 256;
     static thread_local bool configured = false;
     if (!configured) {

@@ -141,7 +141,7 @@ class PoseStages:
     def __init__(self, model: PoseModel, data, graphs: bool = True, edge_index=None, edge_type=None,
                  timed_entry: Optional[str] = None):
         """`timed_entry` ("gn_rgcn_forward_f32" or "gn_distmult[_plan]_forward_f32"): with graphs, the stage that holds
-        that entry point is NOT captured: its one or two launches are made from Python, so that an active
+        that entry point is NOT captured (nor, behind a timed relational layer, the one-kernel decoder): its launches are made from Python, so that an active
         _hip.KernelTimer brackets the entry point itself with HIP events (events around a graph replay would add the
         graph's launch latency, ~7 us, to the measured duration); every other stage is a hipGraph."""
         self.model, self.data = model, data
@@ -161,7 +161,8 @@ class PoseStages:
                     self._genes = Graphed(self._genes_eager).capture()
                     self.x = self._genes()
                     self._drugs_eager()                      # builds the plan; stays eager
-                    self._decode = Graphed(self._decode_eager).capture()
+                    for _ in range(2):                       # the decoder is one launch: as a graph of its own it
+                        self._decode_eager()                 # would cost a graph launch (~7 us) instead of a kernel launch
                 else:
                     self._encode = Graphed(self._encode_eager).capture()
                     if timed_entry not in ("gn_distmult_forward_f32", "gn_distmult_plan_forward_f32"):
