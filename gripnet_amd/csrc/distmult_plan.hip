@@ -5,12 +5,14 @@
 //   out[e] = sigma?( sum_k z[u_e,k] * z[v_e,k] * D[r_e,k] )                          (decoder.py:19-23)
 //
 // What the plan buys over streaming the raw int64 triples every call (distmult_fast.hip):
-//   - HBM: one 32-bit word per edge (u : 13 | v : 13 | position in its 64-edge batch : 6) and one relation word per
-//     batch, instead of 24 bytes per edge and column phase;
+//   - work: triples with the same unordered node pair and relation have the same score, bit for bit (z_u z_v is
+//     commutative) - the reference's positive list holds every edge in both directions (utils.py:132-138,168-198) -
+//     so the plan pairs them up, scores one of a pair and writes its score to both positions: half the batches;
+//   - HBM: 32-bit words per SCORED edge (u : 13 | v : 13; its position; its mirror's position, read in the last phase
+//     only) and one relation word per batch, instead of 24 bytes per edge and column phase;
 //   - LDS: inside a batch the edges are dealt to the (wave step, access group) cells so that the four edges a
 //     16-lane ds_read_b128 access group works on have their u rows - and their v rows - in four different
-//     64-byte bank slots wherever the batch allows it (a batch is 64 consecutive edges of the caller's list, so the
-//     score of an edge still lands in its own 256-byte window of `out`);
+//     64-byte bank slots wherever the batch allows it (a batch is 64 consecutive scored edges of the caller's list);
 //   - VALU: no int64 arithmetic, no range checks (validated once, at plan time), the batch's relation is a
 //     scalar.
 // Same column phases and quad-per-edge arithmetic as the plan-less kernel: results are bitwise the same.

@@ -227,8 +227,10 @@ GN_API gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64_t n
 
 /* The same decoder on a cached, re-encoded STATIC edge list: the positive edges, which the reference scores with the
  * same train_idx / train_et tensors every epoch (GripNet-pose.py:137,185).  The plan validates the triples once
- * (GN_ERR_INDEX_RANGE), packs them into one 32-bit word per edge and orders the edges inside every 64-edge batch for
- * conflict-free LDS gathers; scores come out in the caller's edge order, bitwise equal to gn_distmult_forward_f32.
+ * (GN_ERR_INDEX_RANGE), pairs up triples with the same unordered node pair and relation (both directions of an edge,
+ * utils.py:132-138: the same score bit for bit, computed once and written to both positions), packs the scored ones
+ * into 32-bit words and orders them inside every 64-edge batch for conflict-free LDS gathers; scores come out in the
+ * caller's edge order, bitwise equal to gn_distmult_forward_f32.
  * Plan creation copies the triples to the host and synchronises `stream`.  GN_ERR_UNSUPPORTED: more than 8192 nodes
  * or 65535 relations (create), or a node table that does not fit the LDS in four column phases (forward) - use
  * gn_distmult_forward_f32 then. */

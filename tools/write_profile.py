@@ -34,8 +34,8 @@ Algorithmic bytes of the same launches (SURVEY.md 8d): gn_rgcn_forward_f32 32.5 
 The relational kernel moves 31 MB: 9.4 MB of edge stream, the 7.7 MB of split W_r fragments (written by the external layer's
 launch) once or twice - the plan keeps a relation's units on the slabs of one XCD, so its fragments go into one L2 instead of
 eight (72 MB before that) -, the node table of 256 workgroups where it misses the L2s, 1.5 MB of slabs.
-The planned decoder moves {dm_plan:.0f} MB (4 bytes per edge and phase, the scores once; the partial sums wait in LDS between
-the phases); the plan-less kernel, which negative samples and the first sighting of a list still take, 127-155 MB.
+The planned decoder moves {dm_plan:.0f} MB (three 32-bit words per scored edge - half of the bidirectional list -, the scores
+once per position; the partial sums wait in LDS between the phases); the plan-less kernel, which negative samples and the first sighting of a list still take, 127-155 MB.
 
 ## bench.py line of the profiled run (slower than an un-profiled run: host-side launch gaps under the profiler)
 
