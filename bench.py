@@ -208,6 +208,8 @@ def main():
         "config": {"workload": args.workload if world == 1 else "{} x{} dd relation shards".format(args.workload, world),
                    "edges_aggregated_per_step": A, "n_g": data.n_g_node, "n_d": n_d, "relations": data.n_dd_edge_type,
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
+                   "decoder": "static positive list: every unordered (node pair, relation) scored once, the score written to both "
+                              "directions' positions (same bits as scoring both; parity checked on all E scores)",
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
                    "launch": ("eager; {} HIP-event timed around every launch".format(dom) if launch == "eager" else
                               ("gene and external layers replayed as one hipGraph; {} launched and HIP-event timed from Python, the "
