@@ -21,7 +21,7 @@ _lock = threading.Lock()
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 109                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 110                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -67,7 +67,7 @@ SIGNATURES = {
     "gn_distmult_bwd_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_distmult_bwd_plan_destroy": (None, [_p]),
     "gn_distmult_bwd_plan_workspace_bytes": (_sz, [_p, _i64]),
-    "gn_distmult_backward_planned_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
+    "gn_distmult_backward_planned_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
@@ -570,15 +570,12 @@ class DistMultBwdPlan:
         self._h, self.device, self.num_edges = h, ei.device, e
         self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)
 
-    def backward(self, z, u_v, edge_type, weight, grad_logit, dz, dd, probs=None):
-        """`u_v`, `edge_type`: the tensors the plan was created from."""
-        ei, u, v, e = edge_rows(u_v)
-        et = i64_vec(edge_type)
-        if e != self.num_edges:
-            raise ValueError("the plan was built from {} edges, got {}".format(self.num_edges, e))
+    def backward(self, z, weight, grad_logit, dz, dd, probs=None):
+        if grad_logit.numel() != self.num_edges:
+            raise ValueError("the plan was built from {} edges, got {} gradients".format(self.num_edges, grad_logit.numel()))
         need = int(load().gn_distmult_bwd_plan_workspace_bytes(self._h, z.shape[1]))
         ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
-        _call("gn_distmult_backward_planned_f32", self._h, ptr(z), ld(z), z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
+        _call("gn_distmult_backward_planned_f32", self._h, ptr(z), ld(z), z.shape[1], ptr(weight), ld(weight),
               ptr(grad_logit), ptr(probs), ptr(dz), ld(dz), ptr(dd), ld(dd), ptr(ws), need, stream_ptr(z.device))
         return dz, dd
 

@@ -158,7 +158,7 @@ class DistMultFn(torch.autograd.Function):
         done = False
         if bwd:
             try:
-                bwd.backward(z, ei, et, w, g, dz, dd, probs)
+                bwd.backward(z, w, g, dz, dd, probs)
                 done = True
             except _hip.GripNetHipError as err:                # unaligned rows: the general entry point
                 if err.status != _hip.GN_ERR_UNSUPPORTED:

@@ -26,6 +26,9 @@
 #include "common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+
+#include <unordered_map>
+#include <vector>
 #include <rocprim/device/device_scan.hpp>
 
 namespace {
@@ -654,7 +657,13 @@ gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int64_t ro
 }  // namespace
 
 struct gn_distmult_bwd_plan {
-    int64_t e = 0, n = 0, r = 0, he_tasks_max = 0, pr_tasks_max = 0;
+    int64_t e = 0, n = 0, r = 0, he_tasks_max = 0, pr_tasks_max = 0;   // e: triples after pairing (below)
+    int64_t e_list = 0;                             // triples of the caller's list
+    // Two triples with the same unordered node pair and relation (the two directions of an edge) produce the same
+    // records but for g: they are reduced as ONE triple with g1 + g2.  eu / ev / er: the triples that are left, in list
+    // order; own / mir: where their gradients sit in the caller's list (mir = kNoPair: unpaired).
+    gn::DevBuf<int64_t> eu, ev, er;
+    gn::DevBuf<uint32_t> own, mir;
     gn::DevBuf<int32_t> offsets;                    // [n * kSortWaves + 1] where every wave's records of every node start
     gn::DevBuf<int32_t> he_taskptr, pr_taskptr;     // [n + 1], [R + 1]
     gn::DevBuf<int32_t> he_tasks, pr_tasks;         // int4 descriptors
@@ -664,14 +673,16 @@ namespace {
 
 void bwd_plan_free(gn_distmult_bwd_plan* p) {
     if (!p) return;
+    p->eu.release(); p->ev.release(); p->er.release(); p->own.release(); p->mir.release();
     p->offsets.release(); p->he_taskptr.release(); p->pr_taskptr.release(); p->he_tasks.release(); p->pr_tasks.release();
     delete p;
 }
 
-struct PlanWs { size_t he, pr, partial, total; };
+struct PlanWs { size_t g, he, pr, partial, total; };
 PlanWs plan_ws(const gn_distmult_bwd_plan* p, int64_t f) {
     PlanWs w;
-    w.he = 0;
+    w.g = 0;
+    w.he = w.g + align_up((size_t)(p->e + 64) * sizeof(float));
     w.pr = w.he + align_up((size_t)(2 * p->e + 64) * sizeof(uint64_t));
     w.partial = w.pr + align_up((size_t)(2 * p->e + 64) * sizeof(uint64_t));
     w.total = w.partial + align_up((size_t)std::max(p->he_tasks_max, p->pr_tasks_max) * f * sizeof(float));   // (pr: the spare slots sit at 2 E)
@@ -849,6 +860,19 @@ extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int6
 
 namespace {
 
+constexpr uint32_t kNoPair = 0xffffffffu;
+
+// g of a pair = the sum of its two triples' gradients (each with its own sigmoid factor)
+__global__ void k_pair_grad(const uint32_t* __restrict__ own, const uint32_t* __restrict__ mir, int64_t n, GradSrc gs,
+                            float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = mir[i];
+        float g = gs.at(own[i]);
+        if (m != kNoPair) g += gs.at(m);
+        out[i] = g;
+    }
+}
+
 __global__ void k_is_sorted64(const int64_t* __restrict__ x, int64_t n, int* __restrict__ unsorted) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x)
         if (x[i] > x[i + 1]) *unsorted = 1;
@@ -931,11 +955,60 @@ extern "C" gn_status gn_distmult_bwd_plan_create(const int64_t* u, const int64_t
     if (gn::fast_paths_disabled() || num_nodes < 1 || num_relations < 1 || num_nodes > kSortMaxKeys || num_relations > 65535 ||
         !lds_dz_fits(num_nodes, num_relations) || 2 * num_edges + 64 >= (1ll << 31))
         return gn::fail(GN_ERR_UNSUPPORTED, "node and relation tables do not fit the LDS path (or it is disabled): use gn_distmult_backward_f32");
+    hipStream_t st = gn::as_stream(stream);
+    const int64_t E = num_edges;
+    // pair up the two directions of an edge on the host (once per static list)
+    std::vector<int64_t> hu(E), hv(E), hr(E);
+    if (E > 0) {
+        GN_HIP(hipMemcpyAsync(hu.data(), u, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(hv.data(), v, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(hr.data(), edge_type, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipStreamSynchronize(st));
+    }
+    for (int64_t e = 0; e < E; ++e) {
+        if ((uint64_t)hu[e] >= (uint64_t)num_nodes || (uint64_t)hv[e] >= (uint64_t)num_nodes || (uint64_t)hr[e] >= (uint64_t)num_relations)
+            return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
+                            (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
+                            (long long)num_nodes, (long long)num_relations);
+        if (e > 0 && hr[e] < hr[e - 1])
+            return gn::fail(GN_ERR_UNSUPPORTED, "edge_type is not sorted: the dD records need a sort per call (gn_distmult_backward_f32)");
+    }
+    std::vector<int64_t> eu, ev, er;
+    std::vector<uint32_t> own, mir;
+    {
+        std::unordered_map<uint64_t, int64_t> open;       // key -> index into eu of a triple still without a partner
+        open.reserve((size_t)E);
+        for (int64_t e = 0; e < E; ++e) {
+            const uint64_t lo = (uint64_t)std::min(hu[e], hv[e]), hi = (uint64_t)std::max(hu[e], hv[e]);
+            const uint64_t key = ((uint64_t)hr[e] << 32) | (lo << 16) | hi;      // ids < 65536 on this path
+            auto it = open.find(key);
+            if (it != open.end()) {
+                mir[(size_t)it->second] = (uint32_t)e;
+                open.erase(it);
+            } else {
+                open.emplace(key, (int64_t)eu.size());
+                eu.push_back(hu[e]); ev.push_back(hv[e]); er.push_back(hr[e]);
+                own.push_back((uint32_t)e); mir.push_back(kNoPair);
+            }
+        }
+    }
     gn_distmult_bwd_plan* p = new (std::nothrow) gn_distmult_bwd_plan();
     GN_REQUIRE(p != nullptr, "out of host memory");
-    p->e = num_edges; p->n = num_nodes; p->r = num_relations;
-    if (num_edges > 0) {
-        const gn_status rc = build_bwd_plan(p, u, v, edge_type, gn::as_stream(stream));
+    p->e_list = E; p->e = (int64_t)eu.size(); p->n = num_nodes; p->r = num_relations;
+    if (p->e > 0) {
+        auto up = [&](auto& buf, const auto& host) -> hipError_t {
+            hipError_t err = buf.alloc(host.size());
+            if (err != hipSuccess) return err;
+            return hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice, st);
+        };
+        hipError_t err = hipSuccess;
+        if ((err = up(p->eu, eu)) != hipSuccess || (err = up(p->ev, ev)) != hipSuccess || (err = up(p->er, er)) != hipSuccess ||
+            (err = up(p->own, own)) != hipSuccess || (err = up(p->mir, mir)) != hipSuccess ||
+            (err = hipStreamSynchronize(st)) != hipSuccess) {
+            bwd_plan_free(p);
+            return gn::fail(GN_ERR_HIP, "decoder gradient plan upload failed: %s", hipGetErrorString(err));
+        }
+        const gn_status rc = build_bwd_plan(p, p->eu.p, p->ev.p, p->er.p, st);
         if (rc != GN_OK) { bwd_plan_free(p); return rc; }
     }
     *out = p;
@@ -950,10 +1023,9 @@ extern "C" size_t gn_distmult_bwd_plan_workspace_bytes(const gn_distmult_bwd_pla
 }
 
 extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z, int64_t f,
-                                                      const int64_t* u, const int64_t* v, const int64_t* et, const float* d,
-                                                      int64_t ld_d, const float* grad_logit, const float* sigmoid_scores,
-                                                      float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, void* workspace,
-                                                      size_t workspace_bytes, void* stream) {
+                                                      const float* d, int64_t ld_d, const float* grad_logit,
+                                                      const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd,
+                                                      int64_t ld_dd, void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(f >= 0 && f < (1ll << 31), "bad feature count");
     GN_REQUIRE(f == 0 || (dz && dd && ld_dz >= f && ld_dd >= f), "gradient output pointer is null or its leading dimension too small");
@@ -965,7 +1037,7 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
         GN_HIP(hipMemset2DAsync(dd, ld_dd * sizeof(float), 0, f * sizeof(float), r, st));
         return GN_OK;
     }
-    GN_REQUIRE(z && d && grad_logit && u && v && et && ld_z >= f && ld_d >= f, "operand pointer is null or a leading dimension too small");
+    GN_REQUIRE(z && d && grad_logit && ld_z >= f && ld_d >= f, "operand pointer is null or a leading dimension too small");
     if (f % 4 != 0 || ld_z % 4 != 0 || ld_d % 4 != 0 || ld_dz % 4 != 0 || ld_dd % 4 != 0 ||
         ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dd)) & 15) != 0)
         return gn::fail(GN_ERR_UNSUPPORTED, "rows are not 16-byte aligned float4 columns: use gn_distmult_backward_f32");
@@ -975,7 +1047,13 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
     uint64_t* he = reinterpret_cast<uint64_t*>(ws + w.he);
     uint64_t* pr = reinterpret_cast<uint64_t*>(ws + w.pr);
     float* part = reinterpret_cast<float*>(ws + w.partial);
-    const GradSrc grad = {grad_logit, sigmoid_scores};
+    float* gpair = reinterpret_cast<float*>(ws + w.g);
+    const int64_t* u = plan->eu.p;
+    const int64_t* v = plan->ev.p;
+    const int64_t* et = plan->er.p;
+    k_pair_grad<<<gn::stream_grid(e, 256), 256, 0, st>>>(plan->own.p, plan->mir.p, e, GradSrc{grad_logit, sigmoid_scores}, gpair);
+    GN_LAUNCH_CHECK();
+    const GradSrc grad = {gpair, nullptr};
     static thread_local bool configured = false;
     if (!configured) {
         GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 109 /* 0.1.9 */
+#define GN_VERSION 110 /* 0.1.10 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -270,21 +270,22 @@ GN_API gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64
                                       size_t workspace_bytes, void* stream);
 
 /* The same gradients for a STATIC edge list (the positive edges, scored with the same tensors every epoch,
- * GripNet-pose.py:137): what the sort and the reductions derive from the triples alone - the scanned offsets of the
- * counting sort, the task lists - is built once; a call starts at the scatter pass and runs the two segment
- * reductions (5 launches instead of 12).  u / v / edge_type of the call must be the arrays the plan was created
- * from.  Create validates the triples (GN_ERR_INDEX_RANGE) and synchronises `stream`; GN_ERR_UNSUPPORTED when the
- * tables do not fit the LDS path or edge_type is not sorted (create), when rows are not aligned float4 columns or the
- * list is too long for the staged scatter (backward): use gn_distmult_backward_f32 then.  Results are bitwise those of
- * the plan-less call. */
+ * GripNet-pose.py:137).  What the sort and the reductions derive from the triples alone is built once: the two
+ * directions of an edge (same unordered node pair and relation) are paired up - their records differ only in g, so a
+ * pair is reduced as one triple with g1 + g2 -, and the scanned offsets of the counting sort and the task lists of
+ * what is left are kept; a call sums the pairs' gradients, starts at the scatter pass and runs the two segment
+ * reductions (6 launches instead of 12, on half the records for a bidirectional list).  Create copies the triples to
+ * the host, validates them (GN_ERR_INDEX_RANGE) and synchronises `stream`; GN_ERR_UNSUPPORTED when the tables do not
+ * fit the LDS path or edge_type is not sorted (create), when rows are not aligned float4 columns or the list is too
+ * long for the staged scatter (backward): use gn_distmult_backward_f32 then.  Results equal the plan-less call up to
+ * the rounding of g1 + g2 and are bitwise reproducible. */
 typedef struct gn_distmult_bwd_plan gn_distmult_bwd_plan;
 GN_API gn_status gn_distmult_bwd_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
                                       int64_t num_nodes, int64_t num_relations, void* stream, gn_distmult_bwd_plan** plan);
 GN_API void gn_distmult_bwd_plan_destroy(gn_distmult_bwd_plan* plan);
 GN_API size_t gn_distmult_bwd_plan_workspace_bytes(const gn_distmult_bwd_plan* plan, int64_t num_features);
 GN_API gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z,
-                                           int64_t num_features, const int64_t* u, const int64_t* v,
-                                           const int64_t* edge_type, const float* d, int64_t ld_d,
+                                           int64_t num_features, const float* d, int64_t ld_d,
                                            const float* grad_logit, const float* sigmoid_scores /* nullable */,
                                            float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, void* workspace,
                                            size_t workspace_bytes, void* stream);
