@@ -89,6 +89,10 @@ class RgcnConvFn(torch.autograd.Function):
                 # (the last block zero-padded) instead of falling back to the HBM-table path
                 for c0 in range(0, fin, 32):
                     w = min(32, fin - c0)
+                    if w == 32:                                # a full block: straight into its columns of dx
+                        rev.forward(gm, bt[:, :, c0:c0 + 32].contiguous(), att.detach(), None, None, False,
+                                    dxe[:, c0:c0 + 32], partial=True)
+                        continue
                     blk = torch.zeros((B, fout, 32), dtype=torch.float32, device=x.device)
                     blk[:, :, :w] = bt[:, :, c0:c0 + w]
                     tmp = torch.empty((n, 32), dtype=torch.float32, device=x.device)
