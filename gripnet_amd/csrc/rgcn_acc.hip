@@ -70,7 +70,13 @@ constexpr int kCus = 256;
 #define GN_ACC_ITER_CAP 32
 #endif
 constexpr int kIterCap = GN_ACC_ITER_CAP;       // iterations per unit and tile: longer (relation, row) lists are cut into chunks
-constexpr int kStage = 8;          // stream blocks per LDS window of a wave (1 KB)
+#ifndef GN_ACC_BLOCK_ITERS
+#define GN_ACC_BLOCK_ITERS 4
+#endif
+constexpr int kBI = GN_ACC_BLOCK_ITERS;      // gather iterations per stream block (4: 128-byte blocks, 2: 64-byte blocks)
+static_assert(kBI == 4 || kBI == 2, "stream blocks hold two or four iterations");
+constexpr int kStage = 8;          // 128-byte units per LDS window of a wave (1 KB)
+constexpr int kStageBlocks = kStage * 4 / kBI;   // stream blocks per window
 constexpr int kFoutAcc = 32;       // out_features (slab layout of k_rgcn_slab_finalize)
 constexpr size_t kLdsBudget = 159 * 1024;
 // cost model of the plan-time balancing, in cycles of the wave's SIMD
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     // brings 8 blocks, the next window waits in registers while the current one is consumed (a register
     // ring rotated with moves would have to wait for its youngest load on every trip).
     constexpr int SV = kStage / 8;                                // 16-byte loads per lane and window
-    const u32x4* __restrict__ gp = reinterpret_cast<const u32x4*>(stream) + (size_t)wave_stream[wv] * 8 + lane;
+    const u32x4* __restrict__ gp = reinterpret_cast<const u32x4*>(stream) + (size_t)wave_stream[wv] * (2 * kBI) + lane;
     u32x4 pre[SV];
 #pragma unroll
     for (int i = 0; i < SV; ++i) pre[i] = gp[i * 64];             // the stream ends with two spare windows
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     }
     if (tid < 4 * XS) lds4[a.n * XS + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};   // four zero rows, one per bank slot, for padded edge slots
     u32x4* stage = reinterpret_cast<u32x4*>(lds4 + (a.n + 4) * XS) + wave * (kStage * 8);
-    const u32x2* stage2 = reinterpret_cast<const u32x2*>(stage) + grow;
+    const u32x2* stage2 = reinterpret_cast<const u32x2*>(stage) + grow;          // kBI == 4: 8 bytes per row and block
+    const uint32_t* stage1 = reinterpret_cast<const uint32_t*>(stage) + grow;    // kBI == 2: 4 bytes per row and block
     __syncthreads();
 #ifdef GN_STAMPS
     const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
@@ -250,7 +257,8 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
         pos = 0;
     };
     refill();
-    u32x2 wnext = stage2[0];                                      // LDS is in order per wave: no wait after the stores
+    u32x2 wnext;                                                  // LDS is in order per wave: no wait after the stores
+    if constexpr (kBI == 4) wnext = stage2[0]; else wnext = (u32x2){stage1[0], 0u};
 
     for (; u < u_end; ++u) {
         const AccUnit dn = units[u + 1 < u_end ? u + 1 : u];     // scalar load, a whole unit ahead
@@ -267,8 +275,8 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
 #endif
             for (int k = 0; k < nb; ++k) {
                 const u32x2 w = wnext;
-                if (++pos == kStage) refill();
-                wnext = stage2[pos * 16];
+                if (++pos == kStageBlocks) refill();
+                if constexpr (kBI == 4) wnext = stage2[pos * 16]; else wnext.x = stage1[pos * 16];
 #if GN_ACC_MODE & 4      // every lane reads the same table row: the gather without bank conflicts
                 const uint32_t s0 = pos, s1 = pos + 1, s2 = pos + 2, s3 = pos + 3 + (w.x & w.y & 1u);
 #else
@@ -281,8 +289,13 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
 #if GN_ACC_MODE & 2
                 s[0][0] += __uint_as_float(s0 + s1 + s2 + s3);
 #else
+                if constexpr (kBI == 4) {
 #pragma unroll
-                for (int p = 0; p < KP; ++p) s[p] += (r0[4 * p] + r1[4 * p]) + (r2[4 * p] + r3[4 * p]);
+                    for (int p = 0; p < KP; ++p) s[p] += (r0[4 * p] + r1[4 * p]) + (r2[4 * p] + r3[4 * p]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < KP; ++p) s[p] += r0[4 * p] + r1[4 * p];
+                }
 #endif
             }
 #ifdef GN_STAMPS
@@ -535,8 +548,8 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
                 for (int t = 0; t < kTpg; ++t) {
                     const int tile = q * kTpg + t;
                     const int32_t it = tile < tiles ? std::min(kIterCap, std::max(0, iters[r * tiles + tile] - c * kIterCap)) : 0;
-                    un.blocks[t] = (uint8_t)((it + 3) / 4);
-                    if (it > 0) un.cost += kTileCost + (int64_t)un.blocks[t] * kBlockCost;
+                    un.blocks[t] = (uint8_t)((it + kBI - 1) / kBI);
+                    if (it > 0) un.cost += kTileCost + (int64_t)un.blocks[t] * (kBlockCost * kBI / 4);
                 }
                 un.cost += edges * kEdgeCost;
                 per_q[q].push_back(un);
@@ -637,7 +650,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
         }
         wave_units[w + 1] = (int32_t)units.size();
     }
-    if (blocks_total + 3 * kStage >= ((uint64_t)1 << 26)) return GN_OK;      // 64 B-word index must fit 32 bits
+    if (blocks_total + 3 * kStageBlocks >= ((uint64_t)1 << 26)) return GN_OK;      // 64 B-word index must fit 32 bits
     if (units.empty()) units.push_back(AccUnit{0, {0, 0, 0, 0}, 0, 0});
 
     // ---- the edge streams.  Which edge of a row goes into which iteration is free (the order of a sum), so it is
@@ -646,13 +659,13 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     //      access groups of four rows each.  Per iteration and access group the rows pick edges whose sources
     //      fall into different slots where they can; rows with edges to spare sit an iteration out (their slot
     //      then points at a zero row in a free slot) rather than collide. ----
-    const int64_t words = (int64_t)(blocks_total + 3 * kStage) * 32;         // uint32 words: 16 rows x 2 per block
+    const int64_t words = (int64_t)(blocks_total + 3 * kStageBlocks) * (8 * kBI);   // uint32 words: 16 rows x kBI / 2 per block
     std::vector<uint16_t> stream16((size_t)words * 2);
     static const int kGroupRows[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};   // rows = lanes / 4 of the b128 access groups
     int pos_in_group[16];
     for (int g = 0; g < 4; ++g)
         for (int k = 0; k < 4; ++k) pos_in_group[kGroupRows[g][k]] = k;
-    for (size_t i = 0; i < stream16.size(); ++i) stream16[i] = (uint16_t)(N + pos_in_group[(i >> 2) & 15]);   // padding: four zero rows, one per slot
+    for (size_t i = 0; i < stream16.size(); ++i) stream16[i] = (uint16_t)(N + pos_in_group[(i / kBI) & 15]);   // padding: four zero rows, one per slot
     {
         std::vector<uint16_t> byclass;                       // one row's sources, grouped by slot class
         int cur[16][4], end[16][4], rem[16];
@@ -680,8 +693,8 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
                 const int32_t cb = chunk_base[r * tiles + tile];
                 for (int32_t it = 0; it < L; ++it) {
                     const int32_t left = L - it;             // iterations left, this one included
-                    const size_t blk = (size_t)chunk_off[cb + it / kIterCap] + (size_t)((it % kIterCap) >> 2);
-                    uint16_t* out = stream16.data() + blk * 64 + (it & 3);         // + row * 4
+                    const size_t blk = (size_t)chunk_off[cb + it / kIterCap] + (size_t)((it % kIterCap) / kBI);
+                    uint16_t* out = stream16.data() + blk * (16 * kBI) + (it % kBI);         // + row * kBI
                     for (int g = 0; g < 4; ++g) {
                         int order[4] = {kGroupRows[g][0], kGroupRows[g][1], kGroupRows[g][2], kGroupRows[g][3]};
                         // rows that cannot sit out first, then the fuller ones
@@ -706,7 +719,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
                                     if (n_c > bestcnt) { best = c; bestcnt = n_c; }
                                 }
                             }
-                            out[i * 4] = rowbuf[i][cur[i][best]++];
+                            out[i * kBI] = rowbuf[i][cur[i][best]++];
                             --rem[i];
                             used |= 1u << best;
                         }
@@ -715,7 +728,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
                             const int i = order[k];
                             for (int z = 0; z < 4; ++z) {
                                 const unsigned c = (unsigned)(N + z) & 3u;
-                                if (!((used >> c) & 1)) { out[i * 4] = (uint16_t)(N + z); used |= 1u << c; break; }
+                                if (!((used >> c) & 1)) { out[i * kBI] = (uint16_t)(N + z); used |= 1u << c; break; }
                             }
                         }
                     }
