@@ -16,20 +16,23 @@
 // That general path gathers both factor rows of every record from L2 (2.5 GB per call at 2 M edges x 80
 // features) behind three radix sorts.  When the tables are small - the drug supervertex: a few hundred nodes,
 // ~10^3 relations - the LDS path below is used instead:
-//   * dz: ONE stable sort of 2 E half-edge records (key = the node that receives, payload = the other endpoint,
-//     the relation and g) - dz[i] = sum over the records of i of g z[other] * D[r];
+//   * dz: ONE sort of 2 E half-edge records (key = the node that receives, payload = the other endpoint, the
+//     relation and g) - dz[i] = sum over the records of i of g z[other] * D[r]; a counting sort on wave-private LDS
+//     histograms for up to 4,096 nodes (count pass, scan, scatter pass staged through LDS), rocPRIM's radix sort beyond;
 //   * dD: when the caller says edge_type is sorted (GN_DM_TYPES_SORTED; it is in the reference's layout,
 //     utils.py:168-198) the records stay in edge order and the row offsets come from a binary search;
 //   * k_seg_lds: a workgroup keeps a 16-column block of both tables in LDS, a wave owns a task (<= 512 records of
 //     one key), four lanes per record as in the forward kernel, per-lane sums over the task, one fold across the
-//     16 quads, partial per task; k_seg_lds_combine adds the tasks of a key in order.  Still no atomics.
+//     16 quads, partial per task; k_seg_lds_combine adds the tasks of a key in order.  Still no float atomics.
+//   * a static edge list keeps what depends on the triples only in a gn_distmult_bwd_plan (end of this file): the
+//     pairing of an edge's two directions, the sort's offsets, the task lists.
 #include "common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <unordered_map>
 #include <vector>
-#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
