@@ -22,13 +22,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): the same update in one launch instead of ~6")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, loss, backward, Adam) in one hipGraph and replay it")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     data = make_pose(args.workload).to(dev)
     torch.manual_seed(1111)
     model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=args.graph)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=args.graph, fused=True if args.fused_adam else None)
     neg = torch.randint(0, data.n_d_node, tuple(data.train_idx.shape), device=dev)
 
     # new negative pairs every step, as the reference draws them every epoch (GripNet-pose.py:131): only the positive
