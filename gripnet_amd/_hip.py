@@ -21,7 +21,7 @@ _lock = threading.Lock()
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 110                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 120                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
     "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p, _p]),
     "gn_transform_fusable": (_int, [_i64, _i64]),
+    "gn_graph_plan_build_blocked": (_int, [_p, _i64, _p]),
+    "gn_graph_plan_blocked_cols": (_i64, [_p]),
     "gn_graph_plan_build_transpose": (_int, [_p, _p]),
     "gn_graph_aggregate_t_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
@@ -353,6 +355,23 @@ class GraphPlan:
         plan = cls(h, ei.device, "sum")
         plan.n_rows, plan.n_table = int(num_targets), int(num_sources)
         return plan
+
+    def build_blocked(self, cols: int):
+        """Add the source-blocked encoding (LDS-staged gathers) for rows of up to `cols` floats; a no-op for
+        graphs that do not qualify.  Returns the width the plan covers (0: wave-per-row kernels)."""
+        if self.kind == "gcn" and cols <= 32:
+            with torch.cuda.device(self.device):
+                check(load().gn_graph_plan_build_blocked(self._h, 16 if cols <= 16 else 32, stream_ptr(self.device)))
+        return self.blocked_cols
+
+    @property
+    def blocked_cols(self) -> int:
+        return int(load().gn_graph_plan_blocked_cols(self._h))
+
+    def blocked_ok(self, fin: int, fout: int, x: torch.Tensor) -> bool:
+        """True when gn_graph_aggregate_f32(weight=W) runs on the source-blocked kernels for this input."""
+        return (fout in (16, 32) and fout <= self.blocked_cols and fin in (16, 32, 64) and ld(x) % 4 == 0
+                and x.data_ptr() % 16 == 0)
 
     @property
     def input_edges(self) -> int:

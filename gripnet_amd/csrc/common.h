@@ -82,6 +82,9 @@ inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 8) 
     return static_cast<int>(g);
 }
 
+// Opt a kernel in to more than 64 KB of dynamic LDS, once per (kernel, device).
+gn_status allow_large_lds(const void* kernel, int bytes);
+
 }  // namespace gn
 
 // ---- plan layouts (shared between the builders and the kernels' launchers) --------------
@@ -104,6 +107,22 @@ struct gn_graph_plan {
     gn::DevBuf<int32_t> t_rowptr;        // [table_rows + 1]
     gn::DevBuf<int32_t> t_col;           // [nnz] destination row of every stored coefficient
     gn::DevBuf<float> t_coef;            // [nnz]
+    // LDS-staged encoding (gcn_blocked.hip; GCN plans whose stored weights are all 1, built on demand by
+    // gn_graph_plan_build_blocked): destination rows in ranges x 16-row tiles, 16-bit source ids ordered for the LDS
+    gn::DevBuf<float> dis;               // [rows] deg^-1/2 of every node (GCN plans)
+    int unit_weights = 0;                // every stored weight (self loops included) is exactly 1
+    int blk_ok = 0, blk_cols = 0;        // built for layers of up to blk_cols output features
+    int blk_cw = 0;                      // columns per column group (2, or 1 for larger graphs)
+    int blk_rows = 0;                    // rows of one column group of the table (nodes + the zero row, padded to 1 KB pieces)
+    int blk_cells = 0;                   // ranges of destination rows (workgroups per column group)
+    int64_t blk_iters = 0;               // 512-byte iterations of the id stream
+    gn::DevBuf<float> blk_dis;           // [blk_rows + 16] dis, zero padded
+    gn::DevBuf<int32_t> blk_tile_off;    // [tiles + 4] first iteration of every tile
+    gn::DevBuf<int32_t> blk_tile_rows;   // [tiles + 4][16] destination row of every quad of a tile (-1: none)
+    gn::DevBuf<float> blk_tile_dis;      // [tiles + 4][16] dis of that row
+    gn::DevBuf<uint32_t> blk_ids;        // per iteration 64 lanes x 4 uint16 source ids (512 bytes)
+    gn::DevBuf<int32_t> blk_cell;        // [blk_cells][waves][12] tile and iteration range of every wave of a range, the ends of its first five tiles
+    gn::DevBuf<float> blk_table;         // [blk_cols / blk_cw][blk_rows][blk_cw] dis * (x W) (scratch of the plan)
 };
 
 struct gn_rgcn_plan {

@@ -2,6 +2,12 @@
 // external layer).  Replaces propagate/message/update of myGCN (gripnet/layers.py:92-100).
 #include "aggregate.cuh"
 
+// gcn_blocked.hip: the LDS-staged, source-blocked path
+bool gn_blocked_applicable(const gn_graph_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* w, int64_t fout);
+gn_status gn_blocked_aggregate(const gn_graph_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* w,
+                               int64_t fout, const float* bias, int relu, float* out, int64_t ld_out,
+                               const gn_side_copy& side, hipStream_t st);
+
 extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw,
                                             int64_t num_features, const float* weight, int64_t out_features,
                                             const float* bias, int relu, float* out, int64_t ld_out,
@@ -30,6 +36,9 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.nnz = plan->nnz;
     gn_status ss = gn::check_side(side, plan->rows, &a.side);
     if (ss != GN_OK) return ss;
+    if (gn_blocked_applicable(plan, xw, ld_xw, num_features, weight, width))
+        return gn_blocked_aggregate(plan, xw, ld_xw, num_features, weight, width, bias, relu, out, ld_out, a.side,
+                                    gn::as_stream(stream));
     if (weight) {            // aggregate the input rows, then contract with W in the epilogue
         if (!gn::transform_fusable(num_features, out_features) || (ld_xw % 4) != 0 || !gn::aligned16(xw))
             return gn::fail(GN_ERR_UNSUPPORTED, "no fused transform for %lld -> %lld features (or unaligned rows)",

@@ -11,7 +11,24 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
+
+namespace gn {
+gn_status allow_large_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;     // hipFuncSetAttribute applies to the current device only
+    int dev = 0;
+    GN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return GN_OK;
+    GN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, dev});
+    return GN_OK;
+}
+}  // namespace gn
 
 namespace {
 
@@ -90,6 +107,13 @@ __global__ void k_degree(const int32_t* __restrict__ rowptr, const int32_t* __re
     float r = 1.0f / sqrtf(deg);
     if (r == INFINITY) r = 0.0f;
     dis[i] = r;
+}
+
+// flag[0] = 0 as soon as one stored weight differs from 1
+__global__ void k_all_ones(const float* __restrict__ w, int64_t n, int32_t* __restrict__ flag) {
+    bool ok = true;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) ok = ok && w[i] == 1.0f;
+    if (!ok) atomicAnd(flag, 0);
 }
 
 // GCN: norm in the reference's order, then the CSR copies.
@@ -259,9 +283,21 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
         }
         GN_LAUNCH_CHECK();
     }
+    int32_t ones = 0;
+    if (gcn) {                                             // what the source-blocked path needs (gcn_blocked.hip)
+        GN_HIP(plan->dis.alloc(n_dst));
+        GN_HIP(hipMemcpyAsync(plan->dis.p, dis, n_dst * sizeof(float), hipMemcpyDeviceToDevice, st));
+        GN_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(err), 1, 1, st));
+        if (nnz > 0) {
+            k_all_ones<<<gn::stream_grid(nnz, 256), 256, 0, st>>>(w2, nnz, err);
+            GN_LAUNCH_CHECK();
+        }
+        GN_HIP(hipMemcpyAsync(&ones, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
     std::vector<int32_t> rp(n_dst + 1);
     GN_HIP(hipMemcpyAsync(rp.data(), plan->rowptr.p, (n_dst + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
+    plan->unit_weights = ones;
     int64_t mx = 0;
     for (int64_t i = 0; i < n_dst; ++i) mx = std::max<int64_t>(mx, rp[i + 1] - rp[i]);
     plan->max_row_nnz = mx;
@@ -277,6 +313,14 @@ void free_graph_plan(gn_graph_plan* p) {
     p->t_rowptr.release();
     p->t_col.release();
     p->t_coef.release();
+    p->dis.release();
+    p->blk_dis.release();
+    p->blk_tile_off.release();
+    p->blk_ids.release();
+    p->blk_cell.release();
+    p->blk_tile_rows.release();
+    p->blk_tile_dis.release();
+    p->blk_table.release();
 }
 
 // ---- RGCN ------------------------------------------------------------------------------------

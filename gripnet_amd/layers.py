@@ -90,7 +90,8 @@ class myGCN(Module):
             xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
             _hip.gemm(x, self.weight, xw)                                        # layers.py:73, fp32
             return plan.aggregate_bf16(xw, self.bias, relu, out, side)
-        if _hip.transform_fusable(self.in_channels, self.out_channels, x) and self.weight.is_contiguous():
+        if self.weight.is_contiguous() and (plan.blocked_ok(self.in_channels, self.out_channels, x) or
+                                            _hip.transform_fusable(self.in_channels, self.out_channels, x)):
             # A_norm (x W) = (A_norm x) W: the contraction of layers.py:73 runs on the aggregated row
             done = cowork.cowork_request() if cowork is not None else None      # W_r of a later relational layer, same launch
             y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, cowork=done)
@@ -104,7 +105,11 @@ class myGCN(Module):
     def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None):
         _hip.require_gpu(x, edge_index, edge_weight, self.weight)
         n = x.size(0)
-        plan = self._plan(edge_index, lambda: _hip.GraphPlan.gcn(edge_index, n, edge_weight, self.improved))
+        def build():
+            plan = _hip.GraphPlan.gcn(edge_index, n, edge_weight, self.improved)
+            plan.build_blocked(self.out_channels)        # LDS-staged gathers where the graph qualifies
+            return plan
+        plan = self._plan(edge_index, build)
         return self._run(plan, x, n, _out, _relu, _side)
 
     def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 110 /* 0.1.10 */
+#define GN_VERSION 120 /* 0.1.20 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -108,6 +108,21 @@ GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* 
  * {16,32,64} and out_features in {16,32} (GN_ERR_UNSUPPORTED otherwise: call gn_gemm_f32 first).
  * gn_transform_fusable tells without launching. */
 GN_API int gn_transform_fusable(int64_t in_features, int64_t out_features);
+
+/* Source-blocked encoding of a GCN plan for LDS-staged gathers (the gene supervertex of PoSE: 19,081 nodes, 1.45 M
+ * stored edges).  Applies to plans whose stored weights are all exactly 1, self loops included (edge_weight NULL or
+ * ones and not `improved`: every GripNet caller, GripNet-pose.py:52,117-120): norm_e = dis[src] dis[dst] then
+ * factorises and an edge is a 16-bit source id inside one of <= 16 source blocks whose rows of dis * (x W) fit 160 KB
+ * of LDS.  gn_graph_aggregate_f32 takes this path (two launches: per-block partial sums from LDS, combine in block
+ * order; fixed summation order) when the plan has it and the shapes are covered: out_features 16 or 32 <= cols, with
+ * `weight` num_features in {16,32,64}, x 16-byte aligned with ld % 4 == 0.  The transform x W then runs on the matrix
+ * cores while the rows stream into LDS (bf16 x 3 split product, <= 2^-17 relative per product; GN_GEMM_EXACT=1
+ * selects the fp32 instruction).  The per-block partial sums live in scratch the PLAN owns: calls on one plan must be
+ * stream-ordered.  Graphs that do not qualify (weighted, `improved`, fewer than 4,096 nodes, more than 16 blocks)
+ * keep the wave-per-row kernels and the call returns GN_OK; gn_graph_plan_blocked_cols tells (0 = not built).
+ * Copies the CSR to the host once and synchronises `stream`. */
+GN_API gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t cols, void* stream);
+GN_API int64_t gn_graph_plan_blocked_cols(const gn_graph_plan* plan);
 
 /* bf16 STORAGE of the gathered table (the reference is fp32 throughout, this is the build's own
  * reduced-traffic variant for the node-classification suite): gn_cast_bf16 rounds x W to bf16 once,
