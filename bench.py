@@ -9,12 +9,15 @@ already resident in HBM and the graph plans cached, as the reference caches its 
 edge list after the first epoch (gripnet/layers.py:83-90).  fp32 arithmetic, int64 indices.
 
 N = 1 : workload `pose0-syn` (BASELINE.json configs[1]; SURVEY.md 8d ladder).
-N > 1 : weak scaling.  The dd relation set grows with N (N x the pose0-syn dd edge budget,
-        N=2 ~ pose1-syn, N=4 ~ pose2-syn); every rank owns one contiguous edge range of the
-        type-sorted dd edge list (= relation-id sharding balanced by edge count), computes the
-        un-normalised RGCN partial for its range, one RCCL all-reduce of the [n_d,32] partial,
-        then finalises and scores its own edge range with the DistMult decoder.  The small gene
-        layers (gg, gd) are replicated and counted once.
+N > 1 : weak scaling (default).  The dd relation set grows with N (N x the pose0-syn dd edge
+        budget, N=2 ~ pose1-syn, N=4 ~ pose2-syn); every rank owns one contiguous edge range of
+        the type-sorted dd edge list (= relation-id sharding balanced by edge count), computes
+        the un-normalised RGCN partial for its range, one RCCL all-reduce of the [n_d,32]
+        partial, then finalises and scores its own edge range with the DistMult decoder.  The
+        small gene layers (gg, gd) are replicated and counted once.
+        `--scaling strong` keeps the graph fixed (default workload pose2-syn) and cuts its dd
+        edges into N ranges: `value` is then directly comparable with the N = 1 run of the same
+        workload.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
 kernel, HIP-event timed inside the timed region) and `cpu_baseline` (the oracle, i.e. a port
@@ -55,7 +58,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="pose0-syn")
+    ap.add_argument("--workload", default=None, help="pose0-syn (default), pose1-syn, pose2-syn; strong scaling defaults to pose2-syn")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch", choices=("auto", "eager", "graphs"), default="auto",
                     help="eager: every entry point launched from Python (~100-150 us of host work per step, depending "
@@ -65,6 +69,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "pose2-syn" if args.scaling == "strong" else "pose0-syn"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +95,7 @@ def main():
     from gripnet_amd.utils import shard_edge_ranges
 
     _hip.load()
-    data_cpu = make_pose(args.workload, dd_scale=world)
+    data_cpu = make_pose(args.workload, dd_scale=1 if args.scaling == "strong" else world)
     torch.manual_seed(1111)
     model_cpu = PoseModel(data_cpu.n_g_node, data_cpu.n_d_node, data_cpu.n_dd_edge_type)
     state_cpu = {k: v.detach().clone() for k, v in model_cpu.state_dict().items()}
@@ -100,8 +106,9 @@ def main():
     E_dd = int(data.train_idx.shape[1])
     lo, hi = shard_edge_ranges(E_dd, world)[rank]
     n_d = data.n_d_node
+    # entry points whose launch duration is a roofline candidate (the GCN-style one runs once per gene layer)
     CANDIDATES = {"gn_rgcn_forward_f32": "drugs", "gn_distmult_forward_f32": "decode",
-                  "gn_distmult_plan_forward_f32": "decode"}     # the decoder scores the static positive list through its plan
+                  "gn_distmult_plan_forward_f32": "decode", "gn_graph_aggregate_f32[gcn]": "genes"}
 
     def fence():
         if dist is not None:
@@ -120,11 +127,31 @@ def main():
         sharded = None
         if world == 1 and os.environ.get("GN_BENCH_SHARDED_PATH") != "1":   # (the variable rehearses the N > 1 code path on one GPU)
             from gripnet_amd.pipeline import PoseStages
+            fence()
+            t_plan = time.perf_counter()
             eager = PoseStages(model, data, graphs=False)
-            for _ in range(3):                        # builds the plans
+            for _ in range(3):                        # builds the plans (the decoder's on the second sighting of its list)
                 eager.step()
+            fence()
+            t_plan = time.perf_counter() - t_plan
+            t_steady = time.perf_counter()
+            for _ in range(3):
+                eager.step()
+            fence()
+            plan_build_ms = 1e3 * max(0.0, t_plan - (time.perf_counter() - t_steady))
             per_call0, breakdown = per_entry_us(eager.step, 5)
-            dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
+            # the relational layer with its transform on the exact fp32 matrix instruction (the default splits both
+            # operands into bf16 pairs: three bf16 products, fp32 accumulate)
+            os.environ["GN_ACC_EXACT"] = "1"
+            for _ in range(2):
+                eager.step()
+            exact_call, _ = per_entry_us(eager.step, 5)
+            del os.environ["GN_ACC_EXACT"]
+            for _ in range(2):
+                eager.step()
+            # the entry point timed inside the timed region: the longest single launch.  (A gene layer is two launches
+            # behind one entry point since the LDS-staged path; it is listed in roofline_all with the others.)
+            dom = max((k for k in CANDIDATES if k != "gn_graph_aggregate_f32[gcn]"), key=lambda k: per_call0.get(k, 0.0))
             # graphs: every stage but the one that holds the dominant entry point replays as a hipGraph; that entry
             # point is launched from Python in both modes, with HIP events around it on its stream in EVERY timed step.
             def quick(fn, n=20):                      # under the same event timing as the timed region
@@ -152,10 +179,15 @@ def main():
             from gripnet_amd.pipeline import Graphed
             from gripnet_amd.sharded import ShardedPoseForward
             fwd = sharded = ShardedPoseForward(model, data, rank, world)
+            fence()
+            t_plan = time.perf_counter()
             for _ in range(3):
                 fwd()
+            fence()
+            plan_build_ms = 1e3 * (time.perf_counter() - t_plan)
+            exact_call = {}
             per_call0, breakdown = per_entry_us(fwd, 5)
-            dom = max(CANDIDATES, key=lambda k: per_call0.get(k, 0.0))
+            dom = max((k for k in CANDIDATES if k != "gn_graph_aggregate_f32[gcn]"), key=lambda k: per_call0.get(k, 0.0))
             launch = "eager" if args.launch == "eager" else "graphs"
             if launch == "graphs":                    # replicated gene layers as one graph; the collective is never captured
                 fwd.kernels.encode_genes = Graphed(fwd.kernels.encode_genes).capture()
@@ -185,27 +217,51 @@ def main():
     # ---- roofline of the dominant entry point (HIP events on its stream, inside the timed region) ----
     alg = algorithmic_bytes(data, hi - lo, E_dd)
     stage_bytes = {"gn_distmult_forward_f32": alg["dmt"], "gn_distmult_plan_forward_f32": alg["dmt"],
-                   "gn_rgcn_forward_f32": alg["dd"]}
+                   "gn_rgcn_forward_f32": alg["dd"], "gn_graph_aggregate_f32[gcn]": alg["gg"] // 2,      # per gene layer
+                   "gn_graph_aggregate_f32[bipartite+weights]": alg["gd"], "gn_graph_aggregate_f32[bipartite]": alg["gd"]}
     calls, total_ms = timer.summary()[dom]
     dom_us = 1e3 * total_ms / calls
     achieved = stage_bytes[dom] / (dom_us * 1e-6) / 1e9
-    traffic = None
+    traffic_all, mfma = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if world == 1 and os.path.exists(tpath):      # PMC-measured HBM bytes of the same launch (profiles/, N = 1)
+    if world == 1 and os.path.exists(tpath):      # PMC-measured HBM bytes of the same launches (profiles/, N = 1)
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            traffic_all = json.load(open(tpath)).get(args.workload, {})
         except Exception:
-            traffic = None
+            traffic_all = {}
+    mpath = os.path.join(ROOT, "profiles", "mfma_util.json")
+    if world == 1 and os.path.exists(mpath):      # SQ_VALU_MFMA_BUSY_CYCLES pass of the same command (profiles/)
+        try:
+            mfma = json.load(open(mpath)).get(args.workload)
+        except Exception:
+            mfma = None
+    traffic = traffic_all.get(dom)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_us": round(dom_us, 2),
                 "timed_launches": calls}
 
+    def line(name, us):
+        b = stage_bytes.get(name)
+        return {"entry_point": name, "algorithmic_bytes": b, "us_per_call": round(us, 2),
+                "achieved_GBs": None if b is None else round(b / (us * 1e-6) / 1e9, 1),
+                "frac": None if b is None else round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": traffic_all.get(name)}
+    # every entry point of the step, HIP-event timed around each launch in an eager pass before the timed region
+    roofline_all = [line(k, v) for k, v in sorted(per_call0.items())]
+    roofline_exact = None
+    if exact_call.get("gn_rgcn_forward_f32"):
+        roofline_exact = line("gn_rgcn_forward_f32", exact_call["gn_rgcn_forward_f32"])
+        roofline_exact["note"] = "GN_ACC_EXACT=1: relational transform on v_mfma_f32_16x16x4_f32 (exact fp32)"
+
     result = {
         "metric": "edges aggregated/sec, GripNet forward on pose-0", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload if world == 1 else "{} x{} dd relation shards".format(args.workload, world),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32 (relational transform as bf16x3 split products, fp32 accumulate; everything else fp32)", "data": "synthetic",
+        "config": {"workload": args.workload if world == 1 else (
+                       "{} x{} dd relation shards".format(args.workload, world) if args.scaling == "weak" else
+                       "{} (fixed), dd edges cut into {} ranges".format(args.workload, world)),
                    "edges_aggregated_per_step": A, "n_g": data.n_g_node, "n_d": n_d, "relations": data.n_dd_edge_type,
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "decoder": "static positive list: every unordered (node pair, relation) scored once, the score written to both "
@@ -218,6 +274,10 @@ def main():
                               if sharded is None else
                               "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
         "roofline": roofline,
+        "roofline_exact": roofline_exact,
+        "roofline_all": roofline_all,
+        "mfma_util": mfma,
+        "plan_build_ms": round(plan_build_ms, 1),
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
         "edges_scored_per_sec": (hi - lo) / (per_call0.get("gn_distmult_plan_forward_f32",
                                                            per_call0.get("gn_distmult_forward_f32", float("nan"))) * 1e-6),
@@ -233,10 +293,11 @@ def main():
         inputs = (data_cpu.gg_edge_index, data_cpu.edge_weight, data_cpu.gd_edge_index, data_cpu.train_idx,
                   data_cpu.train_et, data_cpu.train_range)
         with torch.no_grad():
-            ref = orc.pose_forward(state_cpu, *inputs, gcn_cache=cache)      # warm-up, fills the norm cache
+            for _ in range(3):                                                   # warm-ups; the first fills the norm cache
+                ref = orc.pose_forward(state_cpu, *inputs, gcn_cache=cache)
             times = []
             t_begin = time.perf_counter()
-            while len(times) < 3 or (time.perf_counter() - t_begin < args.cpu_seconds and len(times) < 10):
+            while len(times) < 5 or (time.perf_counter() - t_begin < args.cpu_seconds and len(times) < 10):
                 t1 = time.perf_counter()
                 ref = orc.pose_forward(state_cpu, *inputs, gcn_cache=cache)
                 times.append(time.perf_counter() - t1)
@@ -246,8 +307,11 @@ def main():
         err_s = (score.cpu() - ref["score"]).abs().max().item()
         result["cpu_baseline"] = {
             "value": A / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "{} full {} forwards (A={} edges each) after 1 warm-up, median; min {:.3f}s median {:.3f}s".format(
-                len(times), args.workload, A, times[0], med),
+            "host_cpu_count": os.cpu_count(),
+            "sample": "{} full {} forwards (A={} edges each) after 3 warm-ups, median; min {:.3f}s median {:.3f}s; {} threads "
+                      "(the fastest setting for this op mix on the 2 x 64-core host: 8 -> 1.05 s, 16 -> 0.92 s, 32 -> 0.94 s, "
+                      "64 -> 1.2 s, 128 -> 3-6 s per forward)".format(
+                len(times), args.workload, A, times[0], med, torch.get_num_threads()),
         }
         result["parity"] = {"max_abs_err_z": err_z, "max_abs_err_score": err_s, "tolerance": 1e-4,
                             "ok": bool(max(err_z, err_s) <= 1e-4)}

@@ -181,7 +181,15 @@ _timer = None
 
 
 def _call(name, *args, tag=None):
+    """Call an entry point.  Every caller passes `stream_ptr(<device of its operands>)` among the arguments; when that
+    device is not the current one the call is made with it current (a launch on a foreign device's stream fails or
+    lands on the wrong device)."""
+    global _stream_device
     fn = getattr(load(), name)
+    dev, _stream_device = _stream_device, None
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            return _call(name, *args, tag=tag)
     t = _timer
     if t is None or (t.only is not None and name not in t.only):
         return check(fn(*args))
@@ -213,17 +221,20 @@ def side_stream(device) -> "torch.cuda.Stream":
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_stream_device = None       # device index of the last stream_ptr(): read (and cleared) by _call
 
 
 def stream_ptr(device=None) -> int:
     """hipStream_t of torch's current stream on `device` (the raw getter costs a fraction of building a Stream object;
     eager launching of the ~120 us forward is close to host-bound)."""
+    global _stream_device
+    index = device.index if isinstance(device, torch.device) else device
+    if index is None:
+        index = torch.cuda.current_device()
+    _stream_device = index
     if _raw_stream is not None:
-        index = device.index if isinstance(device, torch.device) else device
-        if index is None:
-            index = torch.cuda.current_device()
         return _raw_stream(index)
-    return torch.cuda.current_stream(device).cuda_stream
+    return torch.cuda.current_stream(index).cuda_stream
 
 
 def f32_rows(t: torch.Tensor) -> torch.Tensor:
@@ -460,15 +471,15 @@ class RgcnPlan:
 
     def grad_plans(self):
         """(reversed-graph relational plan, (relation, source)-major sum plan, in-degree divisor) for the
-        backward pass; built on first use, full edge range only."""
+        backward pass; built on first use.  For a shard (edge_lo / edge_hi) the two plans cover the shard's edges only -
+        its share of the sums over edges - while the divisor is the in-degree over the FULL graph, as in the forward."""
         if self._grad is None:
-            if (self.edge_lo, self.edge_hi) != (0, self.num_edges):
-                raise NotImplementedError("backward of a sharded relational layer")
             ei, n, R = self._edge_index, self.num_nodes, self.num_relations
-            rev = RgcnPlan(ei.flip(0).contiguous(), self._range_list, n)
+            lo, hi = self.edge_lo, self.edge_hi
+            rev = RgcnPlan(ei.flip(0).contiguous(), self._range_list, n, lo, hi)   # same edge positions, endpoints swapped
             sizes = (self._range_list[:, 1] - self._range_list[:, 0]).to(self.device)
             rel = torch.repeat_interleave(torch.arange(R, device=self.device), sizes)      # relation of every edge
-            keyed = torch.stack([ei[1], rel * n + ei[0]])                                  # dst -> (relation, src) row
+            keyed = torch.stack([ei[1], rel * n + ei[0]])[:, lo:hi].contiguous()           # dst -> (relation, src) row
             pairs = GraphPlan.plain_sum(keyed, n, R * n)
             deg = torch.zeros(n, dtype=torch.float32, device=self.device)
             deg.index_add_(0, ei[1], torch.ones(e_count(ei), dtype=torch.float32, device=self.device))

@@ -73,48 +73,82 @@ class RgcnConvFn(torch.autograd.Function):
         g = _hip.f32_rows(g.contiguous())
         if ctx.relu:
             g = _hip.merge(torch.empty_like(g), g, 5, src2=out)
-        n, fin = x.shape
-        B, _, fout = basis.shape
-        R = att.shape[0]
-        rev, pairs, deg = ctx.plan.grad_plans()
+        deg = ctx.plan.grad_plans()[2]
         gm = g / deg.view(-1, 1)                                            # gradient of the un-normalised sum
-        dx = dbasis = datt = droot = dbias = None
-        if ctx.needs_input_grad[0]:
-            # dx[s] = sum_{e: src=s} gm[dst_e] W_{r(e)}^T: the same relational layer on the reversed graph
-            # with the transposed bases, un-normalised (HIP, general path), plus the root term
-            dxe = torch.empty((n, fin), dtype=torch.float32, device=x.device)
-            bt = basis.detach().transpose(1, 2)                                  # [B, fout, fin]: W_r^T = sum_b att[r,b] bt[b]
-            if fout == 32 and fin % 32 != 0 and fin > 32:
-                # the LDS-resident kernel produces 32 output features: run it per 32-column block of W_r^T
-                # (the last block zero-padded) instead of falling back to the HBM-table path
-                for c0 in range(0, fin, 32):
-                    w = min(32, fin - c0)
-                    if w == 32:                                # a full block: straight into its columns of dx
-                        rev.forward(gm, bt[:, :, c0:c0 + 32].contiguous(), att.detach(), None, None, False,
-                                    dxe[:, c0:c0 + 32], partial=True)
-                        continue
-                    blk = torch.zeros((B, fout, 32), dtype=torch.float32, device=x.device)
-                    blk[:, :, :w] = bt[:, :, c0:c0 + w]
-                    tmp = torch.empty((n, 32), dtype=torch.float32, device=x.device)
-                    rev.forward(gm, blk, att.detach(), None, None, False, tmp, partial=True)
-                    dxe[:, c0:c0 + w] = tmp[:, :w]
-            else:
-                rev.forward(gm, bt.contiguous(), att.detach(), None, None, False, dxe, partial=True)
-            dx = dxe + g @ root.detach().t()
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            # dW_r = X^T Q_r,  Q_r[s] = sum_{e in r, src=s} gm[dst_e]   (HIP gather-reduce, (relation, source) rows)
+        dxe, dbasis, datt = rgcn_edge_gradients(ctx.plan, x, basis.detach(), att.detach(), gm,
+                                                ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        dx = dxe + g @ root.detach().t() if ctx.needs_input_grad[0] else None
+        droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
+        dbias = g.sum(dim=0) if ctx.needs_input_grad[4] else None
+        return dx, dbasis, datt, droot, dbias, None, None
+
+
+# (relation, source) sums Q of more than this many floats are reduced per slab of relations (the dense Q of a graph
+# with 10^3 relations x 10^5 nodes would need over 12 GB where the reference's per-relation loop needs O(E))
+Q_BUDGET_FLOATS = 1 << 26
+
+
+def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, need_att=True):
+    """The parts of the relational layer's gradient that are sums over the plan's edges (a shard's edge range gives
+    that shard's share; the shares add up): for P = sum_e x[src_e] W_{r(e)} and gm = dL/dP,
+        dx[s]  = sum_{e: src=s} gm[dst_e] W_{r(e)}^T
+        dW_r   = X^T Q_r,  Q_r[s] = sum_{e in r, src=s} gm[dst_e];   dbasis = att^T dW,  datt = dW basis^T."""
+    n, fin = x.shape
+    B, _, fout = basis.shape
+    R = att.shape[0]
+    rev, pairs, _ = plan.grad_plans()
+    dxe = dbasis = datt = None
+    if need_x:
+        # the same relational layer on the reversed graph with the transposed bases, un-normalised
+        dxe = torch.empty((n, fin), dtype=torch.float32, device=x.device)
+        bt = basis.transpose(1, 2)                                           # [B, fout, fin]: W_r^T = sum_b att[r,b] bt[b]
+        if fout == 32 and fin % 32 != 0 and fin > 32:
+            # the LDS-resident kernel produces 32 output features: run it per 32-column block of W_r^T
+            # (the last block zero-padded) instead of falling back to the HBM-table path
+            for c0 in range(0, fin, 32):
+                w = min(32, fin - c0)
+                if w == 32:                                    # a full block: straight into its columns of dx
+                    rev.forward(gm, bt[:, :, c0:c0 + 32].contiguous(), att, None, None, False, dxe[:, c0:c0 + 32], partial=True)
+                    continue
+                blk = torch.zeros((B, fout, 32), dtype=torch.float32, device=x.device)
+                blk[:, :, :w] = bt[:, :, c0:c0 + w]
+                tmp = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+                rev.forward(gm, blk, att, None, None, False, tmp, partial=True)
+                dxe[:, c0:c0 + w] = tmp[:, :w]
+        else:
+            rev.forward(gm, bt.contiguous(), att, None, None, False, dxe, partial=True)
+    if need_basis or need_att:
+        # (HIP gather-reduce over (relation, source) rows, then library GEMMs; relation slabs when Q would be huge)
+        if R * n * fout <= Q_BUDGET_FLOATS:
             q = torch.empty((R * n, fout), dtype=torch.float32, device=x.device)
             pairs.aggregate(gm, None, False, q)
             dw = torch.matmul(x.t(), q.view(R, n, fout)).reshape(R, fin * fout)            # [R, fin*fout]
-            if ctx.needs_input_grad[1]:
-                dbasis = (att.detach().t() @ dw).view(B, fin, fout)
-            if ctx.needs_input_grad[2]:
-                datt = dw @ basis.detach().reshape(B, fin * fout).t()
-        if ctx.needs_input_grad[3]:
-            droot = _hip.xtg(x, g)
-        if ctx.needs_input_grad[4]:
-            dbias = g.sum(dim=0)
-        return dx, dbasis, datt, droot, dbias, None, None
+        else:
+            dw = _relation_slab_dw(plan, x, gm, R, n, fin, fout)
+        if need_basis:
+            dbasis = (att.t() @ dw).view(B, fin, fout)
+        if need_att:
+            datt = dw @ basis.reshape(B, fin * fout).t()
+    return dxe, dbasis, datt
+
+
+def _relation_slab_dw(plan, x, gm, R, n, fin, fout):
+    """dW_r = X^T Q_r without the dense [R n, fout] Q: relations in slabs whose Q fits the budget, each slab's
+    (relation, source) sums scattered from its edge range (O(edges) memory, like the reference's per-relation loop)."""
+    ei, rl = plan._edge_index, plan._range_list
+    dw = torch.zeros((R, fin * fout), dtype=torch.float32, device=x.device)
+    slab = max(1, Q_BUDGET_FLOATS // max(1, n * fout))
+    for r0 in range(0, R, slab):
+        r1 = min(R, r0 + slab)
+        lo, hi = max(int(rl[r0, 0]), plan.edge_lo), min(int(rl[r1 - 1, 1]), plan.edge_hi)
+        if lo >= hi:
+            continue
+        sizes = (rl[r0:r1, 1].clamp(plan.edge_lo, plan.edge_hi) - rl[r0:r1, 0].clamp(plan.edge_lo, plan.edge_hi)).to(x.device)
+        rel = torch.repeat_interleave(torch.arange(r1 - r0, device=x.device), sizes)
+        q = torch.zeros(((r1 - r0) * n, fout), dtype=torch.float32, device=x.device)
+        q.index_add_(0, rel * n + ei[0, lo:hi], gm.index_select(0, ei[1, lo:hi]))
+        dw[r0:r1] = torch.matmul(x.t(), q.view(r1 - r0, n, fout)).reshape(r1 - r0, fin * fout)
+    return dw
 
 
 class DistMultFn(torch.autograd.Function):

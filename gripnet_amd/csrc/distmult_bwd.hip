@@ -627,11 +627,7 @@ gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int64_t ro
                          const float* A, int64_t ld_a,
                          int64_t rows_a, const float* B, int64_t ld_b, int64_t rows_b, int64_t f, float* partial, float* out,
                          int64_t ld_out, hipStream_t st, bool tasks_ready = false) {
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_seg_lds), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     if (!tasks_ready) {
         k_task_ptr<<<1, 1024, 0, st>>>(rowptr, rowptr_stride, (int)keys, taskptr, tasks);
         GN_LAUNCH_CHECK();
@@ -909,11 +905,7 @@ gn_status build_bwd_plan(gn_distmult_bwd_plan* p, const int64_t* u, const int64_
     GN_HIP(hipMemsetAsync(unsorted, 0, sizeof(int), st));
     k_is_sorted64<<<gn::stream_grid(E, 256), 256, 0, st>>>(et, E, unsorted);
     GN_LAUNCH_CHECK();
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_sort<false>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     GN_HIP(p->offsets.alloc(cells));
     const GradSrc none = {nullptr, nullptr};
     const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
@@ -1057,12 +1049,8 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
     k_pair_grad<<<gn::stream_grid(e, 256), 256, 0, st>>>(plan->own.p, plan->mir.p, e, GradSrc{grad_logit, sigmoid_scores}, gpair);
     GN_LAUNCH_CHECK();
     const GradSrc grad = {gpair, nullptr};
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_he_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_sort<true>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_scatter_staged), 128 * 1024); if (lds_status != GN_OK) return lds_status; }
     const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
     const int64_t per_wave = gn::ceil_div(e, kSortWaves);
     const size_t stage_cap = (size_t)2 * per_wave * kSortWavesPerWg;

@@ -158,12 +158,7 @@ gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int6
     if (groups < 1) groups = 1;
     a.edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
     groups = gn::ceil_div(e, a.edges_per_wg);
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_lds),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_lds), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     k_distmult_lds<<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -375,12 +375,7 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
     a.keep_n = a.n_phases > 1 ? (int)std::max<int64_t>(0, std::min(per_wave, room)) : 0;
     a.all_kept = a.n_phases > 1 && a.keep_n >= per_wave;
     const size_t lds_bytes = table_bytes + (size_t)a.keep_n * (kThreads / 64) * 256;
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distmult_plan),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_plan), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     k_distmult_plan<<<(unsigned)groups, kThreads, lds_bytes, gn::as_stream(stream)>>>(a);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -500,11 +500,7 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
     hipStream_t st = gn::as_stream(stream);
     const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kXtgSlices, gn::ceil_div(m, 16)));
     const size_t lds = (size_t)kXtgMaxRows * (k1 + 1 + k2) * sizeof(float);
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xtg_partial), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_xtg_partial), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     k_xtg_partial<<<slices, 256, lds, st>>>(x, ld_x, g, ld_g, m, (int)k1, (int)k2, static_cast<float*>(workspace));
     GN_LAUNCH_CHECK();
     k_xtg_fold<<<(unsigned)gn::ceil_div(k1 * k2, 16), 256, 0, st>>>(static_cast<const float*>(workspace), slices, (int)(k1 * k2), (int)k2,

@@ -462,12 +462,7 @@ bool acc_disabled() {
 template <int FIN, bool SPLIT>
 gn_status launch_acc(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, const f32x4* wfrag, float* slabs,
                      size_t lds_bytes, hipStream_t st) {
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgcn_acc<FIN, kFoutAcc / 16, SPLIT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_acc<FIN, kFoutAcc / 16, SPLIT>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     AccDims dm;
     dm.ld_x = ld_x; dm.n = (int)plan->num_nodes; dm.tiles = plan->acc_tiles; dm.q_groups = plan->acc_q; dm.slabs = plan->acc_g;
     k_rgcn_acc<FIN, kFoutAcc / 16, SPLIT><<<plan->acc_q * plan->acc_g, kThreads, lds_bytes, st>>>(

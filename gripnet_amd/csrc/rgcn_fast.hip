@@ -647,12 +647,7 @@ gn_status sort_keys(Scratch& tmp, const uint64_t* kin, uint64_t* kout, size_t n,
 
 template <int FIN, int RT, int COLS>
 gn_status launch_main(const FastArgs& a, int groups, size_t lds_bytes, hipStream_t st) {
-    static thread_local bool configured = false;
-    if (!configured) {
-        GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgcn_lds<FIN, RT, COLS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_lds<FIN, RT, COLS>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     FastDims dm;
     dm.ld_x = a.ld_x; dm.n = a.n; dm.ts = a.ts; dm.groups = groups;
     k_rgcn_lds<FIN, RT, COLS><<<groups * (kFout / COLS), 32 * COLS, lds_bytes, st>>>(a.x, a.wt, a.packed, a.slot_off, a.work,

@@ -5,6 +5,8 @@
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch.nn import Module, Parameter
@@ -13,37 +15,115 @@ from . import _hip
 from .autograd import ClassLogitsFn, DistMultFn, recording
 
 
+class _EdgeList:
+    """One remembered (edge_index, edge_type) pair of multiRelaInnerProductDecoder."""
+    __slots__ = ("edge_index", "edge_type", "key", "plan", "copy", "registered")
+
+    def __init__(self, edge_index, edge_type, registered=False):
+        self.edge_index, self.edge_type = edge_index, edge_type
+        self.key = (edge_index._version, edge_type._version)
+        self.plan = None                     # None: not built; False: the packed encoding does not fit; else DistMultPlan
+        self.copy = None                     # private copy of the tensors (verify_static)
+        self.registered = registered
+
+    def holds(self, edge_index, edge_type):
+        return self.edge_index is edge_index and self.edge_type is edge_type
+
+
 class multiRelaInnerProductDecoder(Module):
     """``sigmoid(sum_k z[u,k] z[v,k] D[r,k])`` (reference decoder.py:19-23)."""
+
+    # edge lists remembered by plan_for: the reference's epoch loop scores four per epoch (train positives, fresh train
+    # negatives, test positives, static test negatives: GripNet-pose.py:137-186)
+    CACHE_DEPTH = 6
 
     def __init__(self, in_dim, num_et):
         super().__init__()
         self.num_et, self.in_dim = num_et, in_dim
         self.weight = Parameter(torch.empty(num_et, in_dim))
-        self._seen = []                      # recently scored edge lists: [edge_index, edge_type, versions, plan]
+        self._seen = []                      # recently scored edge lists (_EdgeList), most recent first
+        # auto_static: take a list for static the second time the same, unchanged tensors are scored (see plan_for);
+        # False = only lists named with register_static get a plan.
+        self.auto_static = True
+        # verify_static: before every use of a plan, compare the caller's tensors with a private copy taken when the
+        # plan was built and raise if they differ (a full read of the list per call: for callers that refill buffers
+        # behind torch's back, e.g. through raw pointers, where `_version` does not move).  GN_VERIFY_STATIC=1 sets it.
+        self.verify_static = os.environ.get("GN_VERIFY_STATIC") == "1"
         self.reset_parameters()
 
-    def plan_for(self, z, edge_index, edge_type):
-        """Cached plan of a STATIC edge list, or None.  A list is taken to be static the second time the very same
-        tensors (same storage, unchanged in place) are scored: the positive edges of a training loop
-        (GripNet-pose.py:137,185), not the negative samples, which are new tensors every epoch.  The cache holds
-        the tensors, so their storage cannot be handed to another tensor while an entry is alive.
-        (The decision is taken here, in Python, per call: a step captured in a hipGraph replays whatever was decided
-        when it was captured.  A buffer that is refilled in place between replays - negative samples - must also be
-        refilled between the warm-up calls, or it is taken for static and its plan is replayed on new contents.)"""
-        key = (edge_index._version, edge_type._version)
-        for k, entry in enumerate(self._seen):
-            if entry[0] is edge_index and entry[1] is edge_type and entry[2] == key:
-                if entry[3] is None:
-                    try:
-                        entry[3] = _hip.DistMultPlan(edge_index, edge_type, z.shape[0], self.num_et)
-                    except _hip.GripNetHipError:          # too many nodes / relations for the packed encoding
-                        entry[3] = False
-                self._seen.insert(0, self._seen.pop(k))
-                return entry[3] or None
-        self._seen.insert(0, [edge_index, edge_type, key, None])
-        del self._seen[2:]
+    def register_static(self, edge_index, edge_type, num_nodes=None):
+        """Promise that this (edge_index, edge_type) pair is a static list (the positive edges of a training loop,
+        GripNet-pose.py:137,185): its plan is built on first use - or now, when `num_nodes` is given - whatever
+        `auto_static` says, also under stream capture.  The promise holds until forget_static or until the tensors
+        are modified through torch (their `_version` moves)."""
+        entry = self._find(edge_index, edge_type)
+        if entry is None:
+            entry = _EdgeList(edge_index, edge_type)
+            self._insert(entry)
+        entry.registered = True
+        if entry.key != (edge_index._version, edge_type._version):
+            entry.key, entry.plan, entry.copy = (edge_index._version, edge_type._version), None, None
+        if num_nodes is not None and entry.plan is None:
+            self._build(entry, int(num_nodes))
+        return self
+
+    def forget_static(self, edge_index=None, edge_type=None):
+        """Drop the plan of one list (or of every list): the next forward scores the raw tensors again."""
+        self._seen = [] if edge_index is None else [e for e in self._seen if not e.holds(edge_index, edge_type)]
+
+    def _find(self, edge_index, edge_type):
+        for entry in self._seen:
+            if entry.holds(edge_index, edge_type):
+                return entry
         return None
+
+    def _insert(self, entry):
+        self._seen.insert(0, entry)
+        while len(self._seen) > self.CACHE_DEPTH:            # one-shot lists (negative samples) go first, built plans last
+            victims = [k for k in range(len(self._seen) - 1, 0, -1) if not self._seen[k].plan and not self._seen[k].registered]
+            del self._seen[victims[0] if victims else len(self._seen) - 1]
+
+    def _build(self, entry, num_nodes):
+        try:
+            entry.plan = _hip.DistMultPlan(entry.edge_index, entry.edge_type, num_nodes, self.num_et)
+        except _hip.GripNetHipError:                          # too many nodes / relations for the packed encoding
+            entry.plan = False
+
+    def plan_for(self, z, edge_index, edge_type):
+        """Cached plan of a STATIC edge list, or None.  A list is static when the caller said so (register_static) or,
+        with `auto_static`, the second time the very same tensors (same objects, `_version` unchanged) are scored:
+        the positive edges of a training loop (GripNet-pose.py:137,185), not the negative samples, which are new
+        tensors every epoch.  The cache holds the tensors, so their storage cannot be handed to another tensor while
+        an entry is alive.  Nothing is DECIDED while a stream is being captured: a captured step replays what was
+        decided here, so only lists that already have a plan (or were registered) use one inside a capture.
+        Writes that bypass torch (raw pointers, another library) do not move `_version`: such callers either switch
+        `auto_static` off (and do not register the buffer), or set `verify_static` and get a RuntimeError instead of
+        stale scores."""
+        key = (edge_index._version, edge_type._version)
+        entry = self._find(edge_index, edge_type)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if entry is None:
+            if not capturing:
+                self._insert(_EdgeList(edge_index, edge_type))
+            return None
+        if entry.key != key:                                  # modified in place through torch: a new list
+            entry.key, entry.plan, entry.copy = key, None, None
+            return None
+        if entry.plan is None:
+            if not entry.registered and (capturing or not self.auto_static):
+                return None
+            self._build(entry, z.shape[0])
+        if entry is not self._seen[0]:
+            self._seen.remove(entry)
+            self._seen.insert(0, entry)
+        if entry.plan and self.verify_static and not capturing:
+            if entry.copy is None:
+                entry.copy = (edge_index.clone(), edge_type.clone())
+            elif not (torch.equal(entry.copy[0], edge_index) and torch.equal(entry.copy[1], edge_type)):
+                entry.plan, entry.copy = None, None
+                raise RuntimeError("multiRelaInnerProductDecoder: a static edge list changed in place behind its plan "
+                                   "(contents differ from the copy taken when the plan was built)")
+        return entry.plan or None
 
     def forward(self, z, edge_index, edge_type, sigmoid=True):
         _hip.require_gpu(z, edge_index, edge_type, self.weight)
@@ -63,7 +143,7 @@ class multiRelaInnerProductDecoder(Module):
             except _hip.GripNetHipError as err:                    # node table too large for the LDS: the general kernels
                 if err.status != _hip.GN_ERR_UNSUPPORTED:
                     raise
-                self._seen[0][3] = False
+                self._find(edge_index, edge_type).plan = False
         return _hip.distmult(z, edge_index, edge_type, self.weight, sigmoid, out)
 
     def reset_parameters(self):

@@ -153,12 +153,14 @@ class myRGCN(Module):
             self.bias.data.zero_()
 
     def plan_for(self, edge_index, range_list, num_nodes, edge_lo=None, edge_hi=None):
-        """Plan of the static relational graph, rebuilt when the edge tensor changes."""
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               id(range_list), getattr(range_list, "_version", 0), num_nodes, edge_lo, edge_hi)
-        if self._plan is None or self._plan_key != key:
+        """Plan of the static relational graph, rebuilt when another edge tensor or range list arrives or one of them
+        is modified in place.  The cache entry holds the caller's objects (compared with `is`), so an address or id
+        reused by a later tensor cannot pass for the old one."""
+        key = (edge_index._version, getattr(range_list, "_version", 0), num_nodes, edge_lo, edge_hi)
+        held = self._plan_key
+        if (self._plan is None or held is None or held[0] is not edge_index or held[1] is not range_list or held[2] != key):
             self._plan = _hip.RgcnPlan(edge_index, range_list, num_nodes, edge_lo, edge_hi)
-            self._plan_key = key
+            self._plan_key = (edge_index, range_list, key)
         return self._plan
 
     def cowork_request(self):

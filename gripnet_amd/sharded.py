@@ -57,17 +57,44 @@ class HipShardKernels:
         z = self.model.gg(None, self.data.gg_edge_index, edge_weight=self.data.edge_weight, if_catout=True)
         return self.model.gd(z, self.data.gd_edge_index, mod="cat", if_relu=True, _cowork=self.weights)
 
-    def partial(self, x, out):
+    def partial(self, x, out, fresh_weights=False):
+        """`fresh_weights`: compute W_r in this call whatever an earlier launch left in the workspace (training: the
+        parameters move every step)."""
         c = self.conv
-        return self.plan.forward(x, c.basis, c.att, None, None, False, out, partial=True,
-                                 weights_ready=self.weights.ready)
+        ready = self.weights.ready and not fresh_weights
+        return self.plan.forward(x, c.basis.detach(), c.att.detach(), None, None, False, out, partial=True, weights_ready=ready)
 
     def finalize(self, summed, x, out, slot0):
         c = self.conv                                           # concat slot 0 is copied by the same launch
-        return self.plan.finalize(summed, x, c.root, c.bias, True, out, side=(x, slot0, 0))
+        side = None if slot0 is None else (x, slot0, 0)
+        return self.plan.finalize(summed, x, c.root.detach(), None if c.bias is None else c.bias.detach(), True, out, side=side)
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def decoder_weight(self):
+        return self.model.dmt.weight
 
     def score(self, z, sigmoid=True):
         return self.model.dmt(z, self.idx, self.et, sigmoid=sigmoid)
+
+    # ---- training (autograd is recording: the modules route through gripnet_amd.autograd) ----
+    def edge_gradients(self, x, gm):
+        """This shard's share of the sums over edges in the relational layer's gradient."""
+        from .autograd import rgcn_edge_gradients
+        c = self.conv
+        return rgcn_edge_gradients(self.plan, x, c.basis.detach(), c.att.detach(), gm)
+
+    def rgcn_parameters(self):
+        c = self.conv
+        return c.basis, c.att, c.root, c.bias
+
+    def in_degree(self):
+        return self.plan.grad_plans()[2]
+
+    def score_edges(self, z, edge_index, sigmoid=True):
+        """Scores of my edge range's relations on another edge list of the same length (negative samples)."""
+        return self.model.dmt(z, edge_index, self.et, sigmoid=sigmoid)
 
 
 class ShardedPoseForward:
@@ -77,6 +104,7 @@ class ShardedPoseForward:
         self.rank, self.world_size, self.group = int(rank), int(world_size), group
         self.n_d = int(data.n_d_node)
         E = int(data.train_idx.shape[1])
+        self.total_edges = E
         self.edge_lo, self.edge_hi = shard_edge_ranges(E, self.world_size)[self.rank]
         self.kernels = kernels if kernels is not None else HipShardKernels(model, data, self.edge_lo, self.edge_hi)
         conv = model.dd.conv_list[0]
@@ -99,3 +127,91 @@ class ShardedPoseForward:
         # mean / root / bias / ReLU (layers.py:191-197,305) and concat slot 0 (layers.py:264-266)
         k.finalize(self._partial, x, out[:, self.in_dim:], out[:, :self.in_dim])
         return out, k.score(out, sigmoid=sigmoid)
+
+
+# ---- training: the same sharding with gradients (the reference trains every epoch,
+#      GripNet-pose.py:140-146) ------------------------------------------------------------------------------------
+class _SumGradAcrossRanks(torch.autograd.Function):
+    """Identity forward; backward all-reduces the gradient.  z is replicated, every rank scores its own edge range
+    with it: d loss / d z is the sum of the ranks' contributions."""
+
+    @staticmethod
+    def forward(ctx, z, owner):
+        ctx.owner = owner
+        return z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.owner.all_reduce(g.contiguous()), None
+
+
+class _ShardedRgcnFn(torch.autograd.Function):
+    """out = relu( all_reduce(P_k) / deg + x root + b ), P_k = sum over my edge range of x[src] W_r.
+    Backward: the all-reduced partial's gradient gm = g / deg is the same on every rank (the all-reduce of a sum is
+    the identity on its gradient); each rank reduces its own edge range into (dx, dbasis, datt) shares, ONE all-reduce
+    of the three adds them up; the root / bias terms are replicated arithmetic on the full gradient."""
+
+    @staticmethod
+    def forward(ctx, x, basis, att, root, bias, owner):
+        k = owner.kernels
+        xc = x.detach()
+        partial = torch.empty((xc.shape[0], basis.shape[2]), dtype=torch.float32, device=xc.device)
+        k.partial(xc, partial, fresh_weights=True)
+        owner.all_reduce(partial)
+        out = torch.empty_like(partial)
+        k.finalize(partial, xc, out, None)
+        ctx.owner = owner
+        ctx.save_for_backward(xc, root.detach(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, root, out = ctx.saved_tensors
+        owner = ctx.owner
+        g = (g * (out > 0).to(g.dtype)).contiguous()                      # ReLU mask by the saved output
+        gm = g / owner.kernels.in_degree().view(-1, 1)
+        dxe, dbasis, datt = owner.kernels.edge_gradients(x, gm)
+        flat = torch.cat([dxe.reshape(-1), dbasis.reshape(-1), datt.reshape(-1)])
+        owner.all_reduce(flat)                                             # the one exchange step of the backward
+        a, b = dxe.numel(), dxe.numel() + dbasis.numel()
+        dx = flat[:a].view_as(dxe) + g @ root.t()
+        has_bias = ctx.needs_input_grad[4]
+        return (dx, flat[a:b].view_as(dbasis), flat[b:].view_as(datt), x.t() @ g,
+                g.sum(dim=0) if has_bias else None, None)
+
+
+class ShardedPoseTraining(ShardedPoseForward):
+    """One training step of the PoSE model with the dd edges sharded over the ranks:
+
+        loss = step(neg_index)        # leaves .grad on every parameter, identical on all ranks
+
+    Exchange steps: the forward's all-reduce of the partial [n_d, out]; in the backward one all-reduce of d loss / d z
+    ([n_d, in + out]), one of the shards' (dx, dbasis, datt) shares, and one of the decoder weight's gradient - each
+    rank scores only its own edge range.  The gene layers are replicated arithmetic on replicated inputs: their
+    gradients come out identical on every rank and are NOT reduced.  Loss of GripNet-pose.py:140-142."""
+
+    EPS = 1e-13
+
+    def step(self, neg_index, zero_grad: bool = True):
+        k = self.kernels
+        params = list(self.parameters())
+        if zero_grad:
+            for p in params:
+                p.grad = None
+        x = k.encode_genes()                                               # replicated, autograd-tracked
+        basis, att, root, bias = k.rgcn_parameters()
+        out = _ShardedRgcnFn.apply(x, basis, att, root, bias, self)
+        z = _SumGradAcrossRanks.apply(torch.cat([x, out], dim=1), self)
+        pos = k.score(z)
+        neg = k.score_edges(z, neg_index[:, self.edge_lo:self.edge_hi].contiguous())
+        E = float(self.total_edges)
+        local = -(torch.log(pos + self.EPS).sum() + torch.log(1 - neg + self.EPS).sum()) / E
+        local.backward()
+        dw = k.decoder_weight()
+        if dw.grad is not None:
+            self.all_reduce(dw.grad)
+        loss = local.detach().clone()
+        return self.all_reduce(loss)
+
+    def parameters(self):
+        return self.kernels.parameters()

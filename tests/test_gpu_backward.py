@@ -398,3 +398,98 @@ def test_decoder_backward_plan_matches_planless(gpu):
         _hip.DistMultBwdPlan(bad, et, n, R)
     with pytest.raises(_hip.GripNetHipError):
         _hip.DistMultBwdPlan(ei, et[torch.randperm(e, generator=gen).to(gpu)], n, R)
+
+
+def test_sharded_training_step_on_hip_kernels(gpu):
+    """gripnet_amd.sharded.ShardedPoseTraining on the HIP kernels: both ranks of a 2-way job run in this process, one
+    after the other, in lock-step at every exchange (each all-reduce is replaced by the sum over the two ranks'
+    buffers, computed when the second rank arrives).  Loss and every parameter gradient against torch autograd
+    through the oracle, on both ranks."""
+    import threading
+
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.sharded import ShardedPoseTraining
+    from gripnet_amd.synth import make_pose
+    from gripnet_amd.utils import EPS
+    data = make_pose("small")
+    torch.manual_seed(59)
+    base = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: leaf(v) for k, v in base.state_dict().items()}
+    neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=torch.Generator().manual_seed(61))
+    dg = make_pose("small").to(gpu)
+
+    class Exchange:                                          # a 2-party all-reduce between two threads
+        def __init__(self):
+            self.lock, self.bufs, self.barrier = threading.Lock(), [], threading.Barrier(2)
+
+        def all_reduce(self, t):
+            with self.lock:
+                self.bufs.append(t)
+            self.barrier.wait()
+            total = self.bufs[0] + self.bufs[1]              # same order on both ranks: bitwise equal results
+            self.barrier.wait()
+            t.copy_(total)
+            self.barrier.wait()
+            with self.lock:
+                self.bufs.clear() if self.bufs else None
+            self.barrier.wait()
+            return t
+
+    ex, results, errors = Exchange(), {}, []
+
+    def run(rank):
+        try:
+            model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+            model.load_state_dict(base.state_dict())
+            model = model.to(gpu)
+            step = ShardedPoseTraining(model, dg, rank, 2)
+            step.all_reduce = ex.all_reduce
+            loss = step.step(neg.to(gpu))
+            torch.cuda.synchronize()
+            results[rank] = (float(loss), {k: (None if p.grad is None else p.grad.detach().cpu()) for k, p in model.named_parameters()})
+        except Exception as err:                              # surface the failure instead of a barrier time-out
+            errors.append(err)
+            ex.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range)
+    neg_ref = orc.distmult(ref["z_dd"], neg, data.train_et, sd["dmt.weight"])
+    loss_ref = -torch.log(ref["score"] + EPS).mean() - torch.log(1 - neg_ref + EPS).mean()
+    loss_ref.backward()
+    for rank in range(2):
+        loss, grads = results[rank]
+        assert abs(loss - float(loss_ref)) <= 1e-4, (rank, loss, float(loss_ref))
+        for k, g in grads.items():
+            if sd[k].grad is None:
+                continue
+            scale_k = max(1.0, float(sd[k].grad.abs().max()))
+            close(g / scale_k, sd[k].grad / scale_k, 1e-4, what="rank {} {}".format(rank, k))
+    for k in results[0][1]:
+        if results[0][1][k] is not None:
+            assert torch.equal(results[0][1][k], results[1][1][k]), "ranks disagree on " + k
+
+
+def test_rgcn_shard_gradient_shares_add_up(gpu):
+    """The edge sums of the relational layer's gradient over two edge ranges add up to those of the whole graph."""
+    from gripnet_amd import _hip
+    from gripnet_amd.autograd import rgcn_edge_gradients
+    from gripnet_amd.synth import make_pose
+    d = make_pose("small").to(gpu)
+    n, R = d.n_d_node, d.n_dd_edge_type
+    torch.manual_seed(2)
+    x, gm = torch.randn(n, 48, device=gpu), torch.randn(n, 32, device=gpu)
+    basis, att = torch.randn(32, 48, 32, device=gpu) * 0.1, torch.randn(R, 32, device=gpu) * 0.2
+    E = int(d.train_idx.shape[1])
+    cut = E // 3                                               # falls inside a relation
+    full = rgcn_edge_gradients(_hip.RgcnPlan(d.train_idx, d.train_range, n), x, basis, att, gm)
+    a = rgcn_edge_gradients(_hip.RgcnPlan(d.train_idx, d.train_range, n, 0, cut), x, basis, att, gm)
+    b = rgcn_edge_gradients(_hip.RgcnPlan(d.train_idx, d.train_range, n, cut, E), x, basis, att, gm)
+    for name, f, p, q in zip(("dx", "dbasis", "datt"), full, a, b):
+        scale = max(1.0, float(f.abs().max()))
+        close((p + q) / scale, f / scale, 1e-4, what=name)

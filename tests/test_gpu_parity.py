@@ -602,7 +602,7 @@ def test_decoder_plan_matches_planless_scores_bitwise(gpu):
             again = dec(z, ei_g, et_g, sigmoid=sig)
             assert torch.equal(first, again)
             close(again, orc.distmult(z.cpu(), ei, et, dec.weight.detach().cpu(), sigmoid=sig))
-        assert dec._seen[0][3] not in (None, False)                   # the plan exists and was used
+        assert dec._seen[0].plan not in (None, False)                   # the plan exists and was used
         fresh = dec(z, ei_g.clone(), et_g.clone())                    # same values, new tensors: plan-less path
         assert torch.equal(fresh, dec(z, ei_g, et_g))
         ei_g[0, 0] = (ei_g[0, 0] + 1) % n                             # in-place change: the cached plan is stale

@@ -20,8 +20,14 @@ ENTRY = {
     "gn_rgcn_forward_f32": ("k_rgcn_weights_t", "k_rgcn_weights_frag", "k_rgcn_lds", "k_rgcn_acc", "k_rgcn_slab_finalize"),
     "gn_distmult_forward_f32": ("k_distmult_lds", "k_distmult<"),
     "gn_distmult_plan_forward_f32": ("k_distmult_plan",),
-    "gn_graph_aggregate_f32": ("k_aggregate",),
+    "gn_graph_aggregate_f32": ("k_aggregate", "k_col_"),
     "gn_gemm_f32": ("k_gemm_f32",),
+}
+# entry points that are several kernels with their own weights per call: (kernel name prefix, launches per call)
+WEIGHTED = {
+    # one call per gene layer: its transform (two instantiations, one per layer) and its gather (same kernel, both layers)
+    "gn_graph_aggregate_f32[gcn]": (("k_col_transform<32", 0.5), ("k_col_transform<16", 0.5), ("k_col_gather", 1.0)),
+    "gn_graph_aggregate_f32[bipartite+weights]": (("k_aggregate_transform_with_weights", 1.0),),
 }
 
 
@@ -63,6 +69,16 @@ def main():
             continue            # several launches of different sizes per step: per-kernel rows above are averages
         sums[entry] = tot
         print("entry point {}: {:.2f} MB per launch (sum of its kernels)".format(entry, tot / 1e6))
+    for entry, parts in WEIGHTED.items():
+        tot, seen = 0.0, False
+        for prefix, weight in parts:
+            for k, (n, rd, wr) in rows.items():
+                if k.startswith(prefix):
+                    tot += weight * (rd + wr)
+                    seen = True
+        if seen:
+            sums[entry] = tot
+            print("entry point {}: {:.2f} MB per call (weighted sum of its kernels)".format(entry, tot / 1e6))
     if args.json:
         data = {}
         if os.path.exists(args.json):
