@@ -64,6 +64,27 @@ class AminerModel(Module):
         return z, self.mcip(z, node_list, softmax=softmax)
 
 
+class FreebaseAModel(Module):
+    """pp -> mcip on ONE supervertex, no concat (GripNet-freebase-a.py:94,101-104,120-122)."""
+
+    def __init__(self, n_a_node, n_class, pp_nhids=(256, 128, 128)):
+        super().__init__()
+        pp_nhids = list(pp_nhids)
+        self.pp = homoGraph(pp_nhids, start_graph=True, in_dim=n_a_node)
+        self.mcip = multiClassInnerProductDecoder(pp_nhids[-1], n_class)
+
+    def forward(self, data, node_list, softmax=True):
+        z = self.pp(None, data.aa_edge_idx, edge_weight=data.aa_edge_weight)       # freebase-a.py:120 (if_catout off)
+        return z, self.mcip(z, node_list, softmax=softmax)
+
+
+class FreebaseBModel(AminerModel):
+    """The aminer call sequence with freebase-b's widths (GripNet-freebase-b.py:96-98: pa_out = [128, 128])."""
+
+    def __init__(self, n_p_node, n_a_node, n_class, pp_nhids=(128, 64, 64), pa_out=(128, 128), aa_hidden=(128, 32)):
+        super().__init__(n_p_node, n_a_node, n_class, pp_nhids=pp_nhids, pa_out=pa_out, aa_hidden=aa_hidden)
+
+
 class FreebaseCModel(Module):
     """pp -> pa, qq -> qa, (z + z1 + aa_embeddings) / 3 -> aa -> mcip
     (GripNet-freebase-c.py:102-136,150-165; freebase-d is the same shape)."""

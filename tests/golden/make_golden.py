@@ -389,6 +389,41 @@ def main():
     c.meta.update(n_raw=len(raw), p=0.7, np_seed=4242)
     c.save()
 
+    # (10) freebase-a and freebase-b pipelines, tiny (added after every earlier case: their vectors do not move) -----
+    c = Case("freebase_a_tiny")  # GripNet-freebase-a.py:94,101-104,120-122 with smaller widths: one supervertex, no catout
+    pp_nh = [16, 8, 8]
+    pp = homoGraph(pp_nh, start_graph=True, in_dim=data.n_a_node)
+    mcip = multiClassInnerProductDecoder(pp_nh[-1], data.n_a_type)
+    for k in ("aa_edge_idx", "aa_edge_weight"):
+        c.put(k, getattr(data, k))
+    c.put("node_list", nodes)
+    for tag, mod in (("pp.", pp), ("mcip.", mcip)):
+        c.put_state(tag, mod)
+    z = pp(torch.zeros(1), data.aa_edge_idx, edge_weight=data.aa_edge_weight)
+    c.put("out.z", z); c.put("out.score", mcip(z, nodes)); c.put("out.logits", mcip(z, nodes, softmax=False))
+    c.meta.update(pp_nhids=pp_nh, n_a=data.n_a_node, n_class=data.n_a_type)
+    c.save()
+
+    c = Case("freebase_b_tiny")  # GripNet-freebase-b.py:96-98,112-117,129-135 with smaller widths (pa_out of equal halves)
+    pp_nh, pa_out = [16, 8, 8], [16, 16]
+    aa_nh = [sum(pa_out), 16, 4]
+    pp = homoGraph(pp_nh, start_graph=True, in_dim=data.n_p_node)
+    pa = interGraph(sum(pp_nh), pa_out[0], data.n_a_node, target_feat_dim=pa_out[-1])
+    aa = homoGraph(aa_nh)
+    mcip = multiClassInnerProductDecoder(sum(aa_nh), data.n_a_type)
+    for k in ("pp_edge_idx", "pa_edge_idx", "aa_edge_idx", "pp_edge_weight", "aa_edge_weight"):
+        c.put(k, getattr(data, k))
+    c.put("node_list", nodes)
+    for tag, mod in (("pp.", pp), ("pa.", pa), ("aa.", aa), ("mcip.", mcip)):
+        c.put_state(tag, mod)
+    z = pp(torch.zeros(1), data.pp_edge_idx, edge_weight=data.pp_edge_weight, if_catout=True)
+    z = pa(z, data.pa_edge_idx, if_relu=True, mod="cat")
+    z = aa(z, data.aa_edge_idx, edge_weight=data.aa_edge_weight, if_catout=True)
+    c.put("out.z", z); c.put("out.score", mcip(z, nodes))
+    c.meta.update(pp_nhids=pp_nh, pa_out=pa_out, aa_nhids=aa_nh, n_p=data.n_p_node, n_a=data.n_a_node,
+                  n_class=data.n_a_type)
+    c.save()
+
 
 if __name__ == "__main__":
     main()

@@ -400,79 +400,86 @@ def test_decoder_backward_plan_matches_planless(gpu):
         _hip.DistMultBwdPlan(ei, et[torch.randperm(e, generator=gen).to(gpu)], n, R)
 
 
+def _sharded_hip_worker(rank, world, port, q):
+    """One rank of a 2-way sharded training step on the HIP kernels; both ranks share cuda:0, the exchanges travel
+    over gloo through host copies (the product uses RCCL on the ranks' own GPUs: gripnet_amd/sharded.py)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gripnet_amd.pipeline import PoseModel
+        from gripnet_amd.sharded import ShardedPoseTraining
+        from gripnet_amd.synth import make_pose
+        dev = torch.device("cuda:0")
+        data = make_pose("small").to(dev)
+        torch.manual_seed(59)
+        model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+        neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=torch.Generator().manual_seed(61)).to(dev)
+        step = ShardedPoseTraining(model, data, rank, world)
+
+        def all_reduce(t):
+            host = t.detach().cpu()
+            dist.all_reduce(host)
+            t.copy_(host)
+            return t
+        step.all_reduce = all_reduce
+        loss = step.step(neg)
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), {k: (None if p.grad is None else p.grad.detach().cpu().numpy()) for k, p in model.named_parameters()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
 def test_sharded_training_step_on_hip_kernels(gpu):
-    """gripnet_amd.sharded.ShardedPoseTraining on the HIP kernels: both ranks of a 2-way job run in this process, one
-    after the other, in lock-step at every exchange (each all-reduce is replaced by the sum over the two ranks'
-    buffers, computed when the second rank arrives).  Loss and every parameter gradient against torch autograd
-    through the oracle, on both ranks."""
-    import threading
+    """gripnet_amd.sharded.ShardedPoseTraining on the HIP kernels, two ranks = two processes on this GPU.  Loss and
+    every parameter gradient against torch autograd through the oracle, on both ranks; the ranks agree bit for bit."""
+    import socket
+
+    import torch.multiprocessing as mp
 
     from gripnet_amd.pipeline import PoseModel
-    from gripnet_amd.sharded import ShardedPoseTraining
     from gripnet_amd.synth import make_pose
     from gripnet_amd.utils import EPS
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, loss, grads = q.get(timeout=400)
+        got[rank] = (loss, grads)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
     data = make_pose("small")
     torch.manual_seed(59)
     base = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
     sd = {k: leaf(v) for k, v in base.state_dict().items()}
     neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=torch.Generator().manual_seed(61))
-    dg = make_pose("small").to(gpu)
-
-    class Exchange:                                          # a 2-party all-reduce between two threads
-        def __init__(self):
-            self.lock, self.bufs, self.barrier = threading.Lock(), [], threading.Barrier(2)
-
-        def all_reduce(self, t):
-            with self.lock:
-                self.bufs.append(t)
-            self.barrier.wait()
-            total = self.bufs[0] + self.bufs[1]              # same order on both ranks: bitwise equal results
-            self.barrier.wait()
-            t.copy_(total)
-            self.barrier.wait()
-            with self.lock:
-                self.bufs.clear() if self.bufs else None
-            self.barrier.wait()
-            return t
-
-    ex, results, errors = Exchange(), {}, []
-
-    def run(rank):
-        try:
-            model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
-            model.load_state_dict(base.state_dict())
-            model = model.to(gpu)
-            step = ShardedPoseTraining(model, dg, rank, 2)
-            step.all_reduce = ex.all_reduce
-            loss = step.step(neg.to(gpu))
-            torch.cuda.synchronize()
-            results[rank] = (float(loss), {k: (None if p.grad is None else p.grad.detach().cpu()) for k, p in model.named_parameters()})
-        except Exception as err:                              # surface the failure instead of a barrier time-out
-            errors.append(err)
-            ex.barrier.abort()
-
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=120)
-    assert not errors, errors
     ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
                            data.train_et, data.train_range)
     neg_ref = orc.distmult(ref["z_dd"], neg, data.train_et, sd["dmt.weight"])
     loss_ref = -torch.log(ref["score"] + EPS).mean() - torch.log(1 - neg_ref + EPS).mean()
     loss_ref.backward()
     for rank in range(2):
-        loss, grads = results[rank]
+        loss, grads = got[rank]
         assert abs(loss - float(loss_ref)) <= 1e-4, (rank, loss, float(loss_ref))
         for k, g in grads.items():
             if sd[k].grad is None:
                 continue
             scale_k = max(1.0, float(sd[k].grad.abs().max()))
-            close(g / scale_k, sd[k].grad / scale_k, 1e-4, what="rank {} {}".format(rank, k))
-    for k in results[0][1]:
-        if results[0][1][k] is not None:
-            assert torch.equal(results[0][1][k], results[1][1][k]), "ranks disagree on " + k
+            close(torch.from_numpy(g) / scale_k, sd[k].grad / scale_k, 1e-4, what="rank {} {}".format(rank, k))
+    for k, g in got[0][1].items():
+        if g is not None:
+            assert (g == got[1][1][k]).all(), "ranks disagree on " + k
 
 
 def test_rgcn_shard_gradient_shares_add_up(gpu):

@@ -1,0 +1,272 @@
+"""The reference drivers' ways of calling the hot path: activation-checkpointed decoder,
+the epoch loop's four edge lists, static-list plans under in-place refills, the device negative sampler's law,
+parameters that move between replays of a captured step."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.checkpoint import checkpoint
+
+import gripnet_amd
+from gripnet_amd import _hip
+from gripnet_amd.pipeline import PoseModel, PoseStages
+from gripnet_amd.synth import make_pose
+from gripnet_amd.utils import EPS, negative_sampling, set_table_storage
+from oracle import gripnet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(a, b, atol=2e-5, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= atol, "{}: max abs err {:.3e} > {:.1e}".format(what, err, atol)
+
+
+def test_checkpointed_decoder_training_step(gpu):
+    """The reference's default run checkpoints the decoder (`checkpoint(model.dmt, z, pos_index, train_et)`,
+    GripNet-pose.py:133-135, run.sh:5 passes use_checkpoint=1): the forward is recomputed inside backward.  Same loss
+    and gradients as the plain call, also once the static positive list has its plan (second epoch on)."""
+    data = make_pose("small").to(gpu)
+    torch.manual_seed(7)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    neg = torch.randint(0, data.n_d_node, data.train_idx.shape, device=gpu)
+
+    def step(use_checkpoint):
+        model.zero_grad()
+        z = model.encode(data)
+        if use_checkpoint:
+            pos = checkpoint(model.dmt, z, data.train_idx, data.train_et, use_reentrant=False)
+            ng = checkpoint(model.dmt, z, neg, data.train_et, use_reentrant=False)
+        else:
+            pos, ng = model.dmt(z, data.train_idx, data.train_et), model.dmt(z, neg, data.train_et)
+        loss = -torch.log(pos + EPS).mean() - torch.log(1 - ng + EPS).mean()
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    for epoch in range(3):                                   # epoch 0: first sighting; from epoch 1 the positives run on their plan
+        l_ck, g_ck = step(True)
+        l_pl, g_pl = step(False)
+        assert abs(l_ck - l_pl) <= 1e-6, (epoch, l_ck, l_pl)
+        for k in g_pl:
+            scale = max(1.0, float(g_pl[k].abs().max()))
+            close(g_ck[k] / scale, g_pl[k] / scale, 1e-5, what="epoch {} {}".format(epoch, k))
+    entry = model.dmt._find(data.train_idx, data.train_et)
+    assert entry is not None and entry.plan, "the static positive list never got its plan under checkpointing"
+    # reentrant checkpointing (torch's historical default, what the reference's torch >= 1.4 used)
+    model.zero_grad()
+    z = model.encode(data)
+    pos = checkpoint(model.dmt, z, data.train_idx, data.train_et, use_reentrant=True)
+    (-torch.log(pos + EPS).mean()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_epoch_loop_keeps_the_static_lists_on_their_plans(gpu):
+    """train() + test() of GripNet-pose.py:137-186 score four lists per epoch: train positives, FRESH train negatives,
+    test positives, static test negatives.  From the second epoch the three static lists run on plans, the fresh
+    negatives never do, and no plan is dropped (a dropped plan would hipFree in the middle of an epoch)."""
+    data = make_pose("small").to(gpu)
+    torch.manual_seed(3)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    E = data.train_idx.shape[1]
+    test_idx, test_et = data.train_idx[:, : E // 3].contiguous(), data.train_et[: E // 3].contiguous()
+    test_neg = torch.randint(0, data.n_d_node, test_idx.shape, device=gpu)
+    plans = {}
+    with torch.no_grad():
+        z = model.encode(data)
+        for epoch in range(4):
+            neg = torch.randint(0, data.n_d_node, data.train_idx.shape, device=gpu)      # a new tensor every epoch
+            lists = {"pos": (data.train_idx, data.train_et), "neg": (neg, data.train_et),
+                     "test_pos": (test_idx, test_et), "test_neg": (test_neg, test_et)}
+            for name, (ei, et) in lists.items():
+                score = model.dmt(z, ei, et)
+                close(score, orc.distmult(z.cpu(), ei.cpu(), et.cpu(), model.dmt.weight.detach().cpu()), what=name)
+                entry = model.dmt._find(ei, et)
+                if name == "neg":
+                    assert entry is None or not entry.plan
+                elif epoch >= 1:
+                    assert entry is not None and entry.plan, "{} has no plan in epoch {}".format(name, epoch)
+                    assert plans.setdefault(name, entry.plan) is entry.plan, "the plan of {} was rebuilt".format(name)
+
+
+def _raw_fill(t, value):
+    """Overwrite a tensor's storage through the HIP runtime, behind torch's back (`_version` does not move)."""
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    src = torch.full_like(t, value)
+    assert hip.hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(t.numel() * t.element_size()),
+                         ctypes.c_int(3)) == 0          # hipMemcpyDeviceToDevice
+    torch.cuda.synchronize()
+
+
+def test_static_list_refilled_behind_torchs_back(gpu):
+    """A buffer that is refilled through a raw pointer keeps its `_version`: the automatic static-list detection
+    cannot see it.  Never stale scores: with `auto_static` off the raw tensors are scored; with `verify_static` the
+    change is detected and raised; after register_static + forget_static the list is scored afresh."""
+    gen = torch.Generator().manual_seed(11)
+    n, R, F, E = 300, 7, 80, 5000
+    z = torch.randn(n, F, generator=gen).to(gpu)
+    et = torch.sort(torch.randint(0, R, (E,), generator=gen)).values.to(gpu)
+    buf = torch.randint(0, n, (2, E), generator=gen).to(gpu)
+    ref = lambda dm: orc.distmult(z.cpu(), buf.cpu(), et.cpu(), dm.weight.detach().cpu())
+    # (1) automatic detection off: always the contents of the moment
+    dm = gripnet_amd.multiRelaInnerProductDecoder(F, R).to(gpu)
+    dm.auto_static = False
+    with torch.no_grad():
+        for fill in (None, 5, 9):
+            if fill is not None:
+                _raw_fill(buf, fill)
+            for _ in range(3):
+                close(dm(z, buf, et), ref(dm), what="auto_static off")
+    assert dm._find(buf, et).plan is None
+    # (2) verification on: the second sighting builds a plan, the raw refill is caught
+    buf = torch.randint(0, n, (2, E), generator=gen).to(gpu)
+    dm = gripnet_amd.multiRelaInnerProductDecoder(F, R).to(gpu)
+    dm.verify_static = True
+    with torch.no_grad():
+        for _ in range(3):
+            close(dm(z, buf, et), ref(dm), what="verified plan")
+        assert dm._find(buf, et).plan
+        _raw_fill(buf, 3)
+        with pytest.raises(RuntimeError, match="changed in place behind its plan"):
+            dm(z, buf, et)
+        close(dm(z, buf, et), ref(dm), what="after the raised error the raw tensors are scored")
+    # (3) an in-place write THROUGH torch moves `_version`: detected without verification
+    dm = gripnet_amd.multiRelaInnerProductDecoder(F, R).to(gpu)
+    with torch.no_grad():
+        for _ in range(3):
+            dm(z, buf, et)
+        assert dm._find(buf, et).plan
+        buf.copy_(torch.randint(0, n, (2, E), generator=gen))
+        close(dm(z, buf, et), ref(dm), what="torch in-place write")
+    # (4) explicit registration, also while capturing; forgetting
+    dm = gripnet_amd.multiRelaInnerProductDecoder(F, R).to(gpu)
+    dm.register_static(buf, et, num_nodes=n)
+    assert dm._find(buf, et).plan
+    with torch.no_grad():
+        close(dm(z, buf, et), ref(dm), what="registered")
+        dm.forget_static(buf, et)
+        _raw_fill(buf, 1)
+        close(dm(z, buf, et), ref(dm), what="forgotten")
+
+
+def test_no_static_decision_under_capture(gpu):
+    """While a stream is captured nothing is promoted to a static list: a buffer that a replayed step refills in place
+    (negative samples) is scored from its contents on every replay."""
+    gen = torch.Generator().manual_seed(13)
+    n, R, F, E = 200, 5, 80, 4096
+    z = torch.randn(n, F, generator=gen).to(gpu)
+    et = torch.sort(torch.randint(0, R, (E,), generator=gen)).values.to(gpu)
+    neg = torch.randint(0, n, (2, E), generator=gen).to(gpu)
+    dm = gripnet_amd.multiRelaInnerProductDecoder(F, R).to(gpu)
+    out = torch.empty(E, device=gpu)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(side):
+        dm(z, neg, et)                                        # one warm-up sighting, as a capture needs
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        out.copy_(dm(z, neg, et))                             # second sighting, but capturing: stays plan-less
+    entry = dm._find(neg, et)
+    assert entry is None or not entry.plan
+    for _ in range(3):
+        neg.copy_(torch.randint(0, n, (2, E), generator=gen))
+        graph.replay()
+        torch.cuda.synchronize()
+        close(out, orc.distmult(z.cpu(), neg.cpu(), et.cpu(), dm.weight.detach().cpu()), what="replay")
+
+
+# ---- negative sampler: the law of gripnet/utils.py:98-119 ----------------------------------------------------
+def _pair_histogram(sample_fn, n, draws):
+    counts = np.zeros(n * n, dtype=np.int64)
+    for seed in range(draws):
+        neg = sample_fn(seed).cpu().numpy()
+        np.add.at(counts, neg[0] * n + neg[1], 1)
+    return counts
+
+
+def test_device_negative_sampler_matches_the_reference_law(gpu):
+    """gripnet/utils.py:98-119 draws, for every positive edge of a relation block, one pair uniformly (with
+    replacement) from the n^2 pairs that are NOT positives of that block.  Exact enumeration at n = 12: the device
+    sampler's per-block pair histogram (a) never holds a positive of its block, (b) passes a chi-square test against
+    that uniform law, (c) is indistinguishable (two-sample chi-square) from the histogram of the host restatement of
+    the reference's sampler fed with numpy's generator; typed (`typed_negative_sampling`) and untyped form
+    (`negative_sampling(train_idx, n)`, the call GripNet-pose.py:131 makes)."""
+    n, draws = 12, 1500
+    gen = torch.Generator().manual_seed(17)
+    blocks = []
+    for e in (45, 20):                                        # two relation blocks with different positive sets
+        a = torch.randint(0, n, (2, e), generator=gen)
+        a = a[:, a[0] != a[1]]
+        blocks.append(torch.cat([a, a.flip(0)], dim=1))
+    pos = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    posg = pos.to(gpu)
+
+    def check(counts, positives, per_draw, what, other=None):
+        lin = np.unique((positives[0] * n + positives[1]).numpy())
+        assert counts[lin].sum() == 0, what + ": a positive pair was drawn"
+        free = np.setdiff1d(np.arange(n * n), lin)
+        total = per_draw * draws
+        assert counts.sum() == total
+        expected = total / len(free)
+        chi2 = float(((counts[free] - expected) ** 2 / expected).sum())
+        dof = len(free) - 1
+        assert chi2 < dof + 6 * np.sqrt(2 * dof), "{}: chi2 {:.1f} for {} degrees of freedom".format(what, chi2, dof)
+        if other is not None:                                 # two-sample chi-square against the reference's sampler
+            a, b = counts[free].astype(np.float64), other[free].astype(np.float64)
+            chi2 = float(((a - b) ** 2 / (a + b)).sum())
+            assert chi2 < dof + 6 * np.sqrt(2 * dof), "{}: two-sample chi2 {:.1f} for {} dof".format(what, chi2, dof)
+
+    # typed: one law per relation block
+    typed = _hip.NegativeSampler(posg, n, rl)
+    rng = np.random.RandomState(5)
+    for r, (s, e) in enumerate(rl.tolist()):
+        dev = _pair_histogram(lambda seed: typed.sample(seed)[:, s:e], n, draws)
+        host = _pair_histogram(lambda seed: negative_sampling(pos[:, s:e], n, rng), n, draws)
+        check(dev, pos[:, s:e], e - s, "typed block {}".format(r), host)
+    # untyped: the whole list is one block (what the reference's train() calls)
+    untyped = _hip.NegativeSampler(posg, n)
+    dev = _pair_histogram(lambda seed: untyped.sample(seed), n, draws)
+    host = _pair_histogram(lambda seed: negative_sampling(pos, n, rng), n, draws)
+    check(dev, pos, pos.shape[1], "untyped", host)
+    # determinism in the seed, and different seeds differ
+    assert torch.equal(typed.sample(3), typed.sample(3)) and not torch.equal(typed.sample(3), typed.sample(4))
+    _hip.raise_if_index_errors(gpu)
+
+
+# ---- parameters that move between replays (the relational weights' hand-over) ---------------------
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_staged_forward_follows_parameter_updates(gpu, storage):
+    """PoseStages replays its stages as hipGraphs; the relational layer's W_r = att . basis must be recomputed from
+    the CURRENT parameters in every step - also when the external layer does not take the combined launch that
+    normally computes it on the side (bf16 table storage), and when parameters change through `.data` writes, which do
+    not move `_version` (an optimizer step inside a replayed training graph)."""
+    data = make_pose("small")
+    torch.manual_seed(19)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    dg = make_pose("small").to(gpu)
+    model = model.to(gpu)
+    if storage == "bf16":
+        set_table_storage(model, "bf16")
+    conv = model.dd.conv_list[0]
+    for timed in (None, "gn_rgcn_forward_f32"):
+        with torch.no_grad():
+            stages = PoseStages(model, dg, graphs=True, timed_entry=timed)
+            for step in range(3):
+                conv.att.data.mul_(1.25)                       # no _version bump
+                conv.basis.data.add_(0.01)
+                model.gd.conv.weight.data.mul_(0.9)
+                z, score = stages.step()
+                sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+                ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                                       data.train_et, data.train_range)
+                tol = 2e-5 if storage == "fp32" else 2.0 ** -7 * float(ref["z_dd"].abs().max())
+                close(z, ref["z_dd"], tol, what="{} timed={} step {} z".format(storage, timed, step))
+                close(score, ref["score"], max(tol, 2e-5), what="score")

@@ -11,7 +11,7 @@ import torch
 
 import gripnet_amd
 from gripnet_amd import _hip
-from gripnet_amd.pipeline import AminerModel, FreebaseCModel, PoseModel
+from gripnet_amd.pipeline import AminerModel, FreebaseAModel, FreebaseBModel, FreebaseCModel, PoseModel
 from gripnet_amd.synth import Data, make_pose
 from oracle import gripnet_oracle as orc
 
@@ -177,6 +177,30 @@ def test_nc_pipelines_vs_reference(gpu, golden):
     m = load_into(m, sd, gpu)
     data = Data(**{k: g.t(k, gpu) for k in ("pp_edge_idx", "pa_edge_idx", "qq_edge_idx", "qa_edge_idx", "aa_edge_idx",
                                             "pp_edge_weight", "qq_edge_weight", "aa_edge_weight")})
+    with torch.no_grad():
+        z, score = m(data, g.t("node_list", gpu))
+    close(z, g.t("out.z"))
+    close(score, g.t("out.score"))
+
+
+def test_freebase_a_and_b_pipelines_vs_reference(gpu, golden):
+    """BASELINE.json config 5 callers on the golden fixtures: freebase-a (one supervertex, no concat,
+    GripNet-freebase-a.py:94-122) and freebase-b (aminer's call sequence, pa_out halves of equal width,
+    GripNet-freebase-b.py:96-135)."""
+    g = golden("freebase_a_tiny")
+    m = load_into(FreebaseAModel(g.meta["n_a"], g.meta["n_class"], pp_nhids=g.meta["pp_nhids"]), g.state("", strip=False), gpu)
+    data = Data(aa_edge_idx=g.t("aa_edge_idx", gpu), aa_edge_weight=g.t("aa_edge_weight", gpu))
+    with torch.no_grad():
+        z, score = m(data, g.t("node_list", gpu))
+        _, logits = m(data, g.t("node_list", gpu), softmax=False)
+    close(z, g.t("out.z"))
+    close(score, g.t("out.score"))
+    close(logits, g.t("out.logits"))
+    g = golden("freebase_b_tiny")
+    m = FreebaseBModel(g.meta["n_p"], g.meta["n_a"], g.meta["n_class"], pp_nhids=g.meta["pp_nhids"],
+                       pa_out=g.meta["pa_out"], aa_hidden=g.meta["aa_nhids"][1:])
+    m = load_into(m, g.state("", strip=False), gpu)
+    data = Data(**{k: g.t(k, gpu) for k in ("pp_edge_idx", "pa_edge_idx", "aa_edge_idx", "pp_edge_weight", "aa_edge_weight")})
     with torch.no_grad():
         z, score = m(data, g.t("node_list", gpu))
     close(z, g.t("out.z"))
@@ -378,6 +402,42 @@ def test_pose0_syn_vs_oracle(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+def test_pose1_syn_vs_oracle(gpu):
+    """BASELINE.json config 4, first rung: pose1-syn (E_dd = 4.0 M) against the CPU oracle."""
+    data = make_pose("pose1-syn")
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range, sigmoid=False)
+    model = model.to(gpu)
+    data = data.to(gpu)
+    with torch.no_grad():
+        z, logits = model(data, sigmoid=False)
+    close(z, ref["z_dd"], TOL)
+    close(logits, ref["score"], TOL)
+    _hip.raise_if_index_errors(gpu)
+
+
+def test_pose2_syn_logits_vs_oracle(gpu):
+    """BASELINE.json config 4, largest rung: one oracle forward of pose2-syn (E_dd = 8.4 M; a few seconds and
+    ~8 GB of temporaries on the host) against the HIP logits and z."""
+    data = make_pose("pose2-syn")
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                               data.train_et, data.train_range, sigmoid=False)
+    model = model.to(gpu)
+    data = data.to(gpu)
+    with torch.no_grad():
+        z, logits = model(data, sigmoid=False)
+    close(z, ref["z_dd"], TOL)
+    close(logits, ref["score"], TOL)
+    _hip.raise_if_index_errors(gpu)
+
+
 def test_pose2_syn_properties(gpu):
     """Largest configuration: size-independent properties instead of a CPU run."""
     data = make_pose("pose2-syn").to(gpu)
@@ -516,6 +576,66 @@ def test_freebase_c_syn_vs_oracle(gpu):
         z, pred = model(make_nc("aminer-syn").to(gpu), nodes.to(gpu))
     close(z, ref["z"], TOL)
     close(pred, ref["score"], TOL)
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_freebase_a_and_b_syn_vs_oracle(gpu, storage):
+    """freebase-a and freebase-b at the freebase-syn scale (the aminer-syn node / edge scale with the
+    reference's own widths, GripNet-freebase-a.py:94 [256,128,128], GripNet-freebase-b.py:96-98 [128,64,64] /
+    [128,128] / [256,128,32]), fp32 and with bf16 storage of the gathered tables (BASELINE.json config 5; the reference
+    has no reduced precision: tolerance of the bf16 variant = one bf16 rounding of every gathered element, 2^-8 of the
+    largest activation per layer, checked on the class probabilities at 5e-3)."""
+    from gripnet_amd.synth import make_nc
+    from gripnet_amd.utils import set_table_storage
+    data = make_nc("aminer-syn")
+    nodes = torch.arange(2, data.n_a_node, 3)
+    torch.manual_seed(1111)
+    a = FreebaseAModel(data.n_a_node, data.n_a_type)
+    b = FreebaseBModel(data.n_p_node, data.n_a_node, data.n_a_type)
+    sda = {k: v.detach().clone() for k, v in a.state_dict().items()}
+    sdb = {k: v.detach().clone() for k, v in b.state_dict().items()}
+    ref_a = orc.freebase_a_forward(sda, data.aa_edge_idx, data.aa_edge_weight, nodes)
+    ref_b = orc.aminer_forward(sdb, data.pp_edge_idx, data.pp_edge_weight, data.pa_edge_idx, data.aa_edge_idx,
+                               data.aa_edge_weight, nodes)
+    dg = make_nc("aminer-syn").to(gpu)
+    a, b = a.to(gpu), b.to(gpu)
+    if storage == "bf16":
+        assert len(set_table_storage(a, "bf16")) == 2 and len(set_table_storage(b, "bf16")) == 5
+    with torch.no_grad():
+        za, pa = a(dg, nodes.to(gpu))
+        zb, pb = b(dg, nodes.to(gpu))
+    if storage == "fp32":
+        close(za, ref_a["z"], TOL)
+        close(pa, ref_a["score"], TOL)
+        close(zb, ref_b["z"], TOL)
+        close(pb, ref_b["score"], TOL)
+    else:
+        close(za, ref_a["z"], 2.0 ** -7 * float(ref_a["z"].abs().max()))
+        close(zb, ref_b["z"], 2.0 ** -7 * float(ref_b["z"].abs().max()))
+        close(pa, ref_a["score"], 5e-3)
+        close(pb, ref_b["score"], 5e-3)
+
+
+def test_distmult_improved_baseline_caller(gpu):
+    """The reference's third caller of the DistMult decoder (baselines/LP_baselines/dmt_pose.py:54,70,84-97: a learned
+    embedding of ALL nodes -> decoder): n = 20,000 nodes x 64 features is far beyond the LDS-resident tables, so the
+    general kernel (tables in L2) carries it; also through the module's static-list plan, which must refuse this size
+    and fall back."""
+    gen = torch.Generator().manual_seed(131)
+    n, R, F, E = 20000, 37, 64, 300000
+    emb = torch.randn(n, F, generator=gen) * 0.3
+    et = torch.sort(torch.randint(0, R, (E,), generator=gen)).values
+    ei = torch.randint(0, n, (2, E), generator=gen)
+    dm = gripnet_amd.multiRelaInnerProductDecoder(F, R)
+    ref = orc.distmult(emb, ei, et, dm.weight.detach())
+    ref_logits = orc.distmult(emb, ei, et, dm.weight.detach(), sigmoid=False)
+    dm = dm.to(gpu)
+    z, eig, etg = emb.to(gpu), ei.to(gpu), et.to(gpu)
+    with torch.no_grad():
+        for _ in range(3):                                   # 2nd and 3rd call: the same tensors again (static list)
+            close(dm(z, eig, etg), ref, TOL)
+        close(dm(z, eig, etg, sigmoid=False), ref_logits, TOL)
+    _hip.raise_if_index_errors(gpu)
 
 
 def test_rgcn_improved_baseline_caller(gpu):

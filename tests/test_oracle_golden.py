@@ -143,3 +143,22 @@ def test_nc_pipelines(golden):
                                  g.t("node_list"), g.meta["n_a"])
     close(out["z"], g.t("out.z"), 2e-6)
     close(out["score"], g.t("out.score"), 2e-6)
+
+
+def test_freebase_a_and_b_pipelines(golden):
+    """BASELINE.json config 5: the one-supervertex freebase-a caller (no concat) and freebase-b (the aminer call
+    sequence with equal-width pa_out halves), GripNet-freebase-a.py:94-122, GripNet-freebase-b.py:96-135."""
+    g = golden("freebase_a_tiny")
+    sd = g.state("", strip=False)
+    out = orc.freebase_a_forward(sd, g.t("aa_edge_idx"), g.t("aa_edge_weight"), g.t("node_list"))
+    close(out["z"], g.t("out.z"), 2e-6)
+    close(out["score"], g.t("out.score"), 2e-6)
+    logits = orc.freebase_a_forward(sd, g.t("aa_edge_idx"), g.t("aa_edge_weight"), g.t("node_list"), softmax=False)["score"]
+    close(logits, g.t("out.logits"), 2e-6)
+    g = golden("freebase_b_tiny")
+    sd = g.state("", strip=False)
+    out = orc.aminer_forward(sd, g.t("pp_edge_idx"), g.t("pp_edge_weight"), g.t("pa_edge_idx"),
+                             g.t("aa_edge_idx"), g.t("aa_edge_weight"), g.t("node_list"))
+    close(out["z"], g.t("out.z"), 2e-6)
+    close(out["score"], g.t("out.score"), 2e-6)
+
