@@ -57,6 +57,7 @@ SIGNATURES = {
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
+    "gn_distmult_packed_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "gn_distmult_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_distmult_plan_destroy": (None, [_p]),
     "gn_distmult_plan_edges": (_i64, [_p]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
+    "gn_negative_sampler_sample_packed": (_int, [_p, C.c_uint64, _p, _p, _p, _p, _p]),
     "gn_link_metrics_workspace_bytes": (_sz, [_i64, _i64]),
     "gn_link_metrics_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
 }
@@ -555,6 +557,52 @@ def distmult(z, u_v, edge_type, weight, sigmoid, out):
     return out
 
 
+_relation_ids = []          # (edge_type tensor, _version, int16 copy) of the last few edge_type tensors asked about
+
+
+def relation_ids16(et):
+    """The relation ids of a (static) edge_type tensor as 16-bit values, narrowed once per tensor and version."""
+    for t, ver, r16 in _relation_ids:
+        if t is et and ver == et._version:
+            return r16
+    r16 = et.to(torch.int16)
+    _relation_ids.append((et, et._version, r16))
+    del _relation_ids[:-4]
+    return r16
+
+
+def packed_pairs(edge_index):
+    """The (uint32 words, as int32) that NegativeSampler.sample left next to an edge list, or None (another list, or
+    the list was modified since)."""
+    tag = getattr(edge_index, "_gn_packed", None)
+    if tag is None or tag[1] != edge_index._version:
+        return None
+    return tag[0]
+
+
+def distmult_packed(z, packed, edge_type, weight, sigmoid, out):
+    e = int(packed.numel())
+    if edge_type.numel() != e:
+        raise ValueError("edge_type has {} entries for {} edges".format(edge_type.numel(), e))
+    r16 = relation_ids16(edge_type)
+    _call("gn_distmult_packed_forward_f32", ptr(z), ld(z), z.shape[0], z.shape[1], ptr(packed), ptr(r16), ptr(weight),
+          ld(weight), weight.shape[0], e, int(bool(sigmoid)), ptr(out), ptr(error_flag(z.device)), stream_ptr(z.device))
+    return out
+
+
+def distmult_any(z, u_v, edge_type, weight, sigmoid, out):
+    """The plan-less decoder: on the packed pairs a NegativeSampler left with `u_v` when there are any (and ids fit 16
+    bits), else on the raw int64 triples."""
+    packed = packed_pairs(u_v)
+    if packed is not None and z.shape[0] <= 65535 and weight.shape[0] <= 32767:
+        try:
+            return distmult_packed(z, packed, edge_type, weight, sigmoid, out)
+        except GripNetHipError as err:                     # node table too large for the LDS: the general kernels
+            if err.status != GN_ERR_UNSUPPORTED:
+                raise
+    return distmult(z, u_v, edge_type, weight, sigmoid, out)
+
+
 class DistMultPlan:
     """Owner of a gn_distmult_plan handle: one static (edge_index, edge_type) list, validated, packed and ordered
     for the LDS-resident decoder kernel (the positive edges a training loop scores every epoch)."""
@@ -667,11 +715,20 @@ class NegativeSampler:
         with torch.cuda.device(ei.device):
             check(lib.gn_negative_sampler_create(u, v, rl.data_ptr(), rl.shape[0], e, int(num_nodes),
                                                  stream_ptr(ei.device), C.byref(h)))
-        self._h, self.device, self.num_edges = h, ei.device, e
+        self._h, self.device, self.num_edges, self.num_nodes = h, ei.device, e, int(num_nodes)
 
     def sample(self, seed: int = 0) -> torch.Tensor:
+        """[2, E] int64 negative pairs.  For graphs of up to 65,535 nodes the same launch also leaves every pair as one
+        32-bit word; it travels with the returned tensor (`_gn_packed`) and the decoder scores the list from it - 6
+        instead of 24 bytes per edge - as long as the tensor is not modified."""
         out = torch.empty((2, self.num_edges), dtype=torch.int64, device=self.device)
         base = out.data_ptr()
+        if self.num_nodes <= 65535 and self.num_edges > 0:
+            packed = torch.empty((self.num_edges,), dtype=torch.int32, device=self.device)
+            _call("gn_negative_sampler_sample_packed", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, base, base + 8 * self.num_edges,
+                  ptr(packed), ptr(error_flag(self.device)), stream_ptr(self.device))
+            out._gn_packed = (packed, out._version)
+            return out
         _call("gn_negative_sampler_sample", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, base, base + 8 * self.num_edges,
               ptr(error_flag(self.device)), stream_ptr(self.device))
         return out

@@ -168,7 +168,7 @@ class DistMultFn(torch.autograd.Function):
                 if err.status != _hip.GN_ERR_UNSUPPORTED:
                     raise
         if not done:
-            _hip.distmult(zc, edge_index, edge_type, w, sigmoid, out)
+            _hip.distmult_any(zc, edge_index, edge_type, w, sigmoid, out)
         ctx.sigmoid = bool(sigmoid)
         ctx.plan = plan                                        # a static list: its backward plan hangs on the forward one
         ctx.save_for_backward(zc, w, edge_index, edge_type, out if sigmoid else None)

@@ -21,6 +21,7 @@ using namespace gn_dm;
 struct DmFastArgs {
     const float* z; int64_t ld_z; int n; int features;
     const int64_t* u; const int64_t* v; const int64_t* et;
+    const uint32_t* packed; const uint16_t* rel16;   // PACKED: u | v << 16 and the relation of every edge (6 bytes per edge)
     const float* d; int64_t ld_d; int r;
     int64_t e; int64_t edges_per_wg; int sigmoid; float* out; int32_t* err;
     int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
@@ -32,18 +33,24 @@ struct Batch {            // one lane's edge of a 64-edge batch
     float carried;
 };
 
+template <bool PACKED>
 __device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, int64_t hi, bool carry) {
     Batch b;
     b.u = b.v = b.r = 0;
     b.carried = 0.f;
     if (mine < hi) {
-        b.u = a.u[mine]; b.v = a.v[mine]; b.r = a.et[mine];
+        if constexpr (PACKED) {
+            const uint32_t w = a.packed[mine];
+            b.u = w & 0xffffu; b.v = w >> 16; b.r = a.rel16[mine];
+        } else {
+            b.u = a.u[mine]; b.v = a.v[mine]; b.r = a.et[mine];
+        }
         if (carry) b.carried = a.out[mine];
     }
     return b;
 }
 
-template <int W4, int CPL>
+template <int W4, int CPL, bool PACKED>
 __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first, bool last,
                                           int64_t wg_lo, int64_t wg_hi, int wave, int lane) {
     const int l4 = lane & 3;
@@ -55,11 +62,11 @@ __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, 
     constexpr int64_t kStride = (kThreads / 64) * 64;
 
     int64_t e0 = wg_lo + wave * 64;
-    Batch nxt = load_batch(a, e0 + lane, wg_hi, !first);
+    Batch nxt = load_batch<PACKED>(a, e0 + lane, wg_hi, !first);
     for (; e0 < wg_hi; e0 += kStride) {
         const int64_t mine = e0 + lane;
         const Batch cur = nxt;
-        nxt = load_batch(a, mine + kStride, wg_hi, !first);   // in flight while this batch computes
+        nxt = load_batch<PACKED>(a, mine + kStride, wg_hi, !first);   // in flight while this batch computes
         const bool ok = (uint64_t)cur.u < (uint64_t)a.n && (uint64_t)cur.v < (uint64_t)a.n &&
                         (uint64_t)cur.r < (uint64_t)a.r;
         const int iu = ok ? (int)cur.u : 0, iv = ok ? (int)cur.v : 0;
@@ -100,6 +107,7 @@ __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, 
     }
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
     extern __shared__ float4 lds4[];
     const int tid = threadIdx.x;
@@ -120,16 +128,19 @@ __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
         __syncthreads();
         const bool first = ph == 0, last = ph == a.n_phases - 1;
         switch (w4) {                                       // common widths get compile-time addressing
-            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 16: run_phase<16, 4, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 12: run_phase<12, 3, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 8: run_phase<8, 2, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            case 4: run_phase<4, 1, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+            default: run_phase<0, 4, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
         }
     }
 }
 
 }  // namespace
+
+bool gn_distmult_fast_applicable(int64_t n, int64_t f, int64_t ld_z, int64_t ld_d, const void* z, const void* d);
+static gn_status distmult_lds_launch(DmFastArgs& a, int64_t n, int64_t f, int64_t e, bool packed, hipStream_t st);
 
 bool gn_distmult_fast_applicable(int64_t n, int64_t f, int64_t ld_z, int64_t ld_d, const void* z, const void* d) {
     if (gn::fast_paths_disabled()) return false;
@@ -140,13 +151,7 @@ bool gn_distmult_fast_applicable(int64_t n, int64_t f, int64_t ld_z, int64_t ld_
     return phases >= 1 && phases <= 4;   // beyond that the general (L2-gather) kernel is the better choice
 }
 
-gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
-                                   const int64_t* v, const int64_t* et, const float* d, int64_t ld_d, int64_t r,
-                                   int64_t e, int sigmoid, float* out, int32_t* err, hipStream_t st) {
-    GN_REQUIRE(r >= 1, "no relations");
-    DmFastArgs a;
-    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.features = (int)f; a.u = u; a.v = v; a.et = et;
-    a.d = d; a.ld_d = ld_d; a.r = (int)r; a.e = e; a.sigmoid = sigmoid; a.out = out; a.err = err;
+static gn_status distmult_lds_launch(DmFastArgs& a, int64_t n, int64_t f, int64_t e, bool packed, hipStream_t st) {
     a.n_phases = plan_phases(n, f, a.c0, a.width);
     int max_w = 0;
     for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
@@ -158,8 +163,45 @@ gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int6
     if (groups < 1) groups = 1;
     a.edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
     groups = gn::ceil_div(e, a.edges_per_wg);
-    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_lds), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
-    k_distmult_lds<<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
+    if (packed) {
+        { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_lds<true>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
+        k_distmult_lds<true><<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
+    } else {
+        { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_lds<false>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
+        k_distmult_lds<false><<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
+    }
     GN_LAUNCH_CHECK();
     return GN_OK;
+}
+
+gn_status gn_distmult_fast_forward(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
+                                   const int64_t* v, const int64_t* et, const float* d, int64_t ld_d, int64_t r,
+                                   int64_t e, int sigmoid, float* out, int32_t* err, hipStream_t st) {
+    GN_REQUIRE(r >= 1, "no relations");
+    DmFastArgs a;
+    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.features = (int)f; a.u = u; a.v = v; a.et = et; a.packed = nullptr; a.rel16 = nullptr;
+    a.d = d; a.ld_d = ld_d; a.r = (int)r; a.e = e; a.sigmoid = sigmoid; a.out = out; a.err = err;
+    return distmult_lds_launch(a, n, f, e, false, st);
+}
+
+// The same decoder on PACKED triples: u | v << 16 (uint32) and the relation (uint16) of every edge - six bytes per edge
+// and column phase instead of 24.  What gn_negative_sampler_sample_packed writes next to the int64 pairs, with the
+// relation ids of the static edge_type tensor (the negatives of GripNet-pose.py:131,138 are scored with the positives'
+// train_et).  Ids outside their table give NaN and set bit 0 of *error_flag, as in gn_distmult_forward_f32.
+extern "C" gn_status gn_distmult_packed_forward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const uint32_t* packed_uv,
+                                                    const uint16_t* relation, const float* d, int64_t ld_d, int64_t r,
+                                                    int64_t e, int apply_sigmoid, float* out, int32_t* err, void* stream) {
+    GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
+    if (e == 0) return GN_OK;
+    GN_REQUIRE(n > 0 && r > 0, "edges given but the node or relation table is empty");
+    GN_REQUIRE(z && packed_uv && relation && d && out, "operand pointer is null");
+    GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
+    if (n > 65535 || r > 65535 || !gn_distmult_fast_applicable(n, f, ld_z, ld_d, z, d))
+        return gn::fail(GN_ERR_UNSUPPORTED, "the packed decoder needs node and relation ids of 16 bits and a node table that fits the LDS "
+                                            "in four column phases: use gn_distmult_forward_f32");
+    DmFastArgs a;
+    a.z = z; a.ld_z = ld_z; a.n = (int)n; a.features = (int)f; a.u = nullptr; a.v = nullptr; a.et = nullptr;
+    a.packed = packed_uv; a.rel16 = relation;
+    a.d = d; a.ld_d = ld_d; a.r = (int)r; a.e = e; a.sigmoid = apply_sigmoid; a.out = out; a.err = err;
+    return distmult_lds_launch(a, n, f, e, true, gn::as_stream(stream));
 }

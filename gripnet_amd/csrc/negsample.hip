@@ -54,7 +54,7 @@ __global__ void k_pair_keys(const int64_t* __restrict__ u, const int64_t* __rest
 
 __global__ void k_sample_negatives(const uint64_t* __restrict__ keys, const int64_t* __restrict__ starts, int R,
                                    int64_t E, int64_t n, uint64_t seed, int64_t* __restrict__ out_u,
-                                   int64_t* __restrict__ out_v, int32_t* __restrict__ err) {
+                                   int64_t* __restrict__ out_v, uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
     const uint64_t n2 = (uint64_t)n * (uint64_t)n;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int r = relation_of(starts, R, e);
@@ -72,8 +72,10 @@ __global__ void k_sample_negatives(const uint64_t* __restrict__ keys, const int6
             found = !(lo < hi0 && keys[lo] == key);
         }
         if (!found && err) atomicOr(err, 2);                // the block's positives (nearly) cover all n^2 pairs
-        out_u[e] = (int64_t)(lin / (uint64_t)n);
-        out_v[e] = (int64_t)(lin % (uint64_t)n);
+        const uint64_t uu = lin / (uint64_t)n, vv = lin % (uint64_t)n;
+        out_u[e] = (int64_t)uu;
+        out_v[e] = (int64_t)vv;
+        if (packed) packed[e] = (uint32_t)uu | ((uint32_t)vv << 16);
     }
 }
 
@@ -149,7 +151,19 @@ gn_status gn_negative_sampler_sample(const gn_negative_sampler* s, uint64_t seed
     if (s->num_edges == 0) return GN_OK;
     GN_REQUIRE(out_u && out_v, "output pointers are null");
     k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, gn::as_stream(stream)>>>(
-        s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, error_flag);
+        s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, nullptr, error_flag);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* s, uint64_t seed, int64_t* out_u, int64_t* out_v,
+                                            uint32_t* packed_uv, int32_t* error_flag, void* stream) {
+    GN_REQUIRE(s != nullptr, "sampler is null");
+    if (s->num_edges == 0) return GN_OK;
+    GN_REQUIRE(out_u && out_v && packed_uv, "output pointers are null");
+    if (s->num_nodes > 65535) return gn::fail(GN_ERR_UNSUPPORTED, "packed pairs hold node ids of 16 bits");
+    k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, gn::as_stream(stream)>>>(
+        s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, packed_uv, error_flag);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -144,7 +144,7 @@ class multiRelaInnerProductDecoder(Module):
                 if err.status != _hip.GN_ERR_UNSUPPORTED:
                     raise
                 self._find(edge_index, edge_type).plan = False
-        return _hip.distmult(z, edge_index, edge_type, self.weight, sigmoid, out)
+        return _hip.distmult_any(z, edge_index, edge_type, self.weight, sigmoid, out)
 
     def reset_parameters(self):
         self.weight.data.normal_(std=1 / np.sqrt(self.in_dim))                   # decoder.py:25-26

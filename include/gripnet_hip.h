@@ -240,6 +240,17 @@ GN_API gn_status gn_distmult_forward_f32(const float* z, int64_t ld_z, int64_t n
                                   const float* d, int64_t ld_d, int64_t num_relations, int64_t num_edges,
                                   int apply_sigmoid, float* out, int32_t* error_flag, void* stream);
 
+/* The same decoder (same kernel, same arithmetic, same bits) on PACKED triples: packed_uv[e] = u | v << 16 and
+ * relation[e] (uint16): 6 bytes per edge and column phase instead of 24.  For edge lists that change every epoch, where
+ * a plan cannot pay off: the negative samples of GripNet-pose.py:131,138, which gn_negative_sampler_sample_packed writes
+ * in this form; `relation` is the static edge_type of the positives (GripNet-pose.py:138 scores the negatives with
+ * train_et) narrowed once.  GN_ERR_UNSUPPORTED when ids need more than 16 bits or the node table does not fit the LDS
+ * in four column phases. */
+GN_API gn_status gn_distmult_packed_forward_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
+                                         const uint32_t* packed_uv, const uint16_t* relation, const float* d, int64_t ld_d,
+                                         int64_t num_relations, int64_t num_edges, int apply_sigmoid, float* out,
+                                         int32_t* error_flag, void* stream);
+
 /* The same decoder on a cached, re-encoded STATIC edge list: the positive edges, which the reference scores with the
  * same train_idx / train_et tensors every epoch (GripNet-pose.py:137,185).  The plan validates the triples once
  * (GN_ERR_INDEX_RANGE), pairs up triples with the same unordered node pair and relation (both directions of an edge,
@@ -319,6 +330,11 @@ GN_API gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, 
 GN_API void gn_negative_sampler_destroy(gn_negative_sampler* sampler);
 GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
                                      int64_t* out_v, int32_t* error_flag, void* stream);
+/* The same draw, which also leaves every pair as one 32-bit word u | v << 16 (graphs of up to 65,535 nodes) for
+ * gn_distmult_packed_forward_f32: the sampler produces the pairs, so it can hand the decoder 4 bytes per edge instead
+ * of 16.  GN_ERR_UNSUPPORTED for larger graphs. */
+GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
+                                            int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-relation evaluation metrics (replaces the R scikit-learn calls and device -> host copies per epoch

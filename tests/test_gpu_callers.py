@@ -270,3 +270,36 @@ def test_staged_forward_follows_parameter_updates(gpu, storage):
                 tol = 2e-5 if storage == "fp32" else 2.0 ** -7 * float(ref["z_dd"].abs().max())
                 close(z, ref["z_dd"], tol, what="{} timed={} step {} z".format(storage, timed, step))
                 close(score, ref["score"], max(tol, 2e-5), what="score")
+
+
+def test_sampled_negatives_are_scored_from_their_packed_pairs(gpu):
+    """NegativeSampler.sample leaves every pair as one 32-bit word next to the int64 tensor; the decoder scores the list
+    from those words and the 16-bit relation ids of the (static) edge_type: 6 instead of 24 bytes per edge, the same
+    kernel, the same bits as the int64 path, forward and under autograd; a modified tensor falls back to its contents."""
+    data = make_pose("small").to(gpu)
+    n, R = data.n_d_node, data.n_dd_edge_type
+    torch.manual_seed(23)
+    z = torch.randn(n, 80, device=gpu)
+    dm = gripnet_amd.multiRelaInnerProductDecoder(80, R).to(gpu)
+    sampler = _hip.NegativeSampler(data.train_idx, n, data.train_range)
+    neg = sampler.sample(seed=1)
+    assert _hip.packed_pairs(neg) is not None
+    plain = neg.clone()                                       # same contents, no packed companion
+    assert _hip.packed_pairs(plain) is None
+    with torch.no_grad():
+        a, b = dm(z, neg, data.train_et), dm(z, plain, data.train_et)
+        assert torch.equal(a, b)
+        close(a, orc.distmult(z.cpu(), neg.cpu(), data.train_et.cpu(), dm.weight.detach().cpu()), what="packed vs oracle")
+        assert torch.equal(dm(z, neg, data.train_et, sigmoid=False), dm(z, plain, data.train_et, sigmoid=False))
+    zg = z.clone().requires_grad_(True)
+    (dm(zg, neg, data.train_et).sum()).backward()
+    g_packed, w_packed = zg.grad.clone(), dm.weight.grad.clone()
+    zg.grad, dm.weight.grad = None, None
+    (dm(zg, plain, data.train_et).sum()).backward()
+    assert torch.equal(g_packed, zg.grad) and torch.equal(w_packed, dm.weight.grad)
+    neg[0, :10] = 0                                           # modified through torch: the packed words are stale
+    assert _hip.packed_pairs(neg) is None
+    with torch.no_grad():
+        close(dm(z, neg, data.train_et), orc.distmult(z.cpu(), neg.cpu(), data.train_et.cpu(), dm.weight.detach().cpu()),
+              what="modified list")
+    _hip.raise_if_index_errors(gpu)
