@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): the same update in one launch instead of ~6")
+    ap.add_argument("--sampler", action="store_true", help="draw the negatives on the device every step (gn_negative_sampler_sample_packed: "
+                    "the decoder then scores them from 32-bit pairs); eager steps only, the seed is a launch argument")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, loss, backward, Adam) in one hipGraph and replay it")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -38,8 +40,17 @@ def main():
     pool = [torch.randint(0, data.n_d_node, tuple(data.train_idx.shape), device=dev) for _ in range(4)]
     drawn = [0]
 
+    sampler = None
+    if args.sampler and not args.graph:
+        from gripnet_amd._hip import NegativeSampler
+        sampler = NegativeSampler(data.train_idx, data.n_d_node)          # untyped, as GripNet-pose.py:131
+
     def resample():
-        neg.copy_(pool[drawn[0] % len(pool)])
+        nonlocal neg
+        if sampler is not None:
+            neg = sampler.sample(seed=drawn[0])
+        else:
+            neg.copy_(pool[drawn[0] % len(pool)])
         drawn[0] += 1
 
     def step():
