@@ -15,6 +15,9 @@
 #ifndef GN_AGG_U
 #define GN_AGG_U 2
 #endif
+#ifndef GN_AGG_U_WIDE
+#define GN_AGG_U_WIDE 8
+#endif
 // Upper bound of the launch grid (blocks of four waves); rows beyond it are taken grid-stride.
 #ifndef GN_AGG_GRID
 #define GN_AGG_GRID (256 * 8)
@@ -218,8 +221,10 @@ __device__ __forceinline__ void aggregate_transform_body(const AggArgs& a, const
             const uint32_t cl = mine < end ? a.col[mine] : 0u;
             const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
             const int cnt = min(kWave, end - base);
-            // U groups of S neighbour rows are requested before the first one is consumed (see k_aggregate)
-            constexpr int IT = kWave / S, U = IT < GN_AGG_U ? IT : GN_AGG_U;
+            // U groups of S neighbour rows are requested before the first one is consumed (see k_aggregate); wide rows
+            // (16 lanes each: the external layer, a few hundred destination rows of ~30 edges, latency-bound) ask for
+            // eight groups = 32 rows at once
+            constexpr int IT = kWave / S, UW = LPE >= 16 ? GN_AGG_U_WIDE : GN_AGG_U, U = IT < UW ? IT : UW;
             for (int it0 = 0; it0 * S < cnt; it0 += U) {
                 float4 t[U];
                 float vv[U];

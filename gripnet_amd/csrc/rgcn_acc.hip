@@ -81,11 +81,14 @@ constexpr int kFoutAcc = 32;       // out_features (slab layout of k_rgcn_slab_f
 constexpr size_t kLdsBudget = 159 * 1024;
 // cost model of the plan-time balancing, in cycles of the wave's SIMD
 #ifndef GN_ACC_TILE_COST
-#define GN_ACC_TILE_COST 550
-#define GN_ACC_BLOCK_COST 1000
+#define GN_ACC_TILE_COST 2200
+#define GN_ACC_BLOCK_COST 800
 #define GN_ACC_EDGE_COST 0
 #endif
-constexpr int kTileCost = GN_ACC_TILE_COST;    // move to the MFMA layout, split, 10 bf16 MFMAs (measured, tools/acc_stamps.py)
+// (a least-squares fit of the waves' loop times: 0.33 us per block, 0.92 us per non-empty tile - the tile pays for the
+// wait on its unit's W_r fragments as well as for the move to the MFMA layout, the split and the 10 bf16 MFMAs; tile
+// costs of 550 / 1000 / 1500 / 2200 / 3000 cycles gave kernels of 26.5 / 25.9 / 25.5 / 25.45 / 25.6 us on pose0-syn)
+constexpr int kTileCost = GN_ACC_TILE_COST;
 constexpr int kBlockCost = GN_ACC_BLOCK_COST;  // one stream block: 12 LDS reads + adds, with the workgroup's other waves on the LDS
 constexpr int kEdgeCost = GN_ACC_EDGE_COST;    // what a real edge adds to its block (nothing since the plan orders edges for the LDS)
 
