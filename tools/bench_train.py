@@ -43,7 +43,9 @@ def main():
     sampler = None
     if args.sampler and not args.graph:
         from gripnet_amd._hip import NegativeSampler
-        sampler = NegativeSampler(data.train_idx, data.n_d_node)          # untyped, as GripNet-pose.py:131
+        # typed (per relation block): on the synthetic ladder the 2 M positives of all relations together cover nearly every
+        # one of the 645^2 pairs, so the untyped draw of GripNet-pose.py:131 would reject almost for ever
+        sampler = NegativeSampler(data.train_idx, data.n_d_node, data.train_range)
 
     def resample():
         nonlocal neg
