@@ -42,6 +42,11 @@
 #include <numeric>
 #include <vector>
 
+// rgcn_tf.hip
+gn_status gn_rgcn_build_tf_plan(gn_rgcn_plan* plan, const std::vector<int32_t>& rp, const std::vector<uint32_t>& srcs, hipStream_t st);
+bool gn_rgcn_tf_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, bool split);
+gn_status gn_rgcn_tf_launch(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const void* wfrag,
+                            float* slabs, hipStream_t st);
 // rgcn_fast.hip
 gn_status gn_rgcn_slab_finalize_launch(const gn_rgcn_plan* plan, const float* slabs, int groups, const float* x,
                                        int64_t ld_x, int64_t fin, const float* root, const float* bias, int relu,
@@ -745,7 +750,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     plan->acc_tiles = tiles; plan->acc_q = Q; plan->acc_g = G;
     plan->acc_blocks = (int64_t)blocks_total;
     plan->acc_ok = 1;
-    return GN_OK;
+    return gn_rgcn_build_tf_plan(plan, rp, srcs, st);     // the same (relation, destination) order feeds the transform-first kernel
 }
 
 static size_t acc_lds_bytes(int64_t n, int64_t fin) {
@@ -761,7 +766,8 @@ bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout,
 }
 
 size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
-    return acc_w_bytes(plan->num_relations, fin, fout) + (size_t)plan->acc_g * plan->num_nodes * fout * sizeof(float);
+    const size_t groups = (size_t)std::max(plan->acc_g, plan->tf_ok ? plan->tf_g : 0);
+    return acc_w_bytes(plan->num_relations, fin, fout) + groups * plan->num_nodes * fout * sizeof(float);
 }
 
 // Arguments of the weights body for this plan and these parameters (also used by cowork.hip, which runs the body
@@ -799,6 +805,11 @@ gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t 
     if (!weights_ready) {
         gn_status ws_status = gn_rgcn_acc_weights(plan, fin, basis, att, bases, fout, ws, st);
         if (ws_status != GN_OK) return ws_status;
+    }
+    if (gn_rgcn_tf_applicable(plan, fin, fout, split)) {
+        gn_status ts = gn_rgcn_tf_launch(plan, x, ld_x, fin, wfrag, slabs, st);
+        if (ts != GN_OK) return ts;
+        return gn_rgcn_slab_finalize_launch(plan, slabs, plan->tf_g, x, ld_x, fin, root, bias, relu, partial, out, ld_out, side, st);
     }
     const size_t lds = acc_lds_bytes(plan->num_nodes, fin);
     gn_status s;

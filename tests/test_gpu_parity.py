@@ -207,13 +207,14 @@ def test_freebase_a_and_b_pipelines_vs_reference(gpu, golden):
     close(score, g.t("out.score"))
 
 
-@pytest.fixture(params=["acc", "lds", "general"])
+@pytest.fixture(params=["tf", "acc", "lds", "general"])
 def kernel_path(request, monkeypatch):
-    """Run a test once per relational kernel: register-accumulated (default), LDS-resident accumulator, general;
-    the last two also take the shuffle-based form of the 16-wide GCN gather instead of the quad form."""
+    """Run a test once per relational kernel: transform-then-gather (default), register-accumulated, LDS-resident
+    accumulator, general; the last two also take the shuffle-based form of the 16-wide GCN gather instead of the quad form."""
     monkeypatch.setenv("GN_DISABLE_FAST", "1" if request.param == "general" else "0")
+    monkeypatch.setenv("GN_RGCN_TF", "1" if request.param == "tf" else "0")
     monkeypatch.setenv("GN_DISABLE_ACC", "1" if request.param == "lds" else "0")
-    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param == "acc" else "1")
+    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param in ("tf", "acc") else "1")
     return request.param
 
 
@@ -333,14 +334,16 @@ def test_gcn_skewed_degrees_and_empty_rows(gpu, fout):
 
 @pytest.mark.parametrize("n,fin,bases", [(40, 16, 3), (200, 32, 5), (560, 48, 32), (645, 64, 8), (900, 48, 4),
                                          (1000, 32, 2), (1, 16, 1)])
-@pytest.mark.parametrize("path", ["acc", "lds"])
+@pytest.mark.parametrize("path", ["tf", "acc", "lds"])
 def test_rgcn_lds_resident_shapes(gpu, monkeypatch, n, fin, bases, path):
-    """Every specialisation of the two LDS-resident relational kernels (register-accumulated: K depth,
+    """Every specialisation of the three LDS-resident relational kernels (transform-then-gather: K depth, sliced
+    long runs, one to three rows per quad; register-accumulated: K depth,
     row groups, chunked long runs; LDS accumulator: row tiles per wave, 1..16 source tiles): empty
     relations, a relation longer than one work item, duplicate edges, destinations with no in-edges;
     checked against the oracle and for run-to-run equality.  Shapes a kernel does not cover fall
     through to the next one."""
     monkeypatch.setenv("GN_DISABLE_ACC", "1" if path == "lds" else "0")
+    monkeypatch.setenv("GN_RGCN_TF", "1" if path == "tf" else "0")
     gen = torch.Generator().manual_seed(n * 131 + fin)
     torch.manual_seed(n * 17 + fin)                                   # layer weights come from the global RNG
     sizes = [0, 9000, 3, 0, 700, 1, 2500, 0]
