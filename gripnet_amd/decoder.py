@@ -31,7 +31,13 @@ class _EdgeList:
 
 
 class multiRelaInnerProductDecoder(Module):
-    """``sigmoid(sum_k z[u,k] z[v,k] D[r,k])`` (reference decoder.py:19-23)."""
+    """``sigmoid(sum_k z[u,k] z[v,k] D[r,k])`` (reference decoder.py:19-23).
+
+    Ids outside the tables: the reference's advanced indexing raises IndexError at the call (a device synchronisation per
+    call).  Here the kernels write NaN for such an edge and set a per-device flag; the IndexError is raised at the next
+    synchronising check: ``gripnet_amd.utils.relation_metrics`` / ``auprc_auroc_ap`` / ``micro_macro`` / ``acc`` (the
+    points where the reference's epoch loop reads scores back) or an explicit ``_hip.raise_if_index_errors(device)``.
+    Static lists are validated once, when their plan is built, and raise there."""
 
     # edge lists remembered by plan_for: the reference's epoch loop scores four per epoch (train positives, fresh train
     # negatives, test positives, static test negatives: GripNet-pose.py:137-186)

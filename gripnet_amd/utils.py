@@ -128,8 +128,13 @@ def device_negative_sampler(pos_edge_index: torch.Tensor, num_nodes: int, range_
 
 def relation_metrics(pos_score: torch.Tensor, neg_score: torch.Tensor, range_list):
     """Per-relation (auprc, auroc, ap) on the GPU, float64 [R] each: what the reference's epoch loop computes
-    with one `auprc_auroc_ap` call per relation (GripNet-pose.py:148-160)."""
-    from ._hip import link_metrics
+    with one `auprc_auroc_ap` call per relation (GripNet-pose.py:148-160).
+
+    The metrics are where an epoch synchronises anyway, so this is also where an out-of-range id seen by the decoder
+    kernels since the last check becomes the reference's IndexError (the kernels write NaN scores and set a flag; see
+    multiRelaInnerProductDecoder)."""
+    from ._hip import link_metrics, raise_if_index_errors
+    raise_if_index_errors(pos_score.device)
     return link_metrics(pos_score, neg_score, range_list)
 
 
@@ -169,6 +174,10 @@ def shard_edge_ranges(num_edges: int, world_size: int) -> List[Tuple[int, int]]:
 
 # ---- evaluation metrics (host side, scikit-learn; reference: gripnet/utils.py:28-52) ----------------
 def _to_numpy(*tensors):
+    from ._hip import raise_if_index_errors
+    for t in tensors:                                   # the copy synchronises: a natural place for the deferred id check
+        if t.is_cuda:
+            raise_if_index_errors(t.device)
     return [t.detach().cpu().numpy() for t in tensors]
 
 

@@ -252,6 +252,14 @@ def test_errors(gpu):
     with pytest.raises(IndexError):
         _hip.raise_if_index_errors(gpu)
     _hip.raise_if_index_errors(gpu)                                # flag was cleared
+    # the metric helpers are the epoch loop's synchronisation points: the deferred IndexError surfaces there
+    out = dm(x, torch.tensor([[0, 7], [1, 0]], device=gpu), torch.tensor([0, 1], device=gpu))   # node 7 of 6
+    assert torch.isnan(out[1])
+    with pytest.raises(IndexError):
+        gripnet_amd.utils.relation_metrics(out[:1], out[:1], torch.tensor([[0, 1]]))
+    out = dm(x, torch.tensor([[0, 7], [1, 0]], device=gpu), torch.tensor([0, 1], device=gpu))
+    with pytest.raises(IndexError):
+        gripnet_amd.utils.auprc_auroc_ap(torch.tensor([1.0, 0.0], device=gpu), out)
 
 
 def test_empty_inputs(gpu):
