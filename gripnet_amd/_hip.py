@@ -21,7 +21,7 @@ _lock = threading.Lock()
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
 GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 120                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 121                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "gn_distmult_plan_destroy": (None, [_p]),
     "gn_distmult_plan_edges": (_i64, [_p]),
     "gn_distmult_plan_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _int, _p, _p]),
+    "gn_distmult_plan_forward_cols_f32": (_int, [_p, _p, _i64, _i64, _i64, _i64, _p, _i64, _int, _p, _p]),
     "gn_xtg_workspace_bytes": (_sz, [_i64, _i64]),
     "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
@@ -624,6 +625,13 @@ class DistMultPlan:
     def forward(self, z, weight, sigmoid, out):
         _call("gn_distmult_plan_forward_f32", self._h, ptr(z), ld(z), z.shape[1], ptr(weight), ld(weight),
               int(bool(sigmoid)), ptr(out), stream_ptr(z.device))
+        return out
+
+    def forward_cols(self, z, num_features, col_lo, col_hi, weight, sigmoid, out):
+        """Feature columns [col_lo, col_hi) of the scores (z may hold the first col_hi columns only); the launch with
+        col_lo = 0 starts the sums in `out`, the one with col_hi = num_features finishes them."""
+        _call("gn_distmult_plan_forward_cols_f32", self._h, ptr(z), ld(z), int(num_features), int(col_lo), int(col_hi),
+              ptr(weight), ld(weight), int(bool(sigmoid)), ptr(out), stream_ptr(z.device))
         return out
 
     def __del__(self):

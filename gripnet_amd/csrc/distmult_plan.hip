@@ -48,12 +48,18 @@ struct DmPlanArgs {
     int stride4;
     int keep_n;                // batches per wave whose partial sums stay in LDS between the phases
     int all_kept;              // no wave has more batches than that
+    int first_launch;          // the launch starts the sums (column 0 is its first column)
+    int last_launch;           // the launch finishes them (sigmoid, mirror positions); otherwise raw partial sums go to `out`
 };
 
 // All indices are 32-bit here (E < 2^31 is a plan invariant) and everything that depends on the batch only is scalar.
 template <int W4, int CPL>
 __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first,
-                                          bool last, uint32_t b_lo, uint32_t b_hi, uint32_t step, int wave, int lane, float* keep, int keep_n) {
+                                          bool last, uint32_t b_lo, uint32_t b_hi, uint32_t step, int wave, int lane, float* keep,
+                                          int keep_rd, int keep_wr) {
+    // keep_rd / keep_wr: how many of this wave's batches take their carried-in sum from / leave their sum in the LDS
+    // (the rest go through `out`); they differ from keep_n in the first phase of a launch that continues another
+    // launch's sums and in the last phase of a launch that does not finish them
     const int l4 = lane & 3;
     const float* __restrict__ dcol = a.d + c0 + 4 * l4;
     const uint32_t* __restrict__ pk = a.packed + lane;
@@ -84,13 +90,13 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
     // The partial sums of a wave's first keep_n batches wait for the next phase in LDS (`keep`: 256 bytes per batch,
     // beside the table) - the same wave works on the same batches in every phase; only batches beyond that go
     // through `out`.
-    float cnext = (!first && keep_n < 1 && o0 < e32) ? a.out[o0] : 0.f;
+    float cnext = (!first && keep_rd < 1 && o0 < e32) ? a.out[o0] : 0.f;
     int nb = 0;                                             // batch number of this wave (wave-uniform)
     for (; b < b_hi; b += kWavesPerWg, ++nb) {
         const uint32_t w = w0;
         const int rel = r0;
-        const bool kept = nb < keep_n;
-        const float carried = first ? 0.f : (kept ? keep[nb * 64] : cnext);
+        const bool kept_rd = nb < keep_rd, kept_wr = nb < keep_wr;
+        const float carried = first ? 0.f : (kept_rd ? keep[nb * 64] : cnext);
         const uint32_t bn = clampb(b + kWavesPerWg);
         const uint32_t mine = o0, mcur = mnext;
         w0 = w1; w1 = w2; r0 = r1; o0 = o1;
@@ -98,7 +104,7 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
         r1 = brel[clampb(b + 2 * kWavesPerWg)];
         if (need_own) o1 = own[clampb(b + 2 * kWavesPerWg) * 64u];
         if (need_mir) mnext = mir[bn * 64u];
-        cnext = (!first && nb + 1 >= keep_n && o0 < e32) ? a.out[o0] : 0.f;
+        cnext = (!first && nb + 1 >= keep_rd && o0 < e32) ? a.out[o0] : 0.f;
         const int iu = (int)(w & kNodeMask), iv = (int)((w >> kNodeBits) & kNodeMask);
         const bool valid = mine < e32;
         float result = 0.f;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void run_phase(const DmPlanArgs& a, const char* lds, 
             // the same unordered node pair under the same relation elsewhere in the list (the reversed copy of a
             // bidirectional edge, utils.py:132-138): z_u z_v is commutative, so that score is this one, bit for bit
             if (mcur != kNoMirror) a.out[mcur] = total;
-        } else if (kept) {
+        } else if (kept_wr) {
             keep[nb * 64] = total;
         } else if (valid) {
             a.out[mine] = total;
@@ -168,13 +174,15 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
         }
         __syncthreads();
         GN_DM_STAMP(2 + 3 * ph);
-        const bool first = ph == 0, last = ph == a.n_phases - 1;
+        const bool first = a.first_launch && ph == 0, last = a.last_launch && ph == a.n_phases - 1;
+        const int keep_rd = ph == 0 ? 0 : a.keep_n;                       // (a first phase carries nothing, or takes it from `out`)
+        const int keep_wr = (ph == a.n_phases - 1 && !a.last_launch) ? 0 : a.keep_n;
         switch (w4) {
-            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
-            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
-            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
-            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
-            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, a.keep_n); break;
+            case 16: run_phase<16, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, keep_rd, keep_wr); break;
+            case 12: run_phase<12, 3>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, keep_rd, keep_wr); break;
+            case 8: run_phase<8, 2>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, keep_rd, keep_wr); break;
+            case 4: run_phase<4, 1>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, keep_rd, keep_wr); break;
+            default: run_phase<0, 4>(a, lds, a.stride4 * 16, c0, w4, first, last, b_lo, b_hi, step, wave, lane, keep, keep_rd, keep_wr); break;
         }
         GN_DM_STAMP(3 + 3 * ph);
     }
@@ -345,13 +353,18 @@ void gn_distmult_plan_destroy(gn_distmult_plan* p) {
 
 int64_t gn_distmult_plan_edges(const gn_distmult_plan* plan) { return plan ? plan->num_edges : -1; }
 
-gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
-                                       const float* d, int64_t ld_d, int apply_sigmoid, float* out, void* stream) {
+}  // extern "C"
+
+// Columns [col_lo, col_hi) of the feature dimension in one launch; the launch with col_lo = 0 starts the sums, the one
+// with col_hi = num_features finishes them.
+static gn_status plan_forward_cols(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features, int64_t col_lo,
+                                   int64_t col_hi, const float* d, int64_t ld_d, int apply_sigmoid, float* out, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     if (plan->num_edges == 0) return GN_OK;
     GN_REQUIRE(z && d && out, "operand pointer is null");
-    GN_REQUIRE(num_features > 0 && ld_z >= num_features && ld_d >= num_features, "feature count / leading dimension mismatch");
-    const int64_t n = plan->num_nodes, f = num_features;
+    GN_REQUIRE(num_features > 0 && ld_z >= col_hi && ld_d >= num_features, "feature count / leading dimension mismatch");
+    GN_REQUIRE(0 <= col_lo && col_lo < col_hi && col_hi <= num_features && col_lo % 4 == 0, "column range outside the features");
+    const int64_t n = plan->num_nodes, f = col_hi - col_lo;
     DmPlanArgs a;
     a.n_phases = (f % 4 == 0 && ld_z % 4 == 0 && ld_d % 4 == 0 &&
                   ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0)
@@ -359,6 +372,9 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
     if (gn::fast_paths_disabled() || a.n_phases < 1 || a.n_phases > 4)
         return gn::fail(GN_ERR_UNSUPPORTED, "the planned decoder needs a node table that fits the LDS in at most four column "
                                             "phases (n = %lld, features = %lld): use gn_distmult_forward_f32", (long long)n, (long long)f);
+    for (int k = 0; k < a.n_phases; ++k) a.c0[k] += (int)col_lo;
+    a.first_launch = col_lo == 0;
+    a.last_launch = col_hi == num_features;
     a.z = z; a.ld_z = ld_z; a.n = (int)n; a.packed = plan->packed.p; a.batch_rel = plan->batch_rel.p; a.rel16 = plan->rel16.p; a.own = plan->own.p; a.mirror = plan->mirror.p;
     a.d = d; a.ld_d = ld_d; a.e = plan->num_edges; a.batches = plan->batches; a.sigmoid = apply_sigmoid; a.out = out;
     int max_w = 0;
@@ -373,12 +389,26 @@ gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float
     const int64_t per_wave = gn::ceil_div(plan->batches, groups * (kThreads / 64));
     const int64_t room = ((int64_t)160 * 1024 - 1024 - (int64_t)table_bytes) / ((kThreads / 64) * 256);
     a.keep_n = a.n_phases > 1 ? (int)std::max<int64_t>(0, std::min(per_wave, room)) : 0;
-    a.all_kept = a.n_phases > 1 && a.keep_n >= per_wave;
+    // (a launch that takes sums from, or leaves them to, another launch needs the edge positions in those phases too)
+    a.all_kept = a.n_phases > 1 && a.keep_n >= per_wave && a.first_launch && a.last_launch;
     const size_t lds_bytes = table_bytes + (size_t)a.keep_n * (kThreads / 64) * 256;
     { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_plan), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     k_distmult_plan<<<(unsigned)groups, kThreads, lds_bytes, gn::as_stream(stream)>>>(a);
     GN_LAUNCH_CHECK();
     return GN_OK;
+}
+
+extern "C" {
+
+gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
+                                       const float* d, int64_t ld_d, int apply_sigmoid, float* out, void* stream) {
+    return plan_forward_cols(plan, z, ld_z, num_features, 0, num_features, d, ld_d, apply_sigmoid, out, stream);
+}
+
+gn_status gn_distmult_plan_forward_cols_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
+                                            int64_t col_lo, int64_t col_hi, const float* d, int64_t ld_d, int apply_sigmoid,
+                                            float* out, void* stream) {
+    return plan_forward_cols(plan, z, ld_z, num_features, col_lo, col_hi, d, ld_d, apply_sigmoid, out, stream);
 }
 
 }  // extern "C"

@@ -19,6 +19,7 @@ GPU box, "gloo" in the CPU tests.  The arithmetic is behind ``kernels`` so that 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -78,6 +79,32 @@ class HipShardKernels:
     def score(self, z, sigmoid=True):
         return self.model.dmt(z, self.idx, self.et, sigmoid=sigmoid)
 
+    def score_input_columns(self, x, sigmoid=True):
+        """Starts the scores of my edge range on the columns of z that are the relational layer's INPUT (concat slot 0,
+        layers.py:264-266): they do not wait for the all-reduce.  Returns what score_rest needs, or None when the list
+        has no static plan (then score() does everything after the exchange)."""
+        dmt = self.model.dmt
+        if torch.is_grad_enabled() and (x.requires_grad or dmt.weight.requires_grad):
+            return None
+        if x.shape[1] % 4 != 0 or x.shape[1] >= dmt.in_dim:
+            return None
+        dmt.register_static(self.idx, self.et, num_nodes=x.shape[0])     # my edge range is scored every step
+        plan = dmt.plan_for(x, self.idx, self.et)
+        if plan is None or plan.num_nodes != x.shape[0]:
+            return None
+        out = torch.empty((self.idx.shape[1],), dtype=torch.float32, device=x.device)
+        try:
+            plan.forward_cols(self._hip.f32_rows(x), dmt.in_dim, 0, x.shape[1], dmt.weight, sigmoid, out)
+        except self._hip.GripNetHipError as err:                         # node table too large for the LDS
+            if err.status != self._hip.GN_ERR_UNSUPPORTED:
+                raise
+            return None
+        return plan, out, x.shape[1]
+
+    def score_rest(self, started, z, sigmoid=True):
+        plan, out, col = started
+        return plan.forward_cols(z, z.shape[1], col, z.shape[1], self.model.dmt.weight, sigmoid, out)
+
     # ---- training (autograd is recording: the modules route through gripnet_amd.autograd) ----
     def edge_gradients(self, x, gm):
         """This shard's share of the sums over edges in the relational layer's gradient."""
@@ -111,6 +138,9 @@ class ShardedPoseForward:
         self.in_dim, self.out_dim = conv.in_channels, conv.out_channels
         dev = data.train_idx.device
         self._partial = torch.empty((self.n_d, self.out_dim), dtype=torch.float32, device=dev)
+        # None: score the input columns beside the exchange when there is one; True / False force it (tests, measurements)
+        env = os.environ.get("GN_SHARD_OVERLAP")
+        self.overlap_decoder = None if env is None else env == "1"
 
     def all_reduce(self, t: torch.Tensor):
         if self.world_size > 1:
@@ -118,14 +148,34 @@ class ShardedPoseForward:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_begin(self, t: torch.Tensor):
+        """The exchange as an asynchronous collective: what is launched before `all_reduce_end` runs beside it."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    @staticmethod
+    def all_reduce_end(work):
+        if work is not None:
+            work.wait()
+
     def __call__(self, sigmoid: bool = True):
         k = self.kernels
         x = k.encode_genes()                                          # [n_d, in_dim], replicated
         out = torch.empty((self.n_d, self.in_dim + self.out_dim), dtype=torch.float32, device=x.device)
         k.partial(x, self._partial)                                   # un-normalised sum over my edge range
-        self.all_reduce(self._partial)                                # the one exchange step of the path
+        work = self.all_reduce_begin(self._partial)                   # the one exchange step of the path
+        # While the 82 KB travel: the decoder's first column phase.  z = [x | layer output] and the first 48 of its 80
+        # columns are x, which every rank already holds (a second launch: only worth it when there is an exchange).
+        started = None
+        if (self.overlap_decoder if self.overlap_decoder is not None else self.world_size > 1) and hasattr(k, "score_input_columns"):
+            started = k.score_input_columns(x, sigmoid=sigmoid)
+        self.all_reduce_end(work)
         # mean / root / bias / ReLU (layers.py:191-197,305) and concat slot 0 (layers.py:264-266)
         k.finalize(self._partial, x, out[:, self.in_dim:], out[:, :self.in_dim])
+        if started is not None:
+            return out, k.score_rest(started, out, sigmoid=sigmoid)
         return out, k.score(out, sigmoid=sigmoid)
 
 

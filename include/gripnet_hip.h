@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 120 /* 0.1.20 */
+#define GN_VERSION 121 /* 0.1.21 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -267,6 +267,16 @@ GN_API void gn_distmult_plan_destroy(gn_distmult_plan* plan);
 GN_API int64_t gn_distmult_plan_edges(const gn_distmult_plan* plan);
 GN_API gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
                                        const float* d, int64_t ld_d, int apply_sigmoid, float* out, void* stream);
+/* The same scores in several launches: feature columns [col_lo, col_hi) only (col_lo a multiple of 4; z and d point at
+ * column 0, ld_z >= col_hi).  The launch with col_lo = 0 starts the sums; a launch with col_hi < num_features leaves raw
+ * partial sums in `out` (at the edges' own positions), the next one continues from them; the launch with
+ * col_hi = num_features applies the sigmoid and fills the mirror positions.  Split at the column where the
+ * single launch would change phase (48 of 80 at 645 nodes) the scores are the same bits.  For the relation-sharded
+ * forward: the columns that are the relational layer's INPUT (concat slot 0 of homoGraph / interGraph, gripnet/layers.py:264-266)
+ * are scored while the all-reduce of the layer's partial sums is in flight. */
+GN_API gn_status gn_distmult_plan_forward_cols_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
+                                            int64_t col_lo, int64_t col_hi, const float* d, int64_t ld_d, int apply_sigmoid,
+                                            float* out, void* stream);
 
 /* Backward of the DistMult decoder (autograd of decoder.py:19-23 under the loss of GripNet-pose.py:140-146).
  * grad_logit[e] = d loss / d s_e (the caller folds the sigmoid derivative in).  dz [n, F] and dD [R, F]

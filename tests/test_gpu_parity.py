@@ -708,7 +708,47 @@ def test_sharded_forward_on_hip_kernels(gpu):
             scores.append(f.kernels.score(out))
         assert ranks[0].edge_hi == ranks[1].edge_lo
         close(torch.cat(scores), score_ref)
+        # the decoder's input columns scored beside the exchange (what a world_size > 1 job does): same z, same scores
+        if os.environ.get("GN_DISABLE_FAST") != "1":
+            over = ShardedPoseForward(model, data, 0, 1)
+            over.overlap_decoder = True
+            z2, s2 = over()
+            assert torch.equal(z2, z1)
+            close(s2, s1)                                             # (same bits only when the split is a phase boundary of the single launch)
+            z3, l3 = over(sigmoid=False)
+            close(l3, model(data, sigmoid=False)[1])
     _hip.raise_if_index_errors(gpu)
+
+
+@needs_fast_paths
+def test_decoder_plan_in_column_ranges(gpu):
+    """gn_distmult_plan_forward_cols_f32: the planned decoder in two or three launches over column ranges.  Split
+    where the single launch changes phase (48 | 32 at 645 nodes) the scores are the same bits; elsewhere they are the
+    same sums in another association.  The first launch may be given a table that holds the first columns only."""
+    gen = torch.Generator().manual_seed(5)
+    n, f, R = 645, 80, 9
+    sizes = [3000, 0, 41, 7000, 64, 1, 129, 900, 2]
+    ei = torch.cat([gripnet_amd.utils.to_bidirection(torch.randint(0, n, (2, s), generator=gen)) for s in sizes], dim=1).to(gpu)
+    et = torch.cat([torch.full((2 * s,), r, dtype=torch.int64) for r, s in enumerate(sizes)]).to(gpu)
+    z = torch.randn(n, f, generator=gen).to(gpu)
+    w = torch.randn(R, f, generator=gen).to(gpu)
+    plan = _hip.DistMultPlan(ei, et, n, R)
+    E = ei.shape[1]
+    for sigmoid in (True, False):
+        whole = plan.forward(z, w, sigmoid, torch.empty(E, device=gpu))
+        out = torch.full((E,), float("nan"), device=gpu)
+        plan.forward_cols(z[:, :48].contiguous(), f, 0, 48, w, sigmoid, out)      # a table of the first 48 columns only
+        plan.forward_cols(z, f, 48, 80, w, sigmoid, out)
+        assert torch.equal(out, whole)
+        out3 = torch.full((E,), float("nan"), device=gpu)
+        plan.forward_cols(z, f, 0, 16, w, sigmoid, out3)
+        plan.forward_cols(z, f, 16, 36, w, sigmoid, out3)
+        plan.forward_cols(z, f, 36, 80, w, sigmoid, out3)
+        close(out3, whole, 1e-5)
+    ref = orc.distmult(z.cpu(), ei.cpu(), et.cpu(), w.cpu(), sigmoid=True)
+    close(whole if sigmoid else torch.sigmoid(whole), ref)
+    with pytest.raises(ValueError):
+        plan.forward_cols(z, f, 2, 80, w, True, out)                              # not a multiple of 4
 
 
 # ---- the decoder's plan for static edge lists ---------------------------------------------------

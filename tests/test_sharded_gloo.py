@@ -88,6 +88,22 @@ class OracleShardKernels:
         return self.orc.distmult(z, d.train_idx[:, self.lo:self.hi], d.train_et[self.lo:self.hi],
                                  self.sd["dmt.weight"], sigmoid=sigmoid)
 
+    # the decoder in two parts (the input columns of z beside the exchange, the rest after it)
+    def _partial_scores(self, t, c0, c1):
+        d = self.data
+        idx, et = d.train_idx[:, self.lo:self.hi], d.train_et[self.lo:self.hi]
+        w = self.sd["dmt.weight"].detach()[:, c0:c1]
+        return (t[idx[0], c0:c1] * t[idx[1], c0:c1] * w[et]).sum(1)
+
+    def score_input_columns(self, x, sigmoid=True):
+        self.calls = getattr(self, "calls", 0) + 1
+        return self._partial_scores(x, 0, x.shape[1]), x.shape[1]
+
+    def score_rest(self, started, z, sigmoid=True):
+        part, col = started
+        s = part + self._partial_scores(z, col, z.shape[1])
+        return torch.sigmoid(s) if sigmoid else s
+
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, REPO)
@@ -107,6 +123,7 @@ def _worker(rank, world, port, q):
         fwd = ShardedPoseForward(model, data, rank, world, kernels=OracleShardKernels(sd, data, lo, hi))
         assert (fwd.edge_lo, fwd.edge_hi) == (lo, hi)
         z, score = fwd()
+        assert fwd.kernels.calls == 1                         # world_size > 1: the input columns were scored beside the exchange
         # every rank holds the same z; rank 0 gathers the score slices in rank order
         zs = [torch.empty_like(z) for _ in range(world)]
         dist.all_gather(zs, z)
