@@ -42,6 +42,7 @@ struct AggArgs {
     int rows;
     gn_side_copy side = {nullptr, 0, nullptr, 0, 0, 0, 0};   // optional fused row copy (dst == nullptr: none)
     int64_t nnz = -1;      // stored coefficients, when the caller knows them (picks the short-row kernel)
+    int64_t table_rows = -1;   // rows of the gathered table, when the caller knows them (picks the LDS-table kernel)
 };
 
 template <int VEC, int LPE>
@@ -395,6 +396,103 @@ inline gn_status launch_aggregate_transform(const AggArgs& a, const float* w, in
 }
 
 
+// Many short rows over a SMALL table (the (relation, source) sums of the relational layer's weight gradient: 6 x 10^5
+// rows of ~3 edges gathering from the 645 x 32 gradient rows): the table goes into LDS once per workgroup, and a row's
+// neighbours cost LDS reads instead of L2 round trips.  LPE lanes own a row (16 bytes of it each), 64 / LPE rows per
+// wave side by side; a wave works on two batches of rows at a time and reads the row bounds of the batches after them
+// while it does (the chain bounds -> ids -> table would otherwise be paid per batch).  Unit coefficients only.
+template <int LPE>
+__global__ __launch_bounds__(1024) void k_aggregate_lds_table(AggArgs a) {
+    constexpr int S = kWave / LPE;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ f32x4 tab[];
+    const int tid = threadIdx.x, lane = tid & 63, slot = lane / LPE, j = lane % LPE;
+    const bool col_live = 4 * j < a.features;
+    const int tj = col_live ? j : 0;
+    const int units = a.features / 4;                                  // float4 per table row
+    const int n_tab = (int)a.table_rows * units;
+    // (every workgroup reads the same table at the same time: each starts at its own offset, so that they do not all
+    // queue on the same L2 channel)
+    const int rot = (int)((blockIdx.x * 977u) % (unsigned)n_tab);
+    for (int k = tid; k < n_tab; k += 1024) {
+        int i = k + rot;
+        i = i < n_tab ? i : i - n_tab;
+        const int r = i / units, c = i - r * units;
+        tab[i] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)r * a.ld_table + 4 * c);
+    }
+    if (tid < units) tab[n_tab + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};    // one zero row: what the slots past a row's end read
+    __syncthreads();
+    const int wave = (int)blockIdx.x * 16 + (tid >> 6), n_waves = (int)gridDim.x * 16;
+    const int stride = n_waves * S;
+    const uint32_t zero_row = (uint32_t)a.table_rows;
+    int rowA = wave * S + slot, rowB = rowA + stride;
+    // (every load is unconditional with a clamped index: hipcc waits for conditional loads one by one)
+    const int last_row = a.rows - 1, last_id = (int)a.nnz - 1;
+    int bA = a.rowptr[min(rowA, last_row)], eA = a.rowptr[min(rowA, last_row) + 1];
+    int bB = a.rowptr[min(rowB, last_row)], eB = a.rowptr[min(rowB, last_row) + 1];
+    if (rowA >= a.rows) eA = bA;
+    if (rowB >= a.rows) eB = bB;
+    // software pipeline: the bounds run two pairs of batches ahead of the sums, the first eight ids of every row one
+    // pair ahead (the chain bounds -> ids -> table would otherwise be one HBM round trip after the other in every trip).
+    // Every lane of a row reads the row's ids itself, eight at a time as two 16-byte loads (4-byte aligned: the plan's
+    // id array has eight spare entries): handing them round with ds_bpermute cost more LDS time than the table reads.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto ids8 = [&](int first, u32x4& lo, u32x4& hi) {
+        const uint32_t* __restrict__ p = a.col + min(first, last_id);
+        __builtin_memcpy(&lo, p, 16);
+        __builtin_memcpy(&hi, p + 4, 16);
+    };
+    int nA = rowA + 2 * stride, nB = rowB + 2 * stride;
+    int nbA = a.rowptr[min(nA, last_row)], neA = a.rowptr[min(nA, last_row) + 1];
+    int nbB = a.rowptr[min(nB, last_row)], neB = a.rowptr[min(nB, last_row) + 1];
+    if (nA >= a.rows) neA = nbA;
+    if (nB >= a.rows) neB = nbB;
+    u32x4 iA0, iA1, iB0, iB1;
+    ids8(bA, iA0, iA1);
+    ids8(bB, iB0, iB1);
+    const uint32_t piece = (uint32_t)tj;
+    while (__any(rowA < a.rows)) {
+        const int mA = nA + 2 * stride, mB = nB + 2 * stride;
+        int mbA = a.rowptr[min(mA, last_row)], meA = a.rowptr[min(mA, last_row) + 1];
+        int mbB = a.rowptr[min(mB, last_row)], meB = a.rowptr[min(mB, last_row) + 1];
+        if (mA >= a.rows) meA = mbA;
+        if (mB >= a.rows) meB = mbB;
+        u32x4 jA0, jA1, jB0, jB1;                                      // the next pair's first ids
+        ids8(nbA, jA0, jA1);
+        ids8(nbB, jB0, jB1);
+        f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
+        // a slot past the row's end names the zero row, so the adds need no predicate
+        for (int base = 0; __any(bA + base < eA || bB + base < eB); base += 8) {
+            if (base > 0) { ids8(bA + base, iA0, iA1); ids8(bB + base, iB0, iB1); }      // (rows of more than eight edges)
+            const int leftA = eA - bA - base, leftB = eB - bB - base;
+            f32x4 vA[8], vB[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t ia = t < 4 ? iA0[t & 3] : iA1[t & 3], ib = t < 4 ? iB0[t & 3] : iB1[t & 3];
+                vA[t] = tab[(t < leftA ? ia : zero_row) * (uint32_t)units + piece];
+                vB[t] = tab[(t < leftB ? ib : zero_row) * (uint32_t)units + piece];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                accA += vA[t];
+                accB += vB[t];
+            }
+        }
+        {
+        if (rowA < a.rows && col_live) *reinterpret_cast<f32x4*>(a.out + (int64_t)rowA * a.ld_out + 4 * j) = accA;
+        if (rowB < a.rows && col_live) *reinterpret_cast<f32x4*>(a.out + (int64_t)rowB * a.ld_out + 4 * j) = accB;
+        }
+        rowA = nA; rowB = nB; bA = nbA; eA = neA; bB = nbB; eB = neB;
+        nA = mA; nB = mB; nbA = mbA; neA = meA; nbB = mbB; neB = meB;
+        iA0 = jA0; iA1 = jA1; iB0 = jB0; iB1 = jB1;
+    }
+}
+
+inline bool lds_table_disabled() {
+    const char* e = getenv("GN_DISABLE_LDS_TABLE");
+    return e && e[0] == '1';
+}
+
 template <int VEC>
 inline void launch_aggregate_lpe(const AggArgs& a, int lpe, int grid, hipStream_t st) {
     switch (lpe) {
@@ -427,6 +525,24 @@ inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
     int lpe = 1;
     while (lpe < units && lpe < kWave) lpe <<= 1;
     const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), GN_AGG_GRID);
+    // many short rows over a table that fits the LDS, nothing but a plain sum: the table is gathered from there
+    if (vec && lpe >= 4 && lpe <= 16 && a.nnz >= 0 && a.nnz < 8 * (int64_t)a.rows && a.rows >= 65536 && !a.coef && !a.rowdiv &&
+        !a.addend && !a.bias && !a.relu && !a.side.dst && a.table_rows > 0 &&
+        (size_t)a.table_rows * a.features * sizeof(float) <= 128 * 1024 && !fast_paths_disabled() && !lds_table_disabled()) {
+        const size_t lds = (size_t)(a.table_rows + 1) * a.features * sizeof(float);
+        const int wgs = (int)std::min<int64_t>(256, ceil_div((int64_t)a.rows * lpe, 2 * 1024));
+        gn_status ls;
+        switch (lpe) {
+            case 4: ls = allow_large_lds(reinterpret_cast<const void*>(k_aggregate_lds_table<4>), 160 * 1024); if (ls != GN_OK) return ls;
+                    k_aggregate_lds_table<4><<<wgs, 1024, lds, st>>>(a); break;
+            case 8: ls = allow_large_lds(reinterpret_cast<const void*>(k_aggregate_lds_table<8>), 160 * 1024); if (ls != GN_OK) return ls;
+                    k_aggregate_lds_table<8><<<wgs, 1024, lds, st>>>(a); break;
+            default: ls = allow_large_lds(reinterpret_cast<const void*>(k_aggregate_lds_table<16>), 160 * 1024); if (ls != GN_OK) return ls;
+                     k_aggregate_lds_table<16><<<wgs, 1024, lds, st>>>(a); break;
+        }
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     if (vec && lpe <= 16 && a.nnz >= 0 && a.nnz < 8 * (int64_t)a.rows && !fast_paths_disabled()) {
         const int sgrid = (int)std::min<int64_t>(ceil_div((int64_t)a.rows * lpe, 256), GN_AGG_GRID);
         switch (lpe) {

@@ -111,6 +111,7 @@ struct gn_graph_plan {
     // gn_graph_plan_build_blocked): destination rows in ranges x 16-row tiles, 16-bit source ids ordered for the LDS
     gn::DevBuf<float> dis;               // [rows] deg^-1/2 of every node (GCN plans)
     int unit_weights = 0;                // every stored weight (self loops included) is exactly 1
+    int plain_ones = 0;                  // a plain sum without weights: every coefficient is exactly 1
     int blk_ok = 0, blk_cols = 0;        // built for layers of up to blk_cols output features
     int blk_cw = 0;                      // columns per column group (2, or 1 for larger graphs)
     int blk_rows = 0;                    // rows of one column group of the table (nodes + the zero row, padded to 1 KB pieces)

@@ -21,7 +21,7 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     gn::AggArgs a;
     a.rowptr = plan->rowptr.p;
     a.col = reinterpret_cast<const uint32_t*>(plan->col.p);
-    a.coef = plan->coef.p;
+    a.coef = plan->plain_ones ? nullptr : plan->coef.p;       // (null = all ones)
     a.table = xw;
     a.ld_table = ld_xw;
     a.features = (int)num_features;
@@ -34,6 +34,7 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.ld_out = ld_out;
     a.rows = (int)plan->rows;
     a.nnz = plan->nnz;
+    a.table_rows = plan->table_rows;
     gn_status ss = gn::check_side(side, plan->rows, &a.side);
     if (ss != GN_OK) return ss;
     if (gn_blocked_applicable(plan, xw, ld_xw, num_features, weight, width))

@@ -257,7 +257,7 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
     plan->table_rows = n_src;
     plan->is_gcn = gcn ? 1 : 0;
     GN_HIP(plan->rowptr.alloc(n_dst + 1));
-    GN_HIP(plan->col.alloc(nnz));
+    GN_HIP(plan->col.alloc(nnz + 8));                   // (k_aggregate_lds_table reads a row's ids eight at a time)
     GN_HIP(plan->coef.alloc(nnz));
     k_rowptr<<<(int)gn::ceil_div(n_dst + 1, 256), 256, 0, st>>>(sorted_dst, (int)nnz, (int)n_dst, plan->rowptr.p);
     GN_LAUNCH_CHECK();
@@ -298,6 +298,7 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
     GN_HIP(hipMemcpyAsync(rp.data(), plan->rowptr.p, (n_dst + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
     plan->unit_weights = ones;
+    plan->plain_ones = (raw && w == nullptr) ? 1 : 0;
     int64_t mx = 0;
     for (int64_t i = 0; i < n_dst; ++i) mx = std::max<int64_t>(mx, rp[i + 1] - rp[i]);
     plan->max_row_nnz = mx;
