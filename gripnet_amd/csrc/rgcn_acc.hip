@@ -70,7 +70,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kTpg = GN_ACC_TPG;            // 16-row tiles per wave = accumulator tiles kept in registers
 constexpr int kWaves = GN_ACC_WAVES;         // waves per workgroup (one workgroup per CU: the node table fills its LDS)
 constexpr int kThreads = kWaves * 64;
-constexpr int kCus = 256;
 #ifndef GN_ACC_ITER_CAP
 #define GN_ACC_ITER_CAP 32
 #endif
@@ -491,7 +490,14 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     if (acc_disabled() || N < 1 || N > 2500 || R < 1 || E < 1) return GN_OK;
     const int tiles = (int)gn::ceil_div(N, 16);
     const int Q = (int)gn::ceil_div(tiles, kTpg);
-    const int G = std::max(1, kCus / Q);
+    int cus = 256;                                                   // MI355X; asked of the device the plan is built on
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    const int G = std::max(1, cus / Q);
     if (R * N >= ((int64_t)1 << 31) || R * tiles >= ((int64_t)1 << 28)) return GN_OK;
 
     Scratch tmp;
