@@ -526,7 +526,7 @@ inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
     while (lpe < units && lpe < kWave) lpe <<= 1;
     const int grid = (int)std::min<int64_t>(ceil_div(a.rows, 4), GN_AGG_GRID);
     // many short rows over a table that fits the LDS, nothing but a plain sum: the table is gathered from there
-    if (vec && lpe >= 4 && lpe <= 16 && a.nnz >= 0 && a.nnz < 8 * (int64_t)a.rows && a.rows >= 65536 && !a.coef && !a.rowdiv &&
+    if (vec && lpe >= 4 && lpe <= 16 && a.nnz > 0 && a.nnz < 8 * (int64_t)a.rows && a.rows >= 65536 && !a.coef && !a.rowdiv &&
         !a.addend && !a.bias && !a.relu && !a.side.dst && a.table_rows > 0 &&
         (size_t)a.table_rows * a.features * sizeof(float) <= 128 * 1024 && !fast_paths_disabled() && !lds_table_disabled()) {
         const size_t lds = (size_t)(a.table_rows + 1) * a.features * sizeof(float);

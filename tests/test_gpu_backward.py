@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import gripnet_amd
+from gripnet_amd import _hip
 from gripnet_amd.pipeline import AminerModel, FreebaseCModel
 from gripnet_amd.synth import make_nc
 from oracle import gripnet_oracle as orc
@@ -500,3 +501,28 @@ def test_rgcn_shard_gradient_shares_add_up(gpu):
     for name, f, p, q in zip(("dx", "dbasis", "datt"), full, a, b):
         scale = max(1.0, float(f.abs().max()))
         close((p + q) / scale, f / scale, 1e-4, what=name)
+
+
+@pytest.mark.parametrize("features,table_rows", [(32, 645), (16, 1500), (64, 300)])
+def test_short_row_sums_over_a_small_table(gpu, monkeypatch, features, table_rows):
+    """The (relation, source) sums of the relational layer's weight gradient at their real shape: ~10^5 rows of a few
+    edges over a table that fits the LDS (k_aggregate_lds_table), with empty rows, rows of more than eight edges and the
+    last rows of the grid; against index_add in float64, and equal to the wave-per-row kernels' result."""
+    gen = torch.Generator().manual_seed(features + table_rows)
+    rows, edges = 70001, 190000
+    dst = torch.randint(0, rows, (edges,), generator=gen)
+    dst[:4000] = torch.randint(0, 40, (4000,), generator=gen)                  # forty long rows
+    dst[4000:4100] = rows - 1                                                   # the last row is long too
+    src = torch.randint(0, table_rows, (edges,), generator=gen)
+    ei = torch.stack([src, dst]).to(gpu)
+    table = torch.randn(table_rows, features, generator=gen).to(gpu)
+    ref = torch.zeros(rows, features, dtype=torch.float64, device=gpu).index_add_(0, ei[1], table.double().index_select(0, ei[0]))
+    outs = []
+    for disabled in ("0", "1"):
+        monkeypatch.setenv("GN_DISABLE_LDS_TABLE", disabled)
+        plan = _hip.GraphPlan.plain_sum(ei, table_rows, rows)
+        out = torch.full((rows, features), float("nan"), device=gpu)
+        plan.aggregate(table, None, False, out)
+        assert (out.double() - ref).abs().max().item() <= 1e-4
+        outs.append(out)
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
