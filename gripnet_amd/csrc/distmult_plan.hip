@@ -270,52 +270,61 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
     std::vector<int64_t> mirror_of(E, -1);
     std::vector<char> covered(E, 0);
     {
-        std::unordered_map<uint64_t, int64_t> open;
-        open.reserve((size_t)E);
+        // open addressing on a power-of-two table (keys are unique per open triple; an erased slot keeps its key with
+        // value -1 so that probe chains stay intact)
+        size_t cap = 1;
+        while (cap < (size_t)E * 2 + 16) cap <<= 1;
+        std::vector<uint64_t> keys(cap, ~(uint64_t)0);
+        std::vector<int64_t> vals(cap, -1);
         for (int64_t e = 0; e < E; ++e) {
             const uint64_t lo = (uint64_t)std::min(hu[e], hv[e]), hi = (uint64_t)std::max(hu[e], hv[e]);
             const uint64_t key = ((uint64_t)hr[e] << (2 * kNodeBits)) | (lo << kNodeBits) | hi;
-            auto it = open.find(key);
-            if (it != open.end()) {
-                mirror_of[it->second] = e;
+            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while (keys[h] != ~(uint64_t)0 && keys[h] != key) h = (h + 1) & (cap - 1);
+            if (keys[h] == key && vals[h] >= 0) {                // the open copy of this triple: pair up
+                mirror_of[vals[h]] = e;
                 covered[e] = 1;
-                open.erase(it);
-            } else {
-                open.emplace(key, e);
+                vals[h] = -1;
+            } else {                                            // first (or third, fifth, ...) copy: stays open
+                keys[h] = key;
+                vals[h] = e;
             }
         }
     }
-    // batches: 64 consecutive scored edges each, in list order
-    std::vector<uint32_t> packed, own, mirror;
-    std::vector<int32_t> batch_rel;
-    std::vector<uint16_t> rel16;
-    int slot_of_edge[64];
-    int64_t cu[64], cv[64], ce[64];
-    int64_t scan = 0;
-    while (scan < E) {
-        int count = 0;
-        for (; scan < E && count < 64; ++scan)
-            if (!covered[scan]) { cu[count] = hu[scan]; cv[count] = hv[scan]; ce[count] = scan; ++count; }
-        if (count == 0) break;
-        deal_batch(cu, cv, count, slot_of_edge);
-        bool uniform = true;
-        for (int k = 1; k < count; ++k) uniform = uniform && hr[ce[k]] == hr[ce[0]];
-        const size_t s0 = packed.size();
-        packed.resize(s0 + 64); own.resize(s0 + 64); mirror.resize(s0 + 64); rel16.resize(s0 + 64);
-        batch_rel.push_back(uniform ? (int32_t)hr[ce[0]] : -1);
-        bool taken[64] = {false};
-        auto fill = [&](int s, int k) {
-            const int64_t e = ce[k];
-            packed[s0 + s] = (uint32_t)hu[e] | ((uint32_t)hv[e] << kNodeBits);
-            own[s0 + s] = (uint32_t)e;
-            rel16[s0 + s] = (uint16_t)hr[e];
-            mirror[s0 + s] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
-        };
-        for (int k = 0; k < count; ++k) { taken[slot_of_edge[k]] = true; fill(slot_of_edge[k], k); }
-        // a slot without an edge repeats the batch's first one: the same score into the same positions
-        for (int s = 0; s < 64; ++s)
-            if (!taken[s]) fill(s, 0);
-    }
+    // batches: 64 consecutive scored edges each, in list order; a batch's slots are dealt independently of the others
+    std::vector<int64_t> scored;
+    scored.reserve((size_t)E);
+    for (int64_t e = 0; e < E; ++e)
+        if (!covered[e]) scored.push_back(e);
+    const int64_t NBs = gn::ceil_div((int64_t)scored.size(), 64);
+    std::vector<uint32_t> packed((size_t)NBs * 64), own((size_t)NBs * 64), mirror((size_t)NBs * 64);
+    std::vector<int32_t> batch_rel((size_t)NBs);
+    std::vector<uint16_t> rel16((size_t)NBs * 64);
+    gn::parallel_for(NBs, 64, [&](int64_t b0, int64_t b1) {
+        int slot_of_edge[64];
+        int64_t cu[64], cv[64], ce[64];
+        for (int64_t bi = b0; bi < b1; ++bi) {
+            const int count = (int)std::min<int64_t>(64, (int64_t)scored.size() - bi * 64);
+            for (int k = 0; k < count; ++k) { ce[k] = scored[bi * 64 + k]; cu[k] = hu[ce[k]]; cv[k] = hv[ce[k]]; }
+            deal_batch(cu, cv, count, slot_of_edge);
+            bool uniform = true;
+            for (int k = 1; k < count; ++k) uniform = uniform && hr[ce[k]] == hr[ce[0]];
+            const size_t s0 = (size_t)bi * 64;
+            batch_rel[bi] = uniform ? (int32_t)hr[ce[0]] : -1;
+            bool taken[64] = {false};
+            auto fill = [&](int s, int k) {
+                const int64_t e = ce[k];
+                packed[s0 + s] = (uint32_t)hu[e] | ((uint32_t)hv[e] << kNodeBits);
+                own[s0 + s] = (uint32_t)e;
+                rel16[s0 + s] = (uint16_t)hr[e];
+                mirror[s0 + s] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
+            };
+            for (int k = 0; k < count; ++k) { taken[slot_of_edge[k]] = true; fill(slot_of_edge[k], k); }
+            // a slot without an edge repeats the batch's first one: the same score into the same positions
+            for (int s = 0; s < 64; ++s)
+                if (!taken[s]) fill(s, 0);
+        }
+    });
     const int64_t NB = (int64_t)batch_rel.size();
     gn_distmult_plan* p = new gn_distmult_plan();
     p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = NB;

@@ -398,62 +398,77 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     // tiles of 16 rows; a row's edges are dealt to the 4 lanes of its quad, 4 ids per lane and iteration.  Which edge
     // goes into which (iteration, slot) is free (the order of a sum), so it is chosen for the LDS: ds_read_b64 (and
     // b32) serves lanes 0-31 and 32-63 as two access groups, conflict-free when the ids of a group differ mod 32.
-    std::vector<int32_t> tile_off(1, 0), tile_rows, cell;
-    std::vector<uint16_t> ids;
+    // (the ranges are scheduled independently of each other, on the plan builders' threads, and concatenated in order)
+    struct RangeOut { std::vector<int32_t> tile_iters, tile_rows; std::vector<uint16_t> ids; bool failed = false; };
+    std::vector<RangeOut> built(R);
     const uint16_t zero_id = (uint16_t)N;
-    for (int r = 0; r < R; ++r) {
-        const std::vector<int32_t>& rows = range_rows[r];
-        const int tiles_r = (int)gn::ceil_div((int64_t)rows.size(), 16);
-        const int first_tile = (int)tile_off.size() - 1;
-        for (int tl = 0; tl < tiles_r; ++tl) {
-            int32_t trow[16], rem[16];
-            std::vector<uint16_t> bucket[16][32];
-            int iters = 0;
-            for (int qi = 0; qi < 16; ++qi) {
-                const size_t k = (size_t)tl * 16 + qi;
-                trow[qi] = k < rows.size() ? rows[k] : -1;
-                rem[qi] = 0;
-                if (trow[qi] < 0) continue;
-                for (int32_t p = rp[trow[qi]]; p < rp[trow[qi] + 1]; ++p) bucket[qi][col[p] & 31].push_back((uint16_t)col[p]);
-                rem[qi] = rp[trow[qi] + 1] - rp[trow[qi]];
-                iters = std::max(iters, (rem[qi] + 15) / 16);
-            }
-            for (int qi = 0; qi < 16; ++qi) tile_rows.push_back(trow[qi]);
-            const size_t base = ids.size();
-            ids.resize(base + (size_t)iters * 256, zero_id);
-            for (int itn = 0; itn < iters; ++itn)
-                for (int s = 0; s < 4; ++s)                               // one LDS instruction: slot s of every lane
-                    for (int half = 0; half < 2; ++half) {                // its two access groups: rows 0-7, rows 8-15
-                        bool used[32] = {false};
-                        int rows_by_need[8];
-                        for (int k = 0; k < 8; ++k) rows_by_need[k] = half * 8 + k;
-                        std::sort(rows_by_need, rows_by_need + 8, [&](int x, int y) { return rem[x] > rem[y]; });
-                        const int left = (iters - itn) * 4 - s;           // instructions left, this one included
-                        for (int k = 0; k < 8; ++k) {
-                            const int qi = rows_by_need[k];
-                            for (int jl = 0; jl < 4; ++jl) {
-                                if (rem[qi] == 0) break;
-                                // must this lane take an edge now?  (4 lanes x (left - 1) instructions remain after this one)
-                                const bool must = rem[qi] > (left - 1) * 4 + (3 - jl);
-                                int best = -1; size_t bestn = 0;
-                                for (int c = 0; c < 32; ++c)
-                                    if (!used[c] && bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
-                                if (best < 0) {
-                                    if (!must) continue;                  // sits this slot out: the zero row
+    gn::parallel_for(R, 1, [&](int64_t r0, int64_t r1) {
+        std::vector<uint16_t> bucket[16][32];
+        for (int64_t r = r0; r < r1; ++r) {
+            const std::vector<int32_t>& rows = range_rows[r];
+            RangeOut& o = built[r];
+            const int tiles_r = (int)gn::ceil_div((int64_t)rows.size(), 16);
+            for (int tl = 0; tl < tiles_r; ++tl) {
+                int32_t trow[16], rem[16];
+                int iters = 0;
+                for (int qi = 0; qi < 16; ++qi) {
+                    for (int c = 0; c < 32; ++c) bucket[qi][c].clear();
+                    const size_t k = (size_t)tl * 16 + qi;
+                    trow[qi] = k < rows.size() ? rows[k] : -1;
+                    rem[qi] = 0;
+                    if (trow[qi] < 0) continue;
+                    for (int32_t p = rp[trow[qi]]; p < rp[trow[qi] + 1]; ++p) bucket[qi][col[p] & 31].push_back((uint16_t)col[p]);
+                    rem[qi] = rp[trow[qi] + 1] - rp[trow[qi]];
+                    iters = std::max(iters, (rem[qi] + 15) / 16);
+                }
+                for (int qi = 0; qi < 16; ++qi) o.tile_rows.push_back(trow[qi]);
+                const size_t base = o.ids.size();
+                o.ids.resize(base + (size_t)iters * 256, zero_id);
+                for (int itn = 0; itn < iters; ++itn)
+                    for (int s = 0; s < 4; ++s)                               // one LDS instruction: slot s of every lane
+                        for (int half = 0; half < 2; ++half) {                // its two access groups: rows 0-7, rows 8-15
+                            bool used[32] = {false};
+                            int rows_by_need[8];
+                            for (int k = 0; k < 8; ++k) rows_by_need[k] = half * 8 + k;
+                            std::sort(rows_by_need, rows_by_need + 8, [&](int x, int y) { return rem[x] > rem[y]; });
+                            const int left = (iters - itn) * 4 - s;           // instructions left, this one included
+                            for (int k = 0; k < 8; ++k) {
+                                const int qi = rows_by_need[k];
+                                for (int jl = 0; jl < 4; ++jl) {
+                                    if (rem[qi] == 0) break;
+                                    // must this lane take an edge now?  (4 lanes x (left - 1) instructions remain after this one)
+                                    const bool must = rem[qi] > (left - 1) * 4 + (3 - jl);
+                                    int best = -1; size_t bestn = 0;
                                     for (int c = 0; c < 32; ++c)
-                                        if (bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                        if (!used[c] && bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                    if (best < 0) {
+                                        if (!must) continue;                  // sits this slot out: the zero row
+                                        for (int c = 0; c < 32; ++c)
+                                            if (bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                    }
+                                    o.ids[base + ((size_t)itn * 64 + qi * 4 + jl) * 4 + s] = bucket[qi][best].back();
+                                    bucket[qi][best].pop_back();
+                                    used[best] = true;
+                                    --rem[qi];
                                 }
-                                ids[base + ((size_t)itn * 64 + qi * 4 + jl) * 4 + s] = bucket[qi][best].back();
-                                bucket[qi][best].pop_back();
-                                used[best] = true;
-                                --rem[qi];
                             }
                         }
-                    }
-            for (int qi = 0; qi < 16; ++qi)
-                if (rem[qi] != 0) return gn::fail(GN_ERR_UNSUPPORTED, "internal: an edge was not scheduled");
-            tile_off.push_back(tile_off.back() + iters);
+                for (int qi = 0; qi < 16; ++qi)
+                    if (rem[qi] != 0) o.failed = true;
+                o.tile_iters.push_back(iters);
+            }
         }
+    });
+    std::vector<int32_t> tile_off(1, 0), tile_rows, cell;
+    std::vector<uint16_t> ids;
+    for (int r = 0; r < R; ++r) {
+        RangeOut& o = built[r];
+        if (o.failed) return gn::fail(GN_ERR_UNSUPPORTED, "internal: an edge was not scheduled");
+        const int tiles_r = (int)o.tile_iters.size();
+        const int first_tile = (int)tile_off.size() - 1;
+        for (int tl = 0; tl < tiles_r; ++tl) tile_off.push_back(tile_off.back() + o.tile_iters[tl]);
+        tile_rows.insert(tile_rows.end(), o.tile_rows.begin(), o.tile_rows.end());
+        ids.insert(ids.end(), o.ids.begin(), o.ids.end());
         // the range's tiles, cut into the contiguous ranges of the workgroup's waves by iterations (+ a cost per tile)
         auto cost_upto = [&](int tl) { return (int64_t)(tile_off[first_tile + tl] - tile_off[first_tile]) + 2 * (int64_t)tl; };
         int wt = 0;
@@ -470,6 +485,7 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
             cell.push_back(0); cell.push_back(0); cell.push_back(0);
             wt = wt1;
         }
+        o = RangeOut();
     }
     const int64_t iters_total = tile_off.back();
     for (int k = 0; k < 6; ++k) tile_off.push_back((int32_t)iters_total);

@@ -675,11 +675,11 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     for (int g = 0; g < 4; ++g)
         for (int k = 0; k < 4; ++k) pos_in_group[kGroupRows[g][k]] = k;
     for (size_t i = 0; i < stream16.size(); ++i) stream16[i] = (uint16_t)(N + pos_in_group[(i / kBI) & 15]);   // padding: four zero rows, one per slot
-    {
-        std::vector<uint16_t> byclass;                       // one row's sources, grouped by slot class
+    // (every (relation, tile) writes its own stream blocks: the relations are spread over the plan builders' threads)
+    gn::parallel_for(R, 4, [&](int64_t rel0, int64_t rel1) {
         int cur[16][4], end[16][4], rem[16];
         std::vector<uint16_t> rowbuf[16];
-        for (int64_t r = 0; r < R; ++r)
+        for (int64_t r = rel0; r < rel1; ++r)
             for (int tile = 0; tile < tiles; ++tile) {
                 const int32_t L = iters[r * tiles + tile];
                 if (L == 0) continue;
@@ -743,7 +743,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
                     }
                 }
             }
-    }
+    });
     GN_HIP(plan->acc_stream.alloc((size_t)words));
     GN_HIP(plan->acc_units.alloc(units.size() * (sizeof(AccUnit) / sizeof(int32_t))));
     GN_HIP(plan->acc_wave_units.alloc(wave_units.size()));
