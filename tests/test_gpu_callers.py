@@ -311,3 +311,21 @@ def test_sampled_negatives_are_scored_from_their_packed_pairs(gpu):
         close(dm(z, neg, data.train_et), orc.distmult(z.cpu(), neg.cpu(), data.train_et.cpu(), dm.weight.detach().cpu()),
               what="modified list")
     _hip.raise_if_index_errors(gpu)
+
+
+@needs_fast_paths
+def test_plans_do_not_depend_on_the_builder_threads(gpu, monkeypatch):
+    """The host side of the plan builders runs on GN_PLAN_THREADS threads; every chunk writes its own slice of a plan,
+    so one thread and sixteen build the same plans: the forward is the same bits (gene, relational and decoder plans)."""
+    data = make_pose("pose0-syn").to(gpu)
+    outs = []
+    for threads in ("1", "16"):
+        monkeypatch.setenv("GN_PLAN_THREADS", threads)
+        torch.manual_seed(1111)
+        model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+        with torch.no_grad():
+            model(data)                                              # first sighting of the positive list
+            z, score = model(data)                                   # second: the decoder's plan
+        assert model.dmt.plan_for(z, data.train_idx, data.train_et) is not None
+        outs.append((z, score))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
