@@ -325,11 +325,25 @@ void free_graph_plan(gn_graph_plan* p) {
 }
 
 // ---- RGCN ------------------------------------------------------------------------------------
-__global__ void k_indegree(const int64_t* __restrict__ dst, int64_t E, int64_t N, int32_t* __restrict__ cnt,
-                           int32_t* __restrict__ err) {
+// In-degree of every destination.  A supervertex of a few hundred nodes under millions of edges (PoSE: 645 under 2 M)
+// puts thousands of atomic adds on every counter: each workgroup counts into an LDS histogram first when the counters
+// fit there (8,192 nodes), and adds its non-zero bins once (520 -> 43 us on pose0-syn).
+__global__ __launch_bounds__(256) void k_indegree(const int64_t* __restrict__ dst, int64_t E, int64_t N, int32_t* __restrict__ cnt,
+                                                   int32_t* __restrict__ err) {
+    __shared__ int32_t bins[8192];
+    const bool local = N <= 8192;
+    if (local) {
+        for (int i = threadIdx.x; i < (int)N; i += blockDim.x) bins[i] = 0;
+        __syncthreads();
+    }
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t d = dst[e];
-        if ((uint64_t)d < (uint64_t)N) atomicAdd(&cnt[d], 1); else atomicOr(err, 1);
+        if ((uint64_t)d < (uint64_t)N) atomicAdd(local ? &bins[d] : &cnt[d], 1); else atomicOr(err, 1);
+    }
+    if (local) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (int)N; i += blockDim.x)
+            if (bins[i] != 0) atomicAdd(&cnt[i], bins[i]);
     }
 }
 
