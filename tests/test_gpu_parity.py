@@ -749,6 +749,23 @@ def test_decoder_plan_in_column_ranges(gpu):
     close(whole if sigmoid else torch.sigmoid(whole), ref)
     with pytest.raises(ValueError):
         plan.forward_cols(z, f, 2, 80, w, True, out)                              # not a multiple of 4
+    # a table that needs several column phases inside each launch (1,200 nodes: 16 columns per phase): partial sums
+    # wait in LDS between the phases of a launch and travel through `out` between the launches
+    n2 = 1200
+    ei2 = torch.cat([gripnet_amd.utils.to_bidirection(torch.randint(0, n2, (2, s), generator=gen)) for s in sizes], dim=1).to(gpu)
+    z2 = torch.randn(n2, 64, generator=gen).to(gpu)
+    w2 = torch.randn(R, 64, generator=gen).to(gpu)
+    plan2 = _hip.DistMultPlan(ei2, et, n2, R)
+    whole2 = plan2.forward(z2, w2, True, torch.empty(E, device=gpu))
+    ref2 = orc.distmult(z2.cpu(), ei2.cpu(), et.cpu(), w2.cpu(), sigmoid=True)
+    close(whole2, ref2)
+    for cut in (16, 32, 48):
+        out2 = torch.full((E,), float("nan"), device=gpu)
+        plan2.forward_cols(z2, 64, 0, cut, w2, True, out2)
+        plan2.forward_cols(z2, 64, cut, 64, w2, True, out2)
+        close(out2, ref2)
+        if cut == 32:
+            assert torch.equal(out2, whole2)                                      # the single launch's phases are 32 + 32 columns
 
 
 # ---- the decoder's plan for static edge lists ---------------------------------------------------
