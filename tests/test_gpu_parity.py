@@ -373,9 +373,12 @@ def test_rgcn_lds_resident_shapes(gpu, monkeypatch, n, fin, bases, path):
     close(y, ref.float())
 
 
-def test_rgcn_sharded_partials_sum_to_full(gpu):
+@pytest.mark.parametrize("formulation", ["acc", "tf"])
+def test_rgcn_sharded_partials_sum_to_full(gpu, monkeypatch, formulation):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
-    (the multi-GPU contract, here run sequentially on one device)."""
+    (the multi-GPU contract, here run sequentially on one device); with either formulation of the
+    LDS-resident relational kernel."""
+    monkeypatch.setenv("GN_RGCN_TF", "1" if formulation == "tf" else "0")
     data = make_pose("small").to(gpu)
     n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
     conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
