@@ -17,8 +17,8 @@
 //       The product runs as three bf16 MFMAs on split operands (hi.hi + hi.lo + lo.hi, fp32
 //       accumulate; GN_ACC_EXACT=1 selects the fp32 matrix instruction): the fp32 MFMA runs at the
 //       fp32 vector rate and shares the SIMD's issue with the gather's adds.
-// Edge lists reach the waves as one private, contiguous stream per wave of 128-byte blocks: 4
-// "iterations" x 16 rows of uint16 source ids; rows without an edge in an iteration point at one of
+// Edge lists reach the waves as one private, contiguous stream per wave of 64-byte blocks: 2
+// "iterations" x 16 rows of uint16 source ids (GN_ACC_BLOCK_ITERS; 4 = 128-byte blocks); rows without an edge in an iteration point at one of
 // four zero rows of the LDS table (no branches, no bounds).  Which edge of a row goes into which
 // iteration is decided at plan time for the LDS: per iteration, the four rows of a ds_read_b128
 // access group read four different bank slots wherever the graph allows it (conflict cycles are
@@ -75,9 +75,10 @@ constexpr int kThreads = kWaves * 64;
 #endif
 constexpr int kIterCap = GN_ACC_ITER_CAP;       // iterations per unit and tile: longer (relation, row) lists are cut into chunks
 #ifndef GN_ACC_BLOCK_ITERS
-#define GN_ACC_BLOCK_ITERS 4
+#define GN_ACC_BLOCK_ITERS 2
 #endif
-constexpr int kBI = GN_ACC_BLOCK_ITERS;      // gather iterations per stream block (4: 128-byte blocks, 2: 64-byte blocks)
+constexpr int kBI = GN_ACC_BLOCK_ITERS;      // gather iterations per stream block (4: 128-byte blocks, 2: 64-byte blocks; a tile's
+                                             // iterations are rounded up to whole blocks: 2 pads less, 101.5 vs 102.3 us per pose0-syn step)
 static_assert(kBI == 4 || kBI == 2, "stream blocks hold two or four iterations");
 constexpr int kStage = 8;          // 128-byte units per LDS window of a wave (1 KB)
 constexpr int kStageBlocks = kStage * 4 / kBI;   // stream blocks per window
