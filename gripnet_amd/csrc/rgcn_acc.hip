@@ -78,8 +78,8 @@ constexpr int kIterCap = GN_ACC_ITER_CAP;       // iterations per unit and tile:
 #define GN_ACC_BLOCK_ITERS 2
 #endif
 constexpr int kBI = GN_ACC_BLOCK_ITERS;      // gather iterations per stream block (4: 128-byte blocks, 2: 64-byte blocks; a tile's
-                                             // iterations are rounded up to whole blocks: 2 pads less, 101.5 vs 102.3 us per pose0-syn step)
-static_assert(kBI == 4 || kBI == 2, "stream blocks hold two or four iterations");
+                                             // iterations are rounded up to whole blocks: 2 pads less, 101.5 vs 102.3 us per pose0-syn step; 1: no further gain)
+static_assert(kBI == 4 || kBI == 2 || kBI == 1, "stream blocks hold one, two or four iterations");
 constexpr int kStage = 8;          // 128-byte units per LDS window of a wave (1 KB)
 constexpr int kStageBlocks = kStage * 4 / kBI;   // stream blocks per window
 constexpr int kFoutAcc = 32;       // out_features (slab layout of k_rgcn_slab_finalize)
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     u32x4* stage = reinterpret_cast<u32x4*>(lds4 + (a.n + 4) * XS) + wave * (kStage * 8);
     const u32x2* stage2 = reinterpret_cast<const u32x2*>(stage) + grow;          // kBI == 4: 8 bytes per row and block
     const uint32_t* stage1 = reinterpret_cast<const uint32_t*>(stage) + grow;    // kBI == 2: 4 bytes per row and block
+    const uint16_t* stage0 = reinterpret_cast<const uint16_t*>(stage) + grow;    // kBI == 1: 2 bytes per row and block
     __syncthreads();
 #ifdef GN_STAMPS
     const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
     };
     refill();
     u32x2 wnext;                                                  // LDS is in order per wave: no wait after the stores
-    if constexpr (kBI == 4) wnext = stage2[0]; else wnext = (u32x2){stage1[0], 0u};
+    if constexpr (kBI == 4) wnext = stage2[0]; else if constexpr (kBI == 2) wnext = (u32x2){stage1[0], 0u}; else wnext = (u32x2){stage0[0], 0u};
 
     for (; u < u_end; ++u) {
         const AccUnit dn = units[u + 1 < u_end ? u + 1 : u];     // scalar load, a whole unit ahead
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
             for (int k = 0; k < nb; ++k) {
                 const u32x2 w = wnext;
                 if (++pos == kStageBlocks) refill();
-                if constexpr (kBI == 4) wnext = stage2[pos * 16]; else wnext.x = stage1[pos * 16];
+                if constexpr (kBI == 4) wnext = stage2[pos * 16]; else if constexpr (kBI == 2) wnext.x = stage1[pos * 16]; else wnext.x = stage0[pos * 16];
 #if GN_ACC_MODE & 4      // every lane reads the same table row: the gather without bank conflicts
                 const uint32_t s0 = pos, s1 = pos + 1, s2 = pos + 2, s3 = pos + 3 + (w.x & w.y & 1u);
 #else
@@ -300,9 +301,12 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_acc(const float* __restrict__
                 if constexpr (kBI == 4) {
 #pragma unroll
                     for (int p = 0; p < KP; ++p) s[p] += (r0[4 * p] + r1[4 * p]) + (r2[4 * p] + r3[4 * p]);
-                } else {
+                } else if constexpr (kBI == 2) {
 #pragma unroll
                     for (int p = 0; p < KP; ++p) s[p] += r0[4 * p] + r1[4 * p];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < KP; ++p) s[p] += r0[4 * p];
                 }
 #endif
             }
