@@ -21,6 +21,34 @@ import torch
 EPS = 1e-13  # reference: gripnet/utils.py:10
 
 
+def normalize(input: torch.Tensor) -> torch.Tensor:
+    """Rows scaled to unit L2 norm (reference: gripnet/utils.py:13-15)."""
+    return input / torch.sqrt((input ** 2).sum(dim=1).view(-1, 1))
+
+
+def sparse_id(n: int) -> torch.Tensor:
+    """n x n sparse COO identity, fp32 values, int64 indices, on the CPU (reference: gripnet/utils.py:18-25).
+
+    Every driver builds its node features with it (`GripNet-pose.py:50`, `GripNet-aminer.py:58`); the layers ignore
+    that tensor under ``start_graph=True`` (`layers.py:261-262`), so it never reaches a kernel.  Uncoalesced, like the
+    reference's ``torch.sparse.FloatTensor(i, v, size)``."""
+    idx = torch.arange(int(n), dtype=torch.int64)
+    return torch.sparse_coo_tensor(torch.stack([idx, idx]), torch.ones(int(n), dtype=torch.float32), (int(n), int(n)))
+
+
+def load_graph(pt_file_path: str = "./sample_graph.pt"):
+    """``torch.load`` of a pickled graph (reference: gripnet/utils.py:55-80).  The reference's files are pickled
+    ``torch_geometric.data.Data`` objects: unpickling them needs torch_geometric installed."""
+    return torch.load(pt_file_path, weights_only=False)
+
+
+def load_node_idx_to_id_dict(pkl_file_path: str = "./data/pose-1/map.pkl"):
+    """Index -> entity id map of a dataset directory (reference: gripnet/utils.py:83-95)."""
+    import pickle
+    with open(pkl_file_path, "rb") as f:
+        return pickle.load(f)
+
+
 def to_bidirection(edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None):
     """Append the reversed copy of every edge (reference: gripnet/utils.py:132-138)."""
     both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
@@ -44,6 +72,38 @@ def get_range_list(parts: Sequence[torch.Tensor], is_node: bool = False) -> torc
     ends = np.cumsum(sizes, dtype=np.int64)
     starts = ends - np.asarray(sizes, dtype=np.int64)
     return torch.from_numpy(np.stack([starts, ends], axis=1).reshape(-1, 2).astype(np.int64))
+
+
+def process_edge(raw_edges: torch.Tensor, rng: Optional[np.random.RandomState] = None):
+    """One-relation train / test split (reference: gripnet/utils.py:151-165): keep src > dst, Bernoulli(0.9) per
+    undirected edge, both halves back to the bidirectional layout."""
+    half = remove_bidirection(raw_edges)
+    in_train = (rng or np.random).binomial(1, 0.9, half.shape[1]).astype(bool)
+    return (to_bidirection(half[:, torch.from_numpy(np.flatnonzero(in_train))]),
+            to_bidirection(half[:, torch.from_numpy(np.flatnonzero(~in_train))]))
+
+
+def process_node(raw_nodes: torch.Tensor, p: float = 0.9, rng: Optional[np.random.RandomState] = None):
+    """Bernoulli train / test split of a node list (reference: gripnet/utils.py:201-209; like the reference the
+    draw uses 0.9 whatever ``p`` says)."""
+    in_train = (rng or np.random).binomial(1, 0.9, len(raw_nodes)).astype(bool)
+    return raw_nodes[torch.from_numpy(np.flatnonzero(in_train))], raw_nodes[torch.from_numpy(np.flatnonzero(~in_train))]
+
+
+def process_node_multilabel(raw_nodes_list: Sequence[torch.Tensor], rng: Optional[np.random.RandomState] = None):
+    """Per-class node split, class-sorted layout and ranges (reference: gripnet/utils.py:212-247).
+    Returns ``train_idx, train_class, train_range, test_idx, test_class, test_range``."""
+    tr, te = [], []
+    for nodes in raw_nodes_list:
+        a, b = process_node(nodes, rng=rng)
+        tr.append(a)
+        te.append(b)
+
+    def classes(parts):
+        return torch.cat([torch.full((int(q.shape[0]),), c, dtype=torch.long) for c, q in enumerate(parts)])
+
+    return (torch.cat(tr), classes(tr), get_range_list(tr, is_node=True),
+            torch.cat(te), classes(te), get_range_list(te, is_node=True))
 
 
 def process_edge_multirelational(

@@ -424,6 +424,60 @@ def main():
                   n_class=data.n_a_type)
     c.save()
 
+    # (11) the remaining helpers the drivers import by name (utils.py:13-25,151-165,201-247); added last -----
+    c = Case("utils_helpers")
+    sp = ref_utils.sparse_id(7)
+    c.put("sparse_id.indices", sp._indices()); c.put("sparse_id.values", sp._values())
+    c.put("sparse_id.shape", np.asarray(sp.shape)); c.put("sparse_id.dense", sp.to_dense())
+    xn = randn(6, 5)
+    c.put("normalize.in", xn); c.put("normalize.out", ref_utils.normalize(xn))
+    both = ref_utils.to_bidirection(torch.stack([randint(30, 25), randint(30, 25)]))
+    c.put("process_edge.in", both)
+    np.random.seed(777)
+    tr, te = ref_utils.process_edge(both)
+    c.put("process_edge.train", tr); c.put("process_edge.test", te)
+    node_lists = [randint(100, s) for s in (11, 0, 23, 5)]
+    for i, nl in enumerate(node_lists):
+        c.put("nodes{}".format(i), nl)
+    np.random.seed(778)
+    outs = ref_utils.process_node_multilabel(node_lists)
+    for k, v in zip(("train_idx", "train_class", "train_range", "test_idx", "test_class", "test_range"), outs):
+        c.put("multilabel." + k, v)
+    c.meta.update(n=7, seed_edge=777, seed_nodes=778, n_lists=len(node_lists),
+                  sparse_layout=str(sp.layout), sparse_dtype=str(sp.dtype), sparse_device=str(sp.device))
+    c.save()
+
+    # (12) what every caller imports from the package, by name: {script: {module: [names]}} (names only, as data) -----
+    import ast
+    callers = ["GripNet-pose.py", "GripNet-aminer.py", "GripNet-freebase-a.py", "GripNet-freebase-b.py",
+               "GripNet-freebase-c.py", "GripNet-freebase-d.py", "baselines/LP_baselines/rgcn_pose.py",
+               "baselines/LP_baselines/dmt_pose.py", "baselines/LP_baselines/TransE_DistMult_ComplEx_RotatE.py"]
+    names = {}
+    for rel in callers:
+        with open(os.path.join(REFERENCE, rel)) as f:
+            tree = ast.parse(f.read())
+        per = {}
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "gripnet":
+                per.setdefault(node.module, []).extend(a.name for a in node.names)
+        names[rel] = {m: sorted(set(v)) for m, v in sorted(per.items())}
+    public = {}                                  # every top-level def / class / constant of the three library modules
+    for mod in ("utils", "layers", "decoder"):
+        with open(os.path.join(REFERENCE, "gripnet", mod + ".py")) as f:
+            tree = ast.parse(f.read())
+        found = []
+        for node in tree.body:
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                found.append(node.name)
+            elif isinstance(node, ast.Assign):
+                found.extend(t.id for t in node.targets if isinstance(t, ast.Name))
+        public["gripnet." + mod] = sorted(found)
+    names["__library_top_level__"] = public
+    path = os.path.join(HERE, "driver_imports.json")
+    with open(path, "w") as f:
+        json.dump(names, f, indent=1, sort_keys=True)
+    print("wrote", os.path.relpath(path, REPO))
+
 
 if __name__ == "__main__":
     main()
