@@ -211,8 +211,11 @@ __global__ __launch_bounds__(kColThreads) void k_col_gather(ColArgs a, int stamp
     int t = c0;
     vec_t bias = (vec_t)(0.f);
     if (a.bias) bias = *reinterpret_cast<const vec_t*>(a.bias + CW * cg);
-    // 24 (+ 1 for the bias) vector loads were issued behind the DMA loads; loads return in issue order
-    if (a.bias) asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // the LDS-DMA loads have landed
+    // Everything requested so far has to be here: the LDS-DMA loads, and with them the id / row / scale loads issued
+    // behind them.  (Loads return in issue order, so a count that lets exactly those later loads stay in flight would
+    // release the barrier a little earlier - measured: the same total, the gather needs the first ids at once - but such
+    // a count depends on how many vector loads the compiler emits for the lines above.  Zero does not.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef GN_STAMPS
     const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();

@@ -107,7 +107,8 @@ class myGCN(Module):
         n = x.size(0)
         def build():
             plan = _hip.GraphPlan.gcn(edge_index, n, edge_weight, self.improved)
-            plan.build_blocked(self.out_channels)        # LDS-staged gathers where the graph qualifies
+            if self.cached:                              # LDS-staged gathers where the graph qualifies: a host-side
+                plan.build_blocked(self.out_channels)    # schedule of the CSR, worth it only for a graph that is kept
             return plan
         plan = self._plan(edge_index, build)
         return self._run(plan, x, n, _out, _relu, _side)

@@ -55,6 +55,7 @@ class HipShardKernels:
         self.et = data.train_et[lo:hi].contiguous()
 
     def encode_genes(self):
+        self.weights.ready = False            # set again by this call's combined launch, if it takes one (cowork_done)
         z = self.model.gg(None, self.data.gg_edge_index, edge_weight=self.data.edge_weight, if_catout=True)
         return self.model.gd(z, self.data.gd_edge_index, mod="cat", if_relu=True, _cowork=self.weights)
 
@@ -256,10 +257,15 @@ class ShardedPoseTraining(ShardedPoseForward):
         neg = k.score_edges(z, neg_index[:, self.edge_lo:self.edge_hi].contiguous())
         E = float(self.total_edges)
         local = -(torch.log(pos + self.EPS).sum() + torch.log(1 - neg + self.EPS).sum()) / E
-        local.backward()
         dw = k.decoder_weight()
-        if dw.grad is not None:
+        kept, dw.grad = dw.grad, None                                      # only THIS step's share is exchanged: what
+        local.backward()                                                   # earlier steps accumulated is already a sum
+        if dw.grad is not None:                                            # over ranks (zero_grad=False)
             self.all_reduce(dw.grad)
+            if kept is not None:
+                dw.grad += kept
+        else:
+            dw.grad = kept
         loss = local.detach().clone()
         return self.all_reduce(loss)
 

@@ -109,18 +109,19 @@ GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* 
  * gn_transform_fusable tells without launching. */
 GN_API int gn_transform_fusable(int64_t in_features, int64_t out_features);
 
-/* Source-blocked encoding of a GCN plan for LDS-staged gathers (the gene supervertex of PoSE: 19,081 nodes, 1.45 M
- * stored edges).  Applies to plans whose stored weights are all exactly 1, self loops included (edge_weight NULL or
- * ones and not `improved`: every GripNet caller, GripNet-pose.py:52,117-120): norm_e = dis[src] dis[dst] then
- * factorises and an edge is a 16-bit source id inside one of <= 16 source blocks whose rows of dis * (x W) fit 160 KB
- * of LDS.  gn_graph_aggregate_f32 takes this path (two launches: per-block partial sums from LDS, combine in block
- * order; fixed summation order) when the plan has it and the shapes are covered: out_features 16 or 32 <= cols, with
- * `weight` num_features in {16,32,64}, x 16-byte aligned with ld % 4 == 0.  The transform x W then runs on the matrix
- * cores while the rows stream into LDS (bf16 x 3 split product, <= 2^-17 relative per product; GN_GEMM_EXACT=1
- * selects the fp32 instruction).  The per-block partial sums live in scratch the PLAN owns: calls on one plan must be
- * stream-ordered.  Graphs that do not qualify (weighted, `improved`, fewer than 4,096 nodes, more than 16 blocks)
- * keep the wave-per-row kernels and the call returns GN_OK; gn_graph_plan_blocked_cols tells (0 = not built).
- * Copies the CSR to the host once and synchronises `stream`. */
+/* Column-group encoding of a GCN plan for LDS-staged gathers (the gene supervertex of PoSE: 19,081 nodes, 1.45 M
+ * stored edges; gcn_blocked.hip).  Applies to plans whose stored weights are all exactly 1, self loops included
+ * (edge_weight NULL or ones and not `improved`: every GripNet caller, GripNet-pose.py:52,117-120): norm_e =
+ * dis[src] dis[dst] then factorises and an edge is a 16-bit source id.  The table T = dis * (x W) is cut by COLUMNS:
+ * a workgroup holds two fp32 columns (one above ~19,900 nodes, up to ~39,800) of EVERY node in 160 KB of LDS, so it
+ * owns its destination rows outright - no partial sums, no combine pass.  gn_graph_aggregate_f32 takes this path (two
+ * launches: the exact-fp32 transform writing T column-group-major into scratch the PLAN owns, then the gather from
+ * LDS; fixed summation order) when the plan has the encoding and the shapes are covered: out_features 16 or 32 <= cols,
+ * with `weight` num_features in {16,32,64}, x 16-byte aligned with ld % 4 == 0.  Calls on one plan must be
+ * stream-ordered (the scratch table).  Graphs that do not qualify (weighted, `improved`, fewer than 4,096 nodes or
+ * fewer than 16 stored edges per node, too many nodes for one column in LDS) keep the wave-per-row kernels and the call
+ * returns GN_OK; gn_graph_plan_blocked_cols tells (0 = not built).  Copies the CSR to the host once, schedules it there
+ * and synchronises `stream`: meant for graphs that are kept (the Python layer builds it only for `cached=True`). */
 GN_API gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t cols, void* stream);
 GN_API int64_t gn_graph_plan_blocked_cols(const gn_graph_plan* plan);
 

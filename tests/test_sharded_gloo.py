@@ -143,7 +143,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, steps=1):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
@@ -161,6 +161,8 @@ def _train_worker(rank, world, port, q):
         neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=torch.Generator().manual_seed(5))
         step = ShardedPoseTraining(model, data, rank, world, kernels=OracleShardKernels(sd, data, lo, hi))
         loss = step.step(neg)
+        for _ in range(steps - 1):                                 # gradient accumulation: same inputs, grads add up
+            loss = step.step(neg, zero_grad=False)
         q.put((rank, float(loss), {k: (None if v.grad is None else v.grad.numpy()) for k, v in sd.items()}))
     finally:
         dist.destroy_process_group()
@@ -220,9 +222,12 @@ def test_world_size_one_needs_no_process_group():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_training_step_equals_single_process():
+@pytest.mark.parametrize("steps", [1, 2])
+def test_two_rank_sharded_training_step_equals_single_process(steps):
     """Forward + backward with the dd edges on two ranks: the loss and every parameter gradient equal the
-    single-process ones (torch autograd through the oracle), on BOTH ranks."""
+    single-process ones (torch autograd through the oracle), on BOTH ranks.  steps = 2: a second step with
+    zero_grad=False accumulates - every gradient doubles, the decoder weight's included (its exchange must carry
+    only the new step's share)."""
     sys.path.insert(0, REPO)
     from gripnet_amd.pipeline import PoseModel
     from gripnet_amd.synth import make_pose
@@ -230,7 +235,7 @@ def test_two_rank_sharded_training_step_equals_single_process():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, steps)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
@@ -254,6 +259,6 @@ def test_two_rank_sharded_training_step_equals_single_process():
             if k in unused:
                 continue
             assert grads[k] is not None, k
-            err = (torch.from_numpy(grads[k]) - v.grad).abs().max().item()
-            scale = max(1.0, v.grad.abs().max().item())
+            err = (torch.from_numpy(grads[k]) - steps * v.grad).abs().max().item()
+            scale = steps * max(1.0, v.grad.abs().max().item())
             assert err <= 2e-5 * scale, "rank {} {}: {:.3e}".format(rank, k, err)
