@@ -178,6 +178,18 @@ struct gn_rgcn_plan {
     int acc_tiles = 0, acc_q = 0, acc_g = 0;
     int64_t acc_blocks = 0;
     int acc_ok = 0;
+    // destination-major path (rgcn_pair.hip): a workgroup owns up to three destination rows outright; per wave one
+    // flat stream of 64-byte blocks (4 lane groups x 4 edges, each a 32-bit LDS byte offset of a relation's att row)
+    gn::DevBuf<uint32_t> pair_stream;     // blocks of 16 words
+    gn::DevBuf<uint32_t> pair_wave_first; // [groups * 8] first block of every wave
+    gn::DevBuf<uint32_t> pair_desc;       // eight dwords per unit: eight uint16 block counts, chunk | row << 8; pages of eight units per wave
+    gn::DevBuf<uint32_t> pair_wave_units; // [groups * 8] units of every wave
+    gn::DevBuf<uint32_t> pair_wave_desc;  // [groups * 8] first descriptor of every wave
+    gn::DevBuf<int32_t> pair_wg_dst;      // [groups][4] destination rows of a workgroup (-1: none)
+    gn::DevBuf<int32_t> pair_perm;        // [chunks * 32] source node of every K position (num_nodes: none)
+    int pair_groups = 0, pair_d = 0, pair_chunks = 0;
+    int64_t pair_blocks = 0;
+    int pair_ok = 0;
     // transform-then-gather path (rgcn_tf.hip): one workgroup per relation slice, per-wave word streams
     gn::DevBuf<uint32_t> tf_stream;       // 64 bytes per pair of iterations: 16 quads x 2 uint16 source words
     gn::DevBuf<int32_t> tf_wg_parts;      // [groups + 1] ranges of slices

@@ -377,6 +377,8 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
                                       const std::vector<int64_t>& ranges_host, hipStream_t st);
 
 // Implemented in rgcn_acc.hip: per-wave unit lists for the register-accumulated path.
+gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
+                                  const std::vector<int64_t>& ranges, hipStream_t st);
 gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
                                  const std::vector<int64_t>& ranges_host, hipStream_t st);
 
@@ -571,6 +573,8 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
     if (fs != GN_OK) return bail(fs);
     fs = gn_rgcn_build_acc_plan(p, src, dst, ranges, st);
     if (fs != GN_OK) return bail(fs);
+    fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
+    if (fs != GN_OK) return bail(fs);
 #undef GN_TRY
     *out = p;
     return GN_OK;
@@ -592,6 +596,13 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->tf_part_rel.release();
     p->tf_part_wave.release();
     p->tf_cell_row.release();
+    p->pair_stream.release();
+    p->pair_wave_first.release();
+    p->pair_desc.release();
+    p->pair_wave_units.release();
+    p->pair_wave_desc.release();
+    p->pair_wg_dst.release();
+    p->pair_perm.release();
     p->acc_stream.release();
     p->acc_units.release();
     p->acc_wave_units.release();

@@ -17,6 +17,13 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
                                const float* bias, int64_t fout, int relu, int partial, int weights_ready, float* out,
                                int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
+// rgcn_pair.hip
+bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
+                               const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
+                               int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
+                               hipStream_t st);
+
 // rgcn_acc.hip
 bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
 size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
@@ -116,6 +123,9 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     gn_status ss = gn::check_side(side, N, &sc);
     if (ss != GN_OK) return ss;
 
+    if (gn_rgcn_pair_applicable(plan, fin, fout, bases) && (reinterpret_cast<uintptr_t>(basis) & 15) == 0)
+        return gn_rgcn_pair_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
+                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, st);
     if (gn_rgcn_acc_applicable(plan, fin, fout, bases))
         return gn_rgcn_acc_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, weights_ready,
                                    out, ld_out, sc, workspace, workspace_bytes, st);

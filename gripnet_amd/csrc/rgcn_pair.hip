@@ -1,0 +1,826 @@
+// Multi-relational internal layer (myRGCN, gripnet/layers.py:165-197) for small supervertices, destination-major in
+// basis space.
+//
+//   out[i] * deg_i = sum_{e: dst=i} x[src_e] W_{r(e)},  W_r = sum_b att[r,b] basis[b]            (layers.py:172-189)
+//                  = sum_b ( sum_s P_i[s,b] x[s,:] ) basis[b],   P_i[s,:] = sum_{e: s -> i} att[r(e),:]
+//
+// W_r is never formed.  What is gathered per edge is the 128-byte att row of its relation (the whole att table sits in
+// LDS), summed per (destination, source) PAIR; what the matrix cores contract is the dense [bases x sources] block P_i
+// of a destination with the node table x (K = every source node, the same K order for all destinations, so x is a shared
+// MFMA operand that stays in registers); what is left per destination is U_i [bases x in], contracted with basis in the
+// epilogue together with the mean, the root term, the bias and the activation.  A workgroup owns its destination rows
+// outright: no partial sums cross workgroups, no slabs, no finalisation launch, no atomics; results are bitwise
+// reproducible.
+//
+// Lane mapping of the gather = the A-operand layout of v_mfma_f32_16x16x32_bf16: lane (c = lane & 15, kg = lane >> 4)
+// holds bases {BT*c .. BT*c+BT-1} of the eight sources k = 8*kg + t, t = 0..7, of a 32-source chunk.  The four lane
+// groups run four (destination, source) pairs in lock step; a pair's edges come in blocks of four (one 32-bit word per
+// lane quad position, rotated through the quad with DPP so that one ds_read_b32 of the stream serves four steps).
+// The products run as bf16 MFMAs on operands split into three bf16 terms (x = hi + mid + lo exactly): six products
+// hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi in fp32 accumulators, dropping terms below 2^-24 of |p||x| - the same
+// order as fp32's own rounding.  GN_RGCN_ARITH_FAST keeps two terms and three products (<= 2^-16 per product).
+#include "common.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <numeric>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWaves = 8, kThreads = kWaves * 64;
+constexpr int kRowBytes = 128;             // LDS stride of an att row (32 bases; fewer: zero padded)
+constexpr int kRingBlocks = 64;            // per-wave window on its stream: 64 blocks of 64 bytes, refilled a quarter at a time
+constexpr int kRingBytes = kRingBlocks * 64;
+constexpr int kMaxD = 3;                   // destination rows per workgroup
+constexpr int kMaxChunks = 255;            // chunks of 32 sources (a descriptor names its chunk in eight bits)
+constexpr int kSectionCap = 64;            // (<= 255: a descriptor holds a section's blocks in eight bits)
+                                           // pair becomes several units (running sums stay short: fp32 chains of <= 64)
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kSlackBlocks = 192;          // readable blocks behind the last wave's stream (the window reads ahead)
+
+struct PairArgs {
+    const float* x;
+    int64_t ld_x;
+    const float* att;
+    const float* basis;
+    const float* root;
+    const float* bias;
+    const float* indeg;
+    float* out;
+    int64_t ld_out;
+    const uint32_t* stream;
+    const uint32_t* wave_first;          // [groups * 8] first block of a wave's stream
+    const uint32_t* wave_units;          // [groups * 8] units of a wave
+    const uint32_t* wave_desc;           // [groups * 8] first descriptor of a wave (eight dwords each, pages of eight)
+    const uint32_t* desc;
+    const int32_t* wg_dst;
+    const int32_t* perm;
+    int n, R, B, fout, chunks, relu, partial, att_dma;
+    gn_side_copy side;
+};
+
+#ifdef GN_STAMPS
+__device__ unsigned long long g_pair_stamps[2][256 * 8][12];
+#endif
+
+__device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ float bfloat(uint32_t v) { return __builtin_bit_cast(float, v); }
+
+// (v1, v0) -> their bf16 terms, packed {v0 | v1 << 16} per term: v = hi + mid + lo exactly (three 8-bit pieces of the
+// 24-bit significand, each cut by truncation, which keeps every remainder exact).
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const uint32_t a0 = fbits(v0), a1 = fbits(v1);
+    hi = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float r0 = v0 - bfloat(a0 & 0xffff0000u), r1 = v1 - bfloat(a1 & 0xffff0000u);
+    const uint32_t b0 = fbits(r0), b1 = fbits(r1);
+    mid = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    const float s0 = r0 - bfloat(b0 & 0xffff0000u), s1 = r1 - bfloat(b1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(fbits(s1), fbits(s0), 0x07060302u);
+}
+
+template <int BT>
+struct Acc;                                  // BT floats per lane and (destination, source) pair
+template <>
+struct Acc<1> { typedef float type; };
+template <>
+struct Acc<2> { typedef f32x2 type; };
+
+// State of a wave's walk over its stream (uniform, except the lane constants).
+struct Walk {
+    uint32_t lane_off;    // LDS address of this lane's bases inside att row 0
+    uint32_t ring_lane;   // LDS address of this lane's word inside block 0 of the wave's window
+    uint32_t lane16;      // lane * 16: this lane's bytes of a 1 KB refill
+    uint32_t soff;        // byte offset inside the window of the next word to request
+    uint32_t sdma;        // byte offset inside the wave's stream of the next refill
+    uint32_t ring_base;   // LDS address of the window
+    const uint32_t* sbase;   // the wave's stream
+};
+
+// ---- the gather of one unit, as ONE block of assembly (tools/gen_pair_asm.py writes it; the comment there explains
+// the pipeline).  Written in assembly because the compiler, given the same sequence as separate statements, copies the
+// destination registers of LDS requests still in flight and spends ~45 instructions per block on the control flow of
+// the pipeline; this is 22.  Physical registers v216-v249 and s92-s95 belong to the block (clobbers). ----
+#include "rgcn_pair_asm.inc"
+
+#define GN_UNIT_OPERANDS(p)                                                                                            \
+    : [p0] "=&v"(p[0]), [p1] "=&v"(p[1]), [p2] "=&v"(p[2]), [p3] "=&v"(p[3]), [p4] "=&v"(p[4]), [p5] "=&v"(p[5]),     \
+      [p6] "=&v"(p[6]), [p7] "=&v"(p[7]), [soff] "+s"(w.soff), [sdma] "+s"(w.sdma)                                    \
+    : [lo] "v"(w.lane_off), [rlane] "v"(w.ring_lane), [l16] "v"(w.lane16), [rbase] "s"(w.ring_base),                  \
+      [sbase] "s"(w.sbase), [c03] "s"(c03), [c47] "s"(c47)                                                            \
+    : "memory", "scc", "s92", "s93", "s94", "s95", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",    \
+      "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", \
+      "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249"
+
+// c03 / c47: the block counts of the unit's eight sections, eight bits each.
+template <int BT>
+__device__ __forceinline__ void gather_unit(Walk& w, uint32_t c03, uint32_t c47, typename Acc<BT>::type (&p)[8]) {
+    if constexpr (BT == 2) asm volatile(GN_PAIR_UNIT_ASM_B64 GN_UNIT_OPERANDS(p));
+    else asm volatile(GN_PAIR_UNIT_ASM_B32 GN_UNIT_OPERANDS(p));
+}
+
+template <int NT>
+struct XRaw { float v[8][NT]; };             // x[source(8 kg + t)][NT c + j]: this lane's share of a chunk, fp32
+template <int NT>
+struct XFrag { uint32_t w[NT][3][4]; };      // the same as MFMA B operands: [N tile][term][8 bf16]
+
+template <int NT>
+__device__ __forceinline__ void load_chunk(const PairArgs& a, int chunk, int kg, int c, XRaw<NT>& raw) {
+    const bool live = chunk < a.chunks;
+    const int32_t* pk = a.perm + (size_t)(live ? chunk : 0) * 32 + 8 * kg;
+    int32_t s[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s[t] = pk[t];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool ok = live && s[t] < a.n;
+        const float* row = a.x + (int64_t)(ok ? s[t] : 0) * a.ld_x + NT * c;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float v = row[j];
+            raw.v[t][j] = ok ? v : 0.f;
+        }
+    }
+}
+
+template <int NT, int TERMS>
+__device__ __forceinline__ void split_chunk(const XRaw<NT>& raw, XFrag<NT>& f) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t hi, mid, lo;
+            split_pair(raw.v[2 * i][j], raw.v[2 * i + 1][j], hi, mid, lo);
+            f.w[j][0][i] = hi;
+            f.w[j][1][i] = mid;
+            f.w[j][2][i] = TERMS == 3 ? lo : 0u;
+        }
+}
+
+__device__ __forceinline__ bf16x8 as_frag(const uint32_t (&w)[4]) {
+    u32x4 v = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// acc[jm][jn] += P (bases x 32 sources) . X (32 sources x in) for one destination row and one chunk.
+template <int NT, int BT, int TERMS>
+__device__ __forceinline__ void contract(const typename Acc<BT>::type (&p)[8], const XFrag<NT>& xf, f32x4 (&acc)[BT][NT]) {
+#pragma unroll
+    for (int jm = 0; jm < BT; ++jm) {
+        uint32_t t0[4], t1[4], t2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v0, v1;
+            if constexpr (BT == 2) { v0 = p[2 * i][jm]; v1 = p[2 * i + 1][jm]; } else { v0 = p[2 * i]; v1 = p[2 * i + 1]; }
+            split_pair(v0, v1, t0[i], t1[i], t2[i]);
+        }
+        const bf16x8 ph = as_frag(t0), pm = as_frag(t1), pl = as_frag(t2);
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            const bf16x8 xh = as_frag(xf.w[jn][0]), xm = as_frag(xf.w[jn][1]);
+            f32x4 c = acc[jm][jn];
+            if constexpr (TERMS == 3) {                                       // smallest terms first
+                const bf16x8 xl = as_frag(xf.w[jn][2]);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, xh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, xl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, xm, c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, xh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, xm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, xh, c, 0, 0, 0);
+            acc[jm][jn] = c;
+        }
+    }
+}
+
+template <int NT, int BT, int TERMS>
+__global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_set) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    typedef typename Acc<BT>::type acc_t;
+    constexpr int FIN = 16 * NT, BP = 16 * BT, KP = BP * FIN;                 // padded bases, entries of U per destination
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x;
+    const int c = lane & 15, kg = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    const uint32_t att_bytes = (uint32_t)(a.R + 2) * kRowBytes;
+    const uint32_t ring0 = (att_bytes + 1023u) & ~1023u;
+#ifdef GN_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // ---- prologue: this wave's window on its stream, the att table, the wave's first chunk of x ----
+    const uint32_t wave_id = (uint32_t)(g * kWaves + wave);
+    const uint32_t first_block = a.wave_first[wave_id], n_units = a.wave_units[wave_id];
+    const uint32_t* __restrict__ desc = a.desc + (size_t)a.wave_desc[wave_id] * 8;
+    Walk w;
+    w.ring_base = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wave * kRingBytes);
+    {
+        // the stream address as scalars (a saddr operand of the refill below), whatever the compiler thinks of its uniformity
+        const uint64_t sb = reinterpret_cast<uint64_t>(a.stream + (size_t)first_block * 16);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+        w.sbase = reinterpret_cast<const uint32_t*>((uint64_t)hi << 32 | lo);
+    }
+    w.lane_off = lds0 + (uint32_t)c * (BT * 4);
+    w.ring_lane = w.ring_base + (uint32_t)kg * 16u + (uint32_t)(lane & 3) * 4u;
+    w.lane16 = (uint32_t)lane * 16u;
+    w.soff = 128u;                                                             // a unit reads its first two words itself
+    w.sdma = 3u * 1024u;                                                       // the window starts with blocks 0..47
+    {
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(w.sbase) + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)q * 64),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(w.ring_base + q * 1024u), 16, 0, 0);
+    }
+    if (a.att_dma) {
+        // rows of 32 bases are the LDS rows: 1 KB per wave instruction straight into LDS
+        const int pieces = a.R / 8;
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(a.att);
+        for (int i = wave; i < pieces; i += kWaves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + (uint32_t)i * 1024u), 16, 0, 0);
+        for (int e = pieces * 256 + tid; e < a.R * 32; e += kThreads)
+            reinterpret_cast<float*>(lds)[e] = a.att[e];
+    } else {
+        for (int e = tid; e < a.R * 32; e += kThreads) {
+            const int r = e >> 5, b = e & 31;
+            reinterpret_cast<float*>(lds)[e] = b < a.B ? a.att[(size_t)r * a.B + b] : 0.f;
+        }
+    }
+    if (tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
+    // unit descriptors of this wave, eight dwords each: lane L holds dword L of the current page of eight units
+    uint32_t descv = n_units ? desc[lane] : 0u;
+    int cur_chunk = n_units ? (int)(__builtin_amdgcn_readlane(descv, 2) & 0xffu) : 0;
+    XRaw<NT> raw;
+    load_chunk<NT>(a, cur_chunk, kg, c, raw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#ifdef GN_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long cyc_gather = 0, cyc_contract = 0, cyc_x = 0;
+#endif
+
+    f32x4 acc[kMaxD][BT][NT];
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d)
+#pragma unroll
+        for (int jm = 0; jm < BT; ++jm)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) acc[d][jm][jn] = (f32x4)(0.f);
+
+    XFrag<NT> xf;
+    split_chunk<NT, TERMS>(raw, xf);
+
+#pragma unroll 1
+    for (uint32_t u = 0; u < n_units; ++u) {
+        if (u && (u & 7u) == 0u) descv = desc[(size_t)(u >> 3) * 64 + lane];   // next page (waited for at once: rare)
+        const int o = (int)(u & 7u) * 8;
+        const uint32_t c03 = __builtin_amdgcn_readlane(descv, o), c47 = __builtin_amdgcn_readlane(descv, o + 1);
+        const uint32_t where = __builtin_amdgcn_readlane(descv, o + 2);
+        const int chunk = (int)(where & 0xffu), d = (int)((where >> 8) & 3u);
+        if (chunk != cur_chunk) {
+            // the next chunk of x as MFMA operands, fetched here (L2) and waited for at once: holding all of a wave's chunks
+            // from the prologue on costs 24 registers a chunk, which two waves per SIMD do not have
+#ifdef GN_STAMPS
+            const unsigned long long cx0 = __builtin_amdgcn_s_memtime();
+#endif
+            cur_chunk = chunk;
+            load_chunk<NT>(a, chunk, kg, c, raw);
+            split_chunk<NT, TERMS>(raw, xf);
+#ifdef GN_STAMPS
+            asm volatile("" : "+v"(xf.w[0][0][0]));
+            cyc_x += __builtin_amdgcn_s_memtime() - cx0;
+#endif
+        }
+        acc_t p[8];
+#ifdef GN_STAMPS
+        const unsigned long long cg0 = __builtin_amdgcn_s_memtime();
+#endif
+        gather_unit<BT>(w, c03, c47, p);
+#ifdef GN_STAMPS
+        const unsigned long long cg1 = __builtin_amdgcn_s_memtime();
+        cyc_gather += cg1 - cg0;
+#endif
+        if (d == 0) contract<NT, BT, TERMS>(p, xf, acc[0]);
+        else if (d == 1) contract<NT, BT, TERMS>(p, xf, acc[1]);
+        else contract<NT, BT, TERMS>(p, xf, acc[2]);
+#ifdef GN_STAMPS
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(acc[2][0][0]) : "memory");
+        cyc_contract += __builtin_amdgcn_s_memtime() - cg1;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                // window refills retire
+#ifdef GN_STAMPS
+    const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();                                                           // att table and windows are dead from here
+
+    // ---- epilogue 1: U_i = sum over the waves of their shares, through LDS ----
+    // part[wave][d][k'], k' = feature * BP + base (bases innermost: the eight values a lane holds of one feature, bases
+    // BT (4 kg + v) + jm, are 32 contiguous bytes)
+    float* part = reinterpret_cast<float*>(lds);
+    const int32_t* my_dst = a.wg_dst + (size_t)g * 4;
+    int nd = 0;
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) nd += my_dst[d] >= 0 ? 1 : 0;
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) {
+        if (d >= nd) break;
+        float* dstp = part + ((size_t)wave * kMaxD + d) * KP;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            float* q = dstp + (NT * c + jn) * BP + 4 * BT * kg;
+            if constexpr (BT == 2) {
+                *reinterpret_cast<f32x4*>(q) = (f32x4){acc[d][0][jn][0], acc[d][1][jn][0], acc[d][0][jn][1], acc[d][1][jn][1]};
+                *reinterpret_cast<f32x4*>(q + 4) = (f32x4){acc[d][0][jn][2], acc[d][1][jn][2], acc[d][0][jn][3], acc[d][1][jn][3]};
+            } else {
+                *reinterpret_cast<f32x4*>(q) = acc[d][0][jn];
+            }
+        }
+    }
+    __syncthreads();
+#ifdef GN_STAMPS
+    const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // thread -> four consecutive k' of one destination; the sums go to wave 0's slots (read by this thread only).
+    // Behind them: deg_i * x_i (the root term rides through the same contraction as FIN more rows).
+    constexpr int KE = KP + FIN;
+    float* uext = part + (size_t)kWaves * kMaxD * KP;                          // [nd][FIN]
+    for (int e = tid; e < nd * (KP / 4); e += kThreads) {
+        const int d = e / (KP / 4), k4 = e - d * (KP / 4);
+        f32x4 s = (f32x4)(0.f);
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) s += *reinterpret_cast<const f32x4*>(part + ((size_t)ww * kMaxD + d) * KP + 4 * k4);
+        *reinterpret_cast<f32x4*>(part + (size_t)d * KP + 4 * k4) = s;
+    }
+    if (!a.partial)
+        for (int e = tid; e < nd * FIN; e += kThreads) {
+            const int d = e / FIN, f = e - d * FIN;
+            const int i = my_dst[d];
+            uext[e] = a.x[(int64_t)i * a.ld_x + f] * fmaxf(a.indeg[i], 1.0f);
+        }
+    __syncthreads();
+
+#ifdef GN_STAMPS
+    const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- epilogue 2: out_i = act( (U_i . basis + deg_i x_i . root) / max(1, deg_i) + bias ) ----
+    // thread = (four outputs o4, slice of the KE rows); rows in batches of eight loads in flight
+    const int fout = a.fout, og = fout >> 2;                                   // fout % 4 == 0, og in 1..16
+    const int slices = kThreads / og;
+    const int rows = a.partial ? KP : KE;
+    const int o4 = tid % og, sl = tid / og;
+    const int per = (rows + slices - 1) / slices;
+    const int k0 = min(rows, sl * per), k1 = min(rows, k0 + per);
+    f32x4 sum[kMaxD];
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) sum[d] = (f32x4)(0.f);
+    if (sl < slices) {
+        const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis) + o4;
+        const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(a.root) + o4;
+        for (int kb = k0; kb < k1; kb += 8) {
+            f32x4 bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = min(kb + j, k1 - 1);
+                // row k' = feature * BP + base of U is row base * FIN + feature of basis; padded bases carry zeros in U
+                const int feat = k / BP, base = k - feat * BP;
+                const bool is_root = k >= KP;
+                const int brow = min(base, a.B - 1) * FIN + feat;
+                bv[j] = is_root ? rp[(size_t)(k - KP) * og] : bp[(size_t)brow * og];
+                if (!is_root && base >= a.B) bv[j] = (f32x4)(0.f);
+                if (kb + j >= k1) bv[j] = (f32x4)(0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = min(kb + j, k1 - 1);
+#pragma unroll
+                for (int d = 0; d < kMaxD; ++d)
+                    if (d < nd) sum[d] += (k >= KP ? uext[d * FIN + (k - KP)] : part[(size_t)d * KP + k]) * bv[j];
+            }
+        }
+    }
+#ifdef GN_STAMPS
+    asm volatile("" : "+v"(sum[0]));
+    const unsigned long long st5 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float* red = part + (size_t)kMaxD * KP;                                    // [slices][nd][og][4], over the other waves' slots (dead)
+    if (sl < slices)
+#pragma unroll
+        for (int d = 0; d < kMaxD; ++d)
+            if (d < nd) *reinterpret_cast<f32x4*>(red + ((size_t)(sl * kMaxD + d) * og + o4) * 4) = sum[d];
+    __syncthreads();
+    // (destination, output) x four partial sums over the slices, folded inside the lane quad
+    {
+        const int pair_id = tid >> 2, part_id = tid & 3;
+        const bool live = pair_id < nd * fout;
+        const int d = live ? pair_id / fout : 0, o = live ? pair_id - d * fout : 0;
+        float s = 0.f;
+        if (live)
+            for (int q = part_id; q < slices; q += 4) s += red[((size_t)(q * kMaxD + d) * og + (o >> 2)) * 4 + (o & 3)];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (live && part_id == 0) {
+            const int i = my_dst[d];
+            if (!a.partial) {
+                s = s / fmaxf(a.indeg[i], 1.0f) + (a.bias ? a.bias[o] : 0.f);
+                if (a.relu) s = fmaxf(s, 0.f);
+            }
+            a.out[(int64_t)i * a.ld_out + o] = s;
+        }
+    }
+    if (a.side.dst) {                                                          // concat slot 0, by the whole grid
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = (int64_t)g * kThreads + tid; t < total; t += (int64_t)gridDim.x * kThreads) {
+            const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + cc];
+            a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+#ifdef GN_STAMPS
+    if (lane == 0 && g < 256) {
+        unsigned long long* o = g_pair_stamps[stamp_set & 1][g * kWaves + wave];
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = cyc_gather; o[5] = cyc_contract; o[6] = cyc_x; o[7] = ((unsigned long long)n_units << 32) | (w.sdma >> 6);
+        o[8] = st3; o[9] = st4; o[10] = st5;
+    }
+#endif
+}
+
+// ---- plan --------------------------------------------------------------------------------------------------------
+__global__ void k_pair_outdeg(const int64_t* __restrict__ src, int64_t lo, int64_t hi, int32_t* __restrict__ cnt) {
+    for (int64_t e = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(cnt + src[e], 1);                                            // ids validated by the general plan builder
+}
+
+__global__ void k_pair_keys(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                            const int64_t* __restrict__ starts, int R, int64_t lo, int64_t hi, int kpad,
+                            const int32_t* __restrict__ kpos, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+    for (int64_t e = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x) {
+        int a = 0, b = R;                                                      // relation of edge e: last start <= e
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (starts[mid] <= e) a = mid; else b = mid;
+        }
+        key[e - lo] = (uint32_t)(dst[e] * kpad + kpos[src[e]]);
+        val[e - lo] = (uint32_t)a;
+    }
+}
+
+__global__ void k_pair_rowptr(const uint32_t* __restrict__ sorted, int n, int64_t count, int32_t* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i > count) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sorted[mid] < (uint32_t)i) lo = mid + 1; else hi = mid;
+    }
+    out[i] = lo;
+}
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+};
+
+int bits_for(int64_t n) {
+    int b = 1;
+    while (((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+bool pair_disabled() {
+    if (gn::fast_paths_disabled()) return true;
+    const char* e = getenv("GN_DISABLE_PAIR");
+    return e && e[0] == '1';
+}
+
+// The blocks of one section: four lists of relation ids (one per lane group), `nb` blocks of four positions each.
+// Lane groups 0/1 and 2/3 share the 32 lanes of one LDS access: rows of equal parity sit in the same banks, so the
+// lists of a group pair are laid out even rows first / odd rows last against odd rows first / even rows last, and a
+// padded position names the zero row of the parity its partner does not use.
+void lay_out_section(const uint32_t* const (&list)[4], const int (&len)[4], int nb, uint32_t R, std::vector<uint32_t>& out) {
+    const int P = 4 * nb;
+    const uint32_t none = 0xffffffffu;
+    std::vector<uint32_t> pos[4];
+    for (int k = 0; k < 4; ++k) {
+        pos[k].assign(P, none);
+        const bool even_first = (k & 1) == 0;
+        int left = 0, right = P - 1;
+        // first the rows of the leading parity, left aligned, in list order; then the others, right aligned
+        for (int i = 0; i < len[k]; ++i)
+            if (((list[k][i] & 1u) == 0u) == even_first) pos[k][left++] = list[k][i];
+        for (int i = len[k] - 1; i >= 0; --i)
+            if (((list[k][i] & 1u) == 0u) != even_first) pos[k][right--] = list[k][i];
+    }
+    const uint32_t zero_even = (R & 1u) ? R + 1 : R, zero_odd = (R & 1u) ? R : R + 1;
+    const size_t base = out.size();
+    out.resize(base + (size_t)nb * 16);
+    for (int k = 0; k < 4; ++k) {
+        const int partner = k ^ 1;
+        for (int i = 0; i < P; ++i) {
+            uint32_t row = pos[k][i];
+            if (row == none) {
+                const uint32_t other = pos[partner][i];
+                row = (other != none && (other & 1u) == 0u) ? zero_odd : zero_even;
+                if (other == none && (k & 1)) row = zero_odd;                  // two padded partners: one of each
+            }
+            out[base + (size_t)(i >> 2) * 16 + k * 4 + (i & 3)] = row * (uint32_t)kRowBytes;
+        }
+    }
+}
+
+template <int NT, int BT, int TERMS>
+gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st) {
+    gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS>), kLdsBytes);
+    if (s != GN_OK) return s;
+    static int stamp = 0;
+    k_rgcn_pair<NT, BT, TERMS><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+template <int TERMS>
+gn_status dispatch_pair(const gn_rgcn_plan* plan, const PairArgs& a, int nt, int bt, hipStream_t st) {
+    switch (nt * 2 + (bt - 1)) {
+        case 2: return launch_pair<1, 1, TERMS>(plan, a, st);
+        case 3: return launch_pair<1, 2, TERMS>(plan, a, st);
+        case 4: return launch_pair<2, 1, TERMS>(plan, a, st);
+        case 5: return launch_pair<2, 2, TERMS>(plan, a, st);
+        case 6: return launch_pair<3, 1, TERMS>(plan, a, st);
+        case 7: return launch_pair<3, 2, TERMS>(plan, a, st);
+        case 8: return launch_pair<4, 1, TERMS>(plan, a, st);
+        case 9: return launch_pair<4, 2, TERMS>(plan, a, st);
+    }
+    return gn::fail(GN_ERR_UNSUPPORTED, "no destination-major relational kernel for these widths");
+}
+
+}  // namespace
+
+// Builds the per-workgroup destination lists and per-wave streams of the shard.  Leaves plan->pair_ok = 0 when the graph
+// does not qualify (too many nodes for three rows per compute unit, an att table beyond the LDS, nothing to do).
+gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
+                                  const std::vector<int64_t>& ranges, hipStream_t st) {
+    plan->pair_ok = 0;
+    const int64_t N = plan->num_nodes, R = plan->num_relations, E = plan->shard_edges;
+    if (pair_disabled() || N < 1 || R < 1) return GN_OK;
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    const int chunks = (int)gn::ceil_div(N, 32), kpad = chunks * 32;
+    const int D = (int)gn::ceil_div(N, cus);
+    if (D > kMaxD || chunks > kMaxChunks || chunks > 24) return GN_OK;            // up to 768 nodes
+    const int64_t ring0 = ((R + 2) * kRowBytes + 1023) & ~(int64_t)1023;
+    if (ring0 + kWaves * kRingBytes > kLdsBytes) return GN_OK;
+    const int G = (int)std::min<int64_t>(N, cus);
+
+    Scratch tmp;
+    int64_t* starts_dev;
+    int32_t *outdeg_dev, *kpos_dev, *rowptr_dev;
+    uint32_t *key, *key_sorted, *val, *val_sorted;
+    GN_HIP(tmp.get(&starts_dev, R + 1));
+    GN_HIP(tmp.get(&outdeg_dev, N));
+    GN_HIP(tmp.get(&kpos_dev, N));
+    GN_HIP(tmp.get(&key, E));
+    GN_HIP(tmp.get(&key_sorted, E));
+    GN_HIP(tmp.get(&val, E));
+    GN_HIP(tmp.get(&val_sorted, E));
+    GN_HIP(tmp.get(&rowptr_dev, N * kpad + 1));
+    // K order: sources by out-degree (inside the shard), largest first: lock-step partners expect similar runs
+    std::vector<int32_t> outdeg(N, 0);
+    GN_HIP(hipMemsetAsync(outdeg_dev, 0, N * sizeof(int32_t), st));
+    if (E > 0) {
+        k_pair_outdeg<<<gn::stream_grid(E, 256), 256, 0, st>>>(src, plan->edge_lo, plan->edge_hi, outdeg_dev);
+        GN_LAUNCH_CHECK();
+    }
+    GN_HIP(hipMemcpyAsync(outdeg.data(), outdeg_dev, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    std::vector<int32_t> perm(kpad, (int32_t)N), kpos(N);
+    {
+        std::vector<int32_t> order(N);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return outdeg[x] > outdeg[y]; });
+        for (int64_t k = 0; k < N; ++k) { perm[k] = order[k]; kpos[order[k]] = (int32_t)k; }
+    }
+    std::vector<int32_t> rp((size_t)N * kpad + 1, 0);
+    std::vector<uint32_t> rels(E);
+    if (E > 0) {
+        std::vector<int64_t> starts(R + 1, plan->input_edges);
+        for (int64_t r = 0; r < R; ++r) starts[r] = ranges[2 * r];
+        GN_HIP(hipMemcpyAsync(starts_dev, starts.data(), (R + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        GN_HIP(hipMemcpyAsync(kpos_dev, kpos.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        k_pair_keys<<<gn::stream_grid(E, 256), 256, 0, st>>>(src, dst, starts_dev, (int)R, plan->edge_lo, plan->edge_hi, kpad,
+                                                             kpos_dev, key, val);
+        GN_LAUNCH_CHECK();
+        size_t bytes = 0;
+        GN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key, key_sorted, val, val_sorted, (size_t)E, 0, bits_for(N * kpad), st));
+        char* scratch = nullptr;
+        GN_HIP(tmp.get(&scratch, bytes));
+        GN_HIP(rocprim::radix_sort_pairs(scratch, bytes, key, key_sorted, val, val_sorted, (size_t)E, 0, bits_for(N * kpad), st));
+        k_pair_rowptr<<<(int)gn::ceil_div(N * kpad + 1, 256), 256, 0, st>>>(key_sorted, (int)E, N * kpad, rowptr_dev);
+        GN_LAUNCH_CHECK();
+        GN_HIP(hipMemcpyAsync(rp.data(), rowptr_dev, ((size_t)N * kpad + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(rels.data(), val_sorted, (size_t)E * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipStreamSynchronize(st));
+    }
+
+    // A unit = (destination, chunk, slice j of <= kSectionCap blocks per section).  Blocks of a section = the longest of
+    // its four pairs, in fours, at least one; a (destination, chunk) without any edge is no unit at all.
+    auto pair_len = [&](int64_t i, int k) { return rp[(size_t)i * kpad + k + 1] - rp[(size_t)i * kpad + k]; };
+    auto section_blocks = [&](int64_t i, int ch, int t) {
+        int longest = 0;
+        for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
+        return std::max(1, (longest + 3) / 4);
+    };
+    std::vector<int64_t> cost(N, 0);
+    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            int64_t blocks = 0;
+            for (int ch = 0; ch < chunks; ++ch) {
+                if (rp[(size_t)i * kpad + 32 * ch + 32] == rp[(size_t)i * kpad + 32 * ch]) continue;
+                int deepest = 1;
+                for (int t = 0; t < 8; ++t) {
+                    const int nb = section_blocks(i, ch, t);
+                    deepest = std::max(deepest, nb);
+                    blocks += nb;
+                }
+                blocks += 12 * gn::ceil_div(deepest, kSectionCap);             // a unit's split and matrix products, in block times
+            }
+            cost[i] = blocks;
+        }
+    });
+    // destinations to workgroups: longest first, each to the least loaded workgroup that still has room
+    std::vector<std::vector<int32_t>> wg_rows(G);
+    {
+        std::vector<int32_t> order(N);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
+        std::vector<int64_t> load(G, 0);
+        for (int32_t i : order) {
+            int best = -1;
+            for (int gg = 0; gg < G; ++gg)
+                if ((int)wg_rows[gg].size() < D && (best < 0 || load[gg] < load[best])) best = gg;
+            wg_rows[best].push_back(i);
+            load[best] += cost[i];
+        }
+    }
+    // per workgroup: its units in chunk-major order (a wave's units share chunks of x), cut into eight contiguous runs of
+    // equal cost; per wave the descriptors (eight dwords a unit, pages of eight units) and the stream
+    std::vector<std::vector<uint32_t>> wg_stream((size_t)G * kWaves), wg_desc((size_t)G * kWaves);
+    std::vector<uint32_t> wave_units((size_t)G * kWaves, 0u);
+    std::vector<int32_t> wg_dst((size_t)G * 4, -1);
+    gn::parallel_for(G, 1, [&](int64_t b, int64_t e) {
+        struct Unit { int32_t ch, d, slice; int64_t cost; };
+        std::vector<Unit> units;
+        for (int64_t gg = b; gg < e; ++gg) {
+            const std::vector<int32_t>& rows = wg_rows[gg];
+            for (size_t d = 0; d < rows.size(); ++d) wg_dst[gg * 4 + d] = rows[d];
+            units.clear();
+            int64_t total = 0;
+            for (int ch = 0; ch < chunks; ++ch)
+                for (size_t d = 0; d < rows.size(); ++d) {
+                    const int64_t i = rows[d];
+                    if (rp[(size_t)i * kpad + 32 * ch + 32] == rp[(size_t)i * kpad + 32 * ch]) continue;
+                    int nb[8], deepest = 1;
+                    for (int t = 0; t < 8; ++t) { nb[t] = section_blocks(i, ch, t); deepest = std::max(deepest, nb[t]); }
+                    for (int j = 0; j * kSectionCap < deepest; ++j) {
+                        int64_t c = 12;
+                        for (int t = 0; t < 8; ++t) c += std::max(1, std::min(kSectionCap, nb[t] - j * kSectionCap));
+                        units.push_back({ch, (int32_t)d, j, c});
+                        total += c;
+                    }
+                }
+            int64_t seen = 0;
+            for (const Unit& un : units) {
+                // the wave whose share of the cost line holds this unit's midpoint
+                const int wv = total > 0 ? (int)std::min<int64_t>(kWaves - 1, (2 * seen + un.cost) * kWaves / (2 * total)) : 0;
+                seen += un.cost;
+                std::vector<uint32_t>& out = wg_stream[gg * kWaves + wv];
+                std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
+                const size_t at = dv.size();
+                dv.resize(at + 8, 0u);
+                dv[at + 2] = (uint32_t)un.ch | (uint32_t)un.d << 8;
+                const int64_t i = rows[un.d];
+                for (int t = 0; t < 8; ++t) {
+                    const uint32_t* list[4];
+                    int len[4], longest = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        const size_t key_id = (size_t)i * kpad + 32 * un.ch + 8 * k + t;
+                        const int full = rp[key_id + 1] - rp[key_id];
+                        const int from = std::min(full, un.slice * kSectionCap * 4);
+                        list[k] = rels.data() + rp[key_id] + from;
+                        len[k] = std::min(full - from, kSectionCap * 4);
+                        longest = std::max(longest, len[k]);
+                    }
+                    const int nb = std::max(1, (longest + 3) / 4);
+                    dv[at + (t >> 2)] |= (uint32_t)nb << (8 * (t & 3));
+                    lay_out_section(list, len, nb, (uint32_t)R, out);
+                }
+                out.resize(out.size() + 2 * 16, (uint32_t)R * kRowBytes);       // two padding blocks: requested, never added
+                wave_units[gg * kWaves + wv] += 1;
+            }
+            for (int wv = 0; wv < kWaves; ++wv) {                              // whole pages
+                std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
+                dv.resize((dv.size() + 63) / 64 * 64, 0u);
+            }
+        }
+    });
+    std::vector<uint32_t> wave_desc((size_t)G * kWaves);
+    std::vector<uint32_t> desc;
+    for (size_t i = 0; i < wg_desc.size(); ++i) {
+        wave_desc[i] = (uint32_t)(desc.size() / 8);
+        desc.insert(desc.end(), wg_desc[i].begin(), wg_desc[i].end());
+    }
+    desc.resize(desc.size() + 64, 0u);                                          // a wave without units still reads a page
+    std::vector<uint32_t> first((size_t)G * kWaves);
+    size_t total = 0;
+    for (size_t i = 0; i < wg_stream.size(); ++i) { first[i] = (uint32_t)(total / 16); total += wg_stream[i].size(); }
+    if (total / 16 + kSlackBlocks >= ((size_t)1 << 31)) return GN_OK;
+    std::vector<uint32_t> stream(total + (size_t)kSlackBlocks * 16, (uint32_t)R * kRowBytes);
+    gn::parallel_for((int64_t)wg_stream.size(), 64, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i)
+            if (!wg_stream[i].empty()) memcpy(stream.data() + (size_t)first[i] * 16, wg_stream[i].data(), wg_stream[i].size() * sizeof(uint32_t));
+    });
+    GN_HIP(plan->pair_stream.alloc(stream.size()));
+    GN_HIP(plan->pair_wave_first.alloc(first.size()));
+    GN_HIP(plan->pair_desc.alloc(desc.size()));
+    GN_HIP(plan->pair_wave_units.alloc(wave_units.size()));
+    GN_HIP(plan->pair_wave_desc.alloc(wave_desc.size()));
+    GN_HIP(plan->pair_wg_dst.alloc(wg_dst.size()));
+    GN_HIP(plan->pair_perm.alloc(perm.size()));
+    GN_HIP(hipMemcpyAsync(plan->pair_stream.p, stream.data(), stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_wave_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_desc.p, desc.data(), desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_wave_units.p, wave_units.data(), wave_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_wave_desc.p, wave_desc.data(), wave_desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_wg_dst.p, wg_dst.data(), wg_dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_perm.p, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipStreamSynchronize(st));
+    plan->pair_groups = G;
+    plan->pair_d = D;
+    plan->pair_chunks = chunks;
+    plan->pair_blocks = (int64_t)(total / 16);
+    plan->pair_ok = 1;
+    return GN_OK;
+}
+
+#ifdef GN_STAMPS
+extern "C" GN_API int gn_debug_read_pair_stamps(unsigned long long* out) {   // diagnostic build only: [2048][8] of the last launch
+    static int which = 0;
+    (void)which;
+    static unsigned long long both[2][256 * 8][12];
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(both, HIP_SYMBOL(g_pair_stamps), sizeof(both)) != hipSuccess) return 2;
+    // the set written last: the one with the larger entry stamp
+    const int set = both[0][0][0] > both[1][0][0] ? 0 : 1;
+    memcpy(out, both[set], sizeof(both[0]));
+    return 0;
+}
+#endif
+
+bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
+    if (!plan || !plan->pair_ok || pair_disabled()) return false;
+    if (fin % 16 != 0 || fin < 16 || fin > 64 || bases < 1 || bases > 32 || fout % 4 != 0 || fout < 4 || fout > 64) return false;
+    const int64_t nt = fin / 16, bt = (bases + 15) / 16;
+    // the waves' shares of U in LDS: 8 waves x 3 rows x (16 bt x fin) floats, plus the slices' sums behind wave 0's
+    const int64_t kp = 16 * bt * fin;
+    const int64_t part = ((int64_t)kWaves * kMaxD * kp + kMaxD * fin) * 4;     // + deg x rows behind them
+    const int64_t red = (int64_t)kMaxD * kp * 4 + (int64_t)kThreads * kMaxD * 16;   // the slices' sums reuse wave 1's slots on
+    return std::max(part, red) <= kLdsBytes && nt * bt <= 6;     // fin = 64 with more than 16 bases spills registers
+}
+
+gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
+                               const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
+                               int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
+                               hipStream_t st) {
+    PairArgs a;
+    a.x = x; a.ld_x = ld_x; a.att = att; a.basis = basis; a.root = root; a.bias = bias;
+    a.indeg = plan->indeg.p;
+    a.out = out; a.ld_out = ld_out;
+    a.stream = plan->pair_stream.p; a.wave_first = plan->pair_wave_first.p; a.desc = plan->pair_desc.p;
+    a.wave_units = plan->pair_wave_units.p; a.wave_desc = plan->pair_wave_desc.p;
+    a.wg_dst = plan->pair_wg_dst.p; a.perm = plan->pair_perm.p;
+    a.n = (int)plan->num_nodes; a.R = (int)plan->num_relations; a.B = (int)bases; a.fout = (int)fout;
+    a.chunks = plan->pair_chunks; a.relu = relu; a.partial = partial;
+    a.att_dma = bases == 32 && (reinterpret_cast<uintptr_t>(att) & 15) == 0;
+    a.side = side;
+    const int nt = (int)(fin / 16), bt = (int)((bases + 15) / 16);
+    return fast_arith ? dispatch_pair<2>(plan, a, nt, bt, st) : dispatch_pair<3>(plan, a, nt, bt, st);
+}

@@ -213,6 +213,8 @@ GN_API gn_status gn_graph_aggregate_with_rgcn_weights_f32(
 
 #define GN_RGCN_PARTIAL 1        /* flags of gn_rgcn_forward_f32 */
 #define GN_RGCN_WEIGHTS_READY 2  /* `workspace` already holds the output of gn_rgcn_weights_f32 for these parameters */
+#define GN_RGCN_ARITH_FAST 4     /* dense products on two-term bf16 splits (<= 2^-16 relative per product) instead of the
+                                  * default fp32-faithful arithmetic (three-term splits / the fp32 matrix instruction) */
 
 /* flags & GN_RGCN_PARTIAL == 0:  out[i,:] = act( (sum_{e: dst=i} x[src_e] W_{r(e)}) / max(1, indeg_i) + x[i] root + bias )
  * flags & GN_RGCN_PARTIAL:       out[i,:] = sum_{e in [edge_lo,edge_hi): dst=i} x[src_e] W_{r(e)}   (un-normalised
