@@ -36,6 +36,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+# What in-kernel stamps and the issue-rate probe say bounds each entry point: none of them is HBM-bound;
+# "bound": "hbm" names the roofline the path is priced against, this names what actually limits it.
+LIMITERS = {
+    "gn_rgcn_forward_f32": "instruction issue: ~23 instructions per block of 4 x 4 gathered att rows at ~2.6 cycles per instruction and SIMD "
+                           "(tools/probes/issue_probe.hip), lock-step padding 1.8x; HBM moves less than the algorithmic bytes",
+    "gn_distmult_plan_forward_f32": "VALU issue ~ LDS reads (640 B per scored edge)",
+    "gn_distmult_forward_f32": "HBM index stream / LDS reads",
+    "gn_graph_aggregate_f32[gcn]": "launch + LDS fill + id stream latency (two launches per layer)",
+}
 
 
 def algorithmic_bytes(data, n_dd_edges_local, n_dd_edges_global):
@@ -53,6 +62,118 @@ def algorithmic_bytes(data, n_dd_edges_local, n_dd_edges_global):
     }
 
 
+def extra_workloads(dev, budget_s, with_cpu):
+    """The other BASELINE.json configs on one GPU, each with the same event timing as the headline and a CPU-oracle time:
+    pose2-syn (config 4's graph, unsharded), aminer-syn (config 3), freebase-c-syn (config 5, fp32 storage)."""
+    from gripnet_amd import _hip
+    from gripnet_amd.pipeline import AminerModel, FreebaseCModel, PoseModel, PoseStages
+    from gripnet_amd.synth import Data, make_nc, make_pose, pose_edges_aggregated
+    out, t_begin = [], time.perf_counter()
+
+    def left():
+        return budget_s - (time.perf_counter() - t_begin)
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        with _hip.KernelTimer() as t:
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / n
+        return wall, {k: 1e3 * tot / calls for k, (calls, tot) in t.summary().items()}, sum(1e3 * tot / n for _, tot in t.summary().values())
+
+    with torch.no_grad():
+        # ---- pose2-syn: the full step, its relational layer and its decoder against their algorithmic bytes ----
+        if left() > 20:
+            data_cpu = make_pose("pose2-syn")
+            torch.manual_seed(1111)
+            model = PoseModel(data_cpu.n_g_node, data_cpu.n_d_node, data_cpu.n_dd_edge_type).to(dev)
+            data = Data(**data_cpu.__dict__).to(dev)
+            eager = PoseStages(model, data, graphs=False)
+            for _ in range(3):
+                eager.step()
+            _, calls, _ = timed(eager.step, 10)
+            stages = PoseStages(model, data, graphs=True, timed_entry=None)
+            for _ in range(5):
+                stages.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                stages.step()
+            torch.cuda.synchronize()
+            step_us = 1e6 * (time.perf_counter() - t0) / 30
+            E = int(data.train_idx.shape[1])
+            alg = algorithmic_bytes(data, E, E)
+            A = pose_edges_aggregated(data)
+            rel_us = calls.get("gn_rgcn_forward_f32")
+            dec_us = calls.get("gn_distmult_plan_forward_f32", calls.get("gn_distmult_forward_f32"))
+            out.append({"workload": "pose2-syn", "E_dd": E, "us_per_step": round(step_us, 1), "edges_per_s": A / (step_us * 1e-6),
+                        "launch": "every stage replayed as a hipGraph",
+                        "relational": {"us": round(rel_us, 1), "frac": round(alg["dd"] / (rel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "decoder": {"us": round(dec_us, 1), "frac": round(alg["dmt"] / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}})
+            del model, data, eager, stages
+            torch.cuda.empty_cache()
+        # ---- the node-classification models (configs 3 and 5) ----
+        from oracle import gripnet_oracle as orc
+        for name, cls in (("aminer-syn", AminerModel), ("freebase-c-syn", FreebaseCModel)):
+            if left() < 15:
+                break
+            data_cpu = make_nc("aminer-syn")             # the NC ladder shares one synthetic scale (SURVEY.md 8d)
+            torch.manual_seed(1111)
+            model = (cls(data_cpu.n_p_node, data_cpu.n_a_node, data_cpu.n_a_type) if cls is AminerModel else
+                     cls(data_cpu.n_p_node, data_cpu.n_q_node, data_cpu.n_a_node, data_cpu.n_a_type))
+            sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            nodes = torch.arange(0, data_cpu.n_a_node, 3)
+            model = model.to(dev)
+            data = Data(**data_cpu.__dict__).to(dev)
+            nodes_dev = nodes.to(dev)
+            wall, calls, busy = timed(lambda: model(data, nodes_dev), 10)
+            dom = max(calls, key=calls.get)
+            entry = {"workload": name, "forward_us_entry_points": round(busy, 1),
+                     "forward_us_eager_wall": round(1e6 * wall, 1),
+                     "note": "sum of the HIP-event timed entry points of one forward; the wall time of the eager Python loop is host-bound",
+                     "dominant_entry_point": {"name": dom, "us_per_call": round(calls[dom], 1)}}
+            if with_cpu and left() > 10:
+                d = data_cpu
+                t1 = time.perf_counter()
+                if cls is AminerModel:
+                    orc.aminer_forward(sd, d.pp_edge_idx, d.pp_edge_weight, d.pa_edge_idx, d.aa_edge_idx, d.aa_edge_weight, nodes)
+                else:
+                    orc.freebase_c_forward(sd, d.pp_edge_idx, d.pp_edge_weight, d.pa_edge_idx, d.qq_edge_idx, d.qq_edge_weight,
+                                           d.qa_edge_idx, sd["aa_embeddings"], d.aa_edge_idx, d.aa_edge_weight, nodes, d.n_a_node)
+                entry["cpu_oracle_forward_s"] = round(time.perf_counter() - t1, 3)
+                entry["cpu_threads"] = torch.get_num_threads()
+            out.append(entry)
+            del model, data
+            torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(n):
+    """One process per GPU through torch.distributed.run on 127.0.0.1; returns the exit code for this process."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout)
+        sys.stderr.write(proc.stderr)
+        sys.stderr.write("bench.py: the {}-rank job failed (exit code {})\n".format(n, proc.returncode))
+        return proc.returncode or 1
+    print(lines[-1])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,19 +187,22 @@ def main():
                          "on the box, against ~110 us of kernels on pose0-syn); graphs: the stages replayed as hipGraphs, "
                          "except the dominant entry point, which stays a Python launch between HIP events; auto: "
                          "whichever of the two runs the step faster on this box, measured before the timed region")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (pose2-syn, aminer-syn, freebase-c-syn)")
+    ap.add_argument("--extra-seconds", type=float, default=90.0, help="time budget of the extra workloads")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "pose2-syn" if args.scaling == "strong" else "pose0-syn"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks as children of this process (which has not touched the GPU
+        # and will not), relay rank 0's JSON line, and fail loudly with the children's output if any of them fails
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus {} must be launched with torch.distributed.run --nproc-per-node {}".format(
-                args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
@@ -140,13 +264,15 @@ def main():
             fence()
             plan_build_ms = 1e3 * max(0.0, t_plan - (time.perf_counter() - t_steady))
             per_call0, breakdown = per_entry_us(eager.step, 5)
-            # the relational layer with its transform on the exact fp32 matrix instruction (the default splits both
-            # operands into bf16 pairs: three bf16 products, fp32 accumulate)
-            os.environ["GN_ACC_EXACT"] = "1"
-            for _ in range(2):
-                eager.step()
-            exact_call, _ = per_entry_us(eager.step, 5)
-            del os.environ["GN_ACC_EXACT"]
+            # side figure: the same step with the dense products on two-term bf16 splits (GN_RGCN_ARITH_FAST /
+            # GN_GEMM_ARITH_FAST, flags of the C ABI set per layer): narrower than the reference's fp32, never the headline
+            from gripnet_amd.utils import set_arithmetic
+            set_arithmetic(model, "fast")
+            fast_stages = PoseStages(model, data, graphs=False)
+            for _ in range(3):
+                fast_stages.step()
+            fast_call, fast_breakdown = per_entry_us(fast_stages.step, 5)
+            set_arithmetic(model, "fp32")
             for _ in range(2):
                 eager.step()
             # the entry point timed inside the timed region: the longest single launch.  (A gene layer is two launches
@@ -185,7 +311,7 @@ def main():
                 fwd()
             fence()
             plan_build_ms = 1e3 * (time.perf_counter() - t_plan)
-            exact_call = {}
+            fast_call, fast_breakdown = {}, {}
             per_call0, breakdown = per_entry_us(fwd, 5)
             dom = max((k for k in CANDIDATES if k != "gn_graph_aggregate_f32[gcn]"), key=lambda k: per_call0.get(k, 0.0))
             launch = "eager" if args.launch == "eager" else "graphs"
@@ -238,8 +364,10 @@ def main():
     traffic = traffic_all.get(dom)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (PMC passes of tools/profile_round.sh, not counters of this run)" if traffic else None,
                 "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_us": round(dom_us, 2),
-                "timed_launches": calls}
+                "timed_launches": calls,
+                "limiter": LIMITERS.get(dom)}
 
     def line(name, us):
         b = stage_bytes.get(name)
@@ -249,16 +377,18 @@ def main():
                 "traffic": traffic_all.get(name)}
     # every entry point of the step, HIP-event timed around each launch in an eager pass before the timed region
     roofline_all = [line(k, v) for k, v in sorted(per_call0.items())]
-    roofline_exact = None
-    if exact_call.get("gn_rgcn_forward_f32"):
-        roofline_exact = line("gn_rgcn_forward_f32", exact_call["gn_rgcn_forward_f32"])
-        roofline_exact["note"] = "GN_ACC_EXACT=1: relational transform on v_mfma_f32_16x16x4_f32 (exact fp32)"
+    roofline_fast = None
+    if fast_call.get("gn_rgcn_forward_f32"):
+        roofline_fast = line("gn_rgcn_forward_f32", fast_call["gn_rgcn_forward_f32"])
+        roofline_fast["note"] = ("arithmetic 'fast' (GN_RGCN_ARITH_FAST): two-term bf16 splits, <= 2^-16 per product, relation-major "
+                                 "kernel + finalisation, its W_r computed inside the external layer's launch; the eager step with it "
+                                 "takes {:.1f} us of entry points against {:.1f}".format(sum(fast_breakdown.values()), sum(breakdown.values())))
 
     result = {
         "metric": "edges aggregated/sec, GripNet forward on pose-0", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32 (relational transform as bf16x3 split products, fp32 accumulate; everything else fp32)", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload if world == 1 else (
                        "{} x{} dd relation shards".format(args.workload, world) if args.scaling == "weak" else
                        "{} (fixed), dd edges cut into {} ranges".format(args.workload, world)),
@@ -274,9 +404,10 @@ def main():
                               if sharded is None else
                               "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
         "roofline": roofline,
-        "roofline_exact": roofline_exact,
+        "roofline_fast": roofline_fast,
         "roofline_all": roofline_all,
         "mfma_util": mfma,
+        "mfma_util_source": "profiles/mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES pass of tools/mfma_util.sh, not a counter of this run)" if mfma else None,
         "plan_build_ms": round(plan_build_ms, 1),
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
         "edges_scored_per_sec": (hi - lo) / (per_call0.get("gn_distmult_plan_forward_f32",
@@ -316,6 +447,11 @@ def main():
         result["parity"] = {"max_abs_err_z": err_z, "max_abs_err_score": err_s, "tolerance": 1e-4,
                             "ok": bool(max(err_z, err_s) <= 1e-4)}
         assert max(err_z, err_s) <= 1e-4, "GPU result differs from the CPU oracle: {}".format(result["parity"])
+
+    if world == 1 and not args.no_extra:
+        del model, data
+        torch.cuda.empty_cache()
+        result["extra_workloads"] = extra_workloads(dev, args.extra_seconds, not args.no_cpu_baseline)
 
     if rank == 0:
         print(json.dumps(result))

@@ -19,7 +19,10 @@ _lib = None
 _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
-GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY = 1, 2          # flags of gn_rgcn_forward_f32
+GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY, GN_RGCN_ARITH_FAST = 1, 2, 4          # flags of gn_rgcn_forward_f32
+GN_RGCN_PATH_SHIFT = 8
+RGCN_PATHS = {"auto": 0, "pair": 1, "acc": 2, "lds": 3, "general": 4}       # kernel choice (tests, measurements)
+GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
 ABI_VERSION = 121                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
@@ -49,7 +52,8 @@ SIGNATURES = {
     "gn_rgcn_plan_destroy": (None, [_p]),
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
     "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
-    "gn_rgcn_weights_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "gn_rgcn_weights_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _int, _p, _sz, _p]),
+    "gn_rgcn_forward_path": (_int, [_p, _i64, _i64, _i64, _int]),
     "gn_cast_bf16": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "gn_graph_aggregate_bf16": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
     "gn_graph_aggregate_with_rgcn_weights_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p,
@@ -288,14 +292,15 @@ def ptr(t):
 
 # ---- thin typed wrappers ---------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=False, a_rows=None,
-         batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
+         batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None, fast=False):
+    """`fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic."""
     m = (a.shape[0] if a_rows is None else a_rows.shape[0]) if m is None else m
     k = a.shape[1] if k is None else k
     n = b.shape[-1] if n is None else n
     _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
                           ptr(b), ld(b) if ldb is None else ldb, stride_b,
                           ptr(out), ld(out) if ldc is None else ldc, stride_c,
-          m, n, k, batch, ptr(bias), int(bool(relu)), stream_ptr(a.device))
+          m, n, k, batch, ptr(bias), (GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0), stream_ptr(a.device))
     return out
 
 
@@ -495,16 +500,31 @@ class RgcnPlan:
             self._ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
         return self._ws, need
 
-    def weights(self, basis, att):
+    @staticmethod
+    def mode_flags(fast=False, path="auto"):
+        """Arithmetic and kernel-choice bits of gn_rgcn_forward_f32 / gn_rgcn_weights_f32."""
+        return (GN_RGCN_ARITH_FAST if fast else 0) | (RGCN_PATHS[path] << GN_RGCN_PATH_SHIFT)
+
+    def path(self, fin, fout, bases, fast=False, path="auto"):
+        """Name of the kernel a forward with these shapes and flags takes."""
+        code = int(load().gn_rgcn_forward_path(self._h, fin, fout, bases, self.mode_flags(fast, path)))
+        return {v: k for k, v in RGCN_PATHS.items()}.get(code, "?")
+
+    def needs_weights(self, fin, fout, bases, fast=False, path="auto"):
+        """Does the kernel behind these flags read W_r from the workspace (gn_rgcn_weights_f32)?"""
+        return self.path(fin, fout, bases, fast, path) != "pair"
+
+    def weights(self, basis, att, fast=False, path="auto"):
         """W_r = sum_b att[r,b] basis[b] into the plan's workspace, on the current stream (gn_rgcn_weights_f32)."""
         ws, need = self._workspace(basis.shape[1], basis.shape[2], basis.shape[0])
         _call("gn_rgcn_weights_f32", self._h, basis.shape[1], ptr(basis), ptr(att), basis.shape[0], basis.shape[2],
-              ptr(ws), need, stream_ptr(basis.device))
+              self.mode_flags(fast, path), ptr(ws), need, stream_ptr(basis.device))
 
-    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, weights_ready=False):
+    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, weights_ready=False, fast=False,
+                path="auto"):
         ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0])
         sc = side_copy(side)
-        flags = (GN_RGCN_PARTIAL if partial else 0) | (GN_RGCN_WEIGHTS_READY if weights_ready else 0)
+        flags = (GN_RGCN_PARTIAL if partial else 0) | (GN_RGCN_WEIGHTS_READY if weights_ready else 0) | self.mode_flags(fast, path)
         _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
               ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), flags,
               ptr(out), ld(out), _ref(sc), ptr(ws), need, stream_ptr(x.device))

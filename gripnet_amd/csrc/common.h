@@ -190,13 +190,4 @@ struct gn_rgcn_plan {
     int pair_groups = 0, pair_d = 0, pair_chunks = 0;
     int64_t pair_blocks = 0;
     int pair_ok = 0;
-    // transform-then-gather path (rgcn_tf.hip): one workgroup per relation slice, per-wave word streams
-    gn::DevBuf<uint32_t> tf_stream;       // 64 bytes per pair of iterations: 16 quads x 2 uint16 source words
-    gn::DevBuf<int32_t> tf_wg_parts;      // [groups + 1] ranges of slices
-    gn::DevBuf<int32_t> tf_part_rel;      // [slices] relation
-    gn::DevBuf<uint32_t> tf_part_wave;    // [slices][16 waves] {stream offset in 16-byte units, steps per row slot}
-    gn::DevBuf<int32_t> tf_cell_row;      // [3 slots][256 quads] destination row (-1: none)
-    int tf_tiles = 0, tf_g = 0;
-    int64_t tf_parts = 0, tf_iters = 0;
-    int tf_ok = 0;
 };

@@ -9,7 +9,7 @@
 // rgcn.hip / rgcn_acc.hip
 bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
 int gn_rgcn_acc_weights_args(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att, int64_t bases,
-                             int64_t fout, void* ws, gn_rw::WeightsFragArgs* g);
+                             int64_t fout, void* ws, int exact, gn_rw::WeightsFragArgs* g);
 
 namespace {
 
@@ -35,8 +35,8 @@ extern "C" gn_status gn_graph_aggregate_with_rgcn_weights_f32(
                          rgcn_workspace_bytes >= gn_rgcn_workspace_bytes(rgcn_plan, rgcn_in_features, rgcn_out_features, num_bases) &&
                          (reinterpret_cast<uintptr_t>(rgcn_workspace) & 15) == 0;
     if (!fusable) {                                            // any other shape: the two entry points, one after the other
-        gn_status s = gn_rgcn_weights_f32(rgcn_plan, rgcn_in_features, basis, att, num_bases, rgcn_out_features, rgcn_workspace,
-                                          rgcn_workspace_bytes, stream);
+        gn_status s = gn_rgcn_weights_f32(rgcn_plan, rgcn_in_features, basis, att, num_bases, rgcn_out_features,
+                                          GN_RGCN_ARITH_FAST, rgcn_workspace, rgcn_workspace_bytes, stream);
         if (s != GN_OK) return s;
         return gn_graph_aggregate_f32(plan, x, ld_x, num_features, weight, out_features, bias, relu, out, ld_out, side, stream);
     }
@@ -53,7 +53,7 @@ extern "C" gn_status gn_graph_aggregate_with_rgcn_weights_f32(
     if (ss != GN_OK) return ss;
     gn_rw::WeightsFragArgs g;
     const int w_blocks = gn_rgcn_acc_weights_args(rgcn_plan, rgcn_in_features, basis, att, num_bases, rgcn_out_features,
-                                                  rgcn_workspace, &g);
+                                                  rgcn_workspace, /*exact=*/0, &g);   // fragments of the GN_RGCN_ARITH_FAST path
     const int agg_blocks = (int)std::min<int64_t>(gn::ceil_div(a.rows, 4), GN_AGG_GRID);
     hipStream_t st = gn::as_stream(stream);
     switch (key) {

@@ -201,9 +201,28 @@ __global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CH>   // chunks of 32 k known at compile time (all of A's row tile requested up front), 0: any number, one ahead
+// TERMS = 3 (default): v = hi + mid + lo, six products (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi): what is dropped is
+//             below 2^-23 of a product, fp32's own rounding - the fp32-faithful mode.
+// TERMS = 2 (GN_GEMM_ARITH_FAST): v = hi + lo, three products, <= 2^-16 per product.
+template <int TERMS>
+__device__ __forceinline__ void split_terms(float a, float b, uint32_t (&t)[3]) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    t[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {a - __uint_as_float(t[0] << 16), b - __uint_as_float(t[0] & 0xffff0000u)};
+    t[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    if constexpr (TERMS == 3) {
+        const f32x2 q = {r[0] - __uint_as_float(t[1] << 16), r[1] - __uint_as_float(t[1] & 0xffff0000u)};
+        t[2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
+    } else {
+        t[2] = 0u;
+    }
+}
+
+template <int CH, int TERMS>   // CH: chunks of 32 k known at compile time (all of A's row tile requested up front), 0: any number, one ahead
 __global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tiles) {
-    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][hi, lo][64] as 16-byte words
+    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][TERMS][64] as 16-byte words
     u32x4* bsplit = reinterpret_cast<u32x4*>(bfrag);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -217,16 +236,16 @@ __global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tile
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = col < g.n ? g.b[(int64_t)(kb + j) * g.ldb + col] : 0.f;
-        u32x4 hi, lo;
+        u32x4 tv[3];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            uint32_t a, b;
-            gn_rw::split2(v[2 * h], v[2 * h + 1], a, b);
-            hi[h] = a; lo[h] = b;
+            uint32_t w[3];
+            split_terms<TERMS>(v[2 * h], v[2 * h + 1], w);
+            tv[0][h] = w[0]; tv[1][h] = w[1]; tv[2][h] = w[2];
         }
-        u32x4* o = bsplit + ((size_t)(ch * kColTiles + t) * 2) * 64 + l;
-        o[0] = hi;
-        o[64] = lo;
+        u32x4* o = bsplit + ((size_t)(ch * kColTiles + t) * TERMS) * 64 + l;
+#pragma unroll
+        for (int q3 = 0; q3 < TERMS; ++q3) o[64 * q3] = tv[q3];
     }
     __syncthreads();
     for (int tile = blockIdx.x * 8 + wave; tile < row_tiles; tile += gridDim.x * 8) {
@@ -238,23 +257,29 @@ __global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tile
 #pragma unroll
         for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         auto step = [&](int ch, const f32x4& a0, const f32x4& a1) {
-            u32x4 ah, al;
+            u32x4 at[3];
             {
-                uint32_t h, l;
-                gn_rw::split2(a0[0], a0[1], h, l); ah[0] = h; al[0] = l;
-                gn_rw::split2(a0[2], a0[3], h, l); ah[1] = h; al[1] = l;
-                gn_rw::split2(a1[0], a1[1], h, l); ah[2] = h; al[2] = l;
-                gn_rw::split2(a1[2], a1[3], h, l); ah[3] = h; al[3] = l;
+                uint32_t w[3];
+                split_terms<TERMS>(a0[0], a0[1], w); at[0][0] = w[0]; at[1][0] = w[1]; at[2][0] = w[2];
+                split_terms<TERMS>(a0[2], a0[3], w); at[0][1] = w[0]; at[1][1] = w[1]; at[2][1] = w[2];
+                split_terms<TERMS>(a1[0], a1[1], w); at[0][2] = w[0]; at[1][2] = w[1]; at[2][2] = w[2];
+                split_terms<TERMS>(a1[2], a1[3], w); at[0][3] = w[0]; at[1][3] = w[1]; at[2][3] = w[2];
             }
-            if (!a_ok) { ah = (u32x4){0u, 0u, 0u, 0u}; al = ah; }
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah), xl = __builtin_bit_cast(bf16x8, al);
-            const u32x4* __restrict__ bp = bsplit + (size_t)ch * kColTiles * 2 * 64 + lane;
+            if (!a_ok) { at[0] = (u32x4){0u, 0u, 0u, 0u}; at[1] = at[0]; at[2] = at[0]; }
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, at[0]), xm = __builtin_bit_cast(bf16x8, at[1]), xl = __builtin_bit_cast(bf16x8, at[2]);
+            const u32x4* __restrict__ bp = bsplit + (size_t)ch * kColTiles * TERMS * 64 + lane;
 #pragma unroll
             for (int t = 0; t < kColTiles; ++t) {
                 if (t >= n_tiles) break;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[(2 * t) * 64]), bl = __builtin_bit_cast(bf16x8, bp[(2 * t + 1) * 64]);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t], 0, 0, 0);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[(TERMS * t) * 64]), bm = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 1) * 64]);
+                if constexpr (TERMS == 3) {                                     // smallest terms first
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 2) * 64]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bm, acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bm, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[t], 0, 0, 0);
             }
         };
@@ -295,9 +320,25 @@ __global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tile
     }
 }
 
-bool gemm_exact() {
-    const char* e = getenv("GN_GEMM_EXACT");
-    return e && e[0] == '1';
+template <int TERMS>
+gn_status launch_split(const GemmArgs& g, int row_tiles, dim3 sgrid, size_t split_bytes, hipStream_t st) {
+#define GN_SPLIT_CASE(CH)                                                                                              \
+    {                                                                                                                  \
+        gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_gemm_split_lds<CH, TERMS>), 160 * 1024);    \
+        if (ls != GN_OK) return ls;                                                                                    \
+        k_gemm_split_lds<CH, TERMS><<<sgrid, 512, split_bytes, st>>>(g, row_tiles);                                    \
+    }                                                                                                                  \
+    break
+    switch (g.k / 32) {
+        case 1: GN_SPLIT_CASE(1);
+        case 2: GN_SPLIT_CASE(2);
+        case 4: GN_SPLIT_CASE(4);
+        case 8: GN_SPLIT_CASE(8);
+        default: GN_SPLIT_CASE(0);
+    }
+#undef GN_SPLIT_CASE
+    GN_LAUNCH_CHECK();
+    return GN_OK;
 }
 
 __global__ void k_merge(float* __restrict__ dst, int64_t ld_dst, const float* __restrict__ src, int64_t ld_src,
@@ -421,7 +462,8 @@ extern "C" {
 
 gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
-                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int relu, void* stream) {
+                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream) {
+    const int relu = flags & GN_GEMM_RELU, fast = flags & GN_GEMM_ARITH_FAST;
     GN_REQUIRE(m >= 0 && n >= 0 && k >= 0 && batch >= 0, "negative GEMM size");
     if (m == 0 || n == 0 || batch == 0) return GN_OK;
     GN_REQUIRE(a && b && c, "GEMM operand pointer is null");
@@ -436,20 +478,13 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
     if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny, one shared B
         const int row_tiles = (int)gn::ceil_div(m, 16);
-        if (!a_rows && k % 32 == 0 && g.a_vec_ok && !gemm_exact()) {                           // bf16 x 3 on split operands
-            const size_t split_bytes = (size_t)(k / 32) * kColTiles * 2 * 64 * sizeof(f32x4);   // = lds_bytes: 4 bytes per element of B
-            // eight waves per workgroup (two workgroups per CU at k = 256): one row tile per wave on the NC shapes
+        if (!a_rows && k % 32 == 0 && g.a_vec_ok) {                                   // bf16 matrix instruction on split operands
+            const int terms = fast ? 2 : 3;
+            const size_t split_bytes = (size_t)(k / 32) * kColTiles * terms * 64 * sizeof(f32x4);   // 2 bytes per term and element of B
+            // eight waves per workgroup: one row tile per wave on the NC shapes
             dim3 sgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 8), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
             hipStream_t st = gn::as_stream(stream);
-            switch (k / 32) {
-                case 1: k_gemm_split_lds<1><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
-                case 2: k_gemm_split_lds<2><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
-                case 4: k_gemm_split_lds<4><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
-                case 8: k_gemm_split_lds<8><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
-                default: k_gemm_split_lds<0><<<sgrid, 512, split_bytes, st>>>(g, row_tiles); break;
-            }
-            GN_LAUNCH_CHECK();
-            return GN_OK;
+            if (split_bytes <= 160 * 1024) return fast ? launch_split<2>(g, row_tiles, sgrid, split_bytes, st) : launch_split<3>(g, row_tiles, sgrid, split_bytes, st);
         }
         dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
         k_gemm_f32_lds<<<lgrid, 256, lds_bytes, gn::as_stream(stream)>>>(g, row_tiles);

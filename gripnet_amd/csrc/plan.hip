@@ -591,11 +591,6 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->packed.release();
     p->wg_begin.release();
     p->wg_items.release();
-    p->tf_stream.release();
-    p->tf_wg_parts.release();
-    p->tf_part_rel.release();
-    p->tf_part_wave.release();
-    p->tf_cell_row.release();
     p->pair_stream.release();
     p->pair_wave_first.release();
     p->pair_desc.release();

@@ -43,10 +43,6 @@
 #include <vector>
 
 // rgcn_tf.hip
-gn_status gn_rgcn_build_tf_plan(gn_rgcn_plan* plan, const std::vector<int32_t>& rp, const std::vector<uint32_t>& srcs, hipStream_t st);
-bool gn_rgcn_tf_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, bool split);
-gn_status gn_rgcn_tf_launch(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const void* wfrag,
-                            float* slabs, hipStream_t st);
 // rgcn_fast.hip
 gn_status gn_rgcn_slab_finalize_launch(const gn_rgcn_plan* plan, const float* slabs, int groups, const float* x,
                                        int64_t ld_x, int64_t fin, const float* root, const float* bias, int relu,
@@ -452,11 +448,6 @@ int bits_for(int64_t n) {
     return b;
 }
 
-// GN_ACC_EXACT=1: the transform on the fp32 matrix instruction instead of the three bf16 products.
-bool acc_exact() {
-    const char* e = getenv("GN_ACC_EXACT");
-    return e && e[0] == '1';
-}
 
 // 16-byte W fragments per lane and relation (see k_rgcn_acc)
 size_t acc_w_bytes(int64_t relations, int64_t fin, int64_t fout) {
@@ -761,7 +752,7 @@ gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const i
     plan->acc_tiles = tiles; plan->acc_q = Q; plan->acc_g = G;
     plan->acc_blocks = (int64_t)blocks_total;
     plan->acc_ok = 1;
-    return gn_rgcn_build_tf_plan(plan, rp, srcs, st);     // the same (relation, destination) order feeds the transform-first kernel
+    return GN_OK;
 }
 
 static size_t acc_lds_bytes(int64_t n, int64_t fin) {
@@ -777,27 +768,27 @@ bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout,
 }
 
 size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
-    const size_t groups = (size_t)std::max(plan->acc_g, plan->tf_ok ? plan->tf_g : 0);
+    const size_t groups = (size_t)plan->acc_g;
     return acc_w_bytes(plan->num_relations, fin, fout) + groups * plan->num_nodes * fout * sizeof(float);
 }
 
 // Arguments of the weights body for this plan and these parameters (also used by cowork.hip, which runs the body
 // inside another launch); returns the number of 256-thread blocks it needs.
 int gn_rgcn_acc_weights_args(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att, int64_t bases,
-                             int64_t fout, void* ws, gn_rw::WeightsFragArgs* g) {
+                             int64_t fout, void* ws, int exact, gn_rw::WeightsFragArgs* g) {
     const int64_t R = plan->num_relations;
     g->att = att; g->basis = basis; g->wfrag = static_cast<f32x4*>(ws);
     g->relations = (int)R; g->bases = (int)bases; g->fin = (int)fin; g->fout = (int)fout;
     g->tasks = (int)(gn::ceil_div(R, 16) * 4 * ((fin / 4 + 7) / 8) * (fout / 16));
-    g->split = acc_exact() ? 0 : 1;
+    g->split = exact ? 0 : 1;
     return (int)gn::ceil_div(g->tasks, 4);
 }
 
 gn_status gn_rgcn_acc_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
-                              int64_t bases, int64_t fout, void* ws, hipStream_t st) {
+                              int64_t bases, int64_t fout, void* ws, int exact, hipStream_t st) {
     GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
     WeightsFragArgs g;
-    const int blocks = gn_rgcn_acc_weights_args(plan, fin, basis, att, bases, fout, ws, &g);
+    const int blocks = gn_rgcn_acc_weights_args(plan, fin, basis, att, bases, fout, ws, exact, &g);
     k_rgcn_weights_frag<<<blocks, 256, 0, st>>>(g);
     GN_LAUNCH_CHECK();
     return GN_OK;
@@ -805,22 +796,17 @@ gn_status gn_rgcn_acc_weights(const gn_rgcn_plan* plan, int64_t fin, const float
 
 gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                               const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
-                              int relu, int partial, int weights_ready, float* out, int64_t ld_out,
+                              int relu, int partial, int weights_ready, int exact, float* out, int64_t ld_out,
                               const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st) {
     GN_REQUIRE(ld_x % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld_x %% 4 == 0");
     GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
     const int64_t R = plan->num_relations;
     f32x4* wfrag = static_cast<f32x4*>(ws);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + acc_w_bytes(R, fin, fout));
-    const bool split = !acc_exact();
+    const bool split = !exact;
     if (!weights_ready) {
-        gn_status ws_status = gn_rgcn_acc_weights(plan, fin, basis, att, bases, fout, ws, st);
+        gn_status ws_status = gn_rgcn_acc_weights(plan, fin, basis, att, bases, fout, ws, exact, st);
         if (ws_status != GN_OK) return ws_status;
-    }
-    if (gn_rgcn_tf_applicable(plan, fin, fout, split)) {
-        gn_status ts = gn_rgcn_tf_launch(plan, x, ld_x, fin, wfrag, slabs, st);
-        if (ts != GN_OK) return ts;
-        return gn_rgcn_slab_finalize_launch(plan, slabs, plan->tf_g, x, ld_x, fin, root, bias, relu, partial, out, ld_out, side, st);
     }
     const size_t lds = acc_lds_bytes(plan->num_nodes, fin);
     gn_status s;

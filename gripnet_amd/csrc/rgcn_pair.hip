@@ -32,9 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kWaves = 8, kThreads = kWaves * 64;
+constexpr int kWaves = 16, kThreads = kWaves * 64;   // four waves per SIMD: 128 registers each, one destination row per wave
 constexpr int kRowBytes = 128;             // LDS stride of an att row (32 bases; fewer: zero padded)
-constexpr int kRingBlocks = 64;            // per-wave window on its stream: 64 blocks of 64 bytes, refilled a quarter at a time
+constexpr int kRingBlocks = 32;            // per-wave window on its stream: 32 blocks of 64 bytes, refilled a quarter (512 B) at a time
 constexpr int kRingBytes = kRingBlocks * 64;
 constexpr int kMaxD = 3;                   // destination rows per workgroup
 constexpr int kMaxChunks = 255;            // chunks of 32 sources (a descriptor names its chunk in eight bits)
@@ -65,7 +65,7 @@ struct PairArgs {
 };
 
 #ifdef GN_STAMPS
-__device__ unsigned long long g_pair_stamps[2][256 * 8][12];
+__device__ unsigned long long g_pair_stamps[2][256 * kWaves][12];
 #endif
 
 __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
@@ -104,7 +104,7 @@ struct Walk {
 // ---- the gather of one unit, as ONE block of assembly (tools/gen_pair_asm.py writes it; the comment there explains
 // the pipeline).  Written in assembly because the compiler, given the same sequence as separate statements, copies the
 // destination registers of LDS requests still in flight and spends ~45 instructions per block on the control flow of
-// the pipeline; this is 22.  Physical registers v216-v249 and s92-s95 belong to the block (clobbers). ----
+// the pipeline; this is 22.  Physical registers v92-v125 and s92-s95 belong to the block (clobbers). ----
 #include "rgcn_pair_asm.inc"
 
 #define GN_UNIT_OPERANDS(p)                                                                                            \
@@ -112,9 +112,7 @@ struct Walk {
       [p6] "=&v"(p[6]), [p7] "=&v"(p[7]), [soff] "+s"(w.soff), [sdma] "+s"(w.sdma)                                    \
     : [lo] "v"(w.lane_off), [rlane] "v"(w.ring_lane), [l16] "v"(w.lane16), [rbase] "s"(w.ring_base),                  \
       [sbase] "s"(w.sbase), [c03] "s"(c03), [c47] "s"(c47)                                                            \
-    : "memory", "scc", "s92", "s93", "s94", "s95", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",    \
-      "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", \
-      "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249"
+    : "memory", "scc", "s92", "s93", "s94", "s95", GN_PAIR_ASM_CLOBBERS
 
 // c03 / c47: the block counts of the unit's eight sections, eight bits each.
 template <int BT>
@@ -213,14 +211,14 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // ---- prologue: this wave's window on its stream, the att table, the wave's first chunk of x ----
+    // ---- prologue: this wave's window on its stream, the att table ----
     const uint32_t wave_id = (uint32_t)(g * kWaves + wave);
     const uint32_t first_block = a.wave_first[wave_id], n_units = a.wave_units[wave_id];
     const uint32_t* __restrict__ desc = a.desc + (size_t)a.wave_desc[wave_id] * 8;
     Walk w;
     w.ring_base = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wave * kRingBytes);
     {
-        // the stream address as scalars (a saddr operand of the refill below), whatever the compiler thinks of its uniformity
+        // the stream address as scalars (a saddr operand of the refill), whatever the compiler thinks of its uniformity
         const uint64_t sb = reinterpret_cast<uint64_t>(a.stream + (size_t)first_block * 16);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
         w.sbase = reinterpret_cast<const uint32_t*>((uint64_t)hi << 32 | lo);
@@ -229,13 +227,13 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     w.ring_lane = w.ring_base + (uint32_t)kg * 16u + (uint32_t)(lane & 3) * 4u;
     w.lane16 = (uint32_t)lane * 16u;
     w.soff = 128u;                                                             // a unit reads its first two words itself
-    w.sdma = 3u * 1024u;                                                       // the window starts with blocks 0..47
-    {
+    w.sdma = 3u * 512u;                                                        // the window starts with blocks 0..23
+    if (lane < 32) {
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(w.sbase) + lane;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)q * 64),
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(w.ring_base + q * 1024u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)q * 32),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(w.ring_base + q * 512u), 16, 0, 0);
     }
     if (a.att_dma) {
         // rows of 32 bases are the LDS rows: 1 KB per wave instruction straight into LDS
@@ -255,9 +253,6 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     if (tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
     // unit descriptors of this wave, eight dwords each: lane L holds dword L of the current page of eight units
     uint32_t descv = n_units ? desc[lane] : 0u;
-    int cur_chunk = n_units ? (int)(__builtin_amdgcn_readlane(descv, 2) & 0xffu) : 0;
-    XRaw<NT> raw;
-    load_chunk<NT>(a, cur_chunk, kg, c, raw);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef GN_STAMPS
@@ -265,52 +260,40 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     unsigned long long cyc_gather = 0, cyc_contract = 0, cyc_x = 0;
 #endif
 
-    f32x4 acc[kMaxD][BT][NT];
+    f32x4 acc[BT][NT];                                                         // this wave's share of U of ITS destination row
 #pragma unroll
-    for (int d = 0; d < kMaxD; ++d)
+    for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
-        for (int jm = 0; jm < BT; ++jm)
-#pragma unroll
-            for (int jn = 0; jn < NT; ++jn) acc[d][jm][jn] = (f32x4)(0.f);
-
-    XFrag<NT> xf;
-    split_chunk<NT, TERMS>(raw, xf);
+        for (int jn = 0; jn < NT; ++jn) acc[jm][jn] = (f32x4)(0.f);
 
 #pragma unroll 1
     for (uint32_t u = 0; u < n_units; ++u) {
         if (u && (u & 7u) == 0u) descv = desc[(size_t)(u >> 3) * 64 + lane];   // next page (waited for at once: rare)
         const int o = (int)(u & 7u) * 8;
         const uint32_t c03 = __builtin_amdgcn_readlane(descv, o), c47 = __builtin_amdgcn_readlane(descv, o + 1);
-        const uint32_t where = __builtin_amdgcn_readlane(descv, o + 2);
-        const int chunk = (int)(where & 0xffu), d = (int)((where >> 8) & 3u);
-        if (chunk != cur_chunk) {
-            // the next chunk of x as MFMA operands, fetched here (L2) and waited for at once: holding all of a wave's chunks
-            // from the prologue on costs 24 registers a chunk, which two waves per SIMD do not have
+        const int chunk = (int)(__builtin_amdgcn_readlane(descv, o + 2) & 0xffu);
+        // this unit's chunk of x: requested here, split into bf16 terms behind the gather (the other waves of the SIMD
+        // cover the L2 round trips)
 #ifdef GN_STAMPS
-            const unsigned long long cx0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long cx0 = __builtin_amdgcn_s_memtime();
 #endif
-            cur_chunk = chunk;
-            load_chunk<NT>(a, chunk, kg, c, raw);
-            split_chunk<NT, TERMS>(raw, xf);
-#ifdef GN_STAMPS
-            asm volatile("" : "+v"(xf.w[0][0][0]));
-            cyc_x += __builtin_amdgcn_s_memtime() - cx0;
-#endif
-        }
+        XRaw<NT> raw;
+        load_chunk<NT>(a, chunk, kg, c, raw);
         acc_t p[8];
 #ifdef GN_STAMPS
         const unsigned long long cg0 = __builtin_amdgcn_s_memtime();
+        cyc_x += cg0 - cx0;
 #endif
         gather_unit<BT>(w, c03, c47, p);
 #ifdef GN_STAMPS
         const unsigned long long cg1 = __builtin_amdgcn_s_memtime();
         cyc_gather += cg1 - cg0;
 #endif
-        if (d == 0) contract<NT, BT, TERMS>(p, xf, acc[0]);
-        else if (d == 1) contract<NT, BT, TERMS>(p, xf, acc[1]);
-        else contract<NT, BT, TERMS>(p, xf, acc[2]);
+        XFrag<NT> xf;
+        split_chunk<NT, TERMS>(raw, xf);
+        contract<NT, BT, TERMS>(p, xf, acc);
 #ifdef GN_STAMPS
-        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(acc[2][0][0]) : "memory");
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]) : "memory");
         cyc_contract += __builtin_amdgcn_s_memtime() - cg1;
 #endif
     }
@@ -318,120 +301,129 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #ifdef GN_STAMPS
     const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
 #endif
-    __syncthreads();                                                           // att table and windows are dead from here
 
-    // ---- epilogue 1: U_i = sum over the waves of their shares, through LDS ----
-    // part[wave][d][k'], k' = feature * BP + base (bases innermost: the eight values a lane holds of one feature, bases
-    // BT (4 kg + v) + jm, are 32 contiguous bytes)
-    float* part = reinterpret_cast<float*>(lds);
+    // ---- epilogue ----
+    // Rows of basis (and root) this thread will contract: thread = (four outputs o4, slice of the KE rows of U).  Requested
+    // BEFORE the barrier: a wave that finishes early fetches while the others still gather; every compute unit pulls all of
+    // basis (196 KB on PoSE) through its own L2 port, which is what this epilogue costs.
+    constexpr int KE = KP + FIN;                                               // + FIN rows: deg_i x_i against root
+    constexpr int kRowsMax = 14;                                               // rows of a slice held in registers
     const int32_t* my_dst = a.wg_dst + (size_t)g * 4;
     int nd = 0;
 #pragma unroll
     for (int d = 0; d < kMaxD; ++d) nd += my_dst[d] >= 0 ? 1 : 0;
-#pragma unroll
-    for (int d = 0; d < kMaxD; ++d) {
-        if (d >= nd) break;
-        float* dstp = part + ((size_t)wave * kMaxD + d) * KP;
-#pragma unroll
-        for (int jn = 0; jn < NT; ++jn) {
-            float* q = dstp + (NT * c + jn) * BP + 4 * BT * kg;
-            if constexpr (BT == 2) {
-                *reinterpret_cast<f32x4*>(q) = (f32x4){acc[d][0][jn][0], acc[d][1][jn][0], acc[d][0][jn][1], acc[d][1][jn][1]};
-                *reinterpret_cast<f32x4*>(q + 4) = (f32x4){acc[d][0][jn][2], acc[d][1][jn][2], acc[d][0][jn][3], acc[d][1][jn][3]};
-            } else {
-                *reinterpret_cast<f32x4*>(q) = acc[d][0][jn];
-            }
-        }
-    }
-    __syncthreads();
-#ifdef GN_STAMPS
-    const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // thread -> four consecutive k' of one destination; the sums go to wave 0's slots (read by this thread only).
-    // Behind them: deg_i * x_i (the root term rides through the same contraction as FIN more rows).
-    constexpr int KE = KP + FIN;
-    float* uext = part + (size_t)kWaves * kMaxD * KP;                          // [nd][FIN]
-    for (int e = tid; e < nd * (KP / 4); e += kThreads) {
-        const int d = e / (KP / 4), k4 = e - d * (KP / 4);
-        f32x4 s = (f32x4)(0.f);
-#pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) s += *reinterpret_cast<const f32x4*>(part + ((size_t)ww * kMaxD + d) * KP + 4 * k4);
-        *reinterpret_cast<f32x4*>(part + (size_t)d * KP + 4 * k4) = s;
-    }
-    if (!a.partial)
-        for (int e = tid; e < nd * FIN; e += kThreads) {
-            const int d = e / FIN, f = e - d * FIN;
-            const int i = my_dst[d];
-            uext[e] = a.x[(int64_t)i * a.ld_x + f] * fmaxf(a.indeg[i], 1.0f);
-        }
-    __syncthreads();
-
-#ifdef GN_STAMPS
-    const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- epilogue 2: out_i = act( (U_i . basis + deg_i x_i . root) / max(1, deg_i) + bias ) ----
-    // thread = (four outputs o4, slice of the KE rows); rows in batches of eight loads in flight
+    const uint32_t ranges = (uint32_t)my_dst[3];                               // first wave of rows 1 and 2 (eight bits each)
+    const int wb1 = (int)(ranges & 0xffu), wb2 = (int)((ranges >> 8) & 0xffu);
     const int fout = a.fout, og = fout >> 2;                                   // fout % 4 == 0, og in 1..16
     const int slices = kThreads / og;
     const int rows = a.partial ? KP : KE;
     const int o4 = tid % og, sl = tid / og;
-    const int per = (rows + slices - 1) / slices;
+    const int per = (rows + slices - 1) / slices;                              // <= kRowsMax (checked on the host)
     const int k0 = min(rows, sl * per), k1 = min(rows, k0 + per);
+    f32x4 bv[kRowsMax];
+    {
+        const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis) + o4;
+        const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(a.root) + o4;
+#pragma unroll
+        for (int j = 0; j < kRowsMax; ++j) {
+            const int k = min(k0 + j, rows - 1);
+            // row k' = feature * BP + base of U is row base * FIN + feature of basis; padded bases carry zeros in U
+            const int feat = k / BP, base = k - feat * BP;
+            const bool is_root = k >= KP;
+            const int brow = min(base, a.B - 1) * FIN + min(feat, FIN - 1);
+            bv[j] = (sl < slices && j < per) ? (is_root ? rp[(size_t)(k - KP) * og] : bp[(size_t)brow * og]) : (f32x4)(0.f);
+            if ((!is_root && base >= a.B) || k0 + j >= k1) bv[j] = (f32x4)(0.f);
+        }
+    }
+    // the divisor and bias of the output element this thread writes at the very end, and
+    // deg_i * x_i[f] for (row d, feature f) = tid: also requested before the barrier
+    const int fin_pair = tid >> 3, fin_part = tid & 7;
+    const bool fin_live = fin_pair < nd * fout;
+    const int fin_d = fin_live ? fin_pair / fout : 0, fin_o = fin_live ? fin_pair - fin_d * fout : 0;
+    const int fin_i = fin_live ? my_dst[fin_d] : 0;
+    float fin_div = 1.f, fin_bias = 0.f;
+    if (fin_live && !a.partial) {
+        fin_div = fmaxf(a.indeg[fin_i], 1.0f);
+        if (a.bias) fin_bias = a.bias[fin_o];
+    }
+    float ux = 0.f;
+    if (!a.partial && tid < nd * FIN) {
+        const int d = tid / FIN, f = tid - d * FIN;
+        const int i = my_dst[d];
+        ux = a.x[(int64_t)i * a.ld_x + f] * fmaxf(a.indeg[i], 1.0f);
+    }
+    __syncthreads();                                                           // att table and windows are dead from here
+#ifdef GN_STAMPS
+    const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // U_i = sum over the waves of row i of their shares, through LDS: part[wave][k'], k' = feature * BP + base (bases
+    // innermost: the eight values a lane holds of one feature, bases BT (4 kg + v) + jm, are 32 contiguous bytes)
+    float* part = reinterpret_cast<float*>(lds);
+    {
+        float* dstp = part + (size_t)wave * KP;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            float* q = dstp + (NT * c + jn) * BP + 4 * BT * kg;
+            if constexpr (BT == 2) {
+                *reinterpret_cast<f32x4*>(q) = (f32x4){acc[0][jn][0], acc[1][jn][0], acc[0][jn][1], acc[1][jn][1]};
+                *reinterpret_cast<f32x4*>(q + 4) = (f32x4){acc[0][jn][2], acc[1][jn][2], acc[0][jn][3], acc[1][jn][3]};
+            } else {
+                *reinterpret_cast<f32x4*>(q) = acc[0][jn];
+            }
+        }
+    }
+    __syncthreads();
+    // thread -> four consecutive k' of one row; the sums go to the row's first wave's slot (read by this thread only).
+    // Behind the shares: deg_i * x_i (the root term rides through the same contraction as FIN more rows).
+    float* usum = part + (size_t)kWaves * KP;                                  // [nd][KP]
+    float* uext = usum + (size_t)kMaxD * KP;                                   // [nd][FIN]
+    for (int e = tid; e < nd * (KP / 4); e += kThreads) {
+        const int d = e / (KP / 4), k4 = e - d * (KP / 4);
+        const int w0 = d == 0 ? 0 : (d == 1 ? wb1 : wb2), w1 = d == 0 ? (nd > 1 ? wb1 : kWaves) : (d == 1 ? (nd > 2 ? wb2 : kWaves) : kWaves);
+        f32x4 s = (f32x4)(0.f);
+        for (int ww = w0; ww < w1; ++ww) s += *reinterpret_cast<const f32x4*>(part + (size_t)ww * KP + 4 * k4);
+        *reinterpret_cast<f32x4*>(usum + (size_t)d * KP + 4 * k4) = s;
+    }
+    if (!a.partial && tid < nd * FIN) uext[tid] = ux;
+    __syncthreads();
+#ifdef GN_STAMPS
+    const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // out_i = act( (U_i . basis + deg_i x_i . root) / max(1, deg_i) + bias )
     f32x4 sum[kMaxD];
 #pragma unroll
     for (int d = 0; d < kMaxD; ++d) sum[d] = (f32x4)(0.f);
-    if (sl < slices) {
-        const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis) + o4;
-        const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(a.root) + o4;
-        for (int kb = k0; kb < k1; kb += 8) {
-            f32x4 bv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = min(kb + j, k1 - 1);
-                // row k' = feature * BP + base of U is row base * FIN + feature of basis; padded bases carry zeros in U
-                const int feat = k / BP, base = k - feat * BP;
-                const bool is_root = k >= KP;
-                const int brow = min(base, a.B - 1) * FIN + feat;
-                bv[j] = is_root ? rp[(size_t)(k - KP) * og] : bp[(size_t)brow * og];
-                if (!is_root && base >= a.B) bv[j] = (f32x4)(0.f);
-                if (kb + j >= k1) bv[j] = (f32x4)(0.f);
-            }
+    for (int j = 0; j < kRowsMax; ++j) {
+        const int k = min(k0 + j, rows - 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = min(kb + j, k1 - 1);
-#pragma unroll
-                for (int d = 0; d < kMaxD; ++d)
-                    if (d < nd) sum[d] += (k >= KP ? uext[d * FIN + (k - KP)] : part[(size_t)d * KP + k]) * bv[j];
-            }
-        }
+        for (int d = 0; d < kMaxD; ++d)
+            if (d < nd) sum[d] += (k >= KP ? uext[d * FIN + (k - KP)] : usum[(size_t)d * KP + k]) * bv[j];
     }
 #ifdef GN_STAMPS
     asm volatile("" : "+v"(sum[0]));
     const unsigned long long st5 = __builtin_amdgcn_s_memrealtime();
 #endif
-    float* red = part + (size_t)kMaxD * KP;                                    // [slices][nd][og][4], over the other waves' slots (dead)
+    float* red = part;                                                         // [slices][nd][og][4], over the waves' shares (dead)
     if (sl < slices)
 #pragma unroll
         for (int d = 0; d < kMaxD; ++d)
             if (d < nd) *reinterpret_cast<f32x4*>(red + ((size_t)(sl * kMaxD + d) * og + o4) * 4) = sum[d];
     __syncthreads();
-    // (destination, output) x four partial sums over the slices, folded inside the lane quad
+    // (destination, output) x eight partial sums over the slices, folded inside eight adjacent lanes
     {
-        const int pair_id = tid >> 2, part_id = tid & 3;
-        const bool live = pair_id < nd * fout;
-        const int d = live ? pair_id / fout : 0, o = live ? pair_id - d * fout : 0;
         float s = 0.f;
-        if (live)
-            for (int q = part_id; q < slices; q += 4) s += red[((size_t)(q * kMaxD + d) * og + (o >> 2)) * 4 + (o & 3)];
+        if (fin_live)
+            for (int q = fin_part; q < slices; q += 8) s += red[((size_t)(q * kMaxD + fin_d) * og + (fin_o >> 2)) * 4 + (fin_o & 3)];
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
-        if (live && part_id == 0) {
-            const int i = my_dst[d];
+        s += __shfl_xor(s, 4);
+        if (fin_live && fin_part == 0) {
             if (!a.partial) {
-                s = s / fmaxf(a.indeg[i], 1.0f) + (a.bias ? a.bias[o] : 0.f);
+                s = s / fin_div + fin_bias;
                 if (a.relu) s = fmaxf(s, 0.f);
             }
-            a.out[(int64_t)i * a.ld_out + o] = s;
+            a.out[(int64_t)fin_i * a.ld_out + fin_o] = s;
         }
     }
     if (a.side.dst) {                                                          // concat slot 0, by the whole grid
@@ -681,61 +673,87 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
             load[best] += cost[i];
         }
     }
-    // per workgroup: its units in chunk-major order (a wave's units share chunks of x), cut into eight contiguous runs of
-    // equal cost; per wave the descriptors (eight dwords a unit, pages of eight units) and the stream
+    // per workgroup: every destination row gets a share of the sixteen waves in proportion to its cost (at least one), a
+    // wave a contiguous run of its row's units (chunk order) of equal cost; per wave the descriptors (eight dwords a unit,
+    // pages of eight units) and the stream
     std::vector<std::vector<uint32_t>> wg_stream((size_t)G * kWaves), wg_desc((size_t)G * kWaves);
     std::vector<uint32_t> wave_units((size_t)G * kWaves, 0u);
     std::vector<int32_t> wg_dst((size_t)G * 4, -1);
     gn::parallel_for(G, 1, [&](int64_t b, int64_t e) {
-        struct Unit { int32_t ch, d, slice; int64_t cost; };
+        struct Unit { int32_t ch, slice; int64_t cost; };
         std::vector<Unit> units;
         for (int64_t gg = b; gg < e; ++gg) {
             const std::vector<int32_t>& rows = wg_rows[gg];
-            for (size_t d = 0; d < rows.size(); ++d) wg_dst[gg * 4 + d] = rows[d];
-            units.clear();
-            int64_t total = 0;
-            for (int ch = 0; ch < chunks; ++ch)
-                for (size_t d = 0; d < rows.size(); ++d) {
-                    const int64_t i = rows[d];
+            const int nd = (int)rows.size();
+            for (int d = 0; d < nd; ++d) wg_dst[gg * 4 + d] = rows[d];
+            // waves per row: largest remainders of the proportional share
+            int share[kMaxD] = {0, 0, 0};
+            {
+                int64_t total = 0;
+                for (int d = 0; d < nd; ++d) total += std::max<int64_t>(cost[rows[d]], 1);
+                int given = 0;
+                double frac[kMaxD] = {0, 0, 0};
+                for (int d = 0; d < nd; ++d) {
+                    const double want = (double)kWaves * std::max<int64_t>(cost[rows[d]], 1) / total;
+                    share[d] = std::max(1, (int)want);
+                    frac[d] = want - share[d];
+                    given += share[d];
+                }
+                while (given < kWaves) { int best = 0; for (int d = 1; d < nd; ++d) if (frac[d] > frac[best]) best = d; share[best]++; frac[best] -= 1.0; ++given; }
+                while (given > kWaves) { int best = -1; for (int d = 0; d < nd; ++d) if (share[d] > 1 && (best < 0 || frac[d] < frac[best])) best = d; share[best]--; frac[best] += 1.0; --given; }
+            }
+            int wave0 = 0;
+            uint32_t starts = 0;
+            for (int d = 0; d < nd; ++d) {
+                if (d == 1) starts |= (uint32_t)wave0;
+                if (d == 2) starts |= (uint32_t)wave0 << 8;
+                const int64_t i = rows[d];
+                units.clear();
+                int64_t total = 0;
+                for (int ch = 0; ch < chunks; ++ch) {
                     if (rp[(size_t)i * kpad + 32 * ch + 32] == rp[(size_t)i * kpad + 32 * ch]) continue;
                     int nb[8], deepest = 1;
                     for (int t = 0; t < 8; ++t) { nb[t] = section_blocks(i, ch, t); deepest = std::max(deepest, nb[t]); }
                     for (int j = 0; j * kSectionCap < deepest; ++j) {
-                        int64_t c = 12;
+                        int64_t c = 16;                                        // x chunk, split, matrix products: in block times
                         for (int t = 0; t < 8; ++t) c += std::max(1, std::min(kSectionCap, nb[t] - j * kSectionCap));
-                        units.push_back({ch, (int32_t)d, j, c});
+                        units.push_back({ch, j, c});
                         total += c;
                     }
                 }
-            int64_t seen = 0;
-            for (const Unit& un : units) {
-                // the wave whose share of the cost line holds this unit's midpoint
-                const int wv = total > 0 ? (int)std::min<int64_t>(kWaves - 1, (2 * seen + un.cost) * kWaves / (2 * total)) : 0;
-                seen += un.cost;
-                std::vector<uint32_t>& out = wg_stream[gg * kWaves + wv];
-                std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
-                const size_t at = dv.size();
-                dv.resize(at + 8, 0u);
-                dv[at + 2] = (uint32_t)un.ch | (uint32_t)un.d << 8;
-                const int64_t i = rows[un.d];
-                for (int t = 0; t < 8; ++t) {
-                    const uint32_t* list[4];
-                    int len[4], longest = 0;
-                    for (int k = 0; k < 4; ++k) {
-                        const size_t key_id = (size_t)i * kpad + 32 * un.ch + 8 * k + t;
-                        const int full = rp[key_id + 1] - rp[key_id];
-                        const int from = std::min(full, un.slice * kSectionCap * 4);
-                        list[k] = rels.data() + rp[key_id] + from;
-                        len[k] = std::min(full - from, kSectionCap * 4);
-                        longest = std::max(longest, len[k]);
+                int64_t seen = 0;
+                for (const Unit& un : units) {
+                    // the wave of this row whose share of the cost line holds this unit's midpoint
+                    const int wv = wave0 + (total > 0 ? (int)std::min<int64_t>(share[d] - 1, (2 * seen + un.cost) * share[d] / (2 * total)) : 0);
+                    seen += un.cost;
+                    std::vector<uint32_t>& out = wg_stream[gg * kWaves + wv];
+                    std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
+                    const size_t at = dv.size();
+                    dv.resize(at + 8, 0u);
+                    dv[at + 2] = (uint32_t)un.ch;
+                    for (int t = 0; t < 8; ++t) {
+                        const uint32_t* list[4];
+                        int len[4], longest = 0;
+                        for (int k = 0; k < 4; ++k) {
+                            const size_t key_id = (size_t)i * kpad + 32 * un.ch + 8 * k + t;
+                            const int full = rp[key_id + 1] - rp[key_id];
+                            const int from = std::min(full, un.slice * kSectionCap * 4);
+                            list[k] = rels.data() + rp[key_id] + from;
+                            len[k] = std::min(full - from, kSectionCap * 4);
+                            longest = std::max(longest, len[k]);
+                        }
+                        const int nb = std::max(1, (longest + 3) / 4);
+                        dv[at + (t >> 2)] |= (uint32_t)nb << (8 * (t & 3));
+                        lay_out_section(list, len, nb, (uint32_t)R, out);
                     }
-                    const int nb = std::max(1, (longest + 3) / 4);
-                    dv[at + (t >> 2)] |= (uint32_t)nb << (8 * (t & 3));
-                    lay_out_section(list, len, nb, (uint32_t)R, out);
+                    out.resize(out.size() + 2 * 16, (uint32_t)R * kRowBytes);   // two padding blocks: requested, never added
+                    wave_units[gg * kWaves + wv] += 1;
                 }
-                out.resize(out.size() + 2 * 16, (uint32_t)R * kRowBytes);       // two padding blocks: requested, never added
-                wave_units[gg * kWaves + wv] += 1;
+                wave0 += share[d];
             }
+            if (nd < 2) starts |= (uint32_t)kWaves;
+            if (nd < 3) starts |= (uint32_t)kWaves << 8;
+            wg_dst[gg * 4 + 3] = (int32_t)starts;
             for (int wv = 0; wv < kWaves; ++wv) {                              // whole pages
                 std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
                 dv.resize((dv.size() + 63) / 64 * 64, 0u);
@@ -785,7 +803,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
 extern "C" GN_API int gn_debug_read_pair_stamps(unsigned long long* out) {   // diagnostic build only: [2048][8] of the last launch
     static int which = 0;
     (void)which;
-    static unsigned long long both[2][256 * 8][12];
+    static unsigned long long both[2][256 * kWaves][12];
     if (hipDeviceSynchronize() != hipSuccess) return 1;
     if (hipMemcpyFromSymbol(both, HIP_SYMBOL(g_pair_stamps), sizeof(both)) != hipSuccess) return 2;
     // the set written last: the one with the larger entry stamp
@@ -801,9 +819,10 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     const int64_t nt = fin / 16, bt = (bases + 15) / 16;
     // the waves' shares of U in LDS: 8 waves x 3 rows x (16 bt x fin) floats, plus the slices' sums behind wave 0's
     const int64_t kp = 16 * bt * fin;
-    const int64_t part = ((int64_t)kWaves * kMaxD * kp + kMaxD * fin) * 4;     // + deg x rows behind them
-    const int64_t red = (int64_t)kMaxD * kp * 4 + (int64_t)kThreads * kMaxD * 16;   // the slices' sums reuse wave 1's slots on
-    return std::max(part, red) <= kLdsBytes && nt * bt <= 6;     // fin = 64 with more than 16 bases spills registers
+    const int64_t part = ((int64_t)(kWaves + kMaxD) * kp + kMaxD * fin) * 4;   // the waves' shares, the rows' sums, deg x
+    const int64_t red = (int64_t)kThreads * kMaxD * 16;                        // the slices' sums reuse the shares' space
+    const int64_t slices = kThreads / (fout / 4), per = (kp + fin + slices - 1) / slices;
+    return std::max(part, red) <= kLdsBytes && nt * bt <= 6 && per <= 14;      // (rows of basis a thread holds in registers)
 }
 
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,

@@ -43,6 +43,7 @@ class myGCN(Module):
         # "fp32" (the reference's arithmetic) or "bf16": the gathered table x W is rounded to bf16 once and read at
         # half the bytes, everything else stays fp32 (inference path; gripnet_amd.utils.set_table_storage)
         self.table_storage = kwargs.get("table_storage", "fp32")
+        self.arithmetic = "fp32"          # dense x W: "fp32" (fp32-faithful, default) or "fast" (two-term bf16 splits)
         self.cached_result = None
         self.weight = Parameter(torch.empty(in_channels, out_channels))
         if bias:
@@ -99,7 +100,7 @@ class myGCN(Module):
                 cowork.cowork_done()
             return y
         xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
-        _hip.gemm(x, self.weight, xw)                                            # layers.py:73
+        _hip.gemm(x, self.weight, xw, fast=self.arithmetic == "fast")               # layers.py:73
         return plan.aggregate(xw, self.bias, relu, out, side)                    # layers.py:92-100
 
     def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None):
@@ -143,7 +144,18 @@ class myRGCN(Module):
             self.register_parameter("bias", None)
         self._plan = None
         self._plan_key = None
+        # Arithmetic of the dense products (an argument of the C ABI, never the environment): "fp32" (default) is
+        # fp32-faithful - three-term bf16 splits or the fp32 matrix instruction, the reference's precision
+        # (layers.py:172-186 are fp32 matmuls); "fast" keeps two bf16 terms (<= 2^-16 per product).  `kernel` picks a
+        # relational kernel for tests and measurements ("auto": the library decides).
+        self.arithmetic = "fp32"
+        self.kernel = "auto"
         self.reset_parameters()
+
+    def _fast(self):
+        if self.arithmetic not in ("fp32", "fast"):
+            raise ValueError("arithmetic must be 'fp32' or 'fast', got {!r}".format(self.arithmetic))
+        return self.arithmetic == "fast"
 
     def reset_parameters(self):
         self.att.data.normal_(std=1 / np.sqrt(self.num_bases))                   # layers.py:152
@@ -166,8 +178,10 @@ class myRGCN(Module):
 
     def cowork_request(self):
         """(plan, basis, att) for a launch that is asked to compute this layer's W_r on the side, or None (no plan
-        yet, or autograd is recording)."""
-        if self._plan is None or recording(self.basis, self.att):
+        yet, autograd is recording, or the kernel this layer's arithmetic selects never forms W_r)."""
+        if self._plan is None or recording(self.basis, self.att) or not self._fast() or self.kernel != "auto":
+            return None
+        if self._plan.path(self.in_channels, self.out_channels, self.num_bases, fast=True) != "acc":
             return None
         return (self._plan, self.basis, self.att)
 
@@ -184,11 +198,13 @@ class myRGCN(Module):
         plan = self._plan
         if plan is None or recording(self.basis, self.att):
             return False
+        if not plan.needs_weights(self.in_channels, self.out_channels, self.num_bases, self._fast(), self.kernel):
+            return False
         cur = torch.cuda.current_stream(plan.device)
         side = _hip.side_stream(plan.device)
         side.wait_stream(cur)                       # the previous forward still reads the workspace; the optimizer may write the parameters
         with torch.cuda.stream(side):
-            plan.weights(self.basis, self.att)
+            plan.weights(self.basis, self.att, fast=self._fast(), path=self.kernel)
             event = side.record_event()
         self._prefetched = (event, plan, self.basis._version, self.att._version)
         return True
@@ -214,7 +230,8 @@ class myRGCN(Module):
             if pre[0] is not None:                       # computed on another stream (prefetch_weights)
                 torch.cuda.current_stream(x.device).wait_event(pre[0])
             ready = True
-        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, weights_ready=ready)
+        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, weights_ready=ready,
+                            fast=self._fast(), path=self.kernel)
 
     def __repr__(self):
         return "{}({}, {}, num_relations={})".format(self.__class__.__name__, self.in_channels,

@@ -36,7 +36,10 @@ class _ShardWeights:
         self.plan, self.conv, self.ready = plan, conv, False
 
     def cowork_request(self):
-        return (self.plan, self.conv.basis, self.conv.att)
+        c = self.conv                        # only the two-term ("fast") arithmetic runs on a kernel that reads W_r
+        if not c._fast() or c.kernel != "auto" or self.plan.path(c.in_channels, c.out_channels, c.num_bases, fast=True) != "acc":
+            return None
+        return (self.plan, c.basis, c.att)
 
     def cowork_done(self):
         self.ready = True
@@ -64,7 +67,8 @@ class HipShardKernels:
         parameters move every step)."""
         c = self.conv
         ready = self.weights.ready and not fresh_weights
-        return self.plan.forward(x, c.basis.detach(), c.att.detach(), None, None, False, out, partial=True, weights_ready=ready)
+        return self.plan.forward(x, c.basis.detach(), c.att.detach(), None, None, False, out, partial=True, weights_ready=ready,
+                                 fast=c._fast(), path=c.kernel)
 
     def finalize(self, summed, x, out, slot0):
         c = self.conv                                           # concat slot 0 is copied by the same launch
@@ -142,16 +146,19 @@ class ShardedPoseForward:
         # None: score the input columns beside the exchange when there is one; True / False force it (tests, measurements)
         env = os.environ.get("GN_SHARD_OVERLAP")
         self.overlap_decoder = None if env is None else env == "1"
+        # issue the collectives also at world_size 1 (they are the identity there): lets one GPU exercise the RCCL calls,
+        # their stream and their event path (tests/test_gpu_callers.py)
+        self.always_exchange = False
 
     def all_reduce(self, t: torch.Tensor):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.always_exchange:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_reduce_begin(self, t: torch.Tensor):
         """The exchange as an asynchronous collective: what is launched before `all_reduce_end` runs beside it."""
-        if self.world_size > 1:
+        if self.world_size > 1 or self.always_exchange:
             import torch.distributed as dist
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None

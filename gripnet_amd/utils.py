@@ -212,6 +212,20 @@ def set_table_storage(module, storage: str = "bf16"):
     return touched
 
 
+def set_arithmetic(module, arithmetic: str = "fp32"):
+    """Arithmetic of the dense products of every layer under `module`: "fp32" (default) is fp32-faithful - three-term
+    bf16 splits (what is dropped is below 2^-23 of a product) or the fp32 matrix instruction, the reference's
+    precision; "fast" keeps two bf16 terms (<= 2^-16 per product).  The mode travels with every call as a flag of the
+    C ABI.  Returns the layers touched."""
+    from .layers import myGCN, myRGCN
+    if arithmetic not in ("fp32", "fast"):
+        raise ValueError("arithmetic must be 'fp32' or 'fast', got {!r}".format(arithmetic))
+    touched = [m for m in module.modules() if isinstance(m, (myGCN, myRGCN))]
+    for m in touched:
+        m.arithmetic = arithmetic
+    return touched
+
+
 def profile(fn):
     """No-op stand-in for ``pytorch_memlab.profile`` (reference: GripNet-pose.py:18,112)."""
     return fn

@@ -145,14 +145,20 @@ GN_API gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float
                                    float* out, int64_t ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
+ * Dense fp32 contraction on the matrix cores:
  *   C[b] = act( gather_rows(A[b]) @ B[b] + bias ),  b in [0, batch).
  * Replaces torch.matmul at gripnet/layers.py:73,172-173,193,383 and decoder.py:42.
  * a_rows (int64, may be NULL) selects rows of A (z[node_list], decoder.py:42).
- * stride_* are batch strides in elements (0 = shared operand). */
+ * stride_* are batch strides in elements (0 = shared operand).
+ * Arithmetic (part of the contract, never read from the environment): by default fp32-faithful - the fp32 matrix
+ * instruction (v_mfma_f32_16x16x4_f32, exact) or, for tall-skinny products, bf16 matrix instructions on operands split
+ * into THREE bf16 terms (six products; what is dropped is below 2^-23 of a product).  GN_GEMM_ARITH_FAST keeps two terms
+ * and three products (<= 2^-16 relative per product). */
+#define GN_GEMM_RELU 1           /* flags of gn_gemm_f32 */
+#define GN_GEMM_ARITH_FAST 2
 GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
-                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int relu, void* stream);
+                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream);
 
 /* out[k1, k2] = x^T g over m rows (x [m, k1], g [m, k2]; k1 * k2 <= 4096): the weight gradients dW = x^T (A_norm^T g)
  * of the GCN-style layers and d root = x^T g of the relational one (autograd of layers.py:73,193).  Row slices are
@@ -197,13 +203,14 @@ GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_featu
  * The weights depend on the parameters only, so a caller can launch this on a second stream while the layers
  * that produce x are still running, and order the forward behind it with an event. */
 GN_API gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t in_features, const float* basis, const float* att,
-                              int64_t num_bases, int64_t out_features, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              int64_t num_bases, int64_t out_features, int flags /* those of the forward call that follows */,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* gn_graph_aggregate_f32 (first eleven arguments, `weight` required) and gn_rgcn_weights_f32 (the rest) as ONE launch:
  * the external layer's aggregation (gripnet/layers.py:363-370) and the weights of the relational layer that follows it
  * (layers.py:172-173) are independent, short and latency-bound, so the launch takes the longer of the two instead of
- * their sum.  Follow it with gn_rgcn_forward_f32(..., GN_RGCN_WEIGHTS_READY, ...).  Shapes the combined launch does not
+ * their sum.  The weights are those of the GN_RGCN_ARITH_FAST path: follow it with
+ * gn_rgcn_forward_f32(..., GN_RGCN_ARITH_FAST | GN_RGCN_WEIGHTS_READY, ...).  Shapes the combined launch does not
  * cover run as the two entry points, one after the other. */
 GN_API gn_status gn_graph_aggregate_with_rgcn_weights_f32(
     const gn_graph_plan* plan, const float* x, int64_t ld_x, int64_t num_features, const float* weight, int64_t out_features,
@@ -215,6 +222,14 @@ GN_API gn_status gn_graph_aggregate_with_rgcn_weights_f32(
 #define GN_RGCN_WEIGHTS_READY 2  /* `workspace` already holds the output of gn_rgcn_weights_f32 for these parameters */
 #define GN_RGCN_ARITH_FAST 4     /* dense products on two-term bf16 splits (<= 2^-16 relative per product) instead of the
                                   * default fp32-faithful arithmetic (three-term splits / the fp32 matrix instruction) */
+/* Kernel choice, for tests and measurements (0 = the library decides; a kernel that does not cover the shapes is not
+ * forced): (GN_RGCN_PATH_x << GN_RGCN_PATH_SHIFT) in flags.  gn_rgcn_forward_path tells which one a call would take. */
+#define GN_RGCN_PATH_SHIFT 8
+#define GN_RGCN_PATH_PAIR 1      /* destination-major in basis space (rgcn_pair.hip): no W_r, no workspace, one launch */
+#define GN_RGCN_PATH_ACC 2       /* relation-major aggregate-then-transform in registers (rgcn_acc.hip) */
+#define GN_RGCN_PATH_LDS 3       /* LDS accumulator rows (rgcn_fast.hip) */
+#define GN_RGCN_PATH_GENERAL 4   /* transform-then-gather through HBM (rgcn.hip), any size */
+GN_API int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features, int64_t num_bases, int flags);
 
 /* flags & GN_RGCN_PARTIAL == 0:  out[i,:] = act( (sum_{e: dst=i} x[src_e] W_{r(e)}) / max(1, indeg_i) + x[i] root + bias )
  * flags & GN_RGCN_PARTIAL:       out[i,:] = sum_{e in [edge_lo,edge_hi): dst=i} x[src_e] W_{r(e)}   (un-normalised

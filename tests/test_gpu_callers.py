@@ -329,3 +329,63 @@ def test_plans_do_not_depend_on_the_builder_threads(gpu, monkeypatch):
         assert model.dmt.plan_for(z, data.train_idx, data.train_et) is not None
         outs.append((z, score))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ---- RCCL at world_size 1: the collectives of the sharded path on the backend the multi-GPU job uses -------------------
+def _rccl_worker(port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # "nccl" is RCCL on ROCm
+    try:
+        from gripnet_amd.sharded import ShardedPoseForward, ShardedPoseTraining
+        data = make_pose("small").to(dev)
+        torch.manual_seed(1111)
+        model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+        with torch.no_grad():
+            z_ref, s_ref = model(data)
+            fwd = ShardedPoseForward(model, data, 0, 1)
+            fwd.always_exchange = True            # all_reduce(async_op=True) + wait on RCCL's stream, the decoder's first
+            fwd.overlap_decoder = True            # column phase beside it
+            z, s = fwd()
+            z2, s2 = fwd()
+            torch.cuda.synchronize()
+        neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        plain = ShardedPoseTraining(model, data, 0, 1)
+        loss_plain = float(plain.step(neg))
+        grads_plain = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        step = ShardedPoseTraining(model, data, 0, 1)
+        step.always_exchange = True               # the four exchanges of a training step, through RCCL
+        loss = float(step.step(neg))
+        torch.cuda.synchronize()
+        worst = max(float((p.grad - grads_plain[k]).abs().max()) for k, p in model.named_parameters() if p.grad is not None)
+        q.put(dict(err_z=float((z - z_ref).abs().max()), err_s=float((s - s_ref).abs().max()), same=bool(torch.equal(z, z2)),
+                   loss=loss, loss_plain=loss_plain, grad_diff=worst, backend=dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_paths_run_on_rccl_at_world_size_one(gpu):
+    """The relation-sharded forward and training step with every collective really issued on the "nccl" (RCCL) backend:
+    one rank, so each all-reduce is the identity and the results must equal the unsharded ones.  What this covers that
+    the gloo tests cannot: RCCL's own stream, the event hand-over of async_op=True, the decoder launches beside it."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_worker, args=(port, q))
+    proc.start()
+    got = q.get(timeout=500)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    assert got["backend"] == "nccl"
+    assert got["err_z"] <= 2e-5 and got["err_s"] <= 2e-5 and got["same"], got
+    assert abs(got["loss"] - got["loss_plain"]) <= 1e-6 and got["grad_diff"] <= 1e-6, got

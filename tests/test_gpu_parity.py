@@ -207,24 +207,34 @@ def test_freebase_a_and_b_pipelines_vs_reference(gpu, golden):
     close(score, g.t("out.score"))
 
 
-@pytest.fixture(params=["tf", "acc", "lds", "general"])
+def use_relational_kernel(module, kernel, arithmetic="fp32"):
+    """Pins the relational kernel (a flag of gn_rgcn_forward_f32, set per layer) of every myRGCN under `module`."""
+    layers = [m for m in module.modules() if isinstance(m, gripnet_amd.myRGCN)]
+    for m in layers:
+        m.kernel, m.arithmetic = kernel, arithmetic
+    return layers
+
+
+@pytest.fixture(params=["pair", "acc", "acc-fast", "lds", "general"])
 def kernel_path(request, monkeypatch):
-    """Run a test once per relational kernel: transform-then-gather (default), register-accumulated, LDS-resident
-    accumulator, general; the last two also take the shuffle-based form of the 16-wide GCN gather instead of the quad form."""
+    """Run a test once per relational kernel: destination-major (default), register-accumulated (fp32 matrix instruction
+    and two-term splits), LDS-resident accumulator, general; the last two also take the shuffle-based form of the 16-wide
+    GCN gather instead of the quad form."""
     monkeypatch.setenv("GN_DISABLE_FAST", "1" if request.param == "general" else "0")
-    monkeypatch.setenv("GN_RGCN_TF", "1" if request.param == "tf" else "0")
-    monkeypatch.setenv("GN_DISABLE_ACC", "1" if request.param == "lds" else "0")
-    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param in ("tf", "acc") else "1")
+    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param in ("pair", "acc", "acc-fast") else "1")
     return request.param
 
 
 def test_both_kernel_paths_on_pose_small(gpu, golden, kernel_path):
     g = golden("pose_small")
     model = load_into(PoseModel(g.meta["n_g"], g.meta["n_d"], g.meta["R"]), g.state("", strip=False), gpu)
+    layers = use_relational_kernel(model, kernel_path.split("-")[0], "fast" if kernel_path.endswith("fast") else "fp32")
     data = pose_data_from_golden(g, gpu)
     with torch.no_grad():
         z_dd, score = model(data)
         logits = model(data, sigmoid=False)[1]
+    for m in layers:                                          # the kernel asked for is the kernel that ran
+        assert m._plan.path(m.in_channels, m.out_channels, m.num_bases, m._fast(), m.kernel) == kernel_path.split("-")[0]
     close(z_dd, g.t("out.z_dd"))
     close(score, g.t("out.score"))
     close(logits, g.t("out.logits"), TOL)
@@ -342,16 +352,14 @@ def test_gcn_skewed_degrees_and_empty_rows(gpu, fout):
 
 @pytest.mark.parametrize("n,fin,bases", [(40, 16, 3), (200, 32, 5), (560, 48, 32), (645, 64, 8), (900, 48, 4),
                                          (1000, 32, 2), (1, 16, 1)])
-@pytest.mark.parametrize("path", ["tf", "acc", "lds"])
-def test_rgcn_lds_resident_shapes(gpu, monkeypatch, n, fin, bases, path):
-    """Every specialisation of the three LDS-resident relational kernels (transform-then-gather: K depth, sliced
-    long runs, one to three rows per quad; register-accumulated: K depth,
-    row groups, chunked long runs; LDS accumulator: row tiles per wave, 1..16 source tiles): empty
+@pytest.mark.parametrize("path", ["pair", "pair-fast", "acc", "acc-fast", "lds"])
+def test_rgcn_lds_resident_shapes(gpu, n, fin, bases, path):
+    """Every specialisation of the three LDS-resident relational kernels (destination-major: one or two bases per lane,
+    one to four feature tiles, one to three rows per workgroup, a pair run longer than one unit; register-accumulated:
+    K depth, row groups, chunked long runs; LDS accumulator: row tiles per wave, 1..16 source tiles): empty
     relations, a relation longer than one work item, duplicate edges, destinations with no in-edges;
     checked against the oracle and for run-to-run equality.  Shapes a kernel does not cover fall
     through to the next one."""
-    monkeypatch.setenv("GN_DISABLE_ACC", "1" if path == "lds" else "0")
-    monkeypatch.setenv("GN_RGCN_TF", "1" if path == "tf" else "0")
     gen = torch.Generator().manual_seed(n * 131 + fin)
     torch.manual_seed(n * 17 + fin)                                   # layer weights come from the global RNG
     sizes = [0, 9000, 3, 0, 700, 1, 2500, 0]
@@ -362,9 +370,12 @@ def test_rgcn_lds_resident_shapes(gpu, monkeypatch, n, fin, bases, path):
     x = torch.randn(n, fin, generator=gen)
     rg = gripnet_amd.myRGCN(fin, 32, len(sizes), bases, False, bias=True).to(gpu)
     rg.bias.data.normal_()
+    use_relational_kernel(rg, path.split("-")[0], "fast" if path.endswith("fast") else "fp32")
     y = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
     y2 = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
     assert torch.equal(y, y2)
+    if path == "pair" and n <= 768 and not (fin == 64 and bases > 16):
+        assert rg._plan.path(fin, 32, bases) == "pair"        # the default arithmetic takes the destination-major kernel
     # float64 oracle: with thousands of edges into one destination (n == 1: all 12,000 of them) the
     # reference's own sequential fp32 sum is off by ~1e-4; the kernel folds its running sums every 64
     # addends, so it is held to the tight bar against the exact result
@@ -373,16 +384,16 @@ def test_rgcn_lds_resident_shapes(gpu, monkeypatch, n, fin, bases, path):
     close(y, ref.float())
 
 
-@pytest.mark.parametrize("formulation", ["acc", "tf"])
-def test_rgcn_sharded_partials_sum_to_full(gpu, monkeypatch, formulation):
+@pytest.mark.parametrize("formulation", ["pair", "acc"])
+def test_rgcn_sharded_partials_sum_to_full(gpu, formulation):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
     (the multi-GPU contract, here run sequentially on one device); with either formulation of the
     LDS-resident relational kernel."""
-    monkeypatch.setenv("GN_RGCN_TF", "1" if formulation == "tf" else "0")
     data = make_pose("small").to(gpu)
     n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
     conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
     conv.bias.data.normal_()
+    conv.kernel = formulation
     x = torch.randn(n, fin, device=gpu)
     full = conv(x, data.train_idx, None, data.train_range, _relu=True)
     for world in (2, 3, 8):
@@ -390,7 +401,7 @@ def test_rgcn_sharded_partials_sum_to_full(gpu, monkeypatch, formulation):
         for lo, hi in gripnet_amd.utils.shard_edge_ranges(data.train_idx.shape[1], world):
             plan = _hip.RgcnPlan(data.train_idx, data.train_range, n, lo, hi)
             part = torch.empty(n, fout, device=gpu)
-            plan.forward(x, conv.basis, conv.att, None, None, False, part, partial=True)
+            plan.forward(x, conv.basis, conv.att, None, None, False, part, partial=True, path=formulation)
             total += part
         out = torch.empty(n, fout, device=gpu)
         plan.finalize(total, x, conv.root, conv.bias, True, out)
@@ -550,15 +561,13 @@ def test_relation_metrics_match_sklearn(gpu):
 
 
 # ---- BASELINE.json configs 2 and 4 at scale: the NC suite, large supervertices, wide features --------------
-@pytest.mark.parametrize("matrix_instruction", ["bf16x3", "fp32"])
-def test_aminer_syn_vs_oracle(gpu, matrix_instruction, monkeypatch):
+@pytest.mark.parametrize("arithmetic", ["fp32", "fast"])
+def test_aminer_syn_vs_oracle(gpu, arithmetic):
     """aminer-style model at the `aminer-syn` scale with the reference's own layer widths
     (GripNet-aminer.py:96-98: [128,64,64] / [64,64] / [128,128,32], 8 classes): 50,000 / 20,000 nodes per
     supervertex, so nothing is LDS-resident and the wide-row specialisations of the gather run.  The tall-skinny
-    x W products run on split bf16 operands by default and on the fp32 matrix instruction with GN_GEMM_EXACT=1."""
+    x W products run on three-term bf16 splits by default (fp32-faithful) and on two-term splits with arithmetic "fast"."""
     from gripnet_amd.synth import make_nc
-    if matrix_instruction == "fp32":
-        monkeypatch.setenv("GN_GEMM_EXACT", "1")
     data = make_nc("aminer-syn")
     torch.manual_seed(1111)
     model = AminerModel(data.n_p_node, data.n_a_node, data.n_a_type)
@@ -567,6 +576,7 @@ def test_aminer_syn_vs_oracle(gpu, matrix_instruction, monkeypatch):
     ref = orc.aminer_forward(sd, data.pp_edge_idx, data.pp_edge_weight, data.pa_edge_idx, data.aa_edge_idx,
                              data.aa_edge_weight, nodes)
     model = model.to(gpu)
+    gripnet_amd.utils.set_arithmetic(model, arithmetic)
     with torch.no_grad():
         z, pred = model(make_nc("aminer-syn").to(gpu), nodes.to(gpu))
     close(z, ref["z"], TOL)
@@ -824,7 +834,11 @@ def test_rgcn_weights_prefetched_on_a_second_stream(gpu):
     x = torch.randn(n, fin, device=gpu)
     with torch.no_grad():
         assert conv.prefetch_weights() is False                         # no plan before the first forward
+        first = conv(x, data.train_idx, None, data.train_range, _relu=True)
+        assert conv.prefetch_weights() is False                         # the default kernel never forms W_r
+        conv.arithmetic = "fast"                                        # the relation-major kernel reads W_r from the workspace
         base = conv(x, data.train_idx, None, data.train_range, _relu=True)
+        close(base, first)
         assert conv.prefetch_weights() is True
         again = conv(x, data.train_idx, None, data.train_range, _relu=True)
         assert torch.equal(base, again)
@@ -845,6 +859,7 @@ def test_external_layer_computes_relational_weights_in_its_launch(gpu):
     torch.manual_seed(5)
     model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
     conv = model.dd.conv_list[0]
+    conv.arithmetic = "fast"                       # W_r exists only for the relation-major kernel of the two-term arithmetic
     with torch.no_grad():
         z_gg = model.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)
         x_sep = model.gd(z_gg, data.gd_edge_index, mod="cat", if_relu=True)

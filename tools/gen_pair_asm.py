@@ -27,39 +27,48 @@ DPP = ["", " quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf", " quad_perm:[2,3,0
        " quad_perm:[3,0,1,2] row_mask:0xf bank_mask:0xf"]
 
 
+RB = 92            # first of the 34 VGPRs the block owns (v92-v125: the kernel runs four waves per SIMD, 128 registers)
+W = ["v{}".format(RB + 24 + k) for k in range(3)]
+A = [RB + 28 + j for j in range(4)]        # row addresses
+WADDR, VDMA = "v{}".format(RB + 32), "v{}".format(RB + 33)
+
+
 def regs(bt):
     """buffers B0..B2 (4 rows each), words W0..W2"""
     if bt == 2:
-        buf = [["v[{}:{}]".format(216 + 8 * k + 2 * i, 217 + 8 * k + 2 * i) for i in range(4)] for k in range(3)]
+        buf = [["v[{}:{}]".format(RB + 8 * k + 2 * i, RB + 1 + 8 * k + 2 * i) for i in range(4)] for k in range(3)]
     else:
-        buf = [["v{}".format(216 + 4 * k + i) for i in range(4)] for k in range(3)]
-    return buf, ["v240", "v241", "v242"]
+        buf = [["v{}".format(RB + 4 * k + i) for i in range(4)] for k in range(3)]
+    return buf, W
 
 
 def issue(lines, rd, use, req, into):
-    lines.append("v_add_u32 v244, {}, %[lo]".format(use))
+    lines.append("v_add_u32 v{}, {}, %[lo]".format(A[0], use))
     for j in (1, 2, 3):
-        lines.append("v_add_u32_dpp v{}, {}, %[lo]{}".format(244 + j, use, DPP[j]))
+        lines.append("v_add_u32_dpp v{}, {}, %[lo]{}".format(A[j], use, DPP[j]))
     lines += [
-        "s_and_b32 s94, %[soff], 0x3c0",
+        "s_and_b32 s94, %[soff], 0x1c0",
         "s_cbranch_scc1 1f",
-        # entering a quarter of the window: its refill is the second youngest vector-memory request; the quarter two
-        # behind is dead (the words in flight are at most four blocks back): refill it with the blocks two quarters ahead
+        # entering a quarter (eight blocks, 512 bytes) of the 2 KB window: its refill is the second youngest vector-memory
+        # request; the quarter two behind is dead (the words in flight are at most four blocks back): refill it with the
+        # blocks two quarters ahead - one LDS-DMA instruction of the lower 32 lanes (16 bytes each)
         "s_waitcnt vmcnt(1)",
-        "s_sub_u32 s94, %[soff], 0x800",
-        "s_and_b32 s94, s94, 0xc00",
+        "s_sub_u32 s94, %[soff], 0x400",
+        "s_and_b32 s94, s94, 0x600",
         "s_add_u32 m0, s94, %[rbase]",
-        "v_add_u32 v249, %[sdma], %[l16]",
-        "s_add_u32 %[sdma], %[sdma], 0x400",
-        "global_load_lds_dwordx4 v249, %[sbase]",
+        "{} {}, %[sdma], %[l16]".format("v_add_u32", VDMA),
+        "s_add_u32 %[sdma], %[sdma], 0x200",
+        "s_mov_b32 exec_hi, 0",
+        "global_load_lds_dwordx4 {}, %[sbase]".format(VDMA),
+        "s_mov_b32 exec_hi, -1",
         "1:",
-        "v_add_u32 v248, %[soff], %[rlane]",
+        "v_add_u32 {}, %[soff], %[rlane]".format(WADDR),
         "s_add_u32 %[soff], %[soff], 64",
-        "s_and_b32 %[soff], %[soff], 0xfff",
-        "ds_read_b32 {}, v248".format(req),
+        "s_and_b32 %[soff], %[soff], 0x7ff",
+        "ds_read_b32 {}, {}".format(req, WADDR),
     ]
     for j in range(4):
-        lines.append("{} {}, v{}".format(rd, into[j], 244 + j))
+        lines.append("{} {}, v{}".format(rd, into[j], A[j]))
 
 
 def unit(bt):
@@ -71,8 +80,8 @@ def unit(bt):
         L.append(("v_mov_b64 %[p{}], 0" if bt == 2 else "v_mov_b32 %[p{}], 0").format(t))
     # this unit's words 0 and 1 were requested by the unit before (or sit at the start of the window): read them again
     for k, back in ((0, 128), (1, 64)):
-        L += ["s_sub_u32 s94, %[soff], {}".format(back), "s_and_b32 s94, s94, 0xfff", "v_add_u32 v248, s94, %[rlane]",
-              "ds_read_b32 {}, v248".format(w[k])]
+        L += ["s_sub_u32 s94, %[soff], {}".format(back), "s_and_b32 s94, s94, 0x7ff", "v_add_u32 {}, s94, %[rlane]".format(WADDR),
+              "ds_read_b32 {}, {}".format(w[k], WADDR)]
     L.append("s_waitcnt lgkmcnt(0)")
     issue(L, rd, w[0], w[2], buf[0])      # rows(0), word(2)
     issue(L, rd, w[1], w[0], buf[1])      # rows(1), word(3)
@@ -102,6 +111,7 @@ def unit(bt):
 def main():
     with open(OUT, "w") as f:
         f.write("// Generated by tools/gen_pair_asm.py - do not edit.  The gather of one unit (see rgcn_pair.hip).\n")
+        f.write("#define GN_PAIR_ASM_CLOBBERS {}\n\n".format(", ".join('"v{}"'.format(RB + i) for i in range(34))))
         for bt, name in ((2, "GN_PAIR_UNIT_ASM_B64"), (1, "GN_PAIR_UNIT_ASM_B32")):
             f.write("#define {} \\\n".format(name))
             lines = unit(bt)

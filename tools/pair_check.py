@@ -63,9 +63,9 @@ def pose(name="pose0-syn", iters=50):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    print("GN_DISABLE_PAIR =", os.environ.get("GN_DISABLE_PAIR"), flush=True)
+    print("GN_DISABLE_PAIR =", os.environ.get("GN_DISABLE_PAIR"), "GN_ACC_EXACT =", os.environ.get("GN_ACC_EXACT"), flush=True)
     if what in ("all", "shapes"):
         shapes()
     if what in ("all", "pose"):
-        pose("pose0-syn")
-        pose("pose2-syn")
+        for name in (sys.argv[2:] or ["pose0-syn", "pose1-syn", "pose2-syn"]):
+            pose(name)

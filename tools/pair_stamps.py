@@ -27,7 +27,7 @@ def main():
             conv(x, data.train_idx, data.train_et, data.train_range, _relu=True)
     torch.cuda.synchronize()
     lib = _hip.load()
-    buf = np.zeros((2048, 12), dtype=np.uint64)
+    buf = np.zeros((4096, 12), dtype=np.uint64)
     lib.gn_debug_read_pair_stamps.argtypes = [C.c_void_p]
     assert lib.gn_debug_read_pair_stamps(buf.ctypes.data) == 0
     b = buf[buf[:, 0] > 0].astype(np.float64)
