@@ -303,11 +303,11 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #endif
 
     // ---- epilogue ----
-    // Rows of basis (and root) this thread will contract: thread = (four outputs o4, slice of the KE rows of U).  Requested
-    // BEFORE the barrier: a wave that finishes early fetches while the others still gather; every compute unit pulls all of
-    // basis (196 KB on PoSE) through its own L2 port, which is what this epilogue costs.
-    constexpr int KE = KP + FIN;                                               // + FIN rows: deg_i x_i against root
-    constexpr int kRowsMax = 14;                                               // rows of a slice held in registers
+    // Rows of basis this thread will contract: thread = (four outputs o4, slice), rows j * slices + slice in basis' own
+    // order (a wave instruction reads whole consecutive rows).  Requested BEFORE the barrier: a wave that finishes early
+    // fetches while the others still gather; every compute unit pulls all of basis (196 KB on PoSE) through its own L2
+    // port, which is what this epilogue costs.
+    constexpr int kRowsMax = 12;                                               // rows of a slice held in registers
     const int32_t* my_dst = a.wg_dst + (size_t)g * 4;
     int nd = 0;
 #pragma unroll
@@ -316,41 +316,31 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     const int wb1 = (int)(ranges & 0xffu), wb2 = (int)((ranges >> 8) & 0xffu);
     const int fout = a.fout, og = fout >> 2;                                   // fout % 4 == 0, og in 1..16
     const int slices = kThreads / og;
-    const int rows = a.partial ? KP : KE;
+    const int rows = a.B * FIN;                                                // rows of basis
     const int o4 = tid % og, sl = tid / og;
     const int per = (rows + slices - 1) / slices;                              // <= kRowsMax (checked on the host)
-    const int k0 = min(rows, sl * per), k1 = min(rows, k0 + per);
     f32x4 bv[kRowsMax];
     {
-        const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis) + o4;
-        const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(a.root) + o4;
+        const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis);
 #pragma unroll
         for (int j = 0; j < kRowsMax; ++j) {
-            const int k = min(k0 + j, rows - 1);
-            // row k' = feature * BP + base of U is row base * FIN + feature of basis; padded bases carry zeros in U
-            const int feat = k / BP, base = k - feat * BP;
-            const bool is_root = k >= KP;
-            const int brow = min(base, a.B - 1) * FIN + min(feat, FIN - 1);
-            bv[j] = (sl < slices && j < per) ? (is_root ? rp[(size_t)(k - KP) * og] : bp[(size_t)brow * og]) : (f32x4)(0.f);
-            if ((!is_root && base >= a.B) || k0 + j >= k1) bv[j] = (f32x4)(0.f);
+            const int nr = j * slices + sl;                                    // row base * FIN + feature of basis
+            bv[j] = (sl < slices && j < per && nr < rows) ? bp[(uint32_t)(min(nr, rows - 1) * og + o4)] : (f32x4)(0.f);
         }
     }
-    // the divisor and bias of the output element this thread writes at the very end, and
-    // deg_i * x_i[f] for (row d, feature f) = tid: also requested before the barrier
+    // the output element this thread writes at the very end: its divisor, bias and share of the root term x_i . root
+    // (eight adjacent lanes per element), requested before the barrier too
     const int fin_pair = tid >> 3, fin_part = tid & 7;
     const bool fin_live = fin_pair < nd * fout;
     const int fin_d = fin_live ? fin_pair / fout : 0, fin_o = fin_live ? fin_pair - fin_d * fout : 0;
     const int fin_i = fin_live ? my_dst[fin_d] : 0;
-    float fin_div = 1.f, fin_bias = 0.f;
+    float fin_div = 1.f, fin_bias = 0.f, fin_root = 0.f;
     if (fin_live && !a.partial) {
         fin_div = fmaxf(a.indeg[fin_i], 1.0f);
         if (a.bias) fin_bias = a.bias[fin_o];
-    }
-    float ux = 0.f;
-    if (!a.partial && tid < nd * FIN) {
-        const int d = tid / FIN, f = tid - d * FIN;
-        const int i = my_dst[d];
-        ux = a.x[(int64_t)i * a.ld_x + f] * fmaxf(a.indeg[i], 1.0f);
+#pragma unroll
+        for (int f = 0; f < FIN / 8; ++f)
+            fin_root += a.x[(int64_t)fin_i * a.ld_x + fin_part + 8 * f] * a.root[(fin_part + 8 * f) * fout + fin_o];
     }
     __syncthreads();                                                           // att table and windows are dead from here
 #ifdef GN_STAMPS
@@ -373,10 +363,8 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         }
     }
     __syncthreads();
-    // thread -> four consecutive k' of one row; the sums go to the row's first wave's slot (read by this thread only).
-    // Behind the shares: deg_i * x_i (the root term rides through the same contraction as FIN more rows).
+    // thread -> four consecutive k' of one row; the sums go behind the shares
     float* usum = part + (size_t)kWaves * KP;                                  // [nd][KP]
-    float* uext = usum + (size_t)kMaxD * KP;                                   // [nd][FIN]
     for (int e = tid; e < nd * (KP / 4); e += kThreads) {
         const int d = e / (KP / 4), k4 = e - d * (KP / 4);
         const int w0 = d == 0 ? 0 : (d == 1 ? wb1 : wb2), w1 = d == 0 ? (nd > 1 ? wb1 : kWaves) : (d == 1 ? (nd > 2 ? wb2 : kWaves) : kWaves);
@@ -384,21 +372,27 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         for (int ww = w0; ww < w1; ++ww) s += *reinterpret_cast<const f32x4*>(part + (size_t)ww * KP + 4 * k4);
         *reinterpret_cast<f32x4*>(usum + (size_t)d * KP + 4 * k4) = s;
     }
-    if (!a.partial && tid < nd * FIN) uext[tid] = ux;
     __syncthreads();
 #ifdef GN_STAMPS
     const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // out_i = act( (U_i . basis + deg_i x_i . root) / max(1, deg_i) + bias )
+    // out_i = act( (U_i . basis) / max(1, deg_i) + x_i . root + bias ): row base * FIN + feature of basis meets entry
+    // feature * BP + base of U
     f32x4 sum[kMaxD];
 #pragma unroll
     for (int d = 0; d < kMaxD; ++d) sum[d] = (f32x4)(0.f);
+    {
+        int base = sl / FIN, feat = sl - base * FIN;                           // of row j * slices + sl, advanced by slices per step
+        const int dbase = slices / FIN, dfeat = slices - dbase * FIN;
 #pragma unroll
-    for (int j = 0; j < kRowsMax; ++j) {
-        const int k = min(k0 + j, rows - 1);
+        for (int j = 0; j < kRowsMax; ++j) {
+            const int k = min(feat * BP + base, KP - 1);
 #pragma unroll
-        for (int d = 0; d < kMaxD; ++d)
-            if (d < nd) sum[d] += (k >= KP ? uext[d * FIN + (k - KP)] : usum[(size_t)d * KP + k]) * bv[j];
+            for (int d = 0; d < kMaxD; ++d)
+                if (d < nd) sum[d] += usum[(size_t)d * KP + k] * bv[j];
+            base += dbase; feat += dfeat;
+            if (feat >= FIN) { feat -= FIN; ++base; }
+        }
     }
 #ifdef GN_STAMPS
     asm volatile("" : "+v"(sum[0]));
@@ -415,12 +409,13 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         float s = 0.f;
         if (fin_live)
             for (int q = fin_part; q < slices; q += 8) s += red[((size_t)(q * kMaxD + fin_d) * og + (fin_o >> 2)) * 4 + (fin_o & 3)];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
+        float t = fin_root;
+        s += __shfl_xor(s, 1); t += __shfl_xor(t, 1);
+        s += __shfl_xor(s, 2); t += __shfl_xor(t, 2);
+        s += __shfl_xor(s, 4); t += __shfl_xor(t, 4);
         if (fin_live && fin_part == 0) {
             if (!a.partial) {
-                s = s / fin_div + fin_bias;
+                s = s / fin_div + t + fin_bias;
                 if (a.relu) s = fmaxf(s, 0.f);
             }
             a.out[(int64_t)fin_i * a.ld_out + fin_o] = s;
@@ -819,10 +814,10 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     const int64_t nt = fin / 16, bt = (bases + 15) / 16;
     // the waves' shares of U in LDS: 8 waves x 3 rows x (16 bt x fin) floats, plus the slices' sums behind wave 0's
     const int64_t kp = 16 * bt * fin;
-    const int64_t part = ((int64_t)(kWaves + kMaxD) * kp + kMaxD * fin) * 4;   // the waves' shares, the rows' sums, deg x
+    const int64_t part = (int64_t)(kWaves + kMaxD) * kp * 4;                   // the waves' shares, the rows' sums
     const int64_t red = (int64_t)kThreads * kMaxD * 16;                        // the slices' sums reuse the shares' space
-    const int64_t slices = kThreads / (fout / 4), per = (kp + fin + slices - 1) / slices;
-    return std::max(part, red) <= kLdsBytes && nt * bt <= 6 && per <= 14;      // (rows of basis a thread holds in registers)
+    const int64_t slices = kThreads / (fout / 4), per = (bases * fin + slices - 1) / slices;
+    return std::max(part, red) <= kLdsBytes && nt * bt <= 6 && per <= 12;      // (rows of basis a thread holds in registers)
 }
 
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,

@@ -389,3 +389,28 @@ def test_sharded_paths_run_on_rccl_at_world_size_one(gpu):
     assert got["backend"] == "nccl"
     assert got["err_z"] <= 2e-5 and got["err_s"] <= 2e-5 and got["same"], got
     assert abs(got["loss"] - got["loss_plain"]) <= 1e-6 and got["grad_diff"] <= 1e-6, got
+
+
+def test_typed_negative_sampling_draws_on_the_device(gpu):
+    """utils.typed_negative_sampling on a CUDA positive list (what GripNet-pose.py:131 passes): drawn by the device sampler,
+    seeded from numpy's generator like the reference's host loop, reproducible under np.random.seed, no positive of the
+    relation among the negatives, and the packed pairs the decoder prefers travel with the tensor."""
+    from gripnet_amd.utils import typed_negative_sampling
+    data = make_pose("small").to(gpu)
+    n = data.n_d_node
+    np.random.seed(5)
+    a = typed_negative_sampling(data.train_idx, n, data.train_range)
+    np.random.seed(5)
+    b = typed_negative_sampling(data.train_idx, n, data.train_range)
+    c = typed_negative_sampling(data.train_idx, n, data.train_range)
+    assert a.shape == data.train_idx.shape and a.dtype == torch.int64 and a.is_cuda
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert getattr(a, "_gn_packed", None) is not None
+    pos = (data.train_idx[0] * n + data.train_idx[1]).cpu().numpy()
+    neg = (a[0] * n + a[1]).cpu().numpy()
+    rl = data.train_range.cpu().numpy()
+    for r in range(rl.shape[0]):
+        s, e = int(rl[r, 0]), int(rl[r, 1])
+        assert not np.isin(neg[s:e], pos[s:e]).any()
+    host = typed_negative_sampling(data.train_idx.cpu(), n, data.train_range)       # CPU lists: the reference's host loop
+    assert not host.is_cuda and host.shape == a.shape

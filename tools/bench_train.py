@@ -23,8 +23,9 @@ def main():
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): the same update in one launch instead of ~6")
-    ap.add_argument("--sampler", action="store_true", help="draw the negatives on the device every step (gn_negative_sampler_sample_packed: "
-                    "the decoder then scores them from 32-bit pairs); eager steps only, the seed is a launch argument")
+    ap.add_argument("--host-negatives", dest="sampler", action="store_false",
+                    help="one fixed negative list instead of the default: new negatives drawn on the device every step "
+                         "(gn_negative_sampler_sample_packed: the decoder then scores them from 32-bit pairs; eager steps only, the seed is a launch argument)")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, loss, backward, Adam) in one hipGraph and replay it")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
