@@ -925,3 +925,50 @@ def test_nc_pipeline_with_bf16_tables(gpu, golden):
     ref = g.t("out.score")
     assert float((score.cpu() - ref).abs().max()) <= 5e-3
     assert float((score.cpu().argmax(1) == ref.argmax(1)).float().mean()) >= 0.99
+
+
+# ---- the default arithmetic is fp32-faithful (round 3: the mode is a flag of the C ABI, never the environment) ----------
+@pytest.mark.parametrize("n,fin,bases", [(560, 48, 32), (645, 48, 32), (200, 32, 5), (645, 64, 8)])
+def test_default_relational_arithmetic_is_as_exact_as_fp32(gpu, n, fin, bases):
+    """Against the float64 oracle the default relational path (three-term bf16 splits on the matrix cores) is held to the
+    error of the exact fp32 paths (the LDS-accumulator kernel and the relation-major kernel on v_mfma_f32_16x16x4_f32) and
+    of the reference's own fp32 op sequence; the two-term "fast" mode is allowed to be worse and is reported, not held."""
+    gen = torch.Generator().manual_seed(n * 7 + fin)
+    torch.manual_seed(n + fin)
+    sizes = [0, 9000, 3, 0, 700, 1, 2500, 0]
+    blocks = [torch.randint(0, max(1, n - n // 7), (2, s), generator=gen) for s in sizes]
+    rei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    rg = gripnet_amd.myRGCN(fin, 32, len(sizes), bases, False, bias=True).to(gpu)
+    sd = {k: v.detach().cpu() for k, v in rg.state_dict().items()}
+    ref64 = orc.rgcn_forward(x.double(), rei, rl, sd["basis"].double(), sd["att"].double(), sd["root"].double(), sd["bias"].double())
+    ref32 = orc.rgcn_forward(x, rei, rl, sd["basis"], sd["att"], sd["root"], sd["bias"])
+    err = {}
+    for name, kernel, arith in (("default", "auto", "fp32"), ("lds-exact", "lds", "fp32"), ("acc-exact", "acc", "fp32"), ("fast", "auto", "fast")):
+        rg.kernel, rg.arithmetic = kernel, arith
+        y = rg(x.to(gpu), rei.to(gpu), None, rl)
+        err[name] = (y.cpu().double() - ref64).abs().max().item()
+    err["reference-fp32"] = (ref32.double() - ref64).abs().max().item()
+    exact = max(err["lds-exact"], err["acc-exact"], err["reference-fp32"])
+    assert err["default"] <= 1.5 * exact + 1e-7, err
+    assert err["fast"] <= 2e-5, err
+
+
+def test_default_gemm_arithmetic_is_as_exact_as_fp32(gpu, monkeypatch):
+    """gn_gemm_f32 on a tall-skinny product: the default (three-term splits) against the exact fp32 matrix instruction
+    (the general kernel, GN_DISABLE_FAST=1) and torch's fp32 matmul, all measured against float64; "fast" is two-term."""
+    gen = torch.Generator().manual_seed(3)
+    a = torch.randn(5000, 128, generator=gen)
+    b = torch.randn(128, 64, generator=gen) * 0.2
+    ref64 = a.double() @ b.double()
+    ag, bg = a.to(gpu), b.to(gpu)
+    out = torch.empty(5000, 64, device=gpu)
+    err = {}
+    err["default"] = (_hip.gemm(ag, bg, out).cpu().double() - ref64).abs().max().item()
+    err["fast"] = (_hip.gemm(ag, bg, out, fast=True).cpu().double() - ref64).abs().max().item()
+    monkeypatch.setenv("GN_DISABLE_FAST", "1")
+    err["exact"] = (_hip.gemm(ag, bg, out).cpu().double() - ref64).abs().max().item()
+    err["torch-fp32"] = ((a @ b).double() - ref64).abs().max().item()
+    assert err["default"] <= 1.5 * max(err["exact"], err["torch-fp32"]) + 1e-7, err
+    assert err["fast"] > err["default"] and err["fast"] <= 1e-3, err
