@@ -23,6 +23,18 @@
 #define GN_AGG_GRID (256 * 8)
 #endif
 
+// Average row length below which LPE lanes own a row (k_aggregate_short: two gathers in flight per lane; k_aggregate_group:
+// GN_AGG_GROUP_U of them) instead of a wave
+#ifndef GN_AGG_SHORT_MAX_DEG
+#define GN_AGG_SHORT_MAX_DEG 8
+#endif
+#ifndef GN_AGG_GROUP_MAX_DEG
+#define GN_AGG_GROUP_MAX_DEG 48
+#endif
+#ifndef GN_AGG_GROUP_U
+#define GN_AGG_GROUP_U 8
+#endif
+
 namespace gn {
 
 struct AggArgs {
@@ -178,6 +190,68 @@ __global__ __launch_bounds__(256) void k_aggregate_short(AggArgs a) {
             }
             *reinterpret_cast<float4*>(a.out + (int64_t)row * a.ld_out + fcol) = make_float4(o[0], o[1], o[2], o[3]);
         }
+    }
+}
+
+// Rows of a dozen to a few dozen neighbours (the homogeneous layers of the node-classification graphs: 5 x 10^4 rows of
+// ~11 edges over a table far larger than an L2): a wave per row walks rowptr -> col -> gathered rows -> fold as four
+// dependent round trips per row, six rows deep per wave.  Here LPE lanes own a row - 64 / LPE rows per wave side by
+// side, one row per group and no grid-stride loop - the group reads its (col, coef) pairs LPE at a time with one
+// coalesced load and requests U neighbour rows before it consumes the first: the latency chain of a row is paid once
+// per wave, with 64 / LPE x U row gathers in flight.  Every lane sums its own four columns in neighbour order.
+template <int LPE, int U>
+__global__ __launch_bounds__(256) void k_aggregate_group(AggArgs a) {
+    constexpr int S = kWave / LPE;
+    const int lane = threadIdx.x & 63, slot = lane / LPE, j = lane % LPE;
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int fcol = 4 * j;
+    const bool active = fcol < a.features;
+    if (a.side.dst) {
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, c = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + c];
+            a.side.dst[i * a.side.ld_dst + c] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+    const int row = wave * S + slot;
+    const bool live = row < a.rows;
+    const int begin = live ? a.rowptr[row] : 0, end = live ? a.rowptr[row + 1] : 0;
+    const float* __restrict__ tab = a.table + fcol;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = begin; __any(base < end); base += LPE) {
+        const int mine = base + j;
+        const uint32_t c = mine < end ? a.col[mine] : 0u;
+        const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+        const int cnt = min(LPE, end - base);                  // of this group (<= 0 once its row is done)
+        for (int t0 = 0; __any(t0 < cnt); t0 += U) {
+            float4 r[U];
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t cc = (uint32_t)__shfl((int)c, t0 + u, LPE);
+                vv[u] = __shfl(v, t0 + u, LPE);
+                r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + u < cnt && active) r[u] = *reinterpret_cast<const float4*>(tab + (int64_t)cc * a.ld_table);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc.x += vv[u] * r[u].x; acc.y += vv[u] * r[u].y; acc.z += vv[u] * r[u].z; acc.w += vv[u] * r[u].w;
+            }
+        }
+    }
+    if (live && active) {
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float div = a.rowdiv ? fmaxf(a.rowdiv[row], 1.0f) : 1.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float val = a.rowdiv ? o[t] / div : o[t];
+            if (a.addend) val += a.addend[(int64_t)row * a.ld_addend + fcol + t];
+            if (a.bias) val += a.bias[fcol + t];
+            if (a.relu) val = fmaxf(val, 0.f);
+            o[t] = val;
+        }
+        *reinterpret_cast<float4*>(a.out + (int64_t)row * a.ld_out + fcol) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -543,7 +617,7 @@ inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
         GN_LAUNCH_CHECK();
         return GN_OK;
     }
-    if (vec && lpe <= 16 && a.nnz >= 0 && a.nnz < 8 * (int64_t)a.rows && !fast_paths_disabled()) {
+    if (vec && lpe <= 16 && a.nnz >= 0 && a.nnz < GN_AGG_SHORT_MAX_DEG * (int64_t)a.rows && !fast_paths_disabled()) {
         const int sgrid = (int)std::min<int64_t>(ceil_div((int64_t)a.rows * lpe, 256), GN_AGG_GRID);
         switch (lpe) {
             case 1: k_aggregate_short<1><<<sgrid, 256, 0, st>>>(a); break;
@@ -551,6 +625,19 @@ inline gn_status launch_aggregate(const AggArgs& a, hipStream_t st) {
             case 4: k_aggregate_short<4><<<sgrid, 256, 0, st>>>(a); break;
             case 8: k_aggregate_short<8><<<sgrid, 256, 0, st>>>(a); break;
             default: k_aggregate_short<16><<<sgrid, 256, 0, st>>>(a); break;
+        }
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
+    if (vec && lpe <= 32 && a.nnz >= 0 && a.nnz < GN_AGG_GROUP_MAX_DEG * (int64_t)a.rows && !fast_paths_disabled()) {
+        const int ggrid = (int)ceil_div((int64_t)a.rows * lpe, 256);        // one row per lane group, no grid-stride loop
+        switch (lpe) {
+            case 1: k_aggregate_group<1, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 2: k_aggregate_group<2, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 4: k_aggregate_group<4, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 8: k_aggregate_group<8, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 16: k_aggregate_group<16, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            default: k_aggregate_group<32, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
         }
         GN_LAUNCH_CHECK();
         return GN_OK;

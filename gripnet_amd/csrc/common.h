@@ -51,6 +51,18 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the current device (persistent kernels launch one workgroup each); 256 if the query fails.
+inline int compute_units() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cached[dev];
+}
+
 // GN_DISABLE_FAST=1 forces the general kernels (used by the parity tests to cover both paths).
 inline bool fast_paths_disabled() {
     const char* e = getenv("GN_DISABLE_FAST");

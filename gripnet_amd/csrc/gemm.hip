@@ -220,22 +220,29 @@ __device__ __forceinline__ void split_terms(float a, float b, uint32_t (&t)[3]) 
     }
 }
 
-template <int CH, int TERMS>   // CH: chunks of 32 k known at compile time (all of A's row tile requested up front), 0: any number, one ahead
-__global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tiles) {
+// One workgroup of sixteen waves per compute unit, persistent: B is fetched and split once per compute unit, row tile t
+// goes to wave t / grid of workgroup t % grid (a [50000 x K] product is 3125 tiles: at most one per wave, spread over all
+// compute units).  The B words are requested first, the wave's first A tile right behind them (requests return in
+// order: B is split and laid out in LDS while A is still on its way), and every chunk of the next tile is requested as
+// soon as the current tile's chunk has been split into its bf16 terms.
+constexpr int kSplitThreads = 1024, kSplitWaves = kSplitThreads / 64;
+
+template <int CH, int TERMS>   // CH: chunks of 32 k known at compile time (a whole row tile of A in registers), 0: any number, one chunk ahead
+__global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, int row_tiles, int slab) {
     extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][TERMS][64] as 16-byte words
     u32x4* bsplit = reinterpret_cast<u32x4*>(bfrag);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int col0 = blockIdx.y * (16 * kColTiles);
     const int chunks = CH > 0 ? CH : g.k / 32;                // k is a multiple of 32 here
     const int n_tiles = min(kColTiles, (g.n - col0 + 15) / 16);
-    for (int idx = threadIdx.x; idx < chunks * kColTiles * 64; idx += 512) {
+    const int tile_step = gridDim.x * kSplitWaves;
+    int tile = wave * gridDim.x + blockIdx.x;
+
+    auto a_ptr = [&](int t) { return g.a + (int64_t)min(t * 16 + r, g.m - 1) * g.lda + 8 * q; };
+    auto put_b = [&](int idx, const float (&v)[8]) {
         const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
-        const int col = col0 + 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = col < g.n ? g.b[(int64_t)(kb + j) * g.ldb + col] : 0.f;
         u32x4 tv[3];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -246,62 +253,47 @@ __global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tile
         u32x4* o = bsplit + ((size_t)(ch * kColTiles + t) * TERMS) * 64 + l;
 #pragma unroll
         for (int q3 = 0; q3 < TERMS; ++q3) o[64 * q3] = tv[q3];
-    }
-    __syncthreads();
-    for (int tile = blockIdx.x * 8 + wave; tile < row_tiles; tile += gridDim.x * 8) {
-        const int row0 = tile * 16;
-        const int arow = row0 + r;
-        const bool a_ok = arow < g.m;
-        const float* __restrict__ arow_ptr = g.a + (int64_t)min(arow, g.m - 1) * g.lda + 8 * q;
-        f32x4 acc[kColTiles];
+    };
+    auto get_b = [&](int idx, float (&v)[8]) {
+        const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
+        const int col = col0 + 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
 #pragma unroll
-        for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto step = [&](int ch, const f32x4& a0, const f32x4& a1) {
-            u32x4 at[3];
-            {
-                uint32_t w[3];
-                split_terms<TERMS>(a0[0], a0[1], w); at[0][0] = w[0]; at[1][0] = w[1]; at[2][0] = w[2];
-                split_terms<TERMS>(a0[2], a0[3], w); at[0][1] = w[0]; at[1][1] = w[1]; at[2][1] = w[2];
-                split_terms<TERMS>(a1[0], a1[1], w); at[0][2] = w[0]; at[1][2] = w[1]; at[2][2] = w[2];
-                split_terms<TERMS>(a1[2], a1[3], w); at[0][3] = w[0]; at[1][3] = w[1]; at[2][3] = w[2];
-            }
-            if (!a_ok) { at[0] = (u32x4){0u, 0u, 0u, 0u}; at[1] = at[0]; at[2] = at[0]; }
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, at[0]), xm = __builtin_bit_cast(bf16x8, at[1]), xl = __builtin_bit_cast(bf16x8, at[2]);
-            const u32x4* __restrict__ bp = bsplit + (size_t)ch * kColTiles * TERMS * 64 + lane;
+        for (int j = 0; j < 8; ++j) v[j] = g.b[(int64_t)(kb + j) * g.ldb + min(col, g.n - 1)];
+        if (col >= g.n) {
 #pragma unroll
-            for (int t = 0; t < kColTiles; ++t) {
-                if (t >= n_tiles) break;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[(TERMS * t) * 64]), bm = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 1) * 64]);
-                if constexpr (TERMS == 3) {                                     // smallest terms first
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 2) * 64]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bm, acc[t], 0, 0, 0);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bm, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[t], 0, 0, 0);
-            }
-        };
-        if constexpr (CH > 0) {
-            // (requesting the first tile's A before B is prepared was slower: the B loads queue behind it, 19.6 -> 27.7 us)
-            f32x4 av[CH][2];
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) {
-                av[ch][0] = *reinterpret_cast<const f32x4*>(arow_ptr + 32 * ch);
-                av[ch][1] = *reinterpret_cast<const f32x4*>(arow_ptr + 32 * ch + 4);
-            }
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) step(ch, av[ch][0], av[ch][1]);
-        } else {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(arow_ptr), a1 = *reinterpret_cast<const f32x4*>(arow_ptr + 4);
-            for (int ch = 0; ch < chunks; ++ch) {
-                const int nx = (ch + 1 < chunks ? ch + 1 : ch) * 32;
-                const f32x4 n0 = *reinterpret_cast<const f32x4*>(arow_ptr + nx), n1 = *reinterpret_cast<const f32x4*>(arow_ptr + nx + 4);
-                step(ch, a0, a1);
-                a0 = n0; a1 = n1;
-            }
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
         }
+    };
+    f32x4 acc[kColTiles];
+    auto step = [&](int ch, const f32x4& a0, const f32x4& a1, bool a_ok) {
+        u32x4 at[3];
+        {
+            uint32_t w[3];
+            split_terms<TERMS>(a0[0], a0[1], w); at[0][0] = w[0]; at[1][0] = w[1]; at[2][0] = w[2];
+            split_terms<TERMS>(a0[2], a0[3], w); at[0][1] = w[0]; at[1][1] = w[1]; at[2][1] = w[2];
+            split_terms<TERMS>(a1[0], a1[1], w); at[0][2] = w[0]; at[1][2] = w[1]; at[2][2] = w[2];
+            split_terms<TERMS>(a1[2], a1[3], w); at[0][3] = w[0]; at[1][3] = w[1]; at[2][3] = w[2];
+        }
+        if (!a_ok) { at[0] = (u32x4){0u, 0u, 0u, 0u}; at[1] = at[0]; at[2] = at[0]; }
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, at[0]), xm = __builtin_bit_cast(bf16x8, at[1]), xl = __builtin_bit_cast(bf16x8, at[2]);
+        const u32x4* __restrict__ bp = bsplit + (size_t)ch * kColTiles * TERMS * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < kColTiles; ++t) {
+            if (t >= n_tiles) break;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[(TERMS * t) * 64]), bm = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 1) * 64]);
+            if constexpr (TERMS == 3) {                                     // smallest terms first
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 2) * 64]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bm, acc[t], 0, 0, 0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[t], 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int t0) {
+        const int row0 = t0 * 16;
 #pragma unroll
         for (int t = 0; t < kColTiles; ++t) {
             const int col = col0 + 16 * t + r;
@@ -317,19 +309,93 @@ __global__ __launch_bounds__(512) void k_gemm_split_lds(GemmArgs g, int row_tile
                 }
             }
         }
+    };
+
+    if constexpr (CH > 0) {
+        constexpr int NB = (CH * kColTiles * 64 + kSplitThreads - 1) / kSplitThreads;   // B words of 8 k per thread
+        float bv[NB][8];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = threadIdx.x + i * kSplitThreads;
+            get_b(min(idx, CH * kColTiles * 64 - 1), bv[i]);
+        }
+        f32x4 av[CH][2];
+        if (tile < row_tiles) {                                                 // wave-uniform
+            const float* __restrict__ ap = a_ptr(tile);
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                av[ch][0] = *reinterpret_cast<const f32x4*>(ap + 32 * ch);
+                av[ch][1] = *reinterpret_cast<const f32x4*>(ap + 32 * ch + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = threadIdx.x + i * kSplitThreads;
+            if (idx < CH * kColTiles * 64) put_b(idx, bv[i]);
+        }
+        __syncthreads();
+        for (; tile < row_tiles; tile += tile_step) {
+            const bool a_ok = tile * 16 + r < g.m;
+            const int next = tile + tile_step < row_tiles ? tile + tile_step : tile;   // (the last tile re-reads itself, unused)
+            const float* __restrict__ np = a_ptr(next);
+#pragma unroll
+            for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                step(ch, av[ch][0], av[ch][1], a_ok);
+                if (next != tile) {
+                    av[ch][0] = *reinterpret_cast<const f32x4*>(np + 32 * ch);
+                    av[ch][1] = *reinterpret_cast<const f32x4*>(np + 32 * ch + 4);
+                }
+            }
+            store_tile(tile);
+        }
+    } else {
+        // any K (a multiple of 32): B goes through LDS in slabs of `slab` chunks (all of it when it fits), the accumulators
+        // stay in registers across the slabs; the workgroup walks its rounds of row tiles together (barriers around a refill)
+        const int rounds = (row_tiles + tile_step - 1) / tile_step;
+        for (int round = 0; round < rounds; ++round, tile += tile_step) {
+            const bool live = tile < row_tiles;                                 // wave-uniform
+            const bool a_ok = tile * 16 + r < g.m;
+            const float* __restrict__ ap = a_ptr(live ? tile : 0);
+#pragma unroll
+            for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < chunks; s0 += slab) {
+                const int s1 = min(chunks, s0 + slab);
+                f32x4 a0 = (f32x4)(0.f), a1 = a0;
+                if (live) { a0 = *reinterpret_cast<const f32x4*>(ap + 32 * s0); a1 = *reinterpret_cast<const f32x4*>(ap + 32 * s0 + 4); }
+                if (slab < chunks || round == 0) {
+                    if (round > 0 || s0 > 0) __syncthreads();                   // everyone is done with the slab in LDS
+                    for (int idx = threadIdx.x; idx < (s1 - s0) * kColTiles * 64; idx += kSplitThreads) {
+                        float v[8];
+                        get_b(idx + s0 * kColTiles * 64, v);
+                        put_b(idx, v);
+                    }
+                    __syncthreads();
+                }
+                if (live)
+                    for (int ch = s0; ch < s1; ++ch) {
+                        const int nx = (ch + 1 < s1 ? ch + 1 : ch) * 32;
+                        const f32x4 n0 = *reinterpret_cast<const f32x4*>(ap + nx), n1 = *reinterpret_cast<const f32x4*>(ap + nx + 4);
+                        step(ch - s0, a0, a1, a_ok);
+                        a0 = n0; a1 = n1;
+                    }
+            }
+            if (live) store_tile(tile);
+        }
     }
 }
 
 template <int TERMS>
-gn_status launch_split(const GemmArgs& g, int row_tiles, dim3 sgrid, size_t split_bytes, hipStream_t st) {
+gn_status launch_split(const GemmArgs& g, int row_tiles, dim3 sgrid, size_t split_bytes, int slab, hipStream_t st) {
 #define GN_SPLIT_CASE(CH)                                                                                              \
     {                                                                                                                  \
         gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_gemm_split_lds<CH, TERMS>), 160 * 1024);    \
         if (ls != GN_OK) return ls;                                                                                    \
-        k_gemm_split_lds<CH, TERMS><<<sgrid, 512, split_bytes, st>>>(g, row_tiles);                                    \
+        k_gemm_split_lds<CH, TERMS><<<sgrid, kSplitThreads, split_bytes, st>>>(g, row_tiles, slab);                                    \
     }                                                                                                                  \
     break
-    switch (g.k / 32) {
+    switch (slab < g.k / 32 ? 0 : g.k / 32) {
         case 1: GN_SPLIT_CASE(1);
         case 2: GN_SPLIT_CASE(2);
         case 4: GN_SPLIT_CASE(4);
@@ -476,16 +542,19 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     g.m = (int)m; g.n = (int)n; g.k = (int)k; g.bias = bias; g.relu = relu;
     g.a_vec_ok = ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
-    if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny, one shared B
-        const int row_tiles = (int)gn::ceil_div(m, 16);
-        if (!a_rows && k % 32 == 0 && g.a_vec_ok) {                                   // bf16 matrix instruction on split operands
-            const int terms = fast ? 2 : 3;
-            const size_t split_bytes = (size_t)(k / 32) * kColTiles * terms * 64 * sizeof(f32x4);   // 2 bytes per term and element of B
-            // eight waves per workgroup: one row tile per wave on the NC shapes
-            dim3 sgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 8), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
-            hipStream_t st = gn::as_stream(stream);
-            if (split_bytes <= 160 * 1024) return fast ? launch_split<2>(g, row_tiles, sgrid, split_bytes, st) : launch_split<3>(g, row_tiles, sgrid, split_bytes, st);
-        }
+    const int row_tiles = (int)gn::ceil_div(m, 16);
+    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled()) {
+        // tall-skinny, one shared B: the bf16 matrix instruction on split operands
+        const int terms = fast ? 2 : 3;
+        // B in LDS: 2 bytes per term and element; a deeper K goes through in slabs of up to 256 rows of B
+        const int slab = (int)std::min<int64_t>(k / 32, 8);
+        const size_t split_bytes = (size_t)slab * kColTiles * terms * 64 * sizeof(f32x4);
+        // one persistent workgroup of sixteen waves per compute unit (and 64-column block)
+        dim3 sgrid((unsigned)std::min<int64_t>(row_tiles, gn::compute_units()), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
+        hipStream_t st = gn::as_stream(stream);
+        return fast ? launch_split<2>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3>(g, row_tiles, sgrid, split_bytes, slab, st);
+    }
+    if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny on the fp32 instruction
         dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
         k_gemm_f32_lds<<<lgrid, 256, lds_bytes, gn::as_stream(stream)>>>(g, row_tiles);
         GN_LAUNCH_CHECK();

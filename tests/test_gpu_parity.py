@@ -972,3 +972,22 @@ def test_default_gemm_arithmetic_is_as_exact_as_fp32(gpu, monkeypatch):
     err["torch-fp32"] = ((a @ b).double() - ref64).abs().max().item()
     assert err["default"] <= 1.5 * max(err["exact"], err["torch-fp32"]) + 1e-7, err
     assert err["fast"] > err["default"] and err["fast"] <= 1e-3, err
+
+
+@pytest.mark.parametrize("m,k,n", [(2048, 32, 8), (5003, 64, 64), (70001, 96, 48), (4100, 160, 128), (9000, 256, 72),
+                                   (3000, 288, 8), (6000, 512, 128), (2500, 800, 20)])
+@pytest.mark.parametrize("fast", [False, True])
+def test_tall_skinny_gemm_shapes(gpu, m, k, n, fast):
+    """gn_gemm_f32 on the tall-skinny path (B through LDS, K deeper than 256 in slabs, several rounds of row tiles, ragged
+    last tile and column block) against float64, with bias and ReLU in the epilogue."""
+    gen = torch.Generator().manual_seed(m + k + n)
+    a = torch.randn(m, k, generator=gen)
+    b = torch.randn(k, n, generator=gen) * 0.1
+    bias = torch.randn(n, generator=gen)
+    ref64 = torch.relu(a.double() @ b.double() + bias.double())
+    out = torch.full((m, n), float("nan"), device=gpu)
+    _hip.gemm(a.to(gpu), b.to(gpu), out, bias=bias.to(gpu), relu=True, fast=fast)
+    err = (out.cpu().double() - ref64).abs().max().item()
+    ref32 = (torch.relu(a @ b + bias).double() - ref64).abs().max().item()
+    # (fp32 accumulators either way: the order of the K sum differs from the library's, not the precision of the products)
+    assert err <= (2e-3 if fast else 3 * ref32 + 1e-6), (err, ref32)
