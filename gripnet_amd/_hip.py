@@ -48,6 +48,7 @@ SIGNATURES = {
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
     "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "gn_softmax_rows_f32": (_int, [_p, _i64, _i64, _i64, _p]),
+    "gn_class_scores_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "gn_rgcn_plan_create": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_rgcn_plan_destroy": (None, [_p]),
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
@@ -782,6 +783,13 @@ def link_metrics(pos_score, neg_score, range_list):
     ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=pos.device)
     _call("gn_link_metrics_f32", ptr(pos), ptr(neg), rl.data_ptr(), R, E, ptr(out), ptr(ws), need, stream_ptr(pos.device))
     return out[0], out[1], out[2]
+
+
+def class_scores(z, weight, nodes, out, softmax=True):
+    """out = softmax?(z[nodes] @ weight) in one launch (gn_class_scores_f32)."""
+    _call("gn_class_scores_f32", ptr(z), ld(z), z.shape[0], ptr(nodes), out.shape[0], ptr(weight), ld(weight),
+          weight.shape[0], weight.shape[1], int(bool(softmax)), ptr(out), ld(out), stream_ptr(z.device))
+    return out
 
 
 def softmax_rows(x):

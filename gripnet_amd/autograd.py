@@ -207,7 +207,7 @@ class DistMultFn(torch.autograd.Function):
 
 
 class ClassLogitsFn(torch.autograd.Function):
-    """``z[node_list] @ W`` (decoder.py:42); forward on the MFMA row-gather GEMM."""
+    """``z[node_list] @ W`` (decoder.py:42); forward on gn_class_scores_f32."""
 
     @staticmethod
     def forward(ctx, z, weight, node_list):
@@ -215,7 +215,7 @@ class ClassLogitsFn(torch.autograd.Function):
         w = weight.detach()
         nodes = _hip.i64_vec(node_list)
         out = torch.empty((nodes.shape[0], w.shape[1]), dtype=torch.float32, device=zc.device)
-        _hip.gemm(zc, w, out, a_rows=nodes)
+        _hip.class_scores(zc, w, nodes, out, False)
         ctx.save_for_backward(zc, w, nodes)
         return out
 

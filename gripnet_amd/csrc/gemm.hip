@@ -227,22 +227,22 @@ __device__ __forceinline__ void split_terms(float a, float b, uint32_t (&t)[3]) 
 // soon as the current tile's chunk has been split into its bf16 terms.
 constexpr int kSplitThreads = 1024, kSplitWaves = kSplitThreads / 64;
 
-template <int CH, int TERMS>   // CH: chunks of 32 k known at compile time (a whole row tile of A in registers), 0: any number, one chunk ahead
+template <int CH, int TERMS, int CT>   // CT: 16-column tiles per wave (4, or 8: a 128-column block reads A once); CH: chunks of 32 k known at compile time (a whole row tile of A in registers), 0: any number, one chunk ahead
 __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, int row_tiles, int slab) {
-    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][TERMS][64] as 16-byte words
+    extern __shared__ f32x4 bfrag[];                          // [chunks][CT][TERMS][64] as 16-byte words
     u32x4* bsplit = reinterpret_cast<u32x4*>(bfrag);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int col0 = blockIdx.y * (16 * kColTiles);
+    const int col0 = blockIdx.y * (16 * CT);
     const int chunks = CH > 0 ? CH : g.k / 32;                // k is a multiple of 32 here
-    const int n_tiles = min(kColTiles, (g.n - col0 + 15) / 16);
+    const int n_tiles = min(CT, (g.n - col0 + 15) / 16);
     const int tile_step = gridDim.x * kSplitWaves;
     int tile = wave * gridDim.x + blockIdx.x;
 
     auto a_ptr = [&](int t) { return g.a + (int64_t)min(t * 16 + r, g.m - 1) * g.lda + 8 * q; };
     auto put_b = [&](int idx, const float (&v)[8]) {
-        const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
+        const int l = idx & 63, t = (idx >> 6) % CT, ch = idx / (64 * CT);
         u32x4 tv[3];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -250,12 +250,12 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
             split_terms<TERMS>(v[2 * h], v[2 * h + 1], w);
             tv[0][h] = w[0]; tv[1][h] = w[1]; tv[2][h] = w[2];
         }
-        u32x4* o = bsplit + ((size_t)(ch * kColTiles + t) * TERMS) * 64 + l;
+        u32x4* o = bsplit + ((size_t)(ch * CT + t) * TERMS) * 64 + l;
 #pragma unroll
         for (int q3 = 0; q3 < TERMS; ++q3) o[64 * q3] = tv[q3];
     };
     auto get_b = [&](int idx, float (&v)[8]) {
-        const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
+        const int l = idx & 63, t = (idx >> 6) % CT, ch = idx / (64 * CT);
         const int col = col0 + 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = g.b[(int64_t)(kb + j) * g.ldb + min(col, g.n - 1)];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
         }
     };
-    f32x4 acc[kColTiles];
+    f32x4 acc[CT];
     auto step = [&](int ch, const f32x4& a0, const f32x4& a1, bool a_ok) {
         u32x4 at[3];
         {
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
         }
         if (!a_ok) { at[0] = (u32x4){0u, 0u, 0u, 0u}; at[1] = at[0]; at[2] = at[0]; }
         const bf16x8 xh = __builtin_bit_cast(bf16x8, at[0]), xm = __builtin_bit_cast(bf16x8, at[1]), xl = __builtin_bit_cast(bf16x8, at[2]);
-        const u32x4* __restrict__ bp = bsplit + (size_t)ch * kColTiles * TERMS * 64 + lane;
+        const u32x4* __restrict__ bp = bsplit + (size_t)ch * CT * TERMS * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < kColTiles; ++t) {
+        for (int t = 0; t < CT; ++t) {
             if (t >= n_tiles) break;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[(TERMS * t) * 64]), bm = __builtin_bit_cast(bf16x8, bp[(TERMS * t + 1) * 64]);
             if constexpr (TERMS == 3) {                                     // smallest terms first
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
     auto store_tile = [&](int t0) {
         const int row0 = t0 * 16;
 #pragma unroll
-        for (int t = 0; t < kColTiles; ++t) {
+        for (int t = 0; t < CT; ++t) {
             const int col = col0 + 16 * t + r;
             if (col >= g.n) continue;
             const float bias = g.bias ? g.bias[col] : 0.f;
@@ -312,12 +312,12 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
     };
 
     if constexpr (CH > 0) {
-        constexpr int NB = (CH * kColTiles * 64 + kSplitThreads - 1) / kSplitThreads;   // B words of 8 k per thread
+        constexpr int NB = (CH * CT * 64 + kSplitThreads - 1) / kSplitThreads;   // B words of 8 k per thread
         float bv[NB][8];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = threadIdx.x + i * kSplitThreads;
-            get_b(min(idx, CH * kColTiles * 64 - 1), bv[i]);
+            get_b(min(idx, CH * CT * 64 - 1), bv[i]);
         }
         f32x4 av[CH][2];
         if (tile < row_tiles) {                                                 // wave-uniform
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = threadIdx.x + i * kSplitThreads;
-            if (idx < CH * kColTiles * 64) put_b(idx, bv[i]);
+            if (idx < CH * CT * 64) put_b(idx, bv[i]);
         }
         __syncthreads();
         for (; tile < row_tiles; tile += tile_step) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
             const int next = tile + tile_step < row_tiles ? tile + tile_step : tile;   // (the last tile re-reads itself, unused)
             const float* __restrict__ np = a_ptr(next);
 #pragma unroll
-            for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 step(ch, av[ch][0], av[ch][1], a_ok);
@@ -359,16 +359,16 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
             const bool a_ok = tile * 16 + r < g.m;
             const float* __restrict__ ap = a_ptr(live ? tile : 0);
 #pragma unroll
-            for (int t = 0; t < kColTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int s0 = 0; s0 < chunks; s0 += slab) {
                 const int s1 = min(chunks, s0 + slab);
                 f32x4 a0 = (f32x4)(0.f), a1 = a0;
                 if (live) { a0 = *reinterpret_cast<const f32x4*>(ap + 32 * s0); a1 = *reinterpret_cast<const f32x4*>(ap + 32 * s0 + 4); }
                 if (slab < chunks || round == 0) {
                     if (round > 0 || s0 > 0) __syncthreads();                   // everyone is done with the slab in LDS
-                    for (int idx = threadIdx.x; idx < (s1 - s0) * kColTiles * 64; idx += kSplitThreads) {
+                    for (int idx = threadIdx.x; idx < (s1 - s0) * CT * 64; idx += kSplitThreads) {
                         float v[8];
-                        get_b(idx + s0 * kColTiles * 64, v);
+                        get_b(idx + s0 * CT * 64, v);
                         put_b(idx, v);
                     }
                     __syncthreads();
@@ -386,20 +386,20 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
     }
 }
 
-template <int TERMS>
+template <int TERMS, int CT>
 gn_status launch_split(const GemmArgs& g, int row_tiles, dim3 sgrid, size_t split_bytes, int slab, hipStream_t st) {
 #define GN_SPLIT_CASE(CH)                                                                                              \
     {                                                                                                                  \
-        gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_gemm_split_lds<CH, TERMS>), 160 * 1024);    \
+        gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_gemm_split_lds<CH, TERMS, CT>), 160 * 1024); \
         if (ls != GN_OK) return ls;                                                                                    \
-        k_gemm_split_lds<CH, TERMS><<<sgrid, kSplitThreads, split_bytes, st>>>(g, row_tiles, slab);                                    \
+        k_gemm_split_lds<CH, TERMS, CT><<<sgrid, kSplitThreads, split_bytes, st>>>(g, row_tiles, slab);                \
     }                                                                                                                  \
     break
     switch (slab < g.k / 32 ? 0 : g.k / 32) {
         case 1: GN_SPLIT_CASE(1);
         case 2: GN_SPLIT_CASE(2);
         case 4: GN_SPLIT_CASE(4);
-        case 8: GN_SPLIT_CASE(8);
+        case 8: if constexpr (CT == 4) { GN_SPLIT_CASE(8); } else { GN_SPLIT_CASE(0); }
         default: GN_SPLIT_CASE(0);
     }
 #undef GN_SPLIT_CASE
@@ -444,6 +444,93 @@ __global__ void k_softmax_rows(float* __restrict__ x, int64_t ld, int64_t rows, 
         for (int c = lane; c < cols; c += 64) sum += expf(row[c] - mx);
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         for (int c = lane; c < cols; c += 64) row[c] = expf(row[c] - mx) / sum;
+    }
+}
+
+// softmax?( z[node_list] @ W ) for a handful of classes (multiClassInnerProductDecoder, decoder.py:42-43): sixteen lanes
+// per selected row, four rows per wave, one row per lane group and launch-wide no loop on the NC shapes.  W (k x n,
+// n <= 16) sits in LDS as [n / 4][k] 16-byte words (the four lane groups read the same words: broadcasts); a lane sums
+// its columns j, j + 16, ... of the row, eight loads in flight; the n sums are folded over the sixteen lanes with DPP row
+// operations (no LDS traffic), lane c of the group then owns class c: max, exp, sum, divide once per class.  One launch
+// and one pass over the selected rows instead of a row-gather GEMM whose 16 x 16 tiles are mostly padding plus a softmax pass.
+constexpr int kClassMax = 16;
+
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float x) {            // all 16 lanes of a row active
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {          // quad xor 1, quad xor 2, half-row mirror, row mirror
+    x += row_dpp<0xB1>(x); x += row_dpp<0x4E>(x); x += row_dpp<0x141>(x); x += row_dpp<0x140>(x);
+    return x;
+}
+__device__ __forceinline__ float row16_max(float x) {
+    x = fmaxf(x, row_dpp<0xB1>(x)); x = fmaxf(x, row_dpp<0x4E>(x)); x = fmaxf(x, row_dpp<0x141>(x)); x = fmaxf(x, row_dpp<0x140>(x));
+    return x;
+}
+
+__global__ __launch_bounds__(1024) void k_class_scores(const float* __restrict__ z, int64_t ld_z, int64_t table_rows,
+                                                       const int64_t* __restrict__ nodes, int64_t m, const float* __restrict__ w,
+                                                       int64_t ld_w, int k, int n, int softmax, float* __restrict__ out, int64_t ld_out) {
+    extern __shared__ f32x4 wl4[];                             // [kClassMax / 4][k]
+    const int n4 = (n + 3) >> 2;
+    const int j = threadIdx.x & 15;
+    const int64_t group = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+    const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    // the group's first node id is on its way while W is laid out
+    int64_t src_next = group < m ? (nodes ? nodes[group] : group) : 0;
+    for (int i = threadIdx.x; i < k * n4; i += 1024) {
+        const int c4 = i / k, kk = i - c4 * k;
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = 4 * c4 + t < n ? w[(int64_t)kk * ld_w + 4 * c4 + t] : 0.f;
+        wl4[i] = v;
+    }
+    __syncthreads();
+    const int64_t trips = (m + n_groups - 1) / n_groups;       // the wave walks together (DPP rows need every lane)
+    int64_t i = group;
+    for (int64_t trip = 0; trip < trips; ++trip, i += n_groups) {
+        const bool live = i < m;
+        int64_t src = src_next;
+        if (i + n_groups < m) src_next = nodes ? nodes[i + n_groups] : i + n_groups;
+        const bool ok = live && (uint64_t)src < (uint64_t)table_rows;   // out of the table -> a row of zeros, as the row-gather GEMM
+        if (!ok) src = 0;
+        const float* __restrict__ row = z + src * ld_z;
+        float acc[kClassMax];
+#pragma unroll
+        for (int c = 0; c < kClassMax; ++c) acc[c] = 0.f;
+        for (int k0 = 0; k0 < k; k0 += 8 * 16) {                // eight loads of the row in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k0 + 16 * u + j;
+                v[u] = (ok && kk < k) ? row[kk] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + 16 * u >= k) break;
+                const int kk = min(k0 + 16 * u + j, k - 1);     // (beyond k: v is zero)
+#pragma unroll
+                for (int c4 = 0; c4 < kClassMax / 4; ++c4) {
+                    if (c4 >= n4) break;
+                    const f32x4 ww = wl4[c4 * k + kk];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[4 * c4 + t] += v[u] * ww[t];
+                }
+            }
+        }
+        float mine = 0.f;                                      // class j of the group's row
+#pragma unroll
+        for (int c = 0; c < kClassMax; ++c) {
+            if (c >= n) break;
+            const float s = row16_sum(acc[c]);
+            if (c == j) mine = s;
+        }
+        if (softmax) {
+            const float mx = row16_max(j < n ? mine : -INFINITY);
+            const float e = j < n ? expf(mine - mx) : 0.f;
+            mine = e / row16_sum(e);
+        }
+        if (live && j < n) out[i * ld_out + j] = mine;
     }
 }
 
@@ -546,13 +633,16 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled()) {
         // tall-skinny, one shared B: the bf16 matrix instruction on split operands
         const int terms = fast ? 2 : 3;
-        // B in LDS: 2 bytes per term and element; a deeper K goes through in slabs of up to 256 rows of B
-        const int slab = (int)std::min<int64_t>(k / 32, 8);
-        const size_t split_bytes = (size_t)slab * kColTiles * terms * 64 * sizeof(f32x4);
-        // one persistent workgroup of sixteen waves per compute unit (and 64-column block)
-        dim3 sgrid((unsigned)std::min<int64_t>(row_tiles, gn::compute_units()), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
+        // a wave keeps 64 columns of a row tile, or 128 when the product is wider than 64 (A is then read once per 128)
+        const int ct = n > 64 ? 8 : 4;
+        // B in LDS: 2 bytes per term and element, at most 160 KB; a deeper K goes through in slabs
+        const int slab = (int)std::min<int64_t>(k / 32, std::min<int64_t>(8, (160 * 1024) / ((int64_t)ct * terms * 64 * sizeof(f32x4))));
+        const size_t split_bytes = (size_t)slab * ct * terms * 64 * sizeof(f32x4);
+        // one persistent workgroup of sixteen waves per compute unit (and column block)
+        dim3 sgrid((unsigned)std::min<int64_t>(row_tiles, gn::compute_units()), (unsigned)gn::ceil_div(n, 16 * ct), 1);
         hipStream_t st = gn::as_stream(stream);
-        return fast ? launch_split<2>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3>(g, row_tiles, sgrid, split_bytes, slab, st);
+        if (ct == 8) return fast ? launch_split<2, 8>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3, 8>(g, row_tiles, sgrid, split_bytes, slab, st);
+        return fast ? launch_split<2, 4>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3, 4>(g, row_tiles, sgrid, split_bytes, slab, st);
     }
     if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny on the fp32 instruction
         dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
@@ -586,6 +676,29 @@ gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, 
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
+
+gn_status gn_class_scores_f32(const float* z, int64_t ld_z, int64_t table_rows, const int64_t* node_list, int64_t m,
+                              const float* w, int64_t ld_w, int64_t k, int64_t n, int softmax, float* out, int64_t ld_out,
+                              void* stream) {
+    GN_REQUIRE(m >= 0 && k >= 0 && n >= 0 && table_rows >= 0, "negative size");
+    if (m == 0 || n == 0) return GN_OK;
+    GN_REQUIRE(z && w && out, "operand pointer is null");
+    GN_REQUIRE(ld_z >= k && ld_w >= n && ld_out >= n, "leading dimension smaller than the row length");
+    if (n > kClassMax || (size_t)k * kClassMax * sizeof(float) > 160 * 1024 || gn::fast_paths_disabled()) {
+        // many classes: the row-gather GEMM, then the softmax pass
+        gn_status s = gn_gemm_f32(z, ld_z, 0, node_list, table_rows, w, ld_w, 0, out, ld_out, 0, m, n, k, 1, nullptr, 0, stream);
+        if (s != GN_OK || !softmax) return s;
+        return gn_softmax_rows_f32(out, ld_out, m, n, stream);
+    }
+    const size_t lds = (size_t)k * ((n + 3) / 4) * sizeof(f32x4);
+    { gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_class_scores), 160 * 1024); if (ls != GN_OK) return ls; }
+    const int grid = (int)std::min<int64_t>(gn::ceil_div(m, 64), 16 * gn::compute_units());
+    k_class_scores<<<grid, 1024, lds, gn::as_stream(stream)>>>(z, ld_z, table_rows, node_list, m, w, ld_w, (int)k, (int)n, softmax,
+                                                                out, ld_out);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 
 size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2) {
     if (k1 <= 0 || k2 <= 0) return 0;

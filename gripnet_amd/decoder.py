@@ -173,8 +173,7 @@ class multiClassInnerProductDecoder(Module):
         z = _hip.f32_rows(z)
         nodes = _hip.i64_vec(node_list)
         pred = torch.empty((nodes.shape[0], self.num_class), dtype=torch.float32, device=z.device)
-        _hip.gemm(z, self.weight, pred, a_rows=nodes)                            # decoder.py:42
-        return _hip.softmax_rows(pred) if softmax else pred
+        return _hip.class_scores(z, self.weight, nodes, pred, softmax)           # decoder.py:42-43
 
     def reset_parameters(self):
         bound = np.sqrt(6.0 / (self.weight.size(-2) + self.weight.size(-1)))     # decoder.py:47-49

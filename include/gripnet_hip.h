@@ -177,6 +177,14 @@ GN_API gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int6
 
 /* Row softmax in place (decoder.py:43). */
 GN_API gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, void* stream);
+/* out[i, :] = softmax?( z[node_list[i], :] @ W ), i in [0, m): multiClassInnerProductDecoder.forward in one launch
+ * (gripnet/decoder.py:42-43: `pred = torch.matmul(z[node_list], self.weight)`, then `torch.softmax(pred, dim=1)`).
+ * node_list may be NULL (rows 0..m-1); an entry outside [0, table_rows) scores a row of zeros, as gn_gemm_f32's a_rows.
+ * W is [k, n] row-major.  Up to 16 classes run as one pass over the selected rows; more go through gn_gemm_f32 +
+ * gn_softmax_rows_f32. */
+GN_API gn_status gn_class_scores_f32(const float* z, int64_t ld_z, int64_t table_rows, const int64_t* node_list, int64_t m,
+                              const float* w, int64_t ld_w, int64_t k, int64_t n, int softmax, float* out, int64_t ld_out,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Multi-relational internal layer (myRGCN, gripnet/layers.py:165-197).

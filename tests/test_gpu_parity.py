@@ -991,3 +991,20 @@ def test_tall_skinny_gemm_shapes(gpu, m, k, n, fast):
     ref32 = (torch.relu(a @ b + bias).double() - ref64).abs().max().item()
     # (fp32 accumulators either way: the order of the K sum differs from the library's, not the precision of the products)
     assert err <= (2e-3 if fast else 3 * ref32 + 1e-6), (err, ref32)
+
+
+@pytest.mark.parametrize("k,n", [(288, 8), (64, 3), (128, 16), (32, 1), (96, 20), (30, 4)])
+@pytest.mark.parametrize("softmax", [True, False])
+def test_class_scores_vs_torch(gpu, k, n, softmax):
+    """gn_class_scores_f32 = softmax?(z[node_list] @ W) (decoder.py:42-43): the one-pass kernel (<= 16 classes) and the
+    GEMM + softmax route behind the same entry point, with repeated nodes in the list."""
+    gen = torch.Generator().manual_seed(k * 31 + n)
+    z = torch.randn(5000, k, generator=gen)
+    w = torch.randn(k, n, generator=gen) * 0.2
+    nodes = torch.randint(0, 5000, (3001,), generator=gen)
+    ref = z[nodes].double() @ w.double()
+    if softmax:
+        ref = torch.softmax(ref, dim=1)
+    out = torch.full((nodes.shape[0], n), float("nan"), device=gpu)
+    _hip.class_scores(z.to(gpu), w.to(gpu), nodes.to(gpu), out, softmax)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
