@@ -99,10 +99,11 @@ def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, n
     rev, pairs, _ = plan.grad_plans()
     dxe = dbasis = datt = None
     if need_x:
-        # the same relational layer on the reversed graph with the transposed bases, un-normalised
+        # the same relational layer on the reversed graph with the transposed bases, un-normalised (one launch of the
+        # destination-major kernel where it applies: any output width that is a multiple of 4 up to 64)
         dxe = torch.empty((n, fin), dtype=torch.float32, device=x.device)
         bt = basis.transpose(1, 2)                                           # [B, fout, fin]: W_r^T = sum_b att[r,b] bt[b]
-        if fout == 32 and fin % 32 != 0 and fin > 32:
+        if rev.path(fout, fin, B) != "pair" and fout == 32 and fin % 32 != 0 and fin > 32:
             # the LDS-resident kernel produces 32 output features: run it per 32-column block of W_r^T
             # (the last block zero-padded) instead of falling back to the HBM-table path
             for c0 in range(0, fin, 32):

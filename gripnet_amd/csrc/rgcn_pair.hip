@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     // order (a wave instruction reads whole consecutive rows).  Requested BEFORE the barrier: a wave that finishes early
     // fetches while the others still gather; every compute unit pulls all of basis (196 KB on PoSE) through its own L2
     // port, which is what this epilogue costs.
-    constexpr int kRowsMax = 12;                                               // rows of a slice held in registers
+    constexpr int kRowsMax = NT <= 2 ? 16 : 12;                                // rows of a slice held in registers (fewer accumulators: more rows)
     const int32_t* my_dst = a.wg_dst + (size_t)g * 4;
     int nd = 0;
 #pragma unroll
@@ -404,21 +404,35 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         for (int d = 0; d < kMaxD; ++d)
             if (d < nd) *reinterpret_cast<f32x4*>(red + ((size_t)(sl * kMaxD + d) * og + o4) * 4) = sum[d];
     __syncthreads();
-    // (destination, output) x eight partial sums over the slices, folded inside eight adjacent lanes
-    {
+    // (destination, output) x eight partial sums over the slices, folded inside eight adjacent lanes: 128 pairs per pass
+    // (three rows of up to 42 outputs are one pass; the values of the first pass were requested before the barriers)
+    for (int p0 = 0; p0 < nd * fout; p0 += kThreads / 8) {
+        const int pair = p0 + fin_pair;
+        const bool lv = pair < nd * fout;
+        const int pd = lv ? pair / fout : 0, po = lv ? pair - pd * fout : 0, pi = lv ? my_dst[pd] : 0;
+        float div = fin_div, bias_v = fin_bias, t = fin_root;
+        if (p0 > 0) {
+            div = 1.f; bias_v = 0.f; t = 0.f;
+            if (lv && !a.partial) {
+                div = fmaxf(a.indeg[pi], 1.0f);
+                if (a.bias) bias_v = a.bias[po];
+#pragma unroll
+                for (int f = 0; f < FIN / 8; ++f)
+                    t += a.x[(int64_t)pi * a.ld_x + fin_part + 8 * f] * a.root[(fin_part + 8 * f) * fout + po];
+            }
+        }
         float s = 0.f;
-        if (fin_live)
-            for (int q = fin_part; q < slices; q += 8) s += red[((size_t)(q * kMaxD + fin_d) * og + (fin_o >> 2)) * 4 + (fin_o & 3)];
-        float t = fin_root;
+        if (lv)
+            for (int q = fin_part; q < slices; q += 8) s += red[((size_t)(q * kMaxD + pd) * og + (po >> 2)) * 4 + (po & 3)];
         s += __shfl_xor(s, 1); t += __shfl_xor(t, 1);
         s += __shfl_xor(s, 2); t += __shfl_xor(t, 2);
         s += __shfl_xor(s, 4); t += __shfl_xor(t, 4);
-        if (fin_live && fin_part == 0) {
+        if (lv && fin_part == 0) {
             if (!a.partial) {
-                s = s / fin_div + t + fin_bias;
+                s = s / div + t + bias_v;
                 if (a.relu) s = fmaxf(s, 0.f);
             }
-            a.out[(int64_t)fin_i * a.ld_out + fin_o] = s;
+            a.out[(int64_t)pi * a.ld_out + po] = s;
         }
     }
     if (a.side.dst) {                                                          // concat slot 0, by the whole grid
@@ -817,7 +831,7 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     const int64_t part = (int64_t)(kWaves + kMaxD) * kp * 4;                   // the waves' shares, the rows' sums
     const int64_t red = (int64_t)kThreads * kMaxD * 16;                        // the slices' sums reuse the shares' space
     const int64_t slices = kThreads / (fout / 4), per = (bases * fin + slices - 1) / slices;
-    return std::max(part, red) <= kLdsBytes && nt * bt <= 6 && per <= 12;      // (rows of basis a thread holds in registers)
+    return std::max(part, red) <= kLdsBytes && nt * bt <= 6 && per <= (nt <= 2 ? 16 : 12);   // (rows of basis a thread holds in registers)
 }
 
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,

@@ -384,6 +384,28 @@ def test_rgcn_lds_resident_shapes(gpu, n, fin, bases, path):
     close(y, ref.float())
 
 
+@pytest.mark.parametrize("n,fin,fout,bases", [(700, 32, 48, 32), (645, 16, 64, 8), (300, 48, 4, 3), (768, 32, 44, 32)])
+def test_rgcn_destination_major_output_widths(gpu, n, fin, fout, bases):
+    """The destination-major relational kernel on output widths other than 32 (any multiple of 4 up to 64): above 256 nodes a
+    workgroup owns up to three rows, i.e. more than 128 (row, output) pairs for outputs wider than 42 - two passes of its
+    final stage.  32 -> 48 with 32 bases is the reversed layer of the PoSE backward (dx of the 48 -> 32 drug layer)."""
+    gen = torch.Generator().manual_seed(n + fout)
+    torch.manual_seed(n * 3 + fout)
+    sizes = [5000, 0, 2, 1500, 800]
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    rei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    rg = gripnet_amd.myRGCN(fin, fout, len(sizes), bases, False, bias=True).to(gpu)
+    rg.bias.data.normal_()
+    y = rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True)
+    assert rg._plan.path(fin, fout, bases) == "pair"
+    assert torch.equal(y, rg(x.to(gpu), rei.to(gpu), None, rl, _relu=True))
+    sd = {k: v.detach().cpu().double() for k, v in rg.state_dict().items()}
+    ref = torch.relu(orc.rgcn_forward(x.double(), rei, rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
+    close(y, ref.float())
+
+
 @pytest.mark.parametrize("formulation", ["pair", "acc"])
 def test_rgcn_sharded_partials_sum_to_full(gpu, formulation):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
