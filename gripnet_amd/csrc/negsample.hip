@@ -20,6 +20,17 @@ struct gn_negative_sampler {
     int64_t num_edges = 0, num_nodes = 0, num_relations = 0;
     gn::DevBuf<uint64_t> keys;      // [E] sorted (relation << 40) | (u * n + v)
     gn::DevBuf<int64_t> starts;     // [R + 1] block starts
+    // the narrow encoding (n < 2^16, R < 2^16, E < 2^31: every GripNet graph): the pair ids of the sorted keys as 32-bit
+    // words and the relation of every edge position, so that a draw costs one 2-byte load, two block bounds and a binary
+    // search over 4-byte words of a block that sits in L2 (the edges of a wave share their relation)
+    gn::DevBuf<uint32_t> keys32;    // [E] u * n + v in the order of `keys`
+    gn::DevBuf<uint16_t> rel16;     // [E] relation of edge position e
+    int narrow = 0;
+    // and, while R * n^2 bits stay below kBitmapBytes (PoSE: 964 x 645^2 bits = 50 MB), one bit per (relation, pair): a
+    // draw is tested with ONE 4-byte load - a binary search costs ~11 dependent loads whose last steps touch a
+    // different cache line in every lane
+    gn::DevBuf<uint32_t> bitmap;    // [R][words]
+    int64_t words = 0;              // 32-bit words per relation, 0: no bitmap
 };
 
 namespace {
@@ -79,6 +90,94 @@ __global__ void k_sample_negatives(const uint64_t* __restrict__ keys, const int6
     }
 }
 
+__global__ void k_narrow_keys(const uint64_t* __restrict__ keys, const int64_t* __restrict__ starts, int R, int64_t E,
+                              uint32_t* __restrict__ keys32, uint16_t* __restrict__ rel16) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        keys32[e] = (uint32_t)(keys[e] & 0xFFFFFFFFull);
+        rel16[e] = (uint16_t)relation_of(starts, R, e);
+    }
+}
+
+// The narrow sampler: no 64-bit division (u and v are two multiply-high draws of one 64-bit hash: uniform over the n^2
+// pairs), no search for the relation, 32-bit compares.  Same distribution as k_sample_negatives, another stream.
+__global__ __launch_bounds__(256) void k_sample_negatives_narrow(const uint32_t* __restrict__ keys32, const uint16_t* __restrict__ rel16,
+                                                                 const int64_t* __restrict__ starts, int64_t E, uint32_t n, uint64_t seed,
+                                                                 int64_t* __restrict__ out_u, int64_t* __restrict__ out_v,
+                                                                 uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = rel16[e];
+        const int lo0 = (int)starts[r], hi0 = (int)starts[r + 1];
+        const uint64_t base = mix64(seed ^ (uint64_t)e * 0xD6E8FEB86659FD93ull);
+        uint32_t uu = 0, vv = 0;
+        bool found = false;
+        for (int k = 0; k < kMaxAttempts && !found; ++k) {
+            const uint64_t h = mix64(base + (uint64_t)k);
+            uu = __umulhi((uint32_t)h, n);
+            vv = __umulhi((uint32_t)(h >> 32), n);
+            const uint32_t key = uu * n + vv;
+            int lo = lo0, hi = hi0;                           // is `key` one of this block's positives?
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (keys32[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            found = !(lo < hi0 && keys32[lo] == key);
+        }
+        if (!found && err) atomicOr(err, 2);                  // the block's positives (nearly) cover all n^2 pairs
+        out_u[e] = (int64_t)uu;
+        out_v[e] = (int64_t)vv;
+        if (packed) packed[e] = uu | (vv << 16);
+    }
+}
+
+constexpr int64_t kBitmapBytes = 512ll << 20;
+
+__global__ void k_fill_bitmap(const uint32_t* __restrict__ keys32, const uint16_t* __restrict__ rel16, int64_t E, int64_t words,
+                              uint32_t* __restrict__ bitmap) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t key = keys32[e];
+        if ((int64_t)(key >> 5) >= words) continue;           // an edge with a node id out of range (the create call fails after this launch)
+        atomicOr(bitmap + (int64_t)rel16[e] * words + (key >> 5), 1u << (key & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_negatives_bitmap(const uint32_t* __restrict__ bitmap, int64_t words,
+                                                                 const uint16_t* __restrict__ rel16, int64_t E, uint32_t n, uint64_t seed,
+                                                                 int64_t* __restrict__ out_u, int64_t* __restrict__ out_v,
+                                                                 uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t* __restrict__ bits = bitmap + (int64_t)rel16[e] * words;
+        const uint64_t base = mix64(seed ^ (uint64_t)e * 0xD6E8FEB86659FD93ull);   // the stream of the narrow sampler
+        uint32_t uu = 0, vv = 0;
+        bool found = false;
+        for (int k = 0; k < kMaxAttempts && !found; ++k) {
+            const uint64_t h = mix64(base + (uint64_t)k);
+            uu = __umulhi((uint32_t)h, n);
+            vv = __umulhi((uint32_t)(h >> 32), n);
+            const uint32_t key = uu * n + vv;
+            found = !((bits[key >> 5] >> (key & 31)) & 1u);
+        }
+        if (!found && err) atomicOr(err, 2);                  // the block's positives (nearly) cover all n^2 pairs
+        out_u[e] = (int64_t)uu;
+        out_v[e] = (int64_t)vv;
+        if (packed) packed[e] = uu | (vv << 16);
+    }
+}
+
+gn_status launch_sample(const gn_negative_sampler* s, uint64_t seed, int64_t* out_u, int64_t* out_v, uint32_t* packed,
+                        int32_t* error_flag, hipStream_t st) {
+    if (s->words > 0)
+        k_sample_negatives_bitmap<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
+            s->bitmap.p, s->words, s->rel16.p, s->num_edges, (uint32_t)s->num_nodes, seed, out_u, out_v, packed, error_flag);
+    else if (s->narrow)
+        k_sample_negatives_narrow<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
+            s->keys32.p, s->rel16.p, s->starts.p, s->num_edges, (uint32_t)s->num_nodes, seed, out_u, out_v, packed, error_flag);
+    else
+        k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
+            s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, packed, error_flag);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -125,6 +224,25 @@ gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, const i
         hipError_t e3 = rocprim::radix_sort_keys(nullptr, bytes, raw, s->keys.p, (size_t)E, 0, 64, st);
         if (e3 == hipSuccess) e3 = hipMalloc(&scratch, bytes ? bytes : 1);
         if (e3 == hipSuccess) e3 = rocprim::radix_sort_keys(scratch, bytes, raw, s->keys.p, (size_t)E, 0, 64, st);
+        if (e3 == hipSuccess && N < (1ll << 16) && R < (1ll << 16) && E < (1ll << 31) && !gn::fast_paths_disabled()) {
+            e3 = s->keys32.alloc(E);
+            if (e3 == hipSuccess) e3 = s->rel16.alloc(E);
+            if (e3 == hipSuccess) {
+                k_narrow_keys<<<gn::stream_grid(E, 256), 256, 0, st>>>(s->keys.p, s->starts.p, (int)R, E, s->keys32.p, s->rel16.p);
+                e3 = hipGetLastError();
+                s->narrow = 1;
+            }
+            const int64_t words = (N * N + 31) / 32;
+            if (e3 == hipSuccess && R * words * 4 <= kBitmapBytes) {
+                e3 = s->bitmap.alloc(R * words);
+                if (e3 == hipSuccess) e3 = hipMemsetAsync(s->bitmap.p, 0, (size_t)(R * words) * sizeof(uint32_t), st);
+                if (e3 == hipSuccess) {
+                    k_fill_bitmap<<<gn::stream_grid(E, 256), 256, 0, st>>>(s->keys32.p, s->rel16.p, E, words, s->bitmap.p);
+                    e3 = hipGetLastError();
+                    s->words = words;
+                }
+            }
+        }
         if (e3 == hipSuccess) e3 = hipMemcpyAsync(&bad, err, sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
         (void)hipFree(raw); (void)hipFree(err); if (scratch) (void)hipFree(scratch);
@@ -142,6 +260,9 @@ void gn_negative_sampler_destroy(gn_negative_sampler* s) {
     if (!s) return;
     s->keys.release();
     s->starts.release();
+    s->keys32.release();
+    s->rel16.release();
+    s->bitmap.release();
     delete s;
 }
 
@@ -150,10 +271,7 @@ gn_status gn_negative_sampler_sample(const gn_negative_sampler* s, uint64_t seed
     GN_REQUIRE(s != nullptr, "sampler is null");
     if (s->num_edges == 0) return GN_OK;
     GN_REQUIRE(out_u && out_v, "output pointers are null");
-    k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, gn::as_stream(stream)>>>(
-        s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, nullptr, error_flag);
-    GN_LAUNCH_CHECK();
-    return GN_OK;
+    return launch_sample(s, seed, out_u, out_v, nullptr, error_flag, gn::as_stream(stream));
 }
 
 gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* s, uint64_t seed, int64_t* out_u, int64_t* out_v,
@@ -162,10 +280,7 @@ gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* s, uint64
     if (s->num_edges == 0) return GN_OK;
     GN_REQUIRE(out_u && out_v && packed_uv, "output pointers are null");
     if (s->num_nodes > 65535) return gn::fail(GN_ERR_UNSUPPORTED, "packed pairs hold node ids of 16 bits");
-    k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, gn::as_stream(stream)>>>(
-        s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, packed_uv, error_flag);
-    GN_LAUNCH_CHECK();
-    return GN_OK;
+    return launch_sample(s, seed, out_u, out_v, packed_uv, error_flag, gn::as_stream(stream));
 }
 
 }  // extern "C"
