@@ -37,7 +37,7 @@ constexpr int kRowBytes = 128;             // LDS stride of an att row (32 bases
 constexpr int kRingBlocks = 32;            // per-wave window on its stream: 32 blocks of 64 bytes, refilled a quarter (512 B) at a time
 constexpr int kRingBytes = kRingBlocks * 64;
 constexpr int kMaxD = 3;                   // destination rows per workgroup
-constexpr int kMaxChunks = 255;            // chunks of 32 sources (a descriptor names its chunk in eight bits)
+constexpr int kMaxChunks = 255;            // chunks of 32 sources
 constexpr int kSectionCap = 64;            // (<= 255: a descriptor holds a section's blocks in eight bits)
                                            // pair becomes several units (running sums stay short: fp32 chains of <= 64)
 constexpr int kLdsBytes = 160 * 1024;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         if (u && (u & 7u) == 0u) descv = desc[(size_t)(u >> 3) * 64 + lane];   // next page (waited for at once: rare)
         const int o = (int)(u & 7u) * 8;
         const uint32_t c03 = __builtin_amdgcn_readlane(descv, o), c47 = __builtin_amdgcn_readlane(descv, o + 1);
-        const int chunk = (int)(__builtin_amdgcn_readlane(descv, o + 2) & 0xffu);
+        const int chunk = (int)__builtin_amdgcn_readlane(descv, o + 2);       // row of perm: this (destination, chunk)'s sources
         // this unit's chunk of x: requested here, split into bf16 terms behind the gather (the other waves of the SIMD
         // cover the L2 round trips)
 #ifdef GN_STAMPS
@@ -454,9 +454,16 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 }
 
 // ---- plan --------------------------------------------------------------------------------------------------------
-__global__ void k_pair_outdeg(const int64_t* __restrict__ src, int64_t lo, int64_t hi, int32_t* __restrict__ cnt) {
+// (a workgroup counts in LDS first: 2 M global atomics on 645 counters took 520 us)
+__global__ void k_pair_outdeg(const int64_t* __restrict__ src, int64_t lo, int64_t hi, int n, int32_t* __restrict__ cnt) {
+    extern __shared__ int32_t hist[];                                          // [n]
+    for (int i = threadIdx.x; i < n; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
     for (int64_t e = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(cnt + src[e], 1);                                            // ids validated by the general plan builder
+        atomicAdd(hist + src[e], 1);                                           // ids validated by the general plan builder
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (hist[i]) atomicAdd(cnt + i, hist[i]);
 }
 
 __global__ void k_pair_keys(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
@@ -608,7 +615,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     std::vector<int32_t> outdeg(N, 0);
     GN_HIP(hipMemsetAsync(outdeg_dev, 0, N * sizeof(int32_t), st));
     if (E > 0) {
-        k_pair_outdeg<<<gn::stream_grid(E, 256), 256, 0, st>>>(src, plan->edge_lo, plan->edge_hi, outdeg_dev);
+        k_pair_outdeg<<<gn::stream_grid(E, 256, 256), 256, (size_t)N * sizeof(int32_t), st>>>(src, plan->edge_lo, plan->edge_hi, (int)N, outdeg_dev);
         GN_LAUNCH_CHECK();
     }
     GN_HIP(hipMemcpyAsync(outdeg.data(), outdeg_dev, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -644,7 +651,30 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
 
     // A unit = (destination, chunk, slice j of <= kSectionCap blocks per section).  Blocks of a section = the longest of
     // its four pairs, in fours, at least one; a (destination, chunk) without any edge is no unit at all.
-    auto pair_len = [&](int64_t i, int k) { return rp[(size_t)i * kpad + k + 1] - rp[(size_t)i * kpad + k]; };
+    // K order PER DESTINATION: its (destination, source) pairs by edge count, longest first, four consecutive ones to the
+    // four lane groups of a section - lock-step partners then have (nearly) equal runs and what is left of the padding is
+    // the rounding to blocks of four (pose0-syn: 1.83 -> 1.32 x the edges, tools/pair_sim.py).  kord[i][pos] = the global
+    // K position (cell of `rp`) that sits at operand position pos = 32 chunk + 8 group + t of destination i; the sources
+    // of a (destination, chunk) are a row of `perm2` (the kernel reads its x rows through it).
+    std::vector<int32_t> kord((size_t)N * kpad);
+    std::vector<int32_t> perm2((size_t)N * kpad);
+    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
+        std::vector<int32_t> idx(kpad);
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t* r = rp.data() + (size_t)i * kpad;
+            std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return r[x + 1] - r[x] > r[y + 1] - r[y]; });
+            for (int q = 0; q < kpad; ++q) {
+                const int ch = q >> 5, t = (q & 31) >> 2, k = q & 3;
+                const size_t pos = (size_t)i * kpad + 32 * ch + 8 * k + t;
+                kord[pos] = idx[q];
+                perm2[pos] = perm[idx[q]];
+            }
+        }
+    });
+    auto cell = [&](int64_t i, int pos) { return (size_t)i * kpad + kord[(size_t)i * kpad + pos]; };
+    auto pair_len = [&](int64_t i, int pos) { const size_t c = cell(i, pos); return rp[c + 1] - rp[c]; };
+    auto chunk_empty = [&](int64_t i, int ch) { return pair_len(i, 32 * ch) == 0; };   // (position 32 ch holds the chunk's longest pair)
     auto section_blocks = [&](int64_t i, int ch, int t) {
         int longest = 0;
         for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
@@ -655,7 +685,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
         for (int64_t i = b; i < e; ++i) {
             int64_t blocks = 0;
             for (int ch = 0; ch < chunks; ++ch) {
-                if (rp[(size_t)i * kpad + 32 * ch + 32] == rp[(size_t)i * kpad + 32 * ch]) continue;
+                if (chunk_empty(i, ch)) continue;
                 int deepest = 1;
                 for (int t = 0; t < 8; ++t) {
                     const int nb = section_blocks(i, ch, t);
@@ -720,7 +750,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
                 units.clear();
                 int64_t total = 0;
                 for (int ch = 0; ch < chunks; ++ch) {
-                    if (rp[(size_t)i * kpad + 32 * ch + 32] == rp[(size_t)i * kpad + 32 * ch]) continue;
+                    if (chunk_empty(i, ch)) continue;
                     int nb[8], deepest = 1;
                     for (int t = 0; t < 8; ++t) { nb[t] = section_blocks(i, ch, t); deepest = std::max(deepest, nb[t]); }
                     for (int j = 0; j * kSectionCap < deepest; ++j) {
@@ -739,12 +769,12 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
                     std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
                     const size_t at = dv.size();
                     dv.resize(at + 8, 0u);
-                    dv[at + 2] = (uint32_t)un.ch;
+                    dv[at + 2] = (uint32_t)(i * chunks + un.ch);                 // row of perm2: the sources of this (destination, chunk)
                     for (int t = 0; t < 8; ++t) {
                         const uint32_t* list[4];
                         int len[4], longest = 0;
                         for (int k = 0; k < 4; ++k) {
-                            const size_t key_id = (size_t)i * kpad + 32 * un.ch + 8 * k + t;
+                            const size_t key_id = cell(i, 32 * un.ch + 8 * k + t);
                             const int full = rp[key_id + 1] - rp[key_id];
                             const int from = std::min(full, un.slice * kSectionCap * 4);
                             list[k] = rels.data() + rp[key_id] + from;
@@ -791,18 +821,18 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     GN_HIP(plan->pair_wave_units.alloc(wave_units.size()));
     GN_HIP(plan->pair_wave_desc.alloc(wave_desc.size()));
     GN_HIP(plan->pair_wg_dst.alloc(wg_dst.size()));
-    GN_HIP(plan->pair_perm.alloc(perm.size()));
+    GN_HIP(plan->pair_perm.alloc(perm2.size()));
     GN_HIP(hipMemcpyAsync(plan->pair_stream.p, stream.data(), stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wave_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_desc.p, desc.data(), desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wave_units.p, wave_units.data(), wave_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wave_desc.p, wave_desc.data(), wave_desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wg_dst.p, wg_dst.data(), wg_dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(plan->pair_perm.p, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(plan->pair_perm.p, perm2.data(), perm2.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipStreamSynchronize(st));
     plan->pair_groups = G;
     plan->pair_d = D;
-    plan->pair_chunks = chunks;
+    plan->pair_chunks = (int)(N * chunks);                                     // rows of perm2
     plan->pair_blocks = (int64_t)(total / 16);
     plan->pair_ok = 1;
     return GN_OK;
