@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     w.lane_off = lds0 + (uint32_t)c * (BT * 4);
     w.ring_lane = w.ring_base + (uint32_t)kg * 16u + (uint32_t)(lane & 3) * 4u;
     w.lane16 = (uint32_t)lane * 16u;
-    w.soff = 128u;                                                             // a unit reads its first two words itself
+    w.soff = 256u;                                                             // a unit reads its first four words itself (behind soff)
     w.sdma = 3u * 512u;                                                        // the window starts with blocks 0..23
     if (lane < 32) {
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(w.sbase) + lane;
@@ -785,7 +785,6 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
                         dv[at + (t >> 2)] |= (uint32_t)nb << (8 * (t & 3));
                         lay_out_section(list, len, nb, (uint32_t)R, out);
                     }
-                    out.resize(out.size() + 2 * 16, (uint32_t)R * kRowBytes);   // two padding blocks: requested, never added
                     wave_units[gg * kWaves + wv] += 1;
                 }
                 wave0 += share[d];

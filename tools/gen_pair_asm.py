@@ -15,8 +15,9 @@ the unit's blocks, flat across sections:
 Buffers and word registers rotate with period three, so the body of a section is three positions long and is entered
 at the position its first block falls on; which of the three exits a section leaves by decides the entry of the next:
 all static labels, no per-block bookkeeping of the rotation.  The word of a block goes round each lane quad (DPP): lane p
-reads the rows of edges p, p+1, p+2, p+3 (mod 4) of its group's block.  Two padding blocks follow every unit in the
-stream (rows(N), rows(N+1) are requested and dropped); the next unit re-reads its first two words from the window.
+reads the rows of edges p, p+1, p+2, p+3 (mod 4) of its group's block.  The units of a wave follow each other in the stream
+without a gap: the tail of a unit requests rows(N), rows(N+1) - the first two blocks of the next unit - and drops them, and
+the next unit re-reads its first four words from the window (soff stays on its word 4).
 """
 import os
 
@@ -42,10 +43,18 @@ def regs(bt):
     return buf, W
 
 
-def issue(lines, rd, use, req, into):
+def issue(lines, rd, use, req, into, behind=0):
+    """rows of the block whose word is `use` into `into`; word `req` from the window: the next one (soff, which advances),
+    or - `behind` > 0, a unit's prologue - the one `behind` bytes back (already passed by the unit before)"""
     lines.append("v_add_u32 v{}, {}, %[lo]".format(A[0], use))
     for j in (1, 2, 3):
         lines.append("v_add_u32_dpp v{}, {}, %[lo]{}".format(A[j], use, DPP[j]))
+    if behind:
+        lines += ["s_sub_u32 s94, %[soff], {}".format(behind), "s_and_b32 s94, s94, 0x7ff", "v_add_u32 {}, s94, %[rlane]".format(WADDR),
+                  "ds_read_b32 {}, {}".format(req, WADDR)]
+        for j in range(4):
+            lines.append("{} {}, v{}".format(rd, into[j], A[j]))
+        return
     lines += [
         "s_and_b32 s94, %[soff], 0x1c0",
         "s_cbranch_scc1 1f",
@@ -78,13 +87,14 @@ def unit(bt):
     L.append("s_mov_b32 s92, m0")
     for t in range(8):
         L.append(("v_mov_b64 %[p{}], 0" if bt == 2 else "v_mov_b32 %[p{}], 0").format(t))
-    # this unit's words 0 and 1 were requested by the unit before (or sit at the start of the window): read them again
-    for k, back in ((0, 128), (1, 64)):
+    # the units of a wave follow each other in the stream without a gap: this unit's words 0..3 were already requested (and
+    # its rows 0 and 1, dropped) by the tail of the unit before - soff stands at word 4 - so they are read again from the window
+    for k, back in ((0, 256), (1, 192)):
         L += ["s_sub_u32 s94, %[soff], {}".format(back), "s_and_b32 s94, s94, 0x7ff", "v_add_u32 {}, s94, %[rlane]".format(WADDR),
               "ds_read_b32 {}, {}".format(w[k], WADDR)]
     L.append("s_waitcnt lgkmcnt(0)")
-    issue(L, rd, w[0], w[2], buf[0])      # rows(0), word(2)
-    issue(L, rd, w[1], w[0], buf[1])      # rows(1), word(3)
+    issue(L, rd, w[0], w[2], buf[0], behind=128)      # rows(0), word(2)
+    issue(L, rd, w[1], w[0], buf[1], behind=64)       # rows(1), word(3)
     L += ["s_bfe_u32 s93, %[c03], 0x80000", "s_sub_u32 s93, 0, s93"]
     for t in range(8):
         for ph in range(3):
