@@ -72,7 +72,11 @@ __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(u
 __device__ __forceinline__ float bfloat(uint32_t v) { return __builtin_bit_cast(float, v); }
 
 // (v1, v0) -> their bf16 terms, packed {v0 | v1 << 16} per term: v = hi + mid + lo exactly (three 8-bit pieces of the
-// 24-bit significand, each cut by truncation, which keeps every remainder exact).
+// 24-bit significand, each cut by truncation, which keeps every remainder exact): 11 instructions per pair.
+// (Tried: round-to-nearest conversions of the pair, v_cvt_pk_bf16_f32, with the remainders from v_dot2c_f32_bf16 - 7
+// instructions per pair, exact on [1e-25, 1e37], tools/probes/split_probe.hip - but the accumulate-in-place form keeps
+// more values alive: 52 bytes of scratch per lane at 128 registers and 36.0 instead of 33.3 us.  hipcc 7.2 also folds the
+// packed constant (-1, 0) into the inline operand -1.0, which that instruction reads as (0, -1).)
 __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     const uint32_t a0 = fbits(v0), a1 = fbits(v1);
     hi = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
@@ -133,10 +137,13 @@ __device__ __forceinline__ void load_chunk(const PairArgs& a, int chunk, int kg,
     int32_t s[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) s[t] = pk[t];
+    // 32-bit element offsets from the uniform base (24-bit factors: a full-rate multiply-add instead of the quarter-rate
+    // 64-bit address arithmetic, 16 + 8 slow instructions per unit: 34.6 -> 33.6 us, tools/ab_rgcn.sh)
+    const uint32_t ld = (uint32_t)a.ld_x, col = (uint32_t)(NT * c);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const bool ok = live && s[t] < a.n;
-        const float* row = a.x + (int64_t)(ok ? s[t] : 0) * a.ld_x + NT * c;
+        const float* row = a.x + (__umul24(ok ? (uint32_t)s[t] : 0u, ld) + col);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const float v = row[j];
@@ -868,6 +875,7 @@ gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
                                hipStream_t st) {
     PairArgs a;
+    GN_REQUIRE(ld_x < (1ll << 21), "x rows more than 2^21 floats apart are not supported by the destination-major kernel");
     a.x = x; a.ld_x = ld_x; a.att = att; a.basis = basis; a.root = root; a.bias = bias;
     a.indeg = plan->indeg.p;
     a.out = out; a.ld_out = ld_out;
