@@ -41,6 +41,7 @@ SIGNATURES = {
     "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
     "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p, _p]),
     "gn_transform_fusable": (_int, [_i64, _i64]),
+    "gn_graph_transform_fusable": (_int, [_p, _i64, _i64]),
     "gn_graph_plan_build_blocked": (_int, [_p, _i64, _p]),
     "gn_graph_plan_blocked_cols": (_i64, [_p]),
     "gn_graph_plan_build_transpose": (_int, [_p, _p]),
@@ -391,6 +392,11 @@ class GraphPlan:
     def blocked_ok(self, fin: int, fout: int, x: torch.Tensor) -> bool:
         """True when gn_graph_aggregate_f32(weight=W) runs on the source-blocked kernels for this input."""
         return (fout in (16, 32) and fout <= self.blocked_cols and fin in (16, 32, 64) and ld(x) % 4 == 0
+                and x.data_ptr() % 16 == 0)
+
+    def transform_ok(self, fin: int, fout: int, x: torch.Tensor) -> bool:
+        """True when gn_graph_aggregate_f32(weight=W) contracts with W in the gather's launch for this plan and input."""
+        return (bool(load().gn_graph_transform_fusable(self._h, int(fin), int(fout))) and ld(x) % 4 == 0
                 and x.data_ptr() % 16 == 0)
 
     @property

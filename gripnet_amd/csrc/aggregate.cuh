@@ -440,6 +440,166 @@ inline bool transform_fusable(int64_t fin, int64_t fout) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- aggregate, then transform, for wide layers: (A_norm x) W on the matrix cores ------------------------------
+// The layers of the node-classification models whose output is at least as wide as their input (64 -> 64, 128 -> 128:
+// the second layer of every homogeneous stack): transform-first pays a tall-skinny product (a launch, N x in read, N x out
+// written: 14-19 us at 50,000 nodes) before it gathers rows of the SAME width.  Here the input rows are gathered (lane
+// groups own rows as in k_aggregate_group), a block of 64 / 32 aggregated rows is staged in LDS and contracted with W on
+// v_mfma_f32_16x16x32_bf16: both operands in three bf16 terms, six products, fp32 accumulators (the arithmetic of
+// gn_gemm_f32's tall-skinny kernel; GN_GEMM_ARITH_FAST's two terms are not offered here).  W is split once per
+// workgroup into LDS fragments; one persistent workgroup of sixteen waves per compute unit walks the row blocks; per block
+// the sixteen (row tile, column tile) products are one per wave (two for 64 -> 128).
+template <int LPE>
+__global__ __launch_bounds__(1024) void k_aggregate_mfma(AggArgs a, const float* __restrict__ w, int fout, int row_blocks) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    constexpr int FIN = 4 * LPE, S = kWave / LPE, RPI = 16 * S, MT = RPI / 16, CH = FIN / 32, U = 8;
+    constexpr int STRIDE = FIN + 4;                            // floats between staged rows: 16 rows of a tile on 16 different bank quads
+    extern __shared__ f32x4 lds_mfma[];
+    u32x4* wsplit = reinterpret_cast<u32x4*>(lds_mfma);        // [CH][fout / 16][3][64]
+    const int nt_all = fout >> 4;
+    float* stage0 = reinterpret_cast<float*>(wsplit + (size_t)CH * nt_all * 3 * 64);  // [2][RPI][STRIDE]: blocks alternate, ONE barrier a block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = lane / LPE, j = lane % LPE;
+
+    auto split3 = [](float x0, float x1, uint32_t (&t)[3]) {  // truncation split: x = hi + mid + lo exactly
+        const uint32_t a0 = __builtin_bit_cast(uint32_t, x0), a1 = __builtin_bit_cast(uint32_t, x1);
+        t[0] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        const float r0 = x0 - __builtin_bit_cast(float, a0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
+        const uint32_t b0 = __builtin_bit_cast(uint32_t, r0), b1 = __builtin_bit_cast(uint32_t, r1);
+        t[1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+        t[2] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, s0), 0x07060302u);
+    };
+
+    // W as B-operand fragments: lane (n = l & 15, kg = l >> 4) of (chunk, column tile) holds k = 32 chunk + 8 kg .. + 7 of column 16 tile + n
+    for (int idx = tid; idx < CH * nt_all * 64; idx += 1024) {
+        const int l = idx & 63, t = (idx >> 6) % nt_all, ch = idx / (64 * nt_all);
+        const int col = 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = w[(int64_t)(kb + q) * fout + col];
+        u32x4 tv[3];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            uint32_t t3[3];
+            split3(v[2 * h], v[2 * h + 1], t3);
+            tv[0][h] = t3[0]; tv[1][h] = t3[1]; tv[2][h] = t3[2];
+        }
+        u32x4* o = wsplit + ((size_t)(ch * nt_all + t) * 3) * 64 + l;
+        o[0] = tv[0]; o[64] = tv[1]; o[128] = tv[2];
+    }
+    if (a.side.dst) {                                          // concat slot: streamed up front by the whole grid
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + tid; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, c = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + c];
+            a.side.dst[i * a.side.ld_dst + c] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+    __syncthreads();
+
+    const float* __restrict__ tab = a.table + 4 * j;
+    int flip = 0;
+    for (int rb = blockIdx.x; rb < row_blocks; rb += gridDim.x, flip ^= 1) {
+        // (two staging buffers: a wave that is done with the products of block i gathers block i + 1 at once and writes
+        // the other buffer; the buffer of block i - 1 was read by every wave before it arrived at the barrier of block i)
+        float* stage = stage0 + (size_t)flip * RPI * STRIDE;
+        // ---- gather: this lane group's row of the block (k_aggregate_group) ----
+        const int local = wave * S + slot, row = rb * RPI + local;
+        const bool live = row < a.rows;
+        const int begin = live ? a.rowptr[row] : 0, end = live ? a.rowptr[row + 1] : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = begin; __any(base < end); base += LPE) {
+            const int mine = base + j;
+            const uint32_t c = mine < end ? a.col[mine] : 0u;
+            const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+            const int cnt = min(LPE, end - base);
+            for (int t0 = 0; __any(t0 < cnt); t0 += U) {
+                float4 r[U];
+                float vv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t cc = (uint32_t)__shfl((int)c, t0 + u, LPE);
+                    vv[u] = __shfl(v, t0 + u, LPE);
+                    r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t0 + u < cnt) r[u] = *reinterpret_cast<const float4*>(tab + (int64_t)cc * a.ld_table);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc.x += vv[u] * r[u].x; acc.y += vv[u] * r[u].y; acc.z += vv[u] * r[u].z; acc.w += vv[u] * r[u].w;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(stage + (size_t)local * STRIDE + 4 * j) = acc;
+        __syncthreads();
+        // ---- contract the block with W: (row tile, column tile) products dealt to the waves ----
+        const int m = lane & 15, kg = lane >> 4;
+        for (int job = wave; job < MT * nt_all; job += 16) {
+            const int mt = job % MT, nt = job / MT;
+            f32x4 d = (f32x4)(0.f);
+            const float* arow = stage + (size_t)(16 * mt + m) * STRIDE + 8 * kg;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + 32 * ch), a1 = *reinterpret_cast<const f32x4*>(arow + 32 * ch + 4);
+                u32x4 at[3];
+                uint32_t t3[3];
+                split3(a0[0], a0[1], t3); at[0][0] = t3[0]; at[1][0] = t3[1]; at[2][0] = t3[2];
+                split3(a0[2], a0[3], t3); at[0][1] = t3[0]; at[1][1] = t3[1]; at[2][1] = t3[2];
+                split3(a1[0], a1[1], t3); at[0][2] = t3[0]; at[1][2] = t3[1]; at[2][2] = t3[2];
+                split3(a1[2], a1[3], t3); at[0][3] = t3[0]; at[1][3] = t3[1]; at[2][3] = t3[2];
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, at[0]), xm = __builtin_bit_cast(bf16x8, at[1]), xl = __builtin_bit_cast(bf16x8, at[2]);
+                const u32x4* bp = wsplit + ((size_t)(ch * nt_all + nt) * 3) * 64 + lane;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[0]), bm = __builtin_bit_cast(bf16x8, bp[64]), bl = __builtin_bit_cast(bf16x8, bp[128]);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, d, 0, 0, 0);     // smallest terms first
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bm, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bm, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, d, 0, 0, 0);
+            }
+            const int col = 16 * nt + m;                       // D: column = lane & 15, rows 4 (lane >> 4) + i
+            const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int orow = rb * RPI + 16 * mt + 4 * kg + i;
+                if (orow < a.rows) {
+                    float val = d[i] + bias;
+                    if (a.relu) val = fmaxf(val, 0.f);
+                    a.out[(int64_t)orow * a.ld_out + col] = val;
+                }
+            }
+        }
+    }
+}
+
+// in -> out widths the matrix-core form takes (gn_graph_aggregate_f32 with weight != NULL); rows of up to
+// GN_AGG_GROUP_MAX_DEG neighbours on average (longer rows belong to a wave each: the product first, then k_aggregate)
+inline bool mfma_fusable(int64_t fin, int64_t fout, int64_t rows, int64_t nnz) {
+    if (fast_paths_disabled()) return false;
+    if (!(fin == 64 || fin == 128) || fout % 16 != 0 || fout < fin || fout > 128) return false;
+    return nnz >= 0 && nnz < GN_AGG_GROUP_MAX_DEG * rows && rows >= 4096;
+}
+
+inline gn_status launch_aggregate_mfma(const AggArgs& a, const float* w, int fout, hipStream_t st) {
+    if (a.rows == 0) return GN_OK;
+    const int lpe = a.features / 4, rpi = 16 * (kWave / lpe);
+    const int row_blocks = (int)ceil_div(a.rows, rpi);
+    const size_t lds = (size_t)a.features * fout * 6 + 2 * (size_t)rpi * (a.features + 4) * sizeof(float);
+    const int grid = std::min(row_blocks, compute_units());
+    gn_status ls;
+    if (lpe == 16) {
+        ls = allow_large_lds(reinterpret_cast<const void*>(k_aggregate_mfma<16>), 160 * 1024); if (ls != GN_OK) return ls;
+        k_aggregate_mfma<16><<<grid, 1024, lds, st>>>(a, w, fout, row_blocks);
+    } else {
+        ls = allow_large_lds(reinterpret_cast<const void*>(k_aggregate_mfma<32>), 160 * 1024); if (ls != GN_OK) return ls;
+        k_aggregate_mfma<32><<<grid, 1024, lds, st>>>(a, w, fout, row_blocks);
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 // GN_DISABLE_QUAD=1: the shuffle-based kernel for 16- and 32-wide rows as well (parity tests cover both)
 inline bool quad_gather_disabled() {
     const char* e = getenv("GN_DISABLE_QUAD");

@@ -40,6 +40,8 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     if (gn_blocked_applicable(plan, xw, ld_xw, num_features, weight, width))
         return gn_blocked_aggregate(plan, xw, ld_xw, num_features, weight, width, bias, relu, out, ld_out, a.side,
                                     gn::as_stream(stream));
+    if (weight && gn::mfma_fusable(num_features, out_features, plan->rows, plan->nnz) && (ld_xw % 4) == 0 && gn::aligned16(xw))
+        return gn::launch_aggregate_mfma(a, weight, (int)out_features, gn::as_stream(stream));   // wide layers: W on the matrix cores
     if (weight) {            // aggregate the input rows, then contract with W in the epilogue
         if (!gn::transform_fusable(num_features, out_features) || (ld_xw % 4) != 0 || !gn::aligned16(xw))
             return gn::fail(GN_ERR_UNSUPPORTED, "no fused transform for %lld -> %lld features (or unaligned rows)",
@@ -80,4 +82,10 @@ extern "C" gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const f
 
 extern "C" int gn_transform_fusable(int64_t in_features, int64_t out_features) {
     return gn::transform_fusable(in_features, out_features) ? 1 : 0;
+}
+
+extern "C" int gn_graph_transform_fusable(const gn_graph_plan* plan, int64_t in_features, int64_t out_features) {
+    if (!plan) return 0;
+    return (gn::transform_fusable(in_features, out_features) ||
+            gn::mfma_fusable(in_features, out_features, plan->rows, plan->nnz)) ? 1 : 0;
 }

@@ -92,7 +92,7 @@ class myGCN(Module):
             _hip.gemm(x, self.weight, xw)                                        # layers.py:73, fp32
             return plan.aggregate_bf16(xw, self.bias, relu, out, side)
         if self.weight.is_contiguous() and (plan.blocked_ok(self.in_channels, self.out_channels, x) or
-                                            _hip.transform_fusable(self.in_channels, self.out_channels, x)):
+                                            plan.transform_ok(self.in_channels, self.out_channels, x)):
             # A_norm (x W) = (A_norm x) W: the contraction of layers.py:73 runs on the aggregated row
             done = cowork.cowork_request() if cowork is not None else None      # W_r of a later relational layer, same launch
             y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, cowork=done)

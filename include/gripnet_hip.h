@@ -105,9 +105,15 @@ GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* 
 /* With weight != NULL ([num_features, out_features], row-major, contiguous) the table is the layer INPUT x
  * and the call computes act( (A_norm x) W + bias ) = act( A_norm (x W) + bias ): the contraction of
  * layers.py:73 runs on the aggregated row, so no x W launch is needed.  Supported for num_features in
- * {16,32,64} and out_features in {16,32} (GN_ERR_UNSUPPORTED otherwise: call gn_gemm_f32 first).
- * gn_transform_fusable tells without launching. */
+ * {16,32,64} and out_features in {16,32}, and for the wide layers gn_graph_transform_fusable describes
+ * (GN_ERR_UNSUPPORTED otherwise: call gn_gemm_f32 first).  gn_transform_fusable / gn_graph_transform_fusable tell
+ * without launching. */
 GN_API int gn_transform_fusable(int64_t in_features, int64_t out_features);
+/* The same question for one plan: besides the widths above, layers at least as wide as their input (64 or 128 input
+ * features, out_features a multiple of 16 in [in_features, 128]) contract on the matrix cores in the same launch when
+ * the plan's rows average fewer than 48 neighbours and there are at least 4,096 of them (the second layer of the
+ * node-classification stacks: no x W launch, no [N, out] round trip). */
+GN_API int gn_graph_transform_fusable(const gn_graph_plan* plan, int64_t in_features, int64_t out_features);
 
 /* Column-group encoding of a GCN plan for LDS-staged gathers (the gene supervertex of PoSE: 19,081 nodes, 1.45 M
  * stored edges; gcn_blocked.hip).  Applies to plans whose stored weights are all exactly 1, self loops included

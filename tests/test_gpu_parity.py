@@ -319,6 +319,29 @@ def test_random_graphs_vs_oracle(gpu, seed):
           orc.distmult(z, rei, et, dm.weight.detach().cpu(), sigmoid=False))
 
 
+@pytest.mark.parametrize("n,fin,fout", [(5000, 64, 64), (4100, 128, 128), (6001, 64, 128), (4097, 64, 80)])
+def test_gcn_wide_layer_contracts_in_the_gather_launch(gpu, n, fin, fout):
+    """Layers at least as wide as their input (the second layer of the NC stacks): gn_graph_aggregate_f32(weight=W) gathers
+    the input rows and contracts with W on the matrix cores in the same launch (k_aggregate_mfma) - weighted edges, a few
+    long rows, isolated nodes, a ragged last row block, bias + ReLU, written into a column slice of a wider matrix."""
+    gen = torch.Generator().manual_seed(n + fout)
+    ei = torch.randint(0, n - 37, (2, 9 * n), generator=gen)                 # the last 37 nodes stay isolated
+    hub = torch.stack([torch.randint(0, n - 37, (700,), generator=gen), torch.full((700,), 11)])
+    ei = torch.cat([ei, hub], dim=1)
+    w = torch.rand(ei.shape[1], generator=gen) + 0.1
+    x = torch.randn(n, fin, generator=gen)
+    conv = gripnet_amd.myGCN(fin, fout).to(gpu)
+    conv.bias.data.normal_()
+    wide = torch.full((n, fout + 8), float("nan"), device=gpu)
+    with torch.no_grad():                                                    # (slot-fused outputs are the inference path)
+        y = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True, _out=wide[:, 4:4 + fout])
+    plan = _hip.GraphPlan.gcn(ei.to(gpu), n, w.to(gpu))
+    assert plan.transform_ok(fin, fout, x.to(gpu))
+    ref = torch.relu(orc.gcn_forward(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), ei, w))
+    close(y, ref)
+    assert torch.isnan(wide[:, :4]).all() and torch.isnan(wide[:, 4 + fout:]).all()
+
+
 @pytest.mark.parametrize("fout", [16, 32, 64, 128, 20])
 def test_gcn_skewed_degrees_and_empty_rows(gpu, fout):
     """Destination-major aggregation on skewed graphs, one case per lanes-per-neighbour specialisation:
