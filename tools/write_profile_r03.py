@@ -33,8 +33,8 @@ ONE launch, no W_r, no slabs, no workspace), `k_distmult_plan`: seven launches. 
 
 {traffic}
 
-Algorithmic bytes of the same launches (SURVEY.md 8d): gn_rgcn_forward_f32 32.5 MB (the kernel streams 16.4 MB of 32-bit att-row
-offsets, reads the 123 KB att table and 196 KB of basis per workgroup from L2 and writes 82 KB), gn_distmult[_plan]_forward_f32 56.4 MB,
+Algorithmic bytes of the same launches (SURVEY.md 8d): gn_rgcn_forward_f32 32.5 MB (the kernel streams ~10.5 MB of 32-bit att-row
+offsets since the per-destination K order (16.4 MB before), reads the 123 KB att table and 196 KB of basis per workgroup from L2 and writes 82 KB), gn_distmult[_plan]_forward_f32 56.4 MB,
 GCN layer 31.4 MB (a gene layer = one `k_col_transform` + one `k_col_gather`), external layer 5.5 MB.
 
 ## MFMA utilisation of the dense steps (one PMC pass: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; tools/mfma_util.sh)
