@@ -675,7 +675,9 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
                 const int ch = q >> 5, t = (q & 31) >> 2, k = q & 3;
                 const size_t pos = (size_t)i * kpad + 32 * ch + 8 * k + t;
                 kord[pos] = idx[q];
-                perm2[pos] = perm[idx[q]];
+                // a pair without edges names no source: its x row is not read and counts as zero, so a non-finite x[s]
+                // reaches only the destinations s has an edge to (0 . inf would be NaN), as in the reference's edge sum
+                perm2[pos] = r[idx[q] + 1] > r[idx[q]] ? perm[idx[q]] : (int32_t)N;
             }
         }
     });

@@ -1053,3 +1053,25 @@ def test_class_scores_vs_torch(gpu, k, n, softmax):
     out = torch.full((nodes.shape[0], n), float("nan"), device=gpu)
     _hip.class_scores(z.to(gpu), w.to(gpu), nodes.to(gpu), out, softmax)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
+
+
+def test_rgcn_non_finite_input_rows_stay_local(gpu):
+    """A non-finite x[s] reaches the destinations s has an edge to (and s itself through the root term) and no others, as in
+    the reference's sum over edges: the destination-major kernel contracts over ALL sources of a chunk, so pairs without
+    edges must not read their x row (0 . inf = NaN)."""
+    gen = torch.Generator().manual_seed(5)
+    n, fin, R = 300, 48, 6
+    blocks = [torch.randint(0, n, (2, 400), generator=gen) for _ in range(R)]
+    rei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    bad = 17
+    x[bad, 3] = float("inf")
+    rg = gripnet_amd.myRGCN(fin, 32, R, 8, False).to(gpu)
+    with torch.no_grad():
+        y = rg(x.to(gpu), rei.to(gpu), None, rl).cpu()
+    assert rg._plan.path(fin, 32, 8) == "pair"
+    touched = set(rei[1][rei[0] == bad].tolist()) | {bad}
+    finite = torch.isfinite(y).all(dim=1)
+    assert all(bool(finite[i]) for i in range(n) if i not in touched)
+    assert not bool(finite[bad])
