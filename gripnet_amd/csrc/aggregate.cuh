@@ -449,12 +449,21 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // gn_gemm_f32's tall-skinny kernel; GN_GEMM_ARITH_FAST's two terms are not offered here).  W is split once per
 // workgroup into LDS fragments; one persistent workgroup of sixteen waves per compute unit walks the row blocks; per block
 // the sixteen (row tile, column tile) products are one per wave (two for 64 -> 128).
+// 64 input features: W is 24 KB of fragments, so a workgroup per row block (no persistent loop, no 3.05 blocks in 4 rounds)
+// with four row gathers in flight per lane measured 169.3 against 171.6 us on the aminer-syn forward (persistent, eight in
+// flight; one block per workgroup with eight: 174); 128 features (96 KB of W) stay persistent
+#ifndef GN_MFMA_U16
+#define GN_MFMA_U16 4
+#endif
+#ifndef GN_MFMA_PERSIST16
+#define GN_MFMA_PERSIST16 0
+#endif
 template <int LPE>
 __global__ __launch_bounds__(1024) void k_aggregate_mfma(AggArgs a, const float* __restrict__ w, int fout, int row_blocks) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    constexpr int FIN = 4 * LPE, S = kWave / LPE, RPI = 16 * S, MT = RPI / 16, CH = FIN / 32, U = 8;
+    constexpr int FIN = 4 * LPE, S = kWave / LPE, RPI = 16 * S, MT = RPI / 16, CH = FIN / 32, U = LPE == 16 ? GN_MFMA_U16 : 8;
     constexpr int STRIDE = FIN + 4;                            // floats between staged rows: 16 rows of a tile on 16 different bank quads
     extern __shared__ f32x4 lds_mfma[];
     u32x4* wsplit = reinterpret_cast<u32x4*>(lds_mfma);        // [CH][fout / 16][3][64]
@@ -587,7 +596,8 @@ inline gn_status launch_aggregate_mfma(const AggArgs& a, const float* w, int fou
     const int lpe = a.features / 4, rpi = 16 * (kWave / lpe);
     const int row_blocks = (int)ceil_div(a.rows, rpi);
     const size_t lds = (size_t)a.features * fout * 6 + 2 * (size_t)rpi * (a.features + 4) * sizeof(float);
-    const int grid = std::min(row_blocks, compute_units());
+    int grid = std::min(row_blocks, compute_units());
+    if (lpe == 16 && !GN_MFMA_PERSIST16) grid = row_blocks;
     gn_status ls;
     if (lpe == 16) {
         ls = allow_large_lds(reinterpret_cast<const void*>(k_aggregate_mfma<16>), 160 * 1024); if (ls != GN_OK) return ls;
