@@ -26,7 +26,7 @@ struct gn_negative_sampler {
     gn::DevBuf<uint32_t> keys32;    // [E] u * n + v in the order of `keys`
     gn::DevBuf<uint16_t> rel16;     // [E] relation of edge position e
     int narrow = 0;
-    // and, while R * n^2 bits stay below kBitmapBytes (PoSE: 964 x 645^2 bits = 50 MB), one bit per (relation, pair): a
+    // and, while R * n^2 bits stay below kBitmapBytes = 128 MB (PoSE: 964 x 645^2 bits = 50 MB), one bit per (relation, pair): a
     // draw is tested with ONE 4-byte load - a binary search costs ~11 dependent loads whose last steps touch a
     // different cache line in every lane
     gn::DevBuf<uint32_t> bitmap;    // [R][words]
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_sample_negatives_narrow(const uint32_t*
     }
 }
 
-constexpr int64_t kBitmapBytes = 512ll << 20;
+constexpr int64_t kBitmapBytes = 128ll << 20;
 
 __global__ void k_fill_bitmap(const uint32_t* __restrict__ keys32, const uint16_t* __restrict__ rel16, int64_t E, int64_t words,
                               uint32_t* __restrict__ bitmap) {
