@@ -39,9 +39,12 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s 
 # What in-kernel stamps and the issue-rate probe say bounds each entry point: none of them is HBM-bound;
 # "bound": "hbm" names the roofline the path is priced against, this names what actually limits it.
 LIMITERS = {
-    "gn_rgcn_forward_f32": "instruction issue: ~23 instructions per block of 4 x 4 gathered att rows at ~2.6 cycles per instruction and SIMD "
-                           "(tools/probes/issue_probe.hip), lock-step padding 1.8x; HBM moves less than the algorithmic bytes",
-    "gn_distmult_plan_forward_f32": "VALU issue ~ LDS reads (640 B per scored edge)",
+    "gn_rgcn_forward_f32": "instruction issue: ~745 instructions per (destination, 32 sources) unit at ~2.6 cycles per instruction and SIMD "
+                           "(tools/probes/issue_probe.hip) - 415 of them independent of the edges (x chunk, bf16 splits, 36 matrix "
+                           "instructions), 12 blocks x 23 for the gather; 63 units in the three-row workgroups against 52.9 on average, "
+                           "9 us epilogue (196 KB of basis per compute unit); HBM moves less than the algorithmic bytes",
+    "gn_distmult_plan_forward_f32": "LDS bandwidth: 640 B of node rows per scored pair = 640 MB per launch = ~11 us of the 12.8 us of its two "
+                                    "column phases at 128 B/clk/CU; two table fills 5.4 us, phase hand-over 1.5 us (tools/dm_stamps.py)",
     "gn_distmult_forward_f32": "HBM index stream / LDS reads",
     "gn_graph_aggregate_f32[gcn]": "launch + LDS fill + id stream latency (two launches per layer)",
 }
