@@ -194,11 +194,10 @@ struct gn_rgcn_plan {
     // flat stream of 64-byte blocks (4 lane groups x 4 edges, each a 32-bit LDS byte offset of a relation's att row)
     gn::DevBuf<uint32_t> pair_stream;     // blocks of 16 words
     gn::DevBuf<uint32_t> pair_wave_first; // [groups * 8] first block of every wave
-    gn::DevBuf<uint32_t> pair_desc;       // eight dwords per unit: eight uint16 block counts, chunk | row << 8; pages of eight units per wave
+    gn::DevBuf<uint32_t> pair_desc;       // 32 dwords per unit: eight 8-bit block counts, [8..23] the chunk's 32 source ids (16 bits; num_nodes: none); pages of two units per wave
     gn::DevBuf<uint32_t> pair_wave_units; // [groups * 8] units of every wave
-    gn::DevBuf<uint32_t> pair_wave_desc;  // [groups * 8] first descriptor of every wave
+    gn::DevBuf<uint32_t> pair_wave_desc;  // [groups * 16] first descriptor of every wave
     gn::DevBuf<int32_t> pair_wg_dst;      // [groups][4] destination rows of a workgroup (-1: none)
-    gn::DevBuf<int32_t> pair_perm;        // [chunks * 32] source node of every K position (num_nodes: none)
     int pair_groups = 0, pair_d = 0, pair_chunks = 0;
     int64_t pair_blocks = 0;
     int pair_ok = 0;

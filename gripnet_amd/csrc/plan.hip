@@ -597,7 +597,6 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->pair_wave_units.release();
     p->pair_wave_desc.release();
     p->pair_wg_dst.release();
-    p->pair_perm.release();
     p->acc_stream.release();
     p->acc_units.release();
     p->acc_wave_units.release();

@@ -56,10 +56,9 @@ struct PairArgs {
     const uint32_t* stream;
     const uint32_t* wave_first;          // [groups * 8] first block of a wave's stream
     const uint32_t* wave_units;          // [groups * 8] units of a wave
-    const uint32_t* wave_desc;           // [groups * 8] first descriptor of a wave (eight dwords each, pages of eight)
+    const uint32_t* wave_desc;           // [groups * 16] first descriptor of a wave (32 dwords each, pages of two)
     const uint32_t* desc;
     const int32_t* wg_dst;
-    const int32_t* perm;
     int n, R, B, fout, chunks, relu, partial, att_dma;
     gn_side_copy side;
 };
@@ -130,19 +129,24 @@ struct XRaw { float v[8][NT]; };             // x[source(8 kg + t)][NT c + j]: t
 template <int NT>
 struct XFrag { uint32_t w[NT][3][4]; };      // the same as MFMA B operands: [N tile][term][8 bf16]
 
+// The sources of the unit's chunk come with its descriptor (32 ids of 16 bits in dwords 8..23 of the unit's 32, lane
+// group kg's eight in dwords 8 + 4 kg ..): the page was requested two units ago, so the rows of x can be requested at
+// once - read from a table they were a dependent load in front of every unit (1.4 k cycles of each unit's 7.3 k).
 template <int NT>
-__device__ __forceinline__ void load_chunk(const PairArgs& a, int chunk, int kg, int c, XRaw<NT>& raw) {
-    const bool live = chunk < a.chunks;
-    const int32_t* pk = a.perm + (size_t)(live ? chunk : 0) * 32 + 8 * kg;
+__device__ __forceinline__ void load_chunk(const PairArgs& a, uint32_t descv, int o, int kg, int c, XRaw<NT>& raw) {
     int32_t s[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) s[t] = pk[t];
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = (uint32_t)__shfl((int)descv, o + 8 + 4 * kg + i);
+        s[2 * i] = (int32_t)(w & 0xffffu);
+        s[2 * i + 1] = (int32_t)(w >> 16);
+    }
     // 32-bit element offsets from the uniform base (24-bit factors: a full-rate multiply-add instead of the quarter-rate
     // 64-bit address arithmetic, 16 + 8 slow instructions per unit: 34.6 -> 33.6 us, tools/ab_rgcn.sh)
     const uint32_t ld = (uint32_t)a.ld_x, col = (uint32_t)(NT * c);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const bool ok = live && s[t] < a.n;
+        const bool ok = s[t] < a.n;
         const float* row = a.x + (__umul24(ok ? (uint32_t)s[t] : 0u, ld) + col);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     // ---- prologue: this wave's window on its stream, the att table ----
     const uint32_t wave_id = (uint32_t)(g * kWaves + wave);
     const uint32_t first_block = a.wave_first[wave_id], n_units = a.wave_units[wave_id];
-    const uint32_t* __restrict__ desc = a.desc + (size_t)a.wave_desc[wave_id] * 8;
+    const uint32_t* __restrict__ desc = a.desc + (size_t)a.wave_desc[wave_id] * 32;
     Walk w;
     w.ring_base = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wave * kRingBytes);
     {
@@ -258,8 +262,10 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         }
     }
     if (tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
-    // unit descriptors of this wave, eight dwords each: lane L holds dword L of the current page of eight units
+    // unit descriptors of this wave, 32 dwords each (block counts, the chunk's 32 source ids): lane L holds dword L of the
+    // current page of two units, and of the page after it
     uint32_t descv = n_units ? desc[lane] : 0u;
+    uint32_t descn = n_units > 2 ? desc[64 + lane] : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef GN_STAMPS
@@ -275,17 +281,19 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 
 #pragma unroll 1
     for (uint32_t u = 0; u < n_units; ++u) {
-        if (u && (u & 7u) == 0u) descv = desc[(size_t)(u >> 3) * 64 + lane];   // next page (waited for at once: rare)
-        const int o = (int)(u & 7u) * 8;
+        if (u && (u & 1u) == 0u) {                                             // next page: requested a page (two units) ago
+            descv = descn;
+            if (u + 2 < n_units) descn = desc[(size_t)((u >> 1) + 1) * 64 + lane];
+        }
+        const int o = (int)(u & 1u) * 32;
         const uint32_t c03 = __builtin_amdgcn_readlane(descv, o), c47 = __builtin_amdgcn_readlane(descv, o + 1);
-        const int chunk = (int)__builtin_amdgcn_readlane(descv, o + 2);       // row of perm: this (destination, chunk)'s sources
         // this unit's chunk of x: requested here, split into bf16 terms behind the gather (the other waves of the SIMD
         // cover the L2 round trips)
 #ifdef GN_STAMPS
         const unsigned long long cx0 = __builtin_amdgcn_s_memtime();
 #endif
         XRaw<NT> raw;
-        load_chunk<NT>(a, chunk, kg, c, raw);
+        load_chunk<NT>(a, descv, o, kg, c, raw);
         acc_t p[8];
 #ifdef GN_STAMPS
         const unsigned long long cg0 = __builtin_amdgcn_s_memtime();
@@ -777,8 +785,11 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
                     std::vector<uint32_t>& out = wg_stream[gg * kWaves + wv];
                     std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
                     const size_t at = dv.size();
-                    dv.resize(at + 8, 0u);
-                    dv[at + 2] = (uint32_t)(i * chunks + un.ch);                 // row of perm2: the sources of this (destination, chunk)
+                    dv.resize(at + 32, 0u);
+                    for (int q = 0; q < 16; ++q) {                             // the chunk's sources, 16 bits each (N: none)
+                        const int32_t* ids = perm2.data() + ((size_t)i * chunks + un.ch) * 32 + 2 * q;
+                        dv[at + 8 + q] = (uint32_t)ids[0] | (uint32_t)ids[1] << 16;
+                    }
                     for (int t = 0; t < 8; ++t) {
                         const uint32_t* list[4];
                         int len[4], longest = 0;
@@ -810,10 +821,10 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     std::vector<uint32_t> wave_desc((size_t)G * kWaves);
     std::vector<uint32_t> desc;
     for (size_t i = 0; i < wg_desc.size(); ++i) {
-        wave_desc[i] = (uint32_t)(desc.size() / 8);
+        wave_desc[i] = (uint32_t)(desc.size() / 32);
         desc.insert(desc.end(), wg_desc[i].begin(), wg_desc[i].end());
     }
-    desc.resize(desc.size() + 64, 0u);                                          // a wave without units still reads a page
+    desc.resize(desc.size() + 128, 0u);                                         // a wave without units still reads a page (and the one after)
     std::vector<uint32_t> first((size_t)G * kWaves);
     size_t total = 0;
     for (size_t i = 0; i < wg_stream.size(); ++i) { first[i] = (uint32_t)(total / 16); total += wg_stream[i].size(); }
@@ -829,18 +840,16 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     GN_HIP(plan->pair_wave_units.alloc(wave_units.size()));
     GN_HIP(plan->pair_wave_desc.alloc(wave_desc.size()));
     GN_HIP(plan->pair_wg_dst.alloc(wg_dst.size()));
-    GN_HIP(plan->pair_perm.alloc(perm2.size()));
     GN_HIP(hipMemcpyAsync(plan->pair_stream.p, stream.data(), stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wave_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_desc.p, desc.data(), desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wave_units.p, wave_units.data(), wave_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wave_desc.p, wave_desc.data(), wave_desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wg_dst.p, wg_dst.data(), wg_dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(plan->pair_perm.p, perm2.data(), perm2.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipStreamSynchronize(st));
     plan->pair_groups = G;
     plan->pair_d = D;
-    plan->pair_chunks = (int)(N * chunks);                                     // rows of perm2
+    plan->pair_chunks = chunks;
     plan->pair_blocks = (int64_t)(total / 16);
     plan->pair_ok = 1;
     return GN_OK;
@@ -883,7 +892,7 @@ gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     a.out = out; a.ld_out = ld_out;
     a.stream = plan->pair_stream.p; a.wave_first = plan->pair_wave_first.p; a.desc = plan->pair_desc.p;
     a.wave_units = plan->pair_wave_units.p; a.wave_desc = plan->pair_wave_desc.p;
-    a.wg_dst = plan->pair_wg_dst.p; a.perm = plan->pair_perm.p;
+    a.wg_dst = plan->pair_wg_dst.p;
     a.n = (int)plan->num_nodes; a.R = (int)plan->num_relations; a.B = (int)bases; a.fout = (int)fout;
     a.chunks = plan->pair_chunks; a.relu = relu; a.partial = partial;
     a.att_dma = bases == 32 && (reinterpret_cast<uintptr_t>(att) & 15) == 0;
