@@ -434,8 +434,8 @@ __global__ __launch_bounds__(256) void k_aggregate_transform_q(AggArgs a, const 
 // FIN in {16, 32, 64}, FOUT in {16, 32} with at least 4 input features per lane slice
 inline bool transform_fusable(int64_t fin, int64_t fout) {
     if (fast_paths_disabled()) return false;
-    if (!(fin == 16 || fin == 32 || fin == 64) || !(fout == 16 || fout == 32)) return false;
-    return (fin * fout / 64) % 4 == 0;
+    // exactly the specialisations launch_aggregate_transform has (16 -> 32 has none: its K slice per lane would be two floats)
+    return (fout == 16 && (fin == 16 || fin == 32 || fin == 64)) || (fout == 32 && (fin == 32 || fin == 64));
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -104,8 +104,8 @@ GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* 
                                  const gn_side_copy* side /* nullable */, void* stream);
 /* With weight != NULL ([num_features, out_features], row-major, contiguous) the table is the layer INPUT x
  * and the call computes act( (A_norm x) W + bias ) = act( A_norm (x W) + bias ): the contraction of
- * layers.py:73 runs on the aggregated row, so no x W launch is needed.  Supported for num_features in
- * {16,32,64} and out_features in {16,32}, and for the wide layers gn_graph_transform_fusable describes
+ * layers.py:73 runs on the aggregated row, so no x W launch is needed.  Supported for (num_features,
+ * out_features) in {16,32,64} x {16} and {32,64} x {32}, and for the wide layers gn_graph_transform_fusable describes
  * (GN_ERR_UNSUPPORTED otherwise: call gn_gemm_f32 first).  gn_transform_fusable / gn_graph_transform_fusable tell
  * without launching. */
 GN_API int gn_transform_fusable(int64_t in_features, int64_t out_features);

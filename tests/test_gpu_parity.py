@@ -1075,3 +1075,18 @@ def test_rgcn_non_finite_input_rows_stay_local(gpu):
     finite = torch.isfinite(y).all(dim=1)
     assert all(bool(finite[i]) for i in range(n) if i not in touched)
     assert not bool(finite[bad])
+
+
+@pytest.mark.parametrize("fin,fout", [(16, 32), (16, 16), (32, 32), (64, 32), (32, 16), (24, 32), (64, 48)])
+def test_gcn_every_small_width_pair_has_a_path(gpu, fin, fout):
+    """The widths the fused gather + transform kernels cover and the ones next to them (16 -> 32 was reported fusable without
+    a specialisation behind it; found by tools/fuzz_gcn.py): gn_transform_fusable must agree with what the launch supports."""
+    gen = torch.Generator().manual_seed(fin * 100 + fout)
+    n = 900
+    ei = torch.randint(0, n, (2, 7000), generator=gen)
+    x = torch.randn(n, fin, generator=gen)
+    conv = gripnet_amd.myGCN(fin, fout).to(gpu)
+    conv.bias.data.normal_()
+    with torch.no_grad():
+        y = conv(x.to(gpu), ei.to(gpu), None, _relu=True)
+    close(y, torch.relu(orc.gcn_forward(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), ei, None)))
