@@ -24,7 +24,7 @@ GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "acc": 2, "lds": 3, "general": 4}       # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 121                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 130                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -64,7 +64,7 @@ SIGNATURES = {
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "gn_distmult_packed_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
-    "gn_distmult_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_distmult_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_distmult_plan_destroy": (None, [_p]),
     "gn_distmult_plan_edges": (_i64, [_p]),
     "gn_distmult_plan_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _int, _p, _p]),
@@ -635,7 +635,9 @@ class DistMultPlan:
     """Owner of a gn_distmult_plan handle: one static (edge_index, edge_type) list, validated, packed and ordered
     for the LDS-resident decoder kernel (the positive edges a training loop scores every epoch)."""
 
-    def __init__(self, u_v, edge_type, num_nodes, num_relations):
+    def __init__(self, u_v, edge_type, num_nodes, num_relations, num_features=0):
+        """`num_features` (the decoder's in_dim; 0: unknown) lets the plan add the row-class encoding: whole rows of a
+        class of nodes in LDS, one table fill per launch (k_distmult_class)."""
         lib = load()
         require_gpu(u_v, edge_type)
         ei, u, v, e = edge_rows(u_v)
@@ -644,7 +646,7 @@ class DistMultPlan:
             raise ValueError("edge_type has {} entries for {} edges".format(et.numel(), e))
         h = _p()
         with torch.cuda.device(ei.device):
-            check(lib.gn_distmult_plan_create(u, v, ptr(et), e, int(num_nodes), int(num_relations),
+            check(lib.gn_distmult_plan_create(u, v, ptr(et), e, int(num_nodes), int(num_relations), int(num_features),
                                               stream_ptr(ei.device), C.byref(h)))
         self._h, self.device, self.num_edges = h, ei.device, e
         self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)

@@ -29,6 +29,18 @@ struct gn_distmult_plan {
     gn::DevBuf<uint16_t> rel16;      // [batches * 64] relation of every slot (read for mixed batches only)
     gn::DevBuf<uint32_t> own;        // [batches * 64] position of the slot's edge in the caller's list
     gn::DevBuf<uint32_t> mirror;     // [batches * 64] second position that takes the slot's score, or kNoMirror
+    // Row-class encoding (k_distmult_class): built when the caller names the feature count and a class's rows of ALL
+    // its columns fit the LDS.  The nodes are cut into one or three blocks; a class holds the rows of one or two blocks,
+    // a scored pair belongs to a class that holds both its endpoints, a workgroup serves one class and keeps that class's
+    // rows - whole rows, every column - in LDS for the whole launch: one table fill, no column phases, no partial sums
+    // parked between phases.  Steps of 16 pairs share a relation; four steps are a batch (one 32-bit word per lane).
+    int cls_ok = 0, cls_features = 0, cls_groups = 0;
+    int64_t cls_batches = 0;
+    gn::DevBuf<uint32_t> cls_packed;  // [(batches + slack) * 64] local row of u | local row of v << 16
+    gn::DevBuf<uint32_t> cls_own;     // [(batches + slack) * 64] position of the slot's edge, or kNoMirror (padding)
+    gn::DevBuf<uint32_t> cls_mirror;  // [(batches + slack) * 64]
+    gn::DevBuf<uint32_t> cls_rel;     // [(batches + slack) * 2] relation of each of the batch's four steps, 16 bits each
+    gn::DevBuf<int32_t> cls_wg;       // [groups][8] first rows: start, count; second rows: start, count; batches lo, hi; relations lo, count
 };
 
 namespace {
@@ -188,6 +200,168 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
     }
 }
 
+// ---- row-class kernel --------------------------------------------------------------------------------------------
+// One table fill, whole rows.  The column-phase kernel above holds ALL nodes and a slice of the columns, so a launch
+// pays two fills, a hand-over between the phases (every wave waits for the slowest) and its per-batch bookkeeping
+// twice; PMC passes of round 4 (profiles/r04_decoder_pmc.md) show it bound by VALU issue during the phases (6.0 M
+// vector instructions per launch, ~390 per batch of 64 pairs where the arithmetic needs 80) and idle during the
+// fills.  Here a workgroup holds a CLASS of rows with every column: a pair is scored in one go, the sum is split into
+// the same column parts as the phases (so the bits are those of the plan-less kernel), the relation rows of D the
+// workgroup's batches name sit in LDS next to the table, and nothing in the loop needs a clamp or a 64-bit address.
+constexpr int kClsDCache = 64;        // relation rows of D a workgroup keeps in LDS
+constexpr int kClsSlack = 64;         // readable batches behind the last one (the prefetches run ahead unclamped)
+
+struct DmClassArgs {
+    const float* z; int64_t ld_z;
+    const float* d; int64_t ld_d;
+    const uint32_t* packed; const uint32_t* own; const uint32_t* mirror; const uint32_t* rel; const int32_t* wg;
+    float* out; int c0; int sigmoid, first_launch, last_launch;
+};
+
+// One wave step: quad q scores the pair of slot 4 q + S.  J 16-byte chunks per lane (lane l4 of the quad holds chunks
+// l4, l4 + 4, ...: the same columns per lane as the column phases), the first J1 of them are the first part of the sum.
+template <int S, int J, int J1, int STRIDE>
+__device__ __forceinline__ void class_step(const char* __restrict__ lds, uint32_t lane_off, uint32_t w, int l4,
+                                           const f32x4 (&dreg)[J], float& res1, float& res2) {
+    constexpr int kBcast = S * 0x55;     // quad_perm [S,S,S,S]
+    const uint32_t ws = (uint32_t)dpp_i<kBcast>((int)w);
+    const char* pu = lds + (__umul24(ws & 0xffffu, (uint32_t)STRIDE) + lane_off);
+    const char* pv = lds + (__umul24(ws >> 16, (uint32_t)STRIDE) + lane_off);
+    f32x4 P[J], Q[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        P[j] = *reinterpret_cast<const f32x4*>(pu + 64 * j);
+        Q[j] = *reinterpret_cast<const f32x4*>(pv + 64 * j);
+    }
+    f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < J1; ++j) {
+        const f32x2 lo = P[j].xy * Q[j].xy, hi = P[j].zw * Q[j].zw;
+        acc2 = lo * dreg[j].xy + acc2;
+        acc2 = hi * dreg[j].zw + acc2;
+    }
+    float acc = acc2.x + acc2.y;
+    acc = dpp_add<0xB1>(acc);
+    acc = dpp_add<0x4E>(acc);
+    if (l4 == S) res1 = acc;
+    if constexpr (J1 < J) {
+        f32x2 bcc2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = J1; j < J; ++j) {
+            const f32x2 lo = P[j].xy * Q[j].xy, hi = P[j].zw * Q[j].zw;
+            bcc2 = lo * dreg[j].xy + bcc2;
+            bcc2 = hi * dreg[j].zw + bcc2;
+        }
+        float bcc = bcc2.x + bcc2.y;
+        bcc = dpp_add<0xB1>(bcc);
+        bcc = dpp_add<0x4E>(bcc);
+        if (l4 == S) res2 = bcc;
+    }
+}
+
+template <int J, int J1>
+__global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
+    extern __shared__ float4 lds4[];
+    constexpr int ROW4 = 4 * J;                               // float4 per row of the launch's columns
+    constexpr int STR4 = (J & 1) ? ROW4 : ROW4 + 4;           // LDS stride: an odd number of 64-byte bank slots
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int32_t* __restrict__ g = a.wg + (size_t)blockIdx.x * 8;
+    const int r0s = g[0], r0c = g[1], r1s = g[2], r1c = g[3], rel_lo = g[6], nrel = g[7];
+    const uint32_t b_lo = (uint32_t)g[4], b_hi = (uint32_t)g[5];
+    const int rows = r0c + r1c;
+    GN_DM_STAMP(0);
+    {
+        // the class's rows, whole: eight 16-byte loads in flight per thread; every workgroup starts at its own offset
+        const int total = rows * ROW4;
+        const int rot = (int)((blockIdx.x * 977u) % (unsigned)total);
+        for (int base = 0; base < total; base += 8 * kThreads) {
+            float4 v[8];
+            int at[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int i = min(base + k * kThreads + tid, total - 1) + rot;
+                i = i < total ? i : i - total;
+                const int row = i / ROW4, c4 = i - row * ROW4;
+                const int grow = row < r0c ? r0s + row : r1s + (row - r0c);
+                at[k] = row * STR4 + c4;
+                v[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)grow * a.ld_z + a.c0 + 4 * c4);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (base + k * kThreads + tid < total) lds4[at[k]] = v[k];
+        }
+        // the relation rows of D this workgroup's batches name
+        float4* dl = lds4 + (size_t)rows * STR4;
+        for (int i = tid; i < nrel * ROW4; i += kThreads) {
+            const int r = i / ROW4, c4 = i - r * ROW4;
+            dl[i] = *reinterpret_cast<const float4*>(a.d + (int64_t)(rel_lo + r) * a.ld_d + a.c0 + 4 * c4);
+        }
+    }
+    __syncthreads();
+    GN_DM_STAMP(1);
+    const int l4 = lane & 3;
+    const char* lds = reinterpret_cast<const char*>(lds4);
+    const uint32_t lane_off = (uint32_t)l4 * 16u;
+    const f32x4* __restrict__ dl = reinterpret_cast<const f32x4*>(lds4 + (size_t)rows * STR4) + l4;
+    const bool first = a.first_launch, last = a.last_launch;
+    uint32_t b = b_lo + (uint32_t)wave;
+    if (b < b_hi) {
+        const uint32_t* __restrict__ pk = a.packed + lane;
+        const uint32_t* __restrict__ own = a.own + lane;
+        const uint32_t* __restrict__ mir = a.mirror + lane;
+        const uint32_t* __restrict__ rel = a.rel;
+        constexpr uint32_t kStep = kThreads / 64;
+        // every array has kClsSlack readable batches behind the last one: the prefetches need no clamp
+        uint32_t w0 = pk[b * 64u], w1 = pk[(b + kStep) * 64u], w2 = pk[(b + 2 * kStep) * 64u];
+        uint32_t ra0 = rel[2 * b], rb0 = rel[2 * b + 1], ra1 = rel[2 * (b + kStep)], rb1 = rel[2 * (b + kStep) + 1];
+        uint32_t o0 = own[b * 64u], o1 = own[(b + kStep) * 64u];
+        uint32_t m0 = last ? mir[b * 64u] : kNoMirror, m1 = last ? mir[(b + kStep) * 64u] : kNoMirror;
+        float cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
+        int cur = -1;
+        f32x4 dreg[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) dreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define GN_CLS_STEP(S, RELV)                                                                                           \
+        {                                                                                                              \
+            const int rs = (int)(RELV);                                                                                \
+            if (rs != cur) {                                                                                           \
+                cur = rs;                                                                                              \
+                const f32x4* dr = dl + (rs - rel_lo) * ROW4;                                                           \
+                _Pragma("unroll") for (int j = 0; j < J; ++j) dreg[j] = dr[4 * j];                                     \
+            }                                                                                                          \
+            class_step<S, J, J1, STR4 * 16>(lds, lane_off, w, l4, dreg, res1, res2);                                   \
+        }
+#pragma unroll 1
+        for (; b < b_hi; b += kStep) {
+            const uint32_t w = w0, ra = ra0, rb = rb0, mine = o0, mcur = m0;
+            const float carried = cnext;
+            w0 = w1; w1 = w2; ra0 = ra1; rb0 = rb1; o0 = o1; m0 = m1;
+            w2 = pk[(b + 3 * kStep) * 64u];
+            ra1 = rel[2 * (b + 2 * kStep)]; rb1 = rel[2 * (b + 2 * kStep) + 1];
+            o1 = own[(b + 2 * kStep) * 64u];
+            if (last) m1 = mir[(b + 2 * kStep) * 64u];
+            cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
+            float res1 = 0.f, res2 = 0.f;
+            GN_CLS_STEP(0, ra & 0xffffu)
+            GN_CLS_STEP(1, ra >> 16)
+            GN_CLS_STEP(2, rb & 0xffffu)
+            GN_CLS_STEP(3, rb >> 16)
+            float total = carried + res1;                       // the column parts add up in the phases' order
+            if constexpr (J1 < J) total = total + res2;
+            if (last) {
+                if (a.sigmoid) total = sigmoid_f32(total);
+                if (mine != kNoMirror) a.out[mine] = total;
+                if (mcur != kNoMirror) a.out[mcur] = total;
+            } else if (mine != kNoMirror) {
+                a.out[mine] = total;
+            }
+        }
+#undef GN_CLS_STEP
+    }
+    GN_DM_STAMP(2);
+}
+
 // Deals the (up to) 64 edges of a batch to its slots.  Lane l of the wave holds slot l; wave step S works on the
 // slots 4 q + S of the 16 quads q, and ds_read_b128 serves the quads in four access groups.  A cell = (step,
 // access group) = four slots that hit the LDS together: its edges should have four different u % 4 and four
@@ -237,12 +411,214 @@ void deal_batch(const int64_t* u, const int64_t* v, int count, int* slot_of_edge
     }
 }
 
+// Cells of four pairs for one run of pairs that share class and relation: the four pairs of a cell are read by one
+// 16-lane access group of ds_read_b128, so they should have four different (local row of u) % 4 and four different
+// (local row of v) % 4 - the 64-byte bank slot of a row is (row * odd stride) % 4.  Cells fill whole steps first
+// (step = cell / 4): a run is padded to a multiple of 16 pairs, not 64.  order[cell * 4 + k] = pair of the run, or -1.
+void deal_run(const int* lu, const int* lv, int count, std::vector<int>& order) {
+    static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
+                                      {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
+                                      {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
+                                      {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
+    const int steps = (count + 15) / 16;
+    order.assign((size_t)steps * 16, -1);
+    std::vector<int> bucket[4][4];
+    for (int e = count - 1; e >= 0; --e) bucket[lu[e] & 3][lv[e] & 3].push_back(e);   // (popped from the back: list order)
+    int left = count;
+    for (int cell = 0; cell < steps * 4 && left > 0; ++cell) {
+        int chosen[4] = {-1, -1, -1, -1};
+        int best = -1, best_min = 0;
+        for (int p = 0; p < 24; ++p) {
+            int mn = 1 << 30;
+            for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
+            if (mn > best_min) { best_min = mn; best = p; }
+        }
+        if (best >= 0) {
+            for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
+        } else {
+            unsigned used_u = 0, used_v = 0;
+            for (int k = 0; k < 4; ++k) {
+                int bc = -1, bd = -1, bscore = -1;
+                for (int c = 0; c < 4; ++c)
+                    for (int dd = 0; dd < 4; ++dd) {
+                        if (bucket[c][dd].empty()) continue;
+                        const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
+                        if (score > bscore) { bscore = score; bc = c; bd = dd; }
+                    }
+                if (bc < 0) break;
+                chosen[k] = bucket[bc][bd].back();
+                bucket[bc][bd].pop_back();
+                used_u |= 1u << bc; used_v |= 1u << bd;
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            if (chosen[k] >= 0) { order[(size_t)cell * 4 + k] = chosen[k]; --left; }
+    }
+}
+
+// The row-class encoding of the scored pairs (see k_distmult_class).  Leaves plan->cls_ok = 0 when a class's rows do
+// not fit the LDS with `features` columns, or a workgroup's batches name more relations than its D cache holds.
+gn_status build_class_encoding(gn_distmult_plan* p, const std::vector<int64_t>& hu, const std::vector<int64_t>& hv,
+                               const std::vector<int64_t>& hr, const std::vector<int64_t>& scored,
+                               const std::vector<int64_t>& mirror_of, int64_t features, hipStream_t st) {
+    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+    p->cls_ok = 0;
+    const int64_t n = p->num_nodes;
+    if (gn::fast_paths_disabled() || features < 16 || features % 16 != 0 || features > 128 || scored.empty() || n < 1) return GN_OK;
+    const int J = (int)(features / 16), str4 = (J & 1) ? 4 * J : 4 * J + 4;
+    const int64_t rows_fit = ((int64_t)160 * 1024 - (int64_t)kClsDCache * 4 * J * 16) / ((int64_t)str4 * 16);
+    int nblocks = 1;
+    int64_t blk = n;
+    if (n > rows_fit) {
+        blk = gn::ceil_div(n, 3);
+        if (2 * blk > rows_fit) return GN_OK;
+        nblocks = 3;
+    }
+    if (n > 65535) return GN_OK;
+    const int nclasses = nblocks == 1 ? 1 : 3;
+    auto bstart = [&](int b) { return std::min<int64_t>(n, (int64_t)b * blk); };
+    auto bsize = [&](int b) { return bstart(b + 1) - bstart(b); };
+    auto cls_of = [&](int64_t e) {
+        if (nblocks == 1) return 0;
+        const int bu = (int)(hu[e] / blk), bv = (int)(hv[e] / blk);
+        if (bu != bv) return (bu + 1) % 3 == bv ? bu : bv;
+        return (hr[e] & 1) ? (bu + 2) % 3 : bu;                  // a pair inside one block: either class that holds the block
+    };
+    auto local = [&](int64_t node, int k) {
+        const int b = (int)(node / blk);
+        return (int)(b == k ? node - bstart(k) : bsize(k) + node - bstart((k + 1) % 3));
+    };
+    // scored pairs by (class, relation), list order inside
+    const int64_t S = (int64_t)scored.size();
+    std::vector<uint32_t> key((size_t)S);
+    std::vector<int64_t> idx((size_t)S);
+    for (int64_t i = 0; i < S; ++i) { key[i] = (uint32_t)cls_of(scored[i]) << 16 | (uint32_t)hr[scored[i]]; idx[i] = i; }
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });
+    // runs -> steps of 16 slots
+    struct Run { int64_t lo, hi; int cls, rel; int64_t step0; };
+    std::vector<Run> runs;
+    std::vector<int64_t> cls_steps(nclasses, 0);
+    for (int64_t i = 0; i < S;) {
+        int64_t j = i;
+        while (j < S && key[idx[j]] == key[idx[i]]) ++j;
+        const int c = (int)(key[idx[i]] >> 16);
+        runs.push_back({i, j, c, (int)(key[idx[i]] & 0xffffu), cls_steps[c]});
+        cls_steps[c] += gn::ceil_div(j - i, 16);
+        i = j;
+    }
+    std::vector<int64_t> cls_batch0(nclasses + 1, 0);
+    for (int c = 0; c < nclasses; ++c) cls_batch0[c + 1] = cls_batch0[c] + gn::ceil_div(cls_steps[c], 4);
+    const int64_t NB = cls_batch0[nclasses], NBA = NB + kClsSlack;
+    std::vector<uint32_t> packed((size_t)NBA * 64, 0u), own((size_t)NBA * 64, kNoMirror), mirror((size_t)NBA * 64, kNoMirror);
+    std::vector<uint16_t> rel16((size_t)NBA * 4, 0);
+    gn::parallel_for((int64_t)runs.size(), 16, [&](int64_t r0, int64_t r1) {
+        std::vector<int> lu, lv, order;
+        for (int64_t ri = r0; ri < r1; ++ri) {
+            const Run& run = runs[ri];
+            const int count = (int)(run.hi - run.lo);
+            lu.resize(count); lv.resize(count);
+            for (int k = 0; k < count; ++k) {
+                const int64_t e = scored[idx[run.lo + k]];
+                lu[k] = local(hu[e], run.cls); lv[k] = local(hv[e], run.cls);
+            }
+            deal_run(lu.data(), lv.data(), count, order);
+            const int steps = (int)(order.size() / 16);
+            for (int t = 0; t < steps; ++t) {
+                const int64_t gstep = cls_batch0[run.cls] * 4 + run.step0 + t;
+                const int64_t bat = gstep >> 2;
+                const int s_in = (int)(gstep & 3);
+                rel16[(size_t)gstep] = (uint16_t)run.rel;
+                for (int gq = 0; gq < 4; ++gq)
+                    for (int k = 0; k < 4; ++k) {
+                        const int pr = order[(size_t)t * 16 + gq * 4 + k];
+                        const size_t slot = (size_t)bat * 64 + 4 * kGroupQuads[gq][k] + s_in;
+                        const int src = pr >= 0 ? pr : 0;                       // padding repeats the run's first pair, writes nothing
+                        packed[slot] = (uint32_t)lu[src] | (uint32_t)lv[src] << 16;
+                        if (pr >= 0) {
+                            const int64_t e = scored[idx[run.lo + pr]];
+                            own[slot] = (uint32_t)e;
+                            mirror[slot] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
+                        }
+                    }
+            }
+        }
+    });
+    // steps that pad a class to whole batches: the relation of the step before them (no reload), pair (0, 0), no positions
+    for (int c = 0; c < nclasses; ++c)
+        for (int64_t gstep = cls_batch0[c] * 4 + cls_steps[c]; gstep < cls_batch0[c + 1] * 4; ++gstep)
+            rel16[(size_t)gstep] = rel16[(size_t)gstep - 1];
+    for (int64_t gstep = NB * 4; gstep < NBA * 4; ++gstep) rel16[(size_t)gstep] = NB > 0 ? rel16[(size_t)NB * 4 - 1] : 0;
+    // workgroups: a share of the compute units per class in proportion to its batches, contiguous batch ranges
+    const int cus = gn::compute_units();
+    int G = (int)std::min<int64_t>(cus, NB);
+    std::vector<int> share(nclasses, 0);
+    {
+        int given = 0, live = 0;
+        for (int c = 0; c < nclasses; ++c) live += cls_batch0[c + 1] > cls_batch0[c];
+        G = std::max(G, live);
+        std::vector<double> frac(nclasses, 0.0);
+        for (int c = 0; c < nclasses; ++c) {
+            const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
+            if (nb == 0) continue;
+            const double want = (double)G * nb / NB;
+            share[c] = std::max(1, (int)want);
+            frac[c] = want - share[c];
+            given += share[c];
+        }
+        while (given < G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] && (best < 0 || frac[c] > frac[best])) best = c; share[best]++; frac[best] -= 1.0; ++given; }
+        while (given > G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] > 1 && (best < 0 || frac[c] < frac[best])) best = c; if (best < 0) break; share[best]--; frac[best] += 1.0; --given; }
+        G = given;
+    }
+    std::vector<int32_t> wg((size_t)G * 8, 0);
+    int gi = 0;
+    for (int c = 0; c < nclasses; ++c) {
+        const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
+        for (int k = 0; k < share[c]; ++k, ++gi) {
+            const int64_t lo = cls_batch0[c] + nb * k / share[c], hi = cls_batch0[c] + nb * (k + 1) / share[c];
+            int rlo = 1 << 30, rhi = -1;
+            for (int64_t gstep = lo * 4; gstep < hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
+            if (hi <= lo) { rlo = 0; rhi = 0; }
+            if (rhi - rlo + 1 > kClsDCache) return GN_OK;                         // (the column-phase kernel serves such a list)
+            int32_t* d = wg.data() + (size_t)gi * 8;
+            if (nblocks == 1) { d[0] = 0; d[1] = (int32_t)n; d[2] = 0; d[3] = 0; }
+            else { d[0] = (int32_t)bstart(c); d[1] = (int32_t)bsize(c); d[2] = (int32_t)bstart((c + 1) % 3); d[3] = (int32_t)bsize((c + 1) % 3); }
+            d[4] = (int32_t)lo; d[5] = (int32_t)hi; d[6] = rlo; d[7] = rhi - rlo + 1;
+        }
+    }
+    std::vector<uint32_t> rel32((size_t)NBA * 2);
+    for (size_t i = 0; i < rel32.size(); ++i) rel32[i] = (uint32_t)rel16[2 * i] | (uint32_t)rel16[2 * i + 1] << 16;
+    GN_HIP(p->cls_packed.alloc(packed.size()));
+    GN_HIP(p->cls_own.alloc(own.size()));
+    GN_HIP(p->cls_mirror.alloc(mirror.size()));
+    GN_HIP(p->cls_rel.alloc(rel32.size()));
+    GN_HIP(p->cls_wg.alloc(wg.size()));
+    GN_HIP(hipMemcpyAsync(p->cls_packed.p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(p->cls_own.p, own.data(), own.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(p->cls_mirror.p, mirror.data(), mirror.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(p->cls_rel.p, rel32.data(), rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipMemcpyAsync(p->cls_wg.p, wg.data(), wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipStreamSynchronize(st));
+    p->cls_features = (int)features; p->cls_groups = G; p->cls_batches = NB;
+    p->cls_ok = 1;
+    return GN_OK;
+}
+
+template <int J, int J1>
+gn_status launch_class(const gn_distmult_plan* plan, const DmClassArgs& a, int64_t n, hipStream_t st) {
+    gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_class<J, J1>), 160 * 1024);
+    if (s != GN_OK) return s;
+    k_distmult_class<J, J1><<<plan->cls_groups, kThreads, 160 * 1024, st>>>(a);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
-                                  int64_t num_nodes, int64_t num_relations, void* stream, gn_distmult_plan** out) {
+                                  int64_t num_nodes, int64_t num_relations, int64_t num_features, void* stream,
+                                  gn_distmult_plan** out) {
     GN_REQUIRE(out != nullptr, "plan output pointer is null");
     *out = nullptr;
     GN_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_relations >= 0, "negative size");
@@ -346,6 +722,10 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         if ((he = hipMemcpyAsync(p->own.p, own.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
         if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);     // host vectors go out of scope after this
     }
+    if (num_features > 0) {
+        const gn_status cs = build_class_encoding(p, hu, hv, hr, scored, mirror_of, num_features, st);
+        if (cs != GN_OK) { gn_distmult_plan_destroy(p); return cs; }
+    }
     *out = p;
     return GN_OK;
 }
@@ -357,6 +737,11 @@ void gn_distmult_plan_destroy(gn_distmult_plan* p) {
     p->rel16.release();
     p->mirror.release();
     p->own.release();
+    p->cls_packed.release();
+    p->cls_own.release();
+    p->cls_mirror.release();
+    p->cls_rel.release();
+    p->cls_wg.release();
     delete p;
 }
 
@@ -374,6 +759,30 @@ static gn_status plan_forward_cols(const gn_distmult_plan* plan, const float* z,
     GN_REQUIRE(num_features > 0 && ld_z >= col_hi && ld_d >= num_features, "feature count / leading dimension mismatch");
     GN_REQUIRE(0 <= col_lo && col_lo < col_hi && col_hi <= num_features && col_lo % 4 == 0, "column range outside the features");
     const int64_t n = plan->num_nodes, f = col_hi - col_lo;
+    if (plan->cls_ok && f % 16 == 0 && f <= plan->cls_features && ld_z % 4 == 0 && ld_d % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0 && !gn::fast_paths_disabled()) {
+        // the sum keeps the column parts of the phase kernels (plan_phases), so the bits do not depend on the kernel
+        int pc0[kMaxPhases], pw[kMaxPhases];
+        const int parts = plan_phases(n, f, pc0, pw);
+        const int J = (int)(f / 16), J1 = parts >= 1 ? pw[0] / 16 : 0;
+        if ((parts == 1 || (parts == 2 && pw[0] % 16 == 0)) && J1 >= 1) {
+            DmClassArgs c;
+            c.z = z; c.ld_z = ld_z; c.d = d; c.ld_d = ld_d;
+            c.packed = plan->cls_packed.p; c.own = plan->cls_own.p; c.mirror = plan->cls_mirror.p; c.rel = plan->cls_rel.p;
+            c.wg = plan->cls_wg.p; c.out = out; c.c0 = (int)col_lo; c.sigmoid = apply_sigmoid;
+            c.first_launch = col_lo == 0; c.last_launch = col_hi == num_features;
+            hipStream_t st = gn::as_stream(stream);
+            switch (J * 8 + J1) {
+                case 5 * 8 + 3: return launch_class<5, 3>(plan, c, n, st);
+                case 5 * 8 + 4: return launch_class<5, 4>(plan, c, n, st);
+                case 4 * 8 + 4: return launch_class<4, 4>(plan, c, n, st);
+                case 3 * 8 + 3: return launch_class<3, 3>(plan, c, n, st);
+                case 2 * 8 + 2: return launch_class<2, 2>(plan, c, n, st);
+                case 1 * 8 + 1: return launch_class<1, 1>(plan, c, n, st);
+                default: break;                                               // other widths: the column-phase kernel
+            }
+        }
+    }
     DmPlanArgs a;
     a.n_phases = (f % 4 == 0 && ld_z % 4 == 0 && ld_d % 4 == 0 &&
                   ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0)

@@ -91,7 +91,7 @@ class multiRelaInnerProductDecoder(Module):
 
     def _build(self, entry, num_nodes):
         try:
-            entry.plan = _hip.DistMultPlan(entry.edge_index, entry.edge_type, num_nodes, self.num_et)
+            entry.plan = _hip.DistMultPlan(entry.edge_index, entry.edge_type, num_nodes, self.num_et, self.in_dim)
         except _hip.GripNetHipError:                          # too many nodes / relations for the packed encoding
             entry.plan = False
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 121 /* 0.1.21 */
+#define GN_VERSION 130 /* 0.1.30 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -294,7 +294,8 @@ GN_API gn_status gn_distmult_packed_forward_f32(const float* z, int64_t ld_z, in
  * gn_distmult_forward_f32 then. */
 typedef struct gn_distmult_plan gn_distmult_plan;
 GN_API gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
-                                  int64_t num_nodes, int64_t num_relations, void* stream, gn_distmult_plan** plan);
+                                  int64_t num_nodes, int64_t num_relations, int64_t num_features, void* stream,
+                                  gn_distmult_plan** plan);
 GN_API void gn_distmult_plan_destroy(gn_distmult_plan* plan);
 GN_API int64_t gn_distmult_plan_edges(const gn_distmult_plan* plan);
 GN_API gn_status gn_distmult_plan_forward_f32(const gn_distmult_plan* plan, const float* z, int64_t ld_z, int64_t num_features,
