@@ -271,6 +271,24 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
     const uint32_t b_lo = (uint32_t)g[4], b_hi = (uint32_t)g[5];
     const int rows = r0c + r1c;
     GN_DM_STAMP(0);
+#ifdef GN_STAMPS
+    if (tid == 0 && blockIdx.x < 256) g_dm_stamps[blockIdx.x][3] = 0;
+#endif
+    // The first batches' words are requested BEFORE the table fill (their HBM round trip hides behind it).  Every array
+    // has kClsSlack readable batches behind the last one: no prefetch needs a clamp.  The relation words travel as
+    // vector loads too (lanes 0 / 1 of `rw`): a scalar load shares its counter with the LDS reads and would be waited
+    // for as soon as it is issued.
+    const bool first = a.first_launch, last = a.last_launch;
+    constexpr uint32_t kStep = kThreads / 64;
+    uint32_t b = b_lo + (uint32_t)wave;
+    const uint32_t* __restrict__ pk = a.packed + lane;
+    const uint32_t* __restrict__ own = a.own + lane;
+    const uint32_t* __restrict__ mir = a.mirror + lane;
+    const uint32_t* __restrict__ rel = a.rel + (lane & 1);
+    uint32_t w0 = pk[b * 64u], w1 = pk[(b + kStep) * 64u], w2 = pk[(b + 2 * kStep) * 64u];
+    uint32_t rw0 = rel[2 * b], rw1 = rel[2 * (b + kStep)];
+    uint32_t o0 = own[b * 64u], o1 = own[(b + kStep) * 64u];
+    uint32_t m0 = last ? mir[b * 64u] : kNoMirror, m1 = last ? mir[(b + kStep) * 64u] : kNoMirror;
     {
         // the class's rows, whole: eight 16-byte loads in flight per thread; every workgroup starts at its own offset
         const int total = rows * ROW4;
@@ -304,19 +322,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
     const char* lds = reinterpret_cast<const char*>(lds4);
     const uint32_t lane_off = (uint32_t)l4 * 16u;
     const f32x4* __restrict__ dl = reinterpret_cast<const f32x4*>(lds4 + (size_t)rows * STR4) + l4;
-    const bool first = a.first_launch, last = a.last_launch;
-    uint32_t b = b_lo + (uint32_t)wave;
     if (b < b_hi) {
-        const uint32_t* __restrict__ pk = a.packed + lane;
-        const uint32_t* __restrict__ own = a.own + lane;
-        const uint32_t* __restrict__ mir = a.mirror + lane;
-        const uint32_t* __restrict__ rel = a.rel;
-        constexpr uint32_t kStep = kThreads / 64;
-        // every array has kClsSlack readable batches behind the last one: the prefetches need no clamp
-        uint32_t w0 = pk[b * 64u], w1 = pk[(b + kStep) * 64u], w2 = pk[(b + 2 * kStep) * 64u];
-        uint32_t ra0 = rel[2 * b], rb0 = rel[2 * b + 1], ra1 = rel[2 * (b + kStep)], rb1 = rel[2 * (b + kStep) + 1];
-        uint32_t o0 = own[b * 64u], o1 = own[(b + kStep) * 64u];
-        uint32_t m0 = last ? mir[b * 64u] : kNoMirror, m1 = last ? mir[(b + kStep) * 64u] : kNoMirror;
         float cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
         int cur = -1;
         f32x4 dreg[J];
@@ -334,11 +340,12 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
         }
 #pragma unroll 1
         for (; b < b_hi; b += kStep) {
-            const uint32_t w = w0, ra = ra0, rb = rb0, mine = o0, mcur = m0;
+            const uint32_t w = w0, mine = o0, mcur = m0;
+            const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)rw0, 0), rb = (uint32_t)__builtin_amdgcn_readlane((int)rw0, 1);
             const float carried = cnext;
-            w0 = w1; w1 = w2; ra0 = ra1; rb0 = rb1; o0 = o1; m0 = m1;
+            w0 = w1; w1 = w2; rw0 = rw1; o0 = o1; m0 = m1;
             w2 = pk[(b + 3 * kStep) * 64u];
-            ra1 = rel[2 * (b + 2 * kStep)]; rb1 = rel[2 * (b + 2 * kStep) + 1];
+            rw1 = rel[2 * (b + 2 * kStep)];
             o1 = own[(b + 2 * kStep) * 64u];
             if (last) m1 = mir[(b + 2 * kStep) * 64u];
             cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
@@ -360,6 +367,9 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
 #undef GN_CLS_STEP
     }
     GN_DM_STAMP(2);
+#ifdef GN_STAMPS
+    if (lane == 0 && blockIdx.x < 256) atomicMax(&g_dm_stamps[blockIdx.x][3], __builtin_amdgcn_s_memrealtime());   // the workgroup's last wave
+#endif
 }
 
 // Deals the (up to) 64 edges of a batch to its slots.  Lane l of the wave holds slot l; wave step S works on the

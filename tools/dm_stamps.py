@@ -28,5 +28,7 @@ assert lib.gn_debug_read_dm_stamps(buf.ctypes.data) == 0
 b = buf.astype(np.float64) / 100.0
 t0 = b[:, 0].min()
 names = ["entry", "ph0 barrier", "ph0 filled", "ph0 done", "ph1 barrier", "ph1 filled", "ph1 done"]
+if b[:, 4].max() == 0:                            # the row-class kernel stamps entry / table filled / wave 0 done / last wave done
+    names = ["entry", "filled", "wave 0 done", "last wave done"]
 for k, n in enumerate(names):
     print("{:12s} mean {:6.1f} us  min {:6.1f}  max {:6.1f}".format(n, (b[:, k] - t0).mean(), (b[:, k] - t0).min(), (b[:, k] - t0).max()))
