@@ -39,7 +39,9 @@ SIGNATURES = {
     "gn_graph_plan_input_edges": (_i64, [_p]),
     "gn_graph_plan_nnz": (_i64, [_p]),
     "gn_graph_plan_export": (_int, [_p, _p, _p, _p]),
-    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p, _p]),
+    "gn_graph_aggregate_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p, _p, _p]),
+    "gn_split_planes_bytes": (_sz, [_i64, _int]),
+    "gn_split_planes_f32": (_int, [_p, _i64, _i64, _i64, _i64, _p, _p]),
     "gn_transform_fusable": (_int, [_i64, _i64]),
     "gn_graph_transform_fusable": (_int, [_p, _i64, _i64]),
     "gn_graph_plan_build_blocked": (_int, [_p, _i64, _p]),
@@ -60,7 +62,7 @@ SIGNATURES = {
     "gn_graph_aggregate_bf16": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
     "gn_graph_aggregate_with_rgcn_weights_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p,
                                                          _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
-    "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _sz, _p]),
+    "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "gn_distmult_packed_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
@@ -104,6 +106,50 @@ def side_copy(spec):
     sc = SideCopy(src.data_ptr(), ld(src), dst.data_ptr(), ld(dst), src.shape[0], src.shape[1], int(mode))
     sc._keep = (src, dst)
     return sc
+
+
+class SplitPlanesDesc(C.Structure):
+    """gn_split_planes: where a launch leaves the bf16 split planes of what it writes."""
+    _fields_ = [("planes", _p), ("rows", _i64), ("nt", _int), ("col_main", _int), ("col_side", _int)]
+
+
+class SplitPlanes:
+    """The bf16 split planes of a row-major fp32 matrix X [rows, 16 nt] (x = hi + mid + lo exactly): what the
+    relational layer's matrix products run on, left behind by the layer that produces X (gn_split_planes in
+    include/gripnet_hip.h).  Owns the buffer; its last row stays zero."""
+
+    def __init__(self, rows: int, nt: int, device):
+        self.rows, self.nt, self.device = int(rows), int(nt), device
+        self.buf = torch.zeros((int(load().gn_split_planes_bytes(self.rows, self.nt)),), dtype=torch.uint8, device=device)
+        self.generation = 0          # bumped by every launch that rewrites the planes
+
+    def desc(self, col_main=0, col_side=0):
+        d = SplitPlanesDesc(self.buf.data_ptr(), self.rows, self.nt, int(col_main), int(col_side))
+        d._keep = self.buf
+        return d
+
+    def fill_from(self, x: torch.Tensor):
+        """Stand-alone split of an existing matrix (callers without a producing layer)."""
+        d = self.desc()
+        _call("gn_split_planes_f32", ptr(x), ld(x), x.shape[0], x.shape[1], 0, C.byref(d), stream_ptr(x.device))
+        self.generation += 1
+        return self
+
+    def tag(self, x: torch.Tensor):
+        """Remember on `x` that these planes hold its current contents."""
+        x._gn_planes = (self, self.generation, x._version)
+        return x
+
+    @staticmethod
+    def of(x: torch.Tensor, nt: int):
+        """The planes tagged on `x`, if they still describe it (same tensor version, not rewritten since), else None."""
+        t = getattr(x, "_gn_planes", None)
+        if t is None:
+            return None
+        planes, gen, ver = t
+        if planes.generation != gen or x._version != ver or planes.nt != nt or planes.rows != x.shape[0] or planes.device != x.device:
+            return None
+        return planes
 
 
 def _ref(sc):
@@ -420,11 +466,17 @@ class GraphPlan:
     def __iter__(self):          # lets `edge_index, norm = conv.cached_result` keep working
         return iter(self.export())
 
-    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None, cowork=None):
+    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None, cowork=None,
+                  planes=None):
         """out = act(A_norm xw + b), or with `weight` act((A_norm xw) weight + b) (xw is then the layer input).
         `cowork` = (RgcnPlan, basis, att): the relational weights of a later layer are computed by the same launch
-        (gn_graph_aggregate_with_rgcn_weights_f32)."""
+        (gn_graph_aggregate_with_rgcn_weights_f32).  `planes` = (SplitPlanes, col_main, col_side): the launch also
+        leaves the bf16 split planes of its output and of its side copy."""
         sc = side_copy(side)
+        pd = None
+        if planes is not None:
+            pd = planes[0].desc(planes[1], planes[2])
+            planes[0].generation += 1
         if cowork is not None and weight is not None:
             rplan, basis, att = cowork
             ws, need = rplan._workspace(basis.shape[1], basis.shape[2], basis.shape[0])
@@ -435,7 +487,7 @@ class GraphPlan:
             return out
         _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
               0 if weight is None else weight.shape[1], ptr(bias), int(bool(relu)),
-              ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
+              ptr(out), ld(out), _ref(sc), _ref(pd), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
         return out
 
     def aggregate_bf16(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None):
@@ -528,13 +580,16 @@ class RgcnPlan:
               self.mode_flags(fast, path), ptr(ws), need, stream_ptr(basis.device))
 
     def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, weights_ready=False, fast=False,
-                path="auto"):
+                path="auto", x_planes=None):
+        """`x_planes`: SplitPlanes of x left by its producer (the destination-major kernel then skips its own split of x;
+        the other kernels ignore them)."""
         ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0])
         sc = side_copy(side)
         flags = (GN_RGCN_PARTIAL if partial else 0) | (GN_RGCN_WEIGHTS_READY if weights_ready else 0) | self.mode_flags(fast, path)
         _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
               ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), flags,
-              ptr(out), ld(out), _ref(sc), ptr(ws), need, stream_ptr(x.device))
+              ptr(out), ld(out), _ref(sc), None if x_planes is None else x_planes.buf.data_ptr(), ptr(ws), need,
+              stream_ptr(x.device))
         return out
 
     def finalize(self, summed, x, root, bias, relu, out, side=None):

@@ -53,9 +53,36 @@ struct AggArgs {
     int64_t ld_out;
     int rows;
     gn_side_copy side = {nullptr, 0, nullptr, 0, 0, 0, 0};   // optional fused row copy (dst == nullptr: none)
+    gn_split_planes split = {nullptr, 0, 0, 0, 0};           // optional bf16 split planes of what the launch writes
     int64_t nnz = -1;      // stored coefficients, when the caller knows them (picks the short-row kernel)
     int64_t table_rows = -1;   // rows of the gathered table, when the caller knows them (picks the LDS-table kernel)
 };
+
+// One value into the split planes of X (gn_split_planes): its three bf16 terms, cut by truncation exactly as the
+// relational kernel cuts them itself (rgcn_pair.hip: split_pair), so a layer gives the same bits either way.
+__device__ __forceinline__ void write_split(const gn_split_planes& sp, int64_t row, int col, float v) {
+    const int cellb = 4 * ((3 * sp.nt + 1) / 2);
+    const int cell = col / sp.nt, j = col - cell * sp.nt;
+    unsigned short* p = reinterpret_cast<unsigned short*>(static_cast<unsigned char*>(sp.planes) + (row * 16 + cell) * cellb) + j;
+    const uint32_t a = __builtin_bit_cast(uint32_t, v);
+    const float r = v - __builtin_bit_cast(float, a & 0xffff0000u);
+    const uint32_t b = __builtin_bit_cast(uint32_t, r);
+    const float s = r - __builtin_bit_cast(float, b & 0xffff0000u);
+    p[0] = (unsigned short)(a >> 16);
+    p[sp.nt] = (unsigned short)(b >> 16);
+    p[2 * sp.nt] = (unsigned short)(__builtin_bit_cast(uint32_t, s) >> 16);
+}
+
+template <int UNUSED = 0>   // (a template so that the header can define it in every translation unit)
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, int64_t ld_src, int64_t rows, int cols, int col0,
+                                                      gn_split_planes sp) {
+    const int64_t total = rows * cols;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / cols;
+        const int c = (int)(t - i * cols);
+        write_split(sp, i, col0 + c, src[i * ld_src + c]);
+    }
+}
 
 template <int VEC, int LPE>
 __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
@@ -285,7 +312,9 @@ __device__ __forceinline__ void aggregate_transform_body(const AggArgs& a, const
         for (int64_t t = block * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)n_blocks * blockDim.x) {
             const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
             const float v = a.side.src[i * a.side.ld_src + cc];
-            a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
+            const float o = a.side.mode ? fabsf(v) : v;
+            a.side.dst[i * a.side.ld_dst + cc] = o;
+            if (a.split.planes) write_split(a.split, i, a.split.col_side + (int)cc, o);
         }
     }
     for (int row = wave; row < a.rows; row += n_waves) {
@@ -332,6 +361,7 @@ __device__ __forceinline__ void aggregate_transform_body(const AggArgs& a, const
             float val = part + bias;
             if (a.relu) val = fmaxf(val, 0.f);
             a.out[(int64_t)row * a.ld_out + c] = val;
+            if (a.split.planes) write_split(a.split, row, a.split.col_main + c, val);
         }
     }
 }
@@ -615,6 +645,9 @@ inline bool quad_gather_disabled() {
     const char* e = getenv("GN_DISABLE_QUAD");
     return e && e[0] == '1';
 }
+
+// (the quad kernel does not write split planes: its caller follows it with the stand-alone split)
+inline bool transform_takes_quad_kernel(int64_t fin, int64_t fout) { return fin == 16 && fout == 16 && !quad_gather_disabled(); }
 
 inline gn_status launch_aggregate_transform(const AggArgs& a, const float* w, int fout, hipStream_t st) {
     if (a.rows == 0) return GN_OK;

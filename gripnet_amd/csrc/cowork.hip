@@ -38,7 +38,7 @@ extern "C" gn_status gn_graph_aggregate_with_rgcn_weights_f32(
         gn_status s = gn_rgcn_weights_f32(rgcn_plan, rgcn_in_features, basis, att, num_bases, rgcn_out_features,
                                           GN_RGCN_ARITH_FAST, rgcn_workspace, rgcn_workspace_bytes, stream);
         if (s != GN_OK) return s;
-        return gn_graph_aggregate_f32(plan, x, ld_x, num_features, weight, out_features, bias, relu, out, ld_out, side, stream);
+        return gn_graph_aggregate_f32(plan, x, ld_x, num_features, weight, out_features, bias, relu, out, ld_out, side, nullptr, stream);
     }
     GN_REQUIRE(x && out && basis && att, "operand pointer is null");
     GN_REQUIRE(ld_x >= num_features && ld_out >= out_features, "leading dimension smaller than the row length");

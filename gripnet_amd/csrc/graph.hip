@@ -11,7 +11,7 @@ gn_status gn_blocked_aggregate(const gn_graph_plan* plan, const float* x, int64_
 extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw,
                                             int64_t num_features, const float* weight, int64_t out_features,
                                             const float* bias, int relu, float* out, int64_t ld_out,
-                                            const gn_side_copy* side, void* stream) {
+                                            const gn_side_copy* side, const gn_split_planes* planes, void* stream) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(num_features >= 0 && num_features < (1ll << 31), "bad feature count");
     if (plan->rows == 0 || num_features == 0) return GN_OK;
@@ -37,18 +37,52 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.table_rows = plan->table_rows;
     gn_status ss = gn::check_side(side, plan->rows, &a.side);
     if (ss != GN_OK) return ss;
+    if (planes && planes->planes) {
+        GN_REQUIRE(planes->nt >= 1 && planes->nt <= 4 && planes->rows >= plan->rows && planes->col_main >= 0 &&
+                       planes->col_main + width <= 16 * planes->nt &&
+                       (!a.side.dst || (planes->col_side >= 0 && planes->col_side + a.side.cols <= 16 * planes->nt)),
+                   "split planes do not hold the launch's columns");
+    }
+    // the kernels that do not write the planes themselves are followed by the stand-alone split of what they wrote
+    auto then_split = [&](gn_status s) {
+        if (s != GN_OK || !planes || !planes->planes) return s;
+        s = gn_split_planes_f32(out, ld_out, plan->rows, width, planes->col_main, planes, stream);
+        if (s == GN_OK && a.side.dst)
+            s = gn_split_planes_f32(a.side.dst, a.side.ld_dst, a.side.rows, a.side.cols, planes->col_side, planes, stream);
+        return s;
+    };
     if (gn_blocked_applicable(plan, xw, ld_xw, num_features, weight, width))
-        return gn_blocked_aggregate(plan, xw, ld_xw, num_features, weight, width, bias, relu, out, ld_out, a.side,
-                                    gn::as_stream(stream));
+        return then_split(gn_blocked_aggregate(plan, xw, ld_xw, num_features, weight, width, bias, relu, out, ld_out, a.side,
+                                               gn::as_stream(stream)));
     if (weight && gn::mfma_fusable(num_features, out_features, plan->rows, plan->nnz) && (ld_xw % 4) == 0 && gn::aligned16(xw))
-        return gn::launch_aggregate_mfma(a, weight, (int)out_features, gn::as_stream(stream));   // wide layers: W on the matrix cores
+        return then_split(gn::launch_aggregate_mfma(a, weight, (int)out_features, gn::as_stream(stream)));   // wide layers: W on the matrix cores
     if (weight) {            // aggregate the input rows, then contract with W in the epilogue
         if (!gn::transform_fusable(num_features, out_features) || (ld_xw % 4) != 0 || !gn::aligned16(xw))
             return gn::fail(GN_ERR_UNSUPPORTED, "no fused transform for %lld -> %lld features (or unaligned rows)",
                             (long long)num_features, (long long)out_features);
-        return gn::launch_aggregate_transform(a, weight, (int)out_features, gn::as_stream(stream));
+        const bool quad = gn::transform_takes_quad_kernel(num_features, out_features);
+        if (planes && planes->planes && !quad) a.split = *planes;               // written by the kernel's own epilogue
+        const gn_status s = gn::launch_aggregate_transform(a, weight, (int)out_features, gn::as_stream(stream));
+        return quad ? then_split(s) : s;
     }
-    return gn::launch_aggregate(a, gn::as_stream(stream));
+    return then_split(gn::launch_aggregate(a, gn::as_stream(stream)));
+}
+
+extern "C" size_t gn_split_planes_bytes(int64_t rows, int nt) {
+    if (rows < 0 || nt < 1) return 0;
+    return (size_t)(rows + 1) * 64 * (size_t)((3 * nt + 1) / 2);
+}
+
+extern "C" gn_status gn_split_planes_f32(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int64_t col0,
+                                         const gn_split_planes* planes, void* stream) {
+    GN_REQUIRE(planes && planes->planes, "planes are null");
+    GN_REQUIRE(planes->nt >= 1 && planes->nt <= 4 && rows >= 0 && rows <= planes->rows && cols >= 0 && col0 >= 0 &&
+                   col0 + cols <= 16 * planes->nt, "split planes do not hold these columns");
+    if (rows == 0 || cols == 0) return GN_OK;
+    GN_REQUIRE(src && ld_src >= cols, "source matrix is null or its leading dimension too small");
+    gn::k_split_planes<0><<<gn::stream_grid(rows * cols, 256), 256, 0, gn::as_stream(stream)>>>(src, ld_src, rows, (int)cols, (int)col0, *planes);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
 }
 
 // Backward of the aggregation with respect to its table: gxw[s, :] = sum_{e: src(e)=s} coef_e * g[dst(e), :]

@@ -22,7 +22,7 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
-                               hipStream_t st);
+                               const void* x_planes, hipStream_t st);
 
 // rgcn_acc.hip
 bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
@@ -135,7 +135,8 @@ gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t fin, const float
 gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                               const float* basis, const float* att, int64_t bases, const float* root,
                               const float* bias, int64_t fout, int relu, int flags, float* out, int64_t ld_out,
-                              const gn_side_copy* side, void* workspace, size_t workspace_bytes, void* stream) {
+                              const gn_side_copy* side, const void* x_planes, void* workspace, size_t workspace_bytes,
+                              void* stream) {
     const int partial = flags & GN_RGCN_PARTIAL, weights_ready = (flags & GN_RGCN_WEIGHTS_READY) ? 1 : 0;
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
@@ -154,7 +155,7 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     const int path = select_path(plan, fin, fout, bases, flags, basis);
     if (path == GN_RGCN_PATH_PAIR)
         return gn_rgcn_pair_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
-                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, st);
+                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, x_planes, st);
     if (path == GN_RGCN_PATH_ACC)
         return gn_rgcn_acc_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, weights_ready,
                                    !(flags & GN_RGCN_ARITH_FAST), out, ld_out, sc, workspace, workspace_bytes, st);

@@ -30,6 +30,8 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWaves = 16, kThreads = kWaves * 64;   // four waves per SIMD: 128 registers each, one destination row per wave
@@ -46,6 +48,7 @@ constexpr int kSlackBlocks = 192;          // readable blocks behind the last wa
 struct PairArgs {
     const float* x;
     int64_t ld_x;
+    const unsigned char* xp;             // x as bf16 split planes (gn_split_planes), or null: the kernel splits x itself
     const float* att;
     const float* basis;
     const float* root;
@@ -97,7 +100,7 @@ struct Acc<2> { typedef f32x2 type; };
 struct Walk {
     uint32_t lane_off;    // LDS address of this lane's bases inside att row 0
     uint32_t ring_lane;   // LDS address of this lane's word inside block 0 of the wave's window
-    uint32_t lane16;      // lane * 16: this lane's bytes of a 1 KB refill
+    uint32_t lane4;       // lane * 4 (a quarter of this lane's byte offset inside a 1 KB refill)
     uint32_t soff;        // byte offset inside the window of the next word to request
     uint32_t sdma;        // byte offset inside the wave's stream of the next refill
     uint32_t ring_base;   // LDS address of the window
@@ -107,13 +110,13 @@ struct Walk {
 // ---- the gather of one unit, as ONE block of assembly (tools/gen_pair_asm.py writes it; the comment there explains
 // the pipeline).  Written in assembly because the compiler, given the same sequence as separate statements, copies the
 // destination registers of LDS requests still in flight and spends ~45 instructions per block on the control flow of
-// the pipeline; this is 22.  Physical registers v92-v125 and s92-s95 belong to the block (clobbers). ----
+// the pipeline; this is 22.  Physical registers v92-v119 and s92-s95 belong to the block (clobbers). ----
 #include "rgcn_pair_asm.inc"
 
 #define GN_UNIT_OPERANDS(p)                                                                                            \
     : [p0] "=&v"(p[0]), [p1] "=&v"(p[1]), [p2] "=&v"(p[2]), [p3] "=&v"(p[3]), [p4] "=&v"(p[4]), [p5] "=&v"(p[5]),     \
       [p6] "=&v"(p[6]), [p7] "=&v"(p[7]), [soff] "+s"(w.soff), [sdma] "+s"(w.sdma)                                    \
-    : [lo] "v"(w.lane_off), [rlane] "v"(w.ring_lane), [l16] "v"(w.lane16), [rbase] "s"(w.ring_base),                  \
+    : [lo] "v"(w.lane_off), [rlane] "v"(w.ring_lane), [l4] "v"(w.lane4), [rbase] "s"(w.ring_base),                    \
       [sbase] "s"(w.sbase), [c03] "s"(c03), [c47] "s"(c47)                                                            \
     : "memory", "scc", "s92", "s93", "s94", "s95", GN_PAIR_ASM_CLOBBERS
 
@@ -170,43 +173,161 @@ __device__ __forceinline__ void split_chunk(const XRaw<NT>& raw, XFrag<NT>& f) {
         }
 }
 
+// ---- x from the split planes its producer left (gn_split_planes: per row 16 cells - lane c's columns NT c .. NT c +
+// NT - 1 - of 3 NT bf16: term t of column j is half t NT + j).  A lane fetches the cells of its eight sources (20 bytes
+// each at NT = 3) and packs pairs of sources into the B operands with one v_perm per operand dword: the 132 instructions
+// of the in-kernel split, the range checks and the selects of load_chunk are gone (a source that is none names the zero row).
+// The cells come in two requests.  The hi and mid terms (the first 2 NT halves of a cell: NT dwords, the registers the
+// raw fp32 chunk took) are requested IN FRONT of the gather and land behind it, as the raw rows did.  The lo terms are
+// requested behind the gather, into registers the gather has released, and are consumed by the LAST of the six products:
+// P's split, the packing of hi / mid and thirty matrix instructions run while they travel.  (All of a cell behind the
+// gather: the round trip showed - 3.3 k instead of 1.6 k cycles per unit in the contraction; all of it in front: 40
+// registers across the gather, spills.)  The cells' byte offsets are recomputed from the descriptor for the second
+// request rather than kept across the gather.
+// idsel: byte address (lane * 4) of the descriptor dword that holds this lane group's first two ids; lane_b: the byte
+// offset of this lane's cell inside a row.  (ds_bpermute takes the four dwords with an immediate offset each.)
+template <int NT>
+__device__ __forceinline__ void plane_offsets(uint32_t descv, uint32_t idsel, uint32_t lane_b, uint32_t (&off)[8]) {
+    constexpr int CELLB = 4 * ((3 * NT + 1) / 2), ROWB = 16 * CELLB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idsel + 4u * i), (int)descv);
+        off[2 * i] = __umul24(w & 0xffffu, (uint32_t)ROWB) + lane_b;
+        off[2 * i + 1] = __umul24(w >> 16, (uint32_t)ROWB) + lane_b;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_dwords(const uint32_t* p, uint32_t (&d)[N]) {
+    if constexpr (N == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(p); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+    else if constexpr (N == 3) { const u32x3 v = *reinterpret_cast<const u32x3*>(p); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
+    else if constexpr (N == 2) { const u32x2 v = *reinterpret_cast<const u32x2*>(p); d[0] = v[0]; d[1] = v[1]; }
+    else if constexpr (N == 1) { d[0] = p[0]; }
+}
+
+template <int NT>
+struct XHm { uint32_t d[8][NT]; };                       // halves [0, 2 NT) of the eight cells: hi and mid
+template <int NT>
+struct XLo { uint32_t d[8][(NT + 1) / 2]; };             // halves [2 NT, 3 NT): lo
+
+template <int NT>
+__device__ __forceinline__ void load_planes_hm(const unsigned char* xp, uint32_t descv, uint32_t idsel, uint32_t lane_b, XHm<NT>& hm) {
+    uint32_t off[8];
+    plane_offsets<NT>(descv, idsel, lane_b, off);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) load_dwords<NT>(reinterpret_cast<const uint32_t*>(xp + off[t]), hm.d[t]);
+}
+
+template <int NT>
+__device__ __forceinline__ void load_planes_lo(const unsigned char* xp, uint32_t descv, uint32_t idsel, uint32_t lane_b, XLo<NT>& lo) {
+    uint32_t off[8];
+    plane_offsets<NT>(descv, idsel, lane_b, off);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) load_dwords<(NT + 1) / 2>(reinterpret_cast<const uint32_t*>(xp + off[t]) + NT, lo.d[t]);
+}
+
+// B operand dwords of N tile jn, term t, from the cells of the eight sources: half k = t NT + jn of a cell
+template <int NT>
+__device__ __forceinline__ void pack_term(const XHm<NT>& hm, const XLo<NT>& lo, int t, int jn, uint32_t (&w)[4]) {
+    const int k = t * NT + jn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a0 = t < 2 ? hm.d[2 * i][k >> 1] : lo.d[2 * i][(k - 2 * NT) >> 1];
+        const uint32_t a1 = t < 2 ? hm.d[2 * i + 1][k >> 1] : lo.d[2 * i + 1][(k - 2 * NT) >> 1];
+        w[i] = __builtin_amdgcn_perm(a1, a0, (k & 1) ? 0x07060302u : 0x05040100u);
+    }
+}
+
 __device__ __forceinline__ bf16x8 as_frag(const uint32_t (&w)[4]) {
     u32x4 v = {w[0], w[1], w[2], w[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// acc[jm][jn] += P (bases x 32 sources) . X (32 sources x in) for one destination row and one chunk.
-template <int NT, int BT, int TERMS>
-__device__ __forceinline__ void contract(const typename Acc<BT>::type (&p)[8], const XFrag<NT>& xf, f32x4 (&acc)[BT][NT]) {
+// acc[jm][jn] += P (bases x 32 sources) . X (32 sources x in) for one destination row and one chunk: six products on the
+// three-term splits (three on two terms), the small ones first; hi(P) . lo(x) goes LAST - with the planes its operand is
+// the one still travelling.  (Both forms of the kernel keep this order: they give the same bits.)
+__device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int BT>
+__device__ __forceinline__ void split_p(const typename Acc<BT>::type (&p)[8], uint32_t (&t0)[BT][4], uint32_t (&t1)[BT][4], uint32_t (&t2)[BT][4]) {
 #pragma unroll
-    for (int jm = 0; jm < BT; ++jm) {
-        uint32_t t0[4], t1[4], t2[4];
+    for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v0, v1;
             if constexpr (BT == 2) { v0 = p[2 * i][jm]; v1 = p[2 * i + 1][jm]; } else { v0 = p[2 * i]; v1 = p[2 * i + 1]; }
-            split_pair(v0, v1, t0[i], t1[i], t2[i]);
+            split_pair(v0, v1, t0[jm][i], t1[jm][i], t2[jm][i]);
         }
-        const bf16x8 ph = as_frag(t0), pm = as_frag(t1), pl = as_frag(t2);
+}
+
+template <int NT, int BT, int TERMS>
+__device__ __forceinline__ void contract(const typename Acc<BT>::type (&p)[8], const XFrag<NT>& xf, f32x4 (&acc)[BT][NT]) {
+    uint32_t t0[BT][4], t1[BT][4], t2[BT][4];
+    split_p<BT>(p, t0, t1, t2);
+#pragma unroll
+    for (int jm = 0; jm < BT; ++jm) {
+        const bf16x8 ph = as_frag(t0[jm]), pm = as_frag(t1[jm]), pl = as_frag(t2[jm]);
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) {
             const bf16x8 xh = as_frag(xf.w[jn][0]), xm = as_frag(xf.w[jn][1]);
             f32x4 c = acc[jm][jn];
-            if constexpr (TERMS == 3) {                                       // smallest terms first
-                const bf16x8 xl = as_frag(xf.w[jn][2]);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, xh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, xl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, xm, c, 0, 0, 0);
+            if constexpr (TERMS == 3) {
+                c = mfma(pl, xh, c);
+                c = mfma(pm, xm, c);
             }
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, xh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, xm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, xh, c, 0, 0, 0);
+            c = mfma(pm, xh, c);
+            c = mfma(ph, xm, c);
+            c = mfma(ph, xh, c);
+            if constexpr (TERMS == 3) c = mfma(ph, as_frag(xf.w[jn][2]), c);
             acc[jm][jn] = c;
         }
     }
 }
 
+// The same with x from the planes: one N tile at a time - its operand terms are packed from the cells (four registers
+// each) right in front of the products that use them, so the cells, P's terms and the accumulators fit the 128 registers.
 template <int NT, int BT, int TERMS>
+__device__ __forceinline__ void contract_planes(const typename Acc<BT>::type (&p)[8], const XHm<NT>& hm, const XLo<NT>& lo,
+                                                f32x4 (&acc)[BT][NT]) {
+    uint32_t t0[BT][4], t1[BT][4], t2[BT][4];
+    split_p<BT>(p, t0, t1, t2);
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn) {
+        __builtin_amdgcn_sched_barrier(0);                 // (keeps the packing of one tile from drifting in front of another's: registers)
+        uint32_t xh4[4], xm4[4];
+        pack_term<NT>(hm, lo, 0, jn, xh4);
+        pack_term<NT>(hm, lo, 1, jn, xm4);
+        const bf16x8 xh = as_frag(xh4), xm = as_frag(xm4);
+#pragma unroll
+        for (int jm = 0; jm < BT; ++jm) {
+            const bf16x8 ph = as_frag(t0[jm]), pm = as_frag(t1[jm]), pl = as_frag(t2[jm]);
+            f32x4 c = acc[jm][jn];
+            if constexpr (TERMS == 3) {
+                c = mfma(pl, xh, c);
+                c = mfma(pm, xm, c);
+            }
+            c = mfma(pm, xh, c);
+            c = mfma(ph, xm, c);
+            c = mfma(ph, xh, c);
+            acc[jm][jn] = c;
+        }
+    }
+    if constexpr (TERMS == 3) {
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t xl4[4];
+            pack_term<NT>(hm, lo, 2, jn, xl4);
+            const bf16x8 xl = as_frag(xl4);
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm) acc[jm][jn] = mfma(as_frag(t0[jm]), xl, acc[jm][jn]);
+        }
+    }
+}
+
+template <int NT, int BT, int TERMS, bool XP>
 __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_set) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     typedef typename Acc<BT>::type acc_t;
@@ -225,7 +346,12 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     // ---- prologue: this wave's window on its stream, the att table ----
     const uint32_t wave_id = (uint32_t)(g * kWaves + wave);
     const uint32_t first_block = a.wave_first[wave_id], n_units = a.wave_units[wave_id];
-    const uint32_t* __restrict__ desc = a.desc + (size_t)a.wave_desc[wave_id] * 32;
+    // byte offset of this wave's descriptors inside a.desc: uniform, 32 bits (a lane adds its own 4 bytes; the base stays
+    // the kernel argument, so that the loads take the scalar-base form and no lane holds a 64-bit address)
+    const uint32_t desc_b = __builtin_amdgcn_readfirstlane(a.wave_desc[wave_id] * 128u);
+    const unsigned char* __restrict__ descp = reinterpret_cast<const unsigned char*>(a.desc);
+    const unsigned char* __restrict__ xp = a.xp;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
     Walk w;
     w.ring_base = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wave * kRingBytes);
     {
@@ -236,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     }
     w.lane_off = lds0 + (uint32_t)c * (BT * 4);
     w.ring_lane = w.ring_base + (uint32_t)kg * 16u + (uint32_t)(lane & 3) * 4u;
-    w.lane16 = (uint32_t)lane * 16u;
+    w.lane4 = (uint32_t)lane * 4u;
     w.soff = 256u;                                                             // a unit reads its first four words itself (behind soff)
     w.sdma = 3u * 512u;                                                        // the window starts with blocks 0..23
     if (lane < 32) {
@@ -261,11 +387,22 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
             reinterpret_cast<float*>(lds)[e] = b < a.B ? a.att[(size_t)r * a.B + b] : 0.f;
         }
     }
+    // the workgroup's destination rows (read here, not in front of the epilogue's loads: one round trip less behind the loop)
+    int32_t my_dst[4];
+    {
+        const int32_t* __restrict__ wd = a.wg_dst + (size_t)g * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) my_dst[d] = wd[d];
+    }
+    int nd = 0;
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) nd += my_dst[d] >= 0 ? 1 : 0;
+    const uint32_t ranges = (uint32_t)my_dst[3];                               // first wave of rows 1 and 2 (eight bits each)
     if (tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
     // unit descriptors of this wave, 32 dwords each (block counts, the chunk's 32 source ids): lane L holds dword L of the
     // current page of two units, and of the page after it
-    uint32_t descv = n_units ? desc[lane] : 0u;
-    uint32_t descn = n_units > 2 ? desc[64 + lane] : 0u;
+    uint32_t descv = n_units ? *reinterpret_cast<const uint32_t*>(descp + (desc_b + lane4)) : 0u;
+    uint32_t descn = n_units > 2 ? *reinterpret_cast<const uint32_t*>(descp + (desc_b + 256u + lane4)) : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef GN_STAMPS
@@ -283,7 +420,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     for (uint32_t u = 0; u < n_units; ++u) {
         if (u && (u & 1u) == 0u) {                                             // next page: requested a page (two units) ago
             descv = descn;
-            if (u + 2 < n_units) descn = desc[(size_t)((u >> 1) + 1) * 64 + lane];
+            if (u + 2 < n_units) descn = *reinterpret_cast<const uint32_t*>(descp + (desc_b + ((u >> 1) + 1) * 256u + lane4));
         }
         const int o = (int)(u & 1u) * 32;
         const uint32_t c03 = __builtin_amdgcn_readlane(descv, o), c47 = __builtin_amdgcn_readlane(descv, o + 1);
@@ -293,7 +430,11 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         const unsigned long long cx0 = __builtin_amdgcn_s_memtime();
 #endif
         XRaw<NT> raw;
-        load_chunk<NT>(a, descv, o, kg, c, raw);
+        XHm<NT> hm;
+        // (lane constants of the planes path, recomputed from lane * 4 where they are used: registers are what is short)
+        const uint32_t idsel = ((lane4 >> 2) & 0x30u) + 32u + (uint32_t)o * 4u;      // dword 8 + 4 kg (+ the unit's half of the page)
+        const uint32_t lane_b = (lane4 & 0x3cu) * (uint32_t)((3 * NT + 1) / 2);      // c * bytes of a cell
+        if constexpr (XP) load_planes_hm<NT>(xp, descv, idsel, lane_b, hm); else load_chunk<NT>(a, descv, o, kg, c, raw);
         acc_t p[8];
 #ifdef GN_STAMPS
         const unsigned long long cg0 = __builtin_amdgcn_s_memtime();
@@ -304,9 +445,15 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         const unsigned long long cg1 = __builtin_amdgcn_s_memtime();
         cyc_gather += cg1 - cg0;
 #endif
-        XFrag<NT> xf;
-        split_chunk<NT, TERMS>(raw, xf);
-        contract<NT, BT, TERMS>(p, xf, acc);
+        if constexpr (XP) {
+            XLo<NT> lo;
+            if constexpr (TERMS == 3) load_planes_lo<NT>(xp, descv, idsel, lane_b, lo);
+            contract_planes<NT, BT, TERMS>(p, hm, lo, acc);
+        } else {
+            XFrag<NT> xf;
+            split_chunk<NT, TERMS>(raw, xf);
+            contract<NT, BT, TERMS>(p, xf, acc);
+        }
 #ifdef GN_STAMPS
         asm volatile("s_nop 0" :: "v"(acc[0][0][0]) : "memory");
         cyc_contract += __builtin_amdgcn_s_memtime() - cg1;
@@ -323,11 +470,6 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     // fetches while the others still gather; every compute unit pulls all of basis (196 KB on PoSE) through its own L2
     // port, which is what this epilogue costs.
     constexpr int kRowsMax = NT <= 2 ? 16 : 12;                                // rows of a slice held in registers (fewer accumulators: more rows)
-    const int32_t* my_dst = a.wg_dst + (size_t)g * 4;
-    int nd = 0;
-#pragma unroll
-    for (int d = 0; d < kMaxD; ++d) nd += my_dst[d] >= 0 ? 1 : 0;
-    const uint32_t ranges = (uint32_t)my_dst[3];                               // first wave of rows 1 and 2 (eight bits each)
     const int wb1 = (int)(ranges & 0xffu), wb2 = (int)((ranges >> 8) & 0xffu);
     const int fout = a.fout, og = fout >> 2;                                   // fout % 4 == 0, og in 1..16
     const int slices = kThreads / og;
@@ -402,9 +544,11 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #pragma unroll
         for (int j = 0; j < kRowsMax; ++j) {
             const int k = min(feat * BP + base, KP - 1);
+            // (all three rows, whether the workgroup has them or not: what a missing row's slot of usum holds is never
+            // stored, and without the branches the compiler keeps the sums where they are - with them it moved the
+            // twelve accumulator registers around at every merge: 700 moves per thread, 3 us of the epilogue)
 #pragma unroll
-            for (int d = 0; d < kMaxD; ++d)
-                if (d < nd) sum[d] += usum[(size_t)d * KP + k] * bv[j];
+            for (int d = 0; d < kMaxD; ++d) sum[d] += usum[(size_t)d * KP + k] * bv[j];
             base += dbase; feat += dfeat;
             if (feat >= FIN) { feat -= FIN; ++base; }
         }
@@ -413,7 +557,11 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     asm volatile("" : "+v"(sum[0]));
     const unsigned long long st5 = __builtin_amdgcn_s_memrealtime();
 #endif
-    float* red = part;                                                         // [slices][nd][og][4], over the waves' shares (dead)
+    // [slices][kMaxD][og][4] = 12,288 floats: over the waves' shares (dead) where those are at least that long; narrow
+    // layers (KP < 768) keep them behind the rows' sums instead - there the shares are shorter than `red`, and a thread
+    // that has finished its contraction would write into the sums other threads still read
+    constexpr bool kRedOverShares = kWaves * KP >= kThreads * kMaxD * 4;
+    float* red = kRedOverShares ? part : usum + (size_t)kMaxD * KP;
     if (sl < slices)
 #pragma unroll
         for (int d = 0; d < kMaxD; ++d)
@@ -568,10 +716,16 @@ void lay_out_section(const uint32_t* const (&list)[4], const int (&len)[4], int 
 
 template <int NT, int BT, int TERMS>
 gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st) {
-    gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS>), kLdsBytes);
-    if (s != GN_OK) return s;
     static int stamp = 0;
-    k_rgcn_pair<NT, BT, TERMS><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
+    if (a.xp) {
+        gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS, true>), kLdsBytes);
+        if (s != GN_OK) return s;
+        k_rgcn_pair<NT, BT, TERMS, true><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
+    } else {
+        gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS, false>), kLdsBytes);
+        if (s != GN_OK) return s;
+        k_rgcn_pair<NT, BT, TERMS, false><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
+    }
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -878,14 +1032,16 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     const int64_t part = (int64_t)(kWaves + kMaxD) * kp * 4;                   // the waves' shares, the rows' sums
     const int64_t red = (int64_t)kThreads * kMaxD * 16;                        // the slices' sums reuse the shares' space
     const int64_t slices = kThreads / (fout / 4), per = (bases * fin + slices - 1) / slices;
-    return std::max(part, red) <= kLdsBytes && nt * bt <= 6 && per <= (nt <= 2 ? 16 : 12);   // (rows of basis a thread holds in registers)
+    const int64_t need = (int64_t)kWaves * kp >= (int64_t)kThreads * kMaxD * 4 ? std::max(part, red) : part + red;   // (narrow layers: behind the sums)
+    return need <= kLdsBytes && nt * bt <= 6 && per <= (nt <= 2 ? 16 : 12);   // (rows of basis a thread holds in registers)
 }
 
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
-                               hipStream_t st) {
+                               const void* x_planes, hipStream_t st) {
     PairArgs a;
+    a.xp = static_cast<const unsigned char*>(x_planes);
     GN_REQUIRE(ld_x < (1ll << 21), "x rows more than 2^21 floats apart are not supported by the destination-major kernel");
     a.x = x; a.ld_x = ld_x; a.att = att; a.basis = basis; a.root = root; a.bias = bias;
     a.indeg = plan->indeg.p;

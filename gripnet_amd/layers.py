@@ -78,7 +78,8 @@ class myGCN(Module):
             self.cached_result = build()
         return self.cached_result
 
-    def _run(self, plan, x, n_out, out, relu, side, cowork=None):
+    def _run(self, plan, x, n_out, out, relu, side, cowork=None, planes=None):
+        self._planes_written = False                 # did this call's launch leave the split planes it was offered?
         if recording(x, self.weight, self.bias):                                 # training: autograd path
             y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu)
             if side is not None or out is not None:
@@ -95,13 +96,17 @@ class myGCN(Module):
                                             plan.transform_ok(self.in_channels, self.out_channels, x)):
             # A_norm (x W) = (A_norm x) W: the contraction of layers.py:73 runs on the aggregated row
             done = cowork.cowork_request() if cowork is not None else None      # W_r of a later relational layer, same launch
-            y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, cowork=done)
+            if done is not None:
+                planes = None
+            y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, cowork=done, planes=planes)
+            self._planes_written = planes is not None
             if done is not None:
                 cowork.cowork_done()
             return y
         xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
         _hip.gemm(x, self.weight, xw, fast=self.arithmetic == "fast")               # layers.py:73
-        return plan.aggregate(xw, self.bias, relu, out, side)                    # layers.py:92-100
+        self._planes_written = planes is not None
+        return plan.aggregate(xw, self.bias, relu, out, side, planes=planes)     # layers.py:92-100
 
     def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None):
         _hip.require_gpu(x, edge_index, edge_weight, self.weight)
@@ -115,13 +120,13 @@ class myGCN(Module):
         return self._run(plan, x, n, _out, _relu, _side)
 
     def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None,
-                          _cowork=None):
+                          _cowork=None, _planes=None):
         """The conv as interGraph uses it (layers.py:363-368), in closed form: rows are targets."""
         _hip.require_gpu(x, inter_edge_index, edge_weight, self.weight)
         n_src = x.size(0)
         plan = self._plan(inter_edge_index,
                           lambda: _hip.GraphPlan.bipartite(inter_edge_index, n_src, n_target, edge_weight))
-        return self._run(plan, x, n_target, _out, _relu, _side, _cowork)
+        return self._run(plan, x, n_target, _out, _relu, _side, _cowork, _planes)
 
     def __repr__(self):
         return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
@@ -230,8 +235,9 @@ class myRGCN(Module):
             if pre[0] is not None:                       # computed on another stream (prefetch_weights)
                 torch.cuda.current_stream(x.device).wait_event(pre[0])
             ready = True
+        planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None
         return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, weights_ready=ready,
-                            fast=self._fast(), path=self.kernel)
+                            fast=self._fast(), path=self.kernel, x_planes=planes)
 
     def __repr__(self):
         return "{}({}, {}, num_relations={})".format(self.__class__.__name__, self.in_channels,
@@ -341,9 +347,19 @@ class interGraph(Module):
             return self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if mod == "cat":                                                         # layers.py:375-376
             out, (y, tf) = _cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
+            # the same launch leaves [y | |target_feat|] as bf16 split planes: a relational layer that takes this
+            # output as its input (GripNet-pose.py:120-127) contracts with them instead of splitting x in every unit
+            width, planes = self.target_dim + self.target_feat_dim, None
+            if width % 16 == 0 and width <= 64 and self.conv.table_storage == "fp32":
+                planes = getattr(self, "_planes", None)
+                if planes is None or planes.device != dev:
+                    planes = self._planes = _hip.SplitPlanes(self.n_target, width // 16, dev)
             self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu,
                                         _side=(self.target_feat, tf, 1),     # |target_feat| slot, same launch
-                                        _cowork=_cowork)
+                                        _cowork=_cowork,
+                                        _planes=None if planes is None else (planes, 0, self.target_dim))
+            if planes is not None and getattr(self.conv, "_planes_written", False):
+                planes.tag(out)
             return out
         y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if y.shape[1] == self.target_feat.shape[1]:                              # layers.py:378-379

@@ -54,6 +54,22 @@ typedef struct gn_side_copy {
     int mode;
 } gn_side_copy;
 
+/* Optional third output of an aggregation launch, and optional input of gn_rgcn_forward_f32: a row-major matrix
+ * X [rows, 16 nt] as the three bf16 terms the relational layer's matrix products run on (x = hi + mid + lo exactly,
+ * each cut by truncation).  The relational kernel otherwise splits the same 645 x 48 values again in every one of its
+ * 13,500 units (gripnet/layers.py:172-186 is the product this feeds); the layer that PRODUCES x - the external layer
+ * writing y, its side copy writing |target_feat| (layers.py:370,376) - can leave the terms behind for free.
+ * Layout: planes[(row * 16 + cell) * cb + (term * nt + j) * 2], two bytes each: cell = column / nt, j = column % nt,
+ * cb = 4 * ceil(3 nt / 2) bytes per cell, term 0 / 1 / 2 = hi / mid / lo.  The buffer holds rows + 1 rows and the
+ * caller keeps row `rows` ZERO (a source that is none names it): (rows + 1) * 16 * cb bytes (gn_split_planes_bytes). */
+typedef struct gn_split_planes {
+    void* planes;
+    int64_t rows;
+    int nt;           /* columns of X / 16 */
+    int col_main;     /* column of X where the launch's main output starts */
+    int col_side;     /* column of X where the launch's side copy starts (ignored without one) */
+} gn_split_planes;
+
 typedef struct gn_graph_plan gn_graph_plan; /* GCN-style graphs (square or bipartite)  */
 typedef struct gn_rgcn_plan gn_rgcn_plan;   /* multi-relational graph of one supervertex */
 
@@ -101,7 +117,14 @@ GN_API gn_status gn_graph_plan_export(const gn_graph_plan* plan, int64_t* edge_i
 GN_API gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const float* xw, int64_t ld_xw, int64_t num_features,
                                  const float* weight /* nullable */, int64_t out_features,
                                  const float* bias, int relu, float* out, int64_t ld_out,
-                                 const gn_side_copy* side /* nullable */, void* stream);
+                                 const gn_side_copy* side /* nullable */, const gn_split_planes* planes /* nullable */,
+                                 void* stream);
+/* `planes`: the launch also leaves the bf16 split planes of what it writes (main output and side copy, as columns
+ * col_main.. / col_side.. of X).  The wave-per-row transform kernel writes them from its epilogue; the other kernels
+ * are followed by gn_split_planes_f32 launches.  The same planes from a matrix that already exists: */
+GN_API size_t gn_split_planes_bytes(int64_t rows, int nt);
+GN_API gn_status gn_split_planes_f32(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int64_t col0,
+                              const gn_split_planes* planes, void* stream);
 /* With weight != NULL ([num_features, out_features], row-major, contiguous) the table is the layer INPUT x
  * and the call computes act( (A_norm x) W + bias ) = act( A_norm (x W) + bias ): the contraction of
  * layers.py:73 runs on the aggregated row, so no x W launch is needed.  Supported for (num_features,
@@ -252,8 +275,9 @@ GN_API int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t in_features, i
 GN_API gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t in_features,
                               const float* basis, const float* att, int64_t num_bases, const float* root,
                               const float* bias, int64_t out_features, int relu, int flags, float* out,
-                              int64_t ld_out, const gn_side_copy* side /* nullable */, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              int64_t ld_out, const gn_side_copy* side /* nullable */,
+                              const void* x_planes /* nullable: gn_split_planes.planes of x, written by its producer */,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[i,:] = act( summed[i,:] / max(1, indeg_i) + x[i] root + bias )  (layers.py:131,191-197). */
 GN_API gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* summed, int64_t ld_summed, const float* x,

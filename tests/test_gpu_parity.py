@@ -407,6 +407,72 @@ def test_rgcn_lds_resident_shapes(gpu, n, fin, bases, path):
     close(y, ref.float())
 
 
+@needs_fast_paths
+@pytest.mark.parametrize("n,fin,bases,arith", [(645, 48, 32, "fp32"), (300, 16, 5, "fp32"), (520, 32, 16, "fp32"),
+                                               (700, 64, 8, "fp32"), (645, 48, 32, "fast"), (90, 48, 20, "fp32")])
+def test_rgcn_takes_x_as_split_planes(gpu, n, fin, bases, arith):
+    """gn_split_planes: the relational kernel fed with the bf16 terms of x (cut exactly as it cuts them itself) gives the
+    same bits as the kernel that splits x in every unit - for planes written by gn_split_planes_f32 and for planes left
+    by the external layer's own launch (its output and its |target_feat| side copy); planes that no longer describe the
+    tensor (rewritten, or the tensor modified through torch) are not used."""
+    gen = torch.Generator().manual_seed(n * 7 + fin)
+    torch.manual_seed(n + fin + bases)
+    sizes = [3000, 0, 40, 900, 1, 600]
+    blocks = [torch.randint(0, max(1, n - n // 9), (2, s), generator=gen) for s in sizes]
+    rei = torch.cat(blocks, dim=1).to(gpu)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen).to(gpu)
+    x[3, 1] = 0.0
+    x[5] = 1e-30                                                       # small values: the terms underflow to zero together
+    rg = gripnet_amd.myRGCN(fin, 32, len(sizes), bases, False, bias=True).to(gpu)
+    rg.bias.data.normal_()
+    rg.arithmetic = arith
+    rg.kernel = "pair"
+    for prm in rg.parameters():
+        prm.requires_grad_(False)                                      # the inference path (autograd builds its own)
+    y_plain = rg(x, rei, None, rl, _relu=True)
+    assert rg._plan.path(fin, 32, bases, fast=arith == "fast", path="pair") == "pair"
+    planes = _hip.SplitPlanes(n, fin // 16, gpu).fill_from(x)
+    planes.tag(x)
+    assert _hip.SplitPlanes.of(x, fin // 16) is planes
+    y_planes = rg(x, rei, None, rl, _relu=True)
+    assert torch.equal(y_plain, y_planes)
+    # garbage in the planes must show (the tagged planes are really what the kernel read) ...
+    keep = planes.buf.clone()
+    planes.buf[: planes.buf.numel() - 16 * 4 * ((3 * (fin // 16) + 1) // 2)].zero_()
+    assert not torch.equal(rg(x, rei, None, rl, _relu=True), y_plain)
+    planes.buf.copy_(keep)
+    # ... and a tensor modified through torch drops them
+    x.add_(0.0)
+    assert _hip.SplitPlanes.of(x, fin // 16) is None
+    assert torch.equal(rg(x, rei, None, rl, _relu=True), y_plain)
+    sd = {k: v.detach().cpu().double() for k, v in rg.state_dict().items()}
+    ref = torch.relu(orc.rgcn_forward(x.cpu().double(), rei.cpu(), rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
+    close(y_planes, ref.float(), TIGHT if arith == "fp32" else TOL)
+
+
+@needs_fast_paths
+def test_external_layer_leaves_split_planes(gpu):
+    """interGraph(mod="cat") leaves [y | |target_feat|] as split planes in the launch that computes y; they are the bytes
+    gn_split_planes_f32 makes of the finished matrix, and the relational layer behind it uses them (pose pipeline)."""
+    gen = torch.Generator().manual_seed(5)
+    torch.manual_seed(9)
+    n_src, n_tgt = 700, 333
+    ig = gripnet_amd.interGraph(64, 16, n_tgt, target_feat_dim=32).to(gpu)
+    xs = torch.randn(n_src, 64, generator=gen).to(gpu)
+    bei = torch.stack([torch.randint(0, n_src, (4000,), generator=gen), torch.randint(0, n_tgt, (4000,), generator=gen)]).to(gpu)
+    with torch.no_grad():
+        out = ig(xs, bei, mod="cat", if_relu=True)
+    planes = _hip.SplitPlanes.of(out, 3)
+    assert planes is not None and planes is ig._planes
+    ref = _hip.SplitPlanes(n_tgt, 3, gpu).fill_from(out)
+    assert torch.equal(planes.buf, ref.buf)
+    assert int(planes.buf[-16 * 20:].abs().sum()) == 0                 # the zero row stays zero
+    with torch.no_grad():
+        out2 = ig(xs * 2.0, bei, mod="cat", if_relu=True)             # the module's planes now describe out2, not out
+    assert _hip.SplitPlanes.of(out, 3) is None and _hip.SplitPlanes.of(out2, 3) is planes
+
+
 @pytest.mark.parametrize("n,fin,fout,bases", [(700, 32, 48, 32), (645, 16, 64, 8), (300, 48, 4, 3), (768, 32, 44, 32)])
 def test_rgcn_destination_major_output_widths(gpu, n, fin, fout, bases):
     """The destination-major relational kernel on output widths other than 32 (any multiple of 4 up to 64): above 256 nodes a

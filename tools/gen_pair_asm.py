@@ -28,10 +28,11 @@ DPP = ["", " quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf", " quad_perm:[2,3,0
        " quad_perm:[3,0,1,2] row_mask:0xf bank_mask:0xf"]
 
 
-RB = 92            # first of the 34 VGPRs the block owns (v92-v125: the kernel runs four waves per SIMD, 128 registers)
+RB = 92            # first of the 28 VGPRs the block owns (v92-v119: the kernel runs four waves per SIMD, 128 registers)
+NREGS = 28
 W = ["v{}".format(RB + 24 + k) for k in range(3)]
-A = [RB + 28 + j for j in range(4)]        # row addresses
-WADDR, VDMA = "v{}".format(RB + 32), "v{}".format(RB + 33)
+WADDR = VDMA = "v{}".format(RB + 27)   # the refill's address is consumed when it issues, in front of the word's address
+# (a row's LDS address is computed in the first register of the buffer row it is read into: consumed when the read issues)
 
 
 def regs(bt):
@@ -46,6 +47,7 @@ def regs(bt):
 def issue(lines, rd, use, req, into, behind=0):
     """rows of the block whose word is `use` into `into`; word `req` from the window: the next one (soff, which advances),
     or - `behind` > 0, a unit's prologue - the one `behind` bytes back (already passed by the unit before)"""
+    A = [int(r.replace("v[", "").replace("v", "").split(":")[0]) for r in into]
     lines.append("v_add_u32 v{}, {}, %[lo]".format(A[0], use))
     for j in (1, 2, 3):
         lines.append("v_add_u32_dpp v{}, {}, %[lo]{}".format(A[j], use, DPP[j]))
@@ -65,7 +67,7 @@ def issue(lines, rd, use, req, into, behind=0):
         "s_sub_u32 s94, %[soff], 0x400",
         "s_and_b32 s94, s94, 0x600",
         "s_add_u32 m0, s94, %[rbase]",
-        "{} {}, %[sdma], %[l16]".format("v_add_u32", VDMA),
+        "v_lshl_add_u32 {}, %[l4], 2, %[sdma]".format(VDMA),                 # lane * 16 (this lane's bytes of the 1 KB refill) + offset
         "s_add_u32 %[sdma], %[sdma], 0x200",
         "s_mov_b32 exec_hi, 0",
         "global_load_lds_dwordx4 {}, %[sbase]".format(VDMA),
@@ -121,7 +123,7 @@ def unit(bt):
 def main():
     with open(OUT, "w") as f:
         f.write("// Generated by tools/gen_pair_asm.py - do not edit.  The gather of one unit (see rgcn_pair.hip).\n")
-        f.write("#define GN_PAIR_ASM_CLOBBERS {}\n\n".format(", ".join('"v{}"'.format(RB + i) for i in range(34))))
+        f.write("#define GN_PAIR_ASM_CLOBBERS {}\n\n".format(", ".join('"v{}"'.format(RB + i) for i in range(NREGS))))
         for bt, name in ((2, "GN_PAIR_UNIT_ASM_B64"), (1, "GN_PAIR_UNIT_ASM_B32")):
             f.write("#define {} \\\n".format(name))
             lines = unit(bt)

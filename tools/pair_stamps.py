@@ -16,12 +16,15 @@ from gripnet_amd.synth import make_pose
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="pose0-syn")
+    ap.add_argument("--planes", action="store_true", help="x arrives as bf16 split planes (gn_split_planes)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     data = make_pose(args.workload).to(dev)
     torch.manual_seed(1111)
     conv = gripnet_amd.myRGCN(48, 32, data.n_dd_edge_type, 32, False).to(dev)
     x = torch.randn(data.n_d_node, 48, device=dev)
+    if args.planes:
+        _hip.SplitPlanes(data.n_d_node, 3, dev).fill_from(x).tag(x)
     with torch.no_grad():
         for _ in range(5):
             conv(x, data.train_idx, data.train_et, data.train_range, _relu=True)
@@ -47,6 +50,15 @@ def main():
         b[:, 4].mean(), b[:, 4].sum() / blocks.sum(), b[:, 5].mean(), b[:, 5].sum() / max(units.sum(), 1), b[:, 6].mean()))
     e = lambda k: us(b[:, k].mean() - t0)
     print("epilogue (mean over waves): barrier passed + shares written {:.1f}; shares summed {:.1f}; contraction done {:.1f}; exit {:.1f}".format(e(8), e(9), e(10), e(3)))
+    # per workgroup (16 consecutive waves): when its slowest wave left the loop, and the epilogue's stages behind that
+    nw = len(b) // 16 * 16
+    g = b[:nw].reshape(-1, 16, b.shape[1])
+    loop_end = g[:, :, 2].max(1)
+    st = [us(g[:, :, k].max(1) - loop_end) for k in (8, 9, 10, 3)]
+    late = loop_end >= np.percentile(loop_end, 60)                 # the workgroups on the critical path (three rows)
+    for name, sel in (("all workgroups", np.ones(len(loop_end), bool)), ("the 40 % that leave the loop last", late)):
+        print("epilogue behind the workgroup's slowest wave, {}: loop end {:.1f} us; barrier + basis rows here {:.1f}; shares summed {:.1f}; "
+              "contraction done {:.1f}; exit {:.1f}".format(name, us(loop_end[sel].mean() - t0), *[x[sel].mean() for x in st]))
     cyc = b[:, 4] + b[:, 5] + b[:, 6]
     print("stamped cycles / loop time = {:.2f} GHz".format(cyc.sum() / (loop.sum() * 1e3)))
     A = np.stack([blocks, units, np.ones(len(b))], 1)
