@@ -331,7 +331,12 @@ template <int NT, int BT, int TERMS, bool XP>
 __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_set) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     typedef typename Acc<BT>::type acc_t;
-    constexpr int FIN = 16 * NT, BP = 16 * BT, KP = BP * FIN;                 // padded bases, entries of U per destination
+    constexpr int FIN = 16 * NT, BP = 16 * BT;                                 // padded bases
+    // U of a destination in LDS: feature 16 jn + c (= column NT c + jn) at (16 jn + c) * BPP, bases innermost, four pad
+    // floats per feature: the lanes c = 0..7 of a ds_write_b128 group are then BPP = 4 (mod 32) dwords apart - eight
+    // different bank quads.  (Feature NT c + jn at (NT c + jn) * BP put all eight on ONE quad: 64 instead of 8 cycles per
+    // store, 2.6 us of the epilogue.)
+    constexpr int BPP = BP + 4, KP = BPP * FIN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x;
@@ -399,6 +404,14 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     for (int d = 0; d < kMaxD; ++d) nd += my_dst[d] >= 0 ? 1 : 0;
     const uint32_t ranges = (uint32_t)my_dst[3];                               // first wave of rows 1 and 2 (eight bits each)
     if (tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
+    if (a.side.dst) {                                                          // concat slot 0, by the whole grid: its round
+        const int64_t total = a.side.rows * a.side.cols;                       // trip hides behind the table fill (it was the kernel's last act)
+        for (int64_t t = (int64_t)g * kThreads + tid; t < total; t += (int64_t)gridDim.x * kThreads) {
+            const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + cc];
+            a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
+        }
+    }
     // unit descriptors of this wave, 32 dwords each (block counts, the chunk's 32 source ids): lane L holds dword L of the
     // current page of two units, and of the page after it
     uint32_t descv = n_units ? *reinterpret_cast<const uint32_t*>(descp + (desc_b + lane4)) : 0u;
@@ -503,20 +516,23 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #ifdef GN_STAMPS
     const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // U_i = sum over the waves of row i of their shares, through LDS: part[wave][k'], k' = feature * BP + base (bases
-    // innermost: the eight values a lane holds of one feature, bases BT (4 kg + v) + jm, are 32 contiguous bytes)
+    // U_i = sum over the waves of row i of their shares, through LDS: part[wave][k'] (bases innermost: the eight values
+    // a lane holds of one feature, bases BT (4 kg + v) + jm, are 32 contiguous bytes)
     float* part = reinterpret_cast<float*>(lds);
     {
         float* dstp = part + (size_t)wave * KP;
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) {
-            float* q = dstp + (NT * c + jn) * BP + 4 * BT * kg;
+            float* q = dstp + (16 * jn + c) * BPP + 4 * BT * kg;
             if constexpr (BT == 2) {
                 *reinterpret_cast<f32x4*>(q) = (f32x4){acc[0][jn][0], acc[1][jn][0], acc[0][jn][1], acc[1][jn][1]};
                 *reinterpret_cast<f32x4*>(q + 4) = (f32x4){acc[0][jn][2], acc[1][jn][2], acc[0][jn][3], acc[1][jn][3]};
             } else {
                 *reinterpret_cast<f32x4*>(q) = acc[0][jn];
             }
+            // the feature's pad floats are zero: they are summed like the rest, and a thread without a row of basis in
+            // a pass (bv = 0) multiplies the LAST entry of U - a pad - by that zero
+            if (kg == 3) *reinterpret_cast<f32x4*>(q + 4 * BT) = (f32x4)(0.f);
         }
     }
     __syncthreads();
@@ -525,8 +541,16 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     for (int e = tid; e < nd * (KP / 4); e += kThreads) {
         const int d = e / (KP / 4), k4 = e - d * (KP / 4);
         const int w0 = d == 0 ? 0 : (d == 1 ? wb1 : wb2), w1 = d == 0 ? (nd > 1 ? wb1 : kWaves) : (d == 1 ? (nd > 2 ? wb2 : kWaves) : kWaves);
+        // a row has a third of the sixteen waves on average: its shares are requested four at a time (a loop that
+        // waited for every read before asking for the next paid an LDS round trip per wave), added in wave order
         f32x4 s = (f32x4)(0.f);
-        for (int ww = w0; ww < w1; ++ww) s += *reinterpret_cast<const f32x4*>(part + (size_t)ww * KP + 4 * k4);
+        for (int ww = w0; ww < w1; ww += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(part + (size_t)min(ww + i, w1 - 1) * KP + 4 * k4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += (ww + i < w1) ? v[i] : (f32x4)(0.f);
+        }
         *reinterpret_cast<f32x4*>(usum + (size_t)d * KP + 4 * k4) = s;
     }
     __syncthreads();
@@ -543,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         const int dbase = slices / FIN, dfeat = slices - dbase * FIN;
 #pragma unroll
         for (int j = 0; j < kRowsMax; ++j) {
-            const int k = min(feat * BP + base, KP - 1);
+            const int k = min((16 * (feat % NT) + feat / NT) * BPP + base, KP - 1);
             // (all three rows, whether the workgroup has them or not: what a missing row's slot of usum holds is never
             // stored, and without the branches the compiler keeps the sums where they are - with them it moved the
             // twelve accumulator registers around at every merge: 700 moves per thread, 3 us of the epilogue)
@@ -585,8 +609,19 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
             }
         }
         float s = 0.f;
-        if (lv)
-            for (int q = fin_part; q < slices; q += 8) s += red[((size_t)(q * kMaxD + pd) * og + (po >> 2)) * 4 + (po & 3)];
+        if (lv) {
+            // (up to 32 slices per lane at four outputs; requested sixteen at a time, added in slice order)
+            for (int q0 = fin_part; q0 < slices; q0 += 128) {
+                float rv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int q = min(q0 + 8 * i, slices - 1);
+                    rv[i] = red[((size_t)(q * kMaxD + pd) * og + (po >> 2)) * 4 + (po & 3)];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += (q0 + 8 * i < slices) ? rv[i] : 0.f;
+            }
+        }
         s += __shfl_xor(s, 1); t += __shfl_xor(t, 1);
         s += __shfl_xor(s, 2); t += __shfl_xor(t, 2);
         s += __shfl_xor(s, 4); t += __shfl_xor(t, 4);
@@ -596,14 +631,6 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
                 if (a.relu) s = fmaxf(s, 0.f);
             }
             a.out[(int64_t)pi * a.ld_out + po] = s;
-        }
-    }
-    if (a.side.dst) {                                                          // concat slot 0, by the whole grid
-        const int64_t total = a.side.rows * a.side.cols;
-        for (int64_t t = (int64_t)g * kThreads + tid; t < total; t += (int64_t)gridDim.x * kThreads) {
-            const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
-            const float v = a.side.src[i * a.side.ld_src + cc];
-            a.side.dst[i * a.side.ld_dst + cc] = a.side.mode ? fabsf(v) : v;
         }
     }
 #ifdef GN_STAMPS
@@ -1028,7 +1055,7 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     if (fin % 16 != 0 || fin < 16 || fin > 64 || bases < 1 || bases > 32 || fout % 4 != 0 || fout < 4 || fout > 64) return false;
     const int64_t nt = fin / 16, bt = (bases + 15) / 16;
     // the waves' shares of U in LDS: 8 waves x 3 rows x (16 bt x fin) floats, plus the slices' sums behind wave 0's
-    const int64_t kp = 16 * bt * fin;
+    const int64_t kp = (16 * bt + 4) * fin;                                    // (four pad floats per feature, see the kernel)
     const int64_t part = (int64_t)(kWaves + kMaxD) * kp * 4;                   // the waves' shares, the rows' sums
     const int64_t red = (int64_t)kThreads * kMaxD * 16;                        // the slices' sums reuse the shares' space
     const int64_t slices = kThreads / (fout / 4), per = (bases * fin + slices - 1) / slices;
