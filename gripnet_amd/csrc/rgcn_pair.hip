@@ -584,12 +584,15 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     // [slices][kMaxD][og][4] = 12,288 floats: over the waves' shares (dead) where those are at least that long; narrow
     // layers (KP < 768) keep them behind the rows' sums instead - there the shares are shorter than `red`, and a thread
     // that has finished its contraction would write into the sums other threads still read
-    constexpr bool kRedOverShares = kWaves * KP >= kThreads * kMaxD * 4;
+    // a slice's sums are four floats longer than they need to be: the eight lanes that fold one output read eight slices
+    // that far apart - 4 (mod 32) banks, so the 32 lanes of a read hit 32 banks (unpadded: eight addresses on every bank)
+    const int red_stride = kMaxD * og * 4 + 4;
+    constexpr bool kRedOverShares = kWaves * KP >= kThreads * kMaxD * 4 + kThreads * 4;
     float* red = kRedOverShares ? part : usum + (size_t)kMaxD * KP;
     if (sl < slices)
 #pragma unroll
         for (int d = 0; d < kMaxD; ++d)
-            if (d < nd) *reinterpret_cast<f32x4*>(red + ((size_t)(sl * kMaxD + d) * og + o4) * 4) = sum[d];
+            if (d < nd) *reinterpret_cast<f32x4*>(red + (size_t)sl * red_stride + ((size_t)d * og + o4) * 4) = sum[d];
     __syncthreads();
     // (destination, output) x eight partial sums over the slices, folded inside eight adjacent lanes: 128 pairs per pass
     // (three rows of up to 42 outputs are one pass; the values of the first pass were requested before the barriers)
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int q = min(q0 + 8 * i, slices - 1);
-                    rv[i] = red[((size_t)(q * kMaxD + pd) * og + (po >> 2)) * 4 + (po & 3)];
+                    rv[i] = red[(size_t)q * red_stride + ((size_t)pd * og + (po >> 2)) * 4 + (po & 3)];
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s += (q0 + 8 * i < slices) ? rv[i] : 0.f;
@@ -1057,9 +1060,9 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     // the waves' shares of U in LDS: 8 waves x 3 rows x (16 bt x fin) floats, plus the slices' sums behind wave 0's
     const int64_t kp = (16 * bt + 4) * fin;                                    // (four pad floats per feature, see the kernel)
     const int64_t part = (int64_t)(kWaves + kMaxD) * kp * 4;                   // the waves' shares, the rows' sums
-    const int64_t red = (int64_t)kThreads * kMaxD * 16;                        // the slices' sums reuse the shares' space
+    const int64_t red = (int64_t)kThreads * kMaxD * 16 + (int64_t)kThreads * 16;   // the slices' sums (padded) reuse the shares' space
     const int64_t slices = kThreads / (fout / 4), per = (bases * fin + slices - 1) / slices;
-    const int64_t need = (int64_t)kWaves * kp >= (int64_t)kThreads * kMaxD * 4 ? std::max(part, red) : part + red;   // (narrow layers: behind the sums)
+    const int64_t need = (int64_t)kWaves * kp >= (int64_t)kThreads * kMaxD * 4 + kThreads * 4 ? std::max(part, red) : part + red;   // (narrow layers: behind the sums)
     return need <= kLdsBytes && nt * bt <= 6 && per <= (nt <= 2 ? 16 : 12);   // (rows of basis a thread holds in registers)
 }
 
