@@ -613,16 +613,16 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         }
         float s = 0.f;
         if (lv) {
-            // (up to 32 slices per lane at four outputs; requested sixteen at a time, added in slice order)
-            for (int q0 = fin_part; q0 < slices; q0 += 128) {
-                float rv[16];
+            // (sixteen slices per lane at 32 outputs; requested eight at a time, added in slice order)
+            for (int q0 = fin_part; q0 < slices; q0 += 64) {
+                float rv[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < 8; ++i) {
                     const int q = min(q0 + 8 * i, slices - 1);
                     rv[i] = red[(size_t)q * red_stride + ((size_t)pd * og + (po >> 2)) * 4 + (po & 3)];
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s += (q0 + 8 * i < slices) ? rv[i] : 0.f;
+                for (int i = 0; i < 8; ++i) s += (q0 + 8 * i < slices) ? rv[i] : 0.f;
             }
         }
         s += __shfl_xor(s, 1); t += __shfl_xor(t, 1);

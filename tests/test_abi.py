@@ -68,3 +68,32 @@ def test_cache_protocol_is_keyed_by_edge_count_only():
     assert conv._plan(torch.zeros(2, 7, dtype=torch.long), lambda: None) is conv.cached_result
     conv.reset_parameters()
     assert conv.cached_result is None and conv.cached_num_edges is None
+
+
+def test_kernel_register_budgets():
+    """The occupancy the design counts on, read from the gfx950 code objects' metadata (no GPU): the destination-major
+    relational kernel runs sixteen waves per compute unit (four per SIMD: at most 128 registers, and its gather - written
+    in assembly on fixed physical registers v92-v119 - leaves no room for scratch traffic inside the loop), the row-class
+    decoder and the LDS-staged gene gather likewise.  A toolchain change that makes one of them spill fails here, not as
+    a silent slowdown."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from kernel_resources import kernel_resources
+    res = kernel_resources(_hip.library_path())
+    assert len(res) > 50, "no kernels found in the gfx950 code objects"
+    # the kernels of the headline step: no scratch at all
+    strict = ["k_rgcn_pair<3, 2, 3, true>", "k_rgcn_pair<3, 2, 3, false>", "k_rgcn_pair<3, 2, 2, false>", "k_distmult_class<5, 3>",
+              "k_distmult_class<3, 3>", "k_distmult_class<2, 2>", "k_col_gather<2>", "k_col_gather<1>", "k_col_transform<32, 1, 2>",
+              "k_col_transform<16, 1, 2>"]
+    for name in strict:
+        assert name in res, (name, sorted(k for k in res if "rgcn_pair" in k or "distmult_class" in k or "col_" in k))
+        r = res[name]
+        assert r[".vgpr_count"] + r.get(".agpr_count", 0) <= 128, (name, r)
+        assert r[".private_segment_fixed_size"] == 0, (name, r)
+        assert r[".vgpr_spill_count"] == 0 and r[".sgpr_spill_count"] == 0, (name, r)
+    # every instantiation of the destination-major kernel keeps four waves per SIMD (the narrow ones park up to sixteen
+    # rows of basis per thread in their epilogue and spill a few of them THERE, behind the unit loop)
+    for name, r in res.items():
+        if name.startswith("k_rgcn_pair<"):
+            assert r[".vgpr_count"] + r.get(".agpr_count", 0) <= 128, (name, r)
+            assert r[".private_segment_fixed_size"] <= 160, (name, r)

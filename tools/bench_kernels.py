@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--what", default="distmult,rgcn,gcn,full")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--shuffle-types", action="store_true", help="DistMult on a shuffled edge list (unsorted relation ids)")
+    ap.add_argument("--arith", default="fp32", choices=["fp32", "fast"], help="arithmetic of the relational layer")
+    ap.add_argument("--rgcn-kernel", default="auto", help="relational kernel (auto, pair, lds, general)")
     ap.add_argument("--flush", type=int, default=0, help="MB of unrelated data streamed between launches (cold L2, as inside the forward)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -76,6 +78,7 @@ def main():
             report("distmult E={}".format(E), us, E * 28 + n_d * 80 * 4 + R * 80 * 4)
         if "rgcn" in what:
             conv = model.dd.conv_list[0]
+            conv.arithmetic, conv.kernel = args.arith, args.rgcn_kernel
             x = z[:, :48].contiguous()
             out = torch.empty(n_d, 32, device=dev)
             us = timed(lambda: conv(x, data.train_idx, data.train_et, data.train_range, _out=out, _relu=True), args.iters)
