@@ -65,6 +65,95 @@ def algorithmic_bytes(data, n_dd_edges_local, n_dd_edges_global):
     }
 
 
+def nc_algorithmic_bytes(model, n_nodes_scored):
+    """Compulsory HBM bytes of one node-classification forward with the reference's data types (the same
+    model as the headline): per GCN-style layer E' x 20 + N x 4 x (F_in + F_out) (the transform fused, tables once), the
+    external layers E x 20 + source table + target rows, the three-way merge of freebase-c, the class decoder's gathered
+    rows.  Read off the modules and their cached plans after a forward.  Returns (total, per entry-point tag)."""
+    from gripnet_amd.layers import homoGraph, interGraph
+    from gripnet_amd.decoder import multiClassInnerProductDecoder
+    per = {}
+
+    def add(tag, b):
+        per[tag] = per.get(tag, 0) + int(b)
+    for m in model.modules():
+        if isinstance(m, homoGraph) and not m.multi_relational:
+            for conv in m.conv_list:
+                plan = conv.cached_result
+                add("gn_graph_aggregate_f32[gcn]", plan.nnz * 20 + plan.n_rows * 4 * (conv.in_channels + conv.out_channels))
+        elif isinstance(m, interGraph):
+            plan = m.conv.cached_result
+            tgt = m.target_dim + (2 * m.target_feat_dim if m.if_one_external else 0)
+            add("gn_graph_aggregate_f32[bipartite]", plan.nnz * 20 + plan.n_table * m.source_dim * 4 + plan.n_rows * tgt * 4)
+        elif isinstance(m, multiClassInnerProductDecoder):
+            add("gn_class_scores_f32", n_nodes_scored * (8 + 4 * m.in_dim + 4 * m.num_class) + 4 * m.in_dim * m.num_class)
+    if hasattr(model, "aa_embeddings"):                          # (z + z1 + aa_embeddings) / 3, GripNet-freebase-c.py:159
+        add("gn_merge_f32", 4 * model.aa_embeddings.numel() * 4)
+    return sum(per.values()), per
+
+
+def train_step_entry(dev, steps=20):
+    """One full training step of the PoSE model on pose0-syn (forward, both decoder calls, loss, backward, Adam: the loop
+    body of GripNet-pose.py:112-146) as ONE hipGraph replay per step, with new negative pairs drawn on the device before
+    every replay (gn_negative_sampler_sample_packed into the buffer the captured step scores)."""
+    from gripnet_amd import _hip
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.synth import make_pose
+    from gripnet_amd.utils import EPS
+    data = make_pose("pose0-syn").to(dev)
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=True)
+    sampler = _hip.NegativeSampler(data.train_idx, data.n_d_node, data.train_range)
+    neg = sampler.sample(seed=0)
+    drawn = [1]
+
+    def resample():
+        sampler.sample(seed=drawn[0], out=neg)
+        drawn[0] += 1
+
+    def step():
+        opt.zero_grad()
+        z = model.encode(data)
+        pos = model.dmt(z, data.train_idx, data.train_et)
+        negs = model.dmt(z, neg, data.train_et)
+        loss = -torch.log(pos + EPS).mean() - torch.log(1 - negs + EPS).mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):                                     # plans, relation-order check, optimizer state
+            resample()
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    resample()
+    with torch.cuda.graph(graph):
+        loss = step()
+    losses = []
+    for _ in range(3):
+        resample()
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        resample()
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    losses.append(float(loss))
+    _hip.raise_if_index_errors(dev)
+    return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
+            "what": "forward + DistMult on positives and on fresh negatives + loss + backward + fused Adam, one hipGraph replay per step; "
+                    "the negatives of every step are drawn on the device (typed sampler, 32 us) in front of the replay",
+            "loss_after": round(losses[-1], 5)}
+
+
 def extra_workloads(dev, budget_s, with_cpu):
     """The other BASELINE.json configs on one GPU, each with the same event timing as the headline and a CPU-oracle time:
     pose2-syn (config 4's graph, unsharded), aminer-syn (config 3), freebase-c-syn (config 5, fp32 storage)."""
@@ -121,7 +210,9 @@ def extra_workloads(dev, budget_s, with_cpu):
             torch.cuda.empty_cache()
         # ---- the node-classification models (configs 3 and 5) ----
         from oracle import gripnet_oracle as orc
-        for name, cls in (("aminer-syn", AminerModel), ("freebase-c-syn", FreebaseCModel)):
+        from gripnet_amd.utils import set_table_storage
+        for name, cls, storage in (("aminer-syn", AminerModel, "fp32"), ("freebase-c-syn", FreebaseCModel, "fp32"),
+                                   ("freebase-c-syn, bf16 table storage", FreebaseCModel, "bf16")):
             if left() < 15:
                 break
             data_cpu = make_nc("aminer-syn")             # the NC ladder shares one synthetic scale
@@ -131,9 +222,12 @@ def extra_workloads(dev, budget_s, with_cpu):
             sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
             nodes = torch.arange(0, data_cpu.n_a_node, 3)
             model = model.to(dev)
+            if storage == "bf16":                       # BASELINE config 5 as written: gathered tables rounded to bf16, fp32 sums
+                set_table_storage(model, "bf16")
             data = Data(**data_cpu.__dict__).to(dev)
             nodes_dev = nodes.to(dev)
             wall, calls, busy = timed(lambda: model(data, nodes_dev), 10)
+            alg_total, alg_per = nc_algorithmic_bytes(model, int(nodes.numel()))
             dom = max(calls, key=calls.get)
             # the same forward as ONE hipGraph replay: what the device needs without the Python loop between the launches
             from gripnet_amd.pipeline import Graphed
@@ -147,13 +241,19 @@ def extra_workloads(dev, budget_s, with_cpu):
             torch.cuda.synchronize()
             graph_us = 1e6 * (time.perf_counter() - t1) / 20
             del replay
-            entry = {"workload": name, "forward_us": round(graph_us, 1), "forward_us_entry_points": round(busy, 1),
+            dom_bytes = alg_per.get(dom)
+            dom_calls = {"gn_graph_aggregate_f32[gcn]": sum(len(m.conv_list) for m in model.modules() if hasattr(m, "conv_list")),
+                         "gn_graph_aggregate_f32[bipartite]": sum(1 for m in model.modules() if hasattr(m, "if_one_external"))}.get(dom, 1)
+            entry = {"workload": name, "table_storage": storage, "forward_us": round(graph_us, 1), "forward_us_entry_points": round(busy, 1),
                      "forward_us_eager_wall": round(1e6 * wall, 1),
+                     "algorithmic_bytes": alg_total, "frac": round(alg_total / (graph_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "forward_us: one hipGraph replay per forward, wall clock over 20 replays; forward_us_entry_points: sum of the "
                              "HIP-event timed entry points of one eager forward (each pays its events); the wall time of the eager "
                              "Python loop is host-bound",
-                     "dominant_entry_point": {"name": dom, "us_per_call": round(calls[dom], 1)}}
-            if with_cpu and left() > 10:
+                     "dominant_entry_point": {"name": dom, "us_per_call": round(calls[dom], 1),
+                                              "algorithmic_bytes_per_call": None if dom_bytes is None else dom_bytes // max(dom_calls, 1),
+                                              "frac": None if dom_bytes is None else round(dom_bytes / max(dom_calls, 1) / (calls[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+            if with_cpu and storage == "fp32" and left() > 10:
                 d = data_cpu
                 t1 = time.perf_counter()
                 if cls is AminerModel:
@@ -166,6 +266,9 @@ def extra_workloads(dev, budget_s, with_cpu):
             out.append(entry)
             del model, data
             torch.cuda.empty_cache()
+    if left() > 10:
+        out.append(train_step_entry(dev))
+        torch.cuda.empty_cache()
     return out
 
 
@@ -347,6 +450,15 @@ def main():
                 z, score = step()
         fence()
         elapsed = time.perf_counter() - t0
+        # two more repeats of the same K steps, for the spread only (`value` and `ms_per_step` are the region above)
+        repeats = [elapsed]
+        for _ in range(2):
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            repeats.append(time.perf_counter() - t1)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -355,13 +467,17 @@ def main():
 
     A = pose_edges_aggregated(data)                    # replicated gg/gd counted once, dd over all ranks
     ms_per_step = 1e3 * elapsed / args.steps
+    rep_ms = sorted(1e3 * r / args.steps for r in repeats)
+    spread = {"ms_per_step_min": round(rep_ms[0], 5), "ms_per_step_median": round(rep_ms[len(rep_ms) // 2], 5),
+              "ms_per_step_max": round(rep_ms[-1], 5), "repeats": len(rep_ms),
+              "note": "K steps each, rank-local clocks; the first repeat is the timed region `value` is computed from"}
     value = A * args.steps / elapsed
 
     # ---- roofline of the dominant entry point (HIP events on its stream, inside the timed region) ----
     alg = algorithmic_bytes(data, hi - lo, E_dd)
     stage_bytes = {"gn_distmult_forward_f32": alg["dmt"], "gn_distmult_plan_forward_f32": alg["dmt"],
                    "gn_rgcn_forward_f32": alg["dd"], "gn_graph_aggregate_f32[gcn]": alg["gg"] // 2,      # per gene layer
-                   "gn_graph_aggregate_f32[bipartite+weights]": alg["gd"], "gn_graph_aggregate_f32[bipartite]": alg["gd"]}
+                   "gn_graph_aggregate_f32[bipartite]": alg["gd"]}
     calls, total_ms = timer.summary()[dom]
     dom_us = 1e3 * total_ms / calls
     achieved = stage_bytes[dom] / (dom_us * 1e-6) / 1e9
@@ -397,9 +513,9 @@ def main():
     roofline_fast = None
     if fast_call.get("gn_rgcn_forward_f32"):
         roofline_fast = line("gn_rgcn_forward_f32", fast_call["gn_rgcn_forward_f32"])
-        roofline_fast["note"] = ("arithmetic 'fast' (GN_RGCN_ARITH_FAST): two-term bf16 splits, <= 2^-16 per product, relation-major "
-                                 "kernel + finalisation, its W_r computed inside the external layer's launch; the eager step with it "
-                                 "takes {:.1f} us of entry points against {:.1f}".format(sum(fast_breakdown.values()), sum(breakdown.values())))
+        roofline_fast["note"] = ("arithmetic 'fast' (GN_RGCN_ARITH_FAST): the same destination-major kernel on two-term bf16 splits "
+                                 "(three products instead of six, <= 2^-16 per product); the eager step with it takes {:.1f} us of entry "
+                                 "points against {:.1f}".format(sum(fast_breakdown.values()), sum(breakdown.values())))
 
     result = {
         "metric": "edges aggregated/sec, GripNet forward on pose-0", "value": value, "unit": "edges/s",
@@ -420,6 +536,7 @@ def main():
                                "hipGraph replay of every stage but {}, which is launched and HIP-event timed from Python".format(dom))
                               if sharded is None else
                               "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
+        "spread": spread,
         "roofline": roofline,
         "roofline_fast": roofline_fast,
         "roofline_all": roofline_all,

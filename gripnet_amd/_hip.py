@@ -19,9 +19,9 @@ _lib = None
 _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
-GN_RGCN_PARTIAL, GN_RGCN_WEIGHTS_READY, GN_RGCN_ARITH_FAST = 1, 2, 4          # flags of gn_rgcn_forward_f32
+GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST = 1, 4                                  # flags of gn_rgcn_forward_f32
 GN_RGCN_PATH_SHIFT = 8
-RGCN_PATHS = {"auto": 0, "pair": 1, "acc": 2, "lds": 3, "general": 4}       # kernel choice (tests, measurements)
+RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
 ABI_VERSION = 130                                       # GN_VERSION of include/gripnet_hip.h this module binds
@@ -55,13 +55,10 @@ SIGNATURES = {
     "gn_rgcn_plan_create": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_rgcn_plan_destroy": (None, [_p]),
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
-    "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
-    "gn_rgcn_weights_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _int, _p, _sz, _p]),
+    "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64, _int]),
     "gn_rgcn_forward_path": (_int, [_p, _i64, _i64, _i64, _int]),
     "gn_cast_bf16": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "gn_graph_aggregate_bf16": (_int, [_p, _p, _i64, _i64, _p, _int, _p, _i64, _p, _p]),
-    "gn_graph_aggregate_with_rgcn_weights_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _int, _p, _i64, _p,
-                                                         _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
     "gn_rgcn_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _int, _int, _p, _i64, _p, _p, _p, _sz, _p]),
     "gn_rgcn_finalize_f32": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "gn_distmult_forward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
@@ -466,25 +463,15 @@ class GraphPlan:
     def __iter__(self):          # lets `edge_index, norm = conv.cached_result` keep working
         return iter(self.export())
 
-    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None, cowork=None,
-                  planes=None):
+    def aggregate(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None, weight=None, planes=None):
         """out = act(A_norm xw + b), or with `weight` act((A_norm xw) weight + b) (xw is then the layer input).
-        `cowork` = (RgcnPlan, basis, att): the relational weights of a later layer are computed by the same launch
-        (gn_graph_aggregate_with_rgcn_weights_f32).  `planes` = (SplitPlanes, col_main, col_side): the launch also
-        leaves the bf16 split planes of its output and of its side copy."""
+        `planes` = (SplitPlanes, col_main, col_side): the launch also leaves the bf16 split planes of its output and of
+        its side copy."""
         sc = side_copy(side)
         pd = None
         if planes is not None:
             pd = planes[0].desc(planes[1], planes[2])
             planes[0].generation += 1
-        if cowork is not None and weight is not None:
-            rplan, basis, att = cowork
-            ws, need = rplan._workspace(basis.shape[1], basis.shape[2], basis.shape[0])
-            _call("gn_graph_aggregate_with_rgcn_weights_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
-                  weight.shape[1], ptr(bias), int(bool(relu)), ptr(out), ld(out), _ref(sc),
-                  rplan._h, basis.shape[1], ptr(basis), ptr(att), basis.shape[0], basis.shape[2], ptr(ws), need,
-                  stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}+weights]".format(self.kind))
-            return out
         _call("gn_graph_aggregate_f32", self._h, ptr(xw), ld(xw), xw.shape[1], ptr(weight),
               0 if weight is None else weight.shape[1], ptr(bias), int(bool(relu)),
               ptr(out), ld(out), _ref(sc), _ref(pd), stream_ptr(xw.device), tag="gn_graph_aggregate_f32[{}]".format(self.kind))
@@ -553,15 +540,15 @@ class RgcnPlan:
             self._grad = (rev, pairs, deg.clamp_(min=1.0))
         return self._grad
 
-    def _workspace(self, fin, fout, bases):
-        need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases))
+    def _workspace(self, fin, fout, bases, flags=0):
+        need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases, flags))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
         return self._ws, need
 
     @staticmethod
     def mode_flags(fast=False, path="auto"):
-        """Arithmetic and kernel-choice bits of gn_rgcn_forward_f32 / gn_rgcn_weights_f32."""
+        """Arithmetic and kernel-choice bits of gn_rgcn_forward_f32."""
         return (GN_RGCN_ARITH_FAST if fast else 0) | (RGCN_PATHS[path] << GN_RGCN_PATH_SHIFT)
 
     def path(self, fin, fout, bases, fast=False, path="auto"):
@@ -569,23 +556,13 @@ class RgcnPlan:
         code = int(load().gn_rgcn_forward_path(self._h, fin, fout, bases, self.mode_flags(fast, path)))
         return {v: k for k, v in RGCN_PATHS.items()}.get(code, "?")
 
-    def needs_weights(self, fin, fout, bases, fast=False, path="auto"):
-        """Does the kernel behind these flags read W_r from the workspace (gn_rgcn_weights_f32)?"""
-        return self.path(fin, fout, bases, fast, path) != "pair"
-
-    def weights(self, basis, att, fast=False, path="auto"):
-        """W_r = sum_b att[r,b] basis[b] into the plan's workspace, on the current stream (gn_rgcn_weights_f32)."""
-        ws, need = self._workspace(basis.shape[1], basis.shape[2], basis.shape[0])
-        _call("gn_rgcn_weights_f32", self._h, basis.shape[1], ptr(basis), ptr(att), basis.shape[0], basis.shape[2],
-              self.mode_flags(fast, path), ptr(ws), need, stream_ptr(basis.device))
-
-    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, weights_ready=False, fast=False,
-                path="auto", x_planes=None):
+    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, fast=False, path="auto", x_planes=None):
         """`x_planes`: SplitPlanes of x left by its producer (the destination-major kernel then skips its own split of x;
         the other kernels ignore them)."""
-        ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0])
+        mode = self.mode_flags(fast, path)
+        ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0], mode)
         sc = side_copy(side)
-        flags = (GN_RGCN_PARTIAL if partial else 0) | (GN_RGCN_WEIGHTS_READY if weights_ready else 0) | self.mode_flags(fast, path)
+        flags = (GN_RGCN_PARTIAL if partial else 0) | mode
         _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
               ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), flags,
               ptr(out), ld(out), _ref(sc), None if x_planes is None else x_planes.buf.data_ptr(), ptr(ws), need,
@@ -809,14 +786,21 @@ class NegativeSampler:
                                                  stream_ptr(ei.device), C.byref(h)))
         self._h, self.device, self.num_edges, self.num_nodes = h, ei.device, e, int(num_nodes)
 
-    def sample(self, seed: int = 0) -> torch.Tensor:
+    def sample(self, seed: int = 0, out=None) -> torch.Tensor:
         """[2, E] int64 negative pairs.  For graphs of up to 65,535 nodes the same launch also leaves every pair as one
         32-bit word; it travels with the returned tensor (`_gn_packed`) and the decoder scores the list from it - 6
         instead of 24 bytes per edge - as long as the tensor is not modified."""
-        out = torch.empty((2, self.num_edges), dtype=torch.int64, device=self.device)
+        if out is None:
+            out = torch.empty((2, self.num_edges), dtype=torch.int64, device=self.device)
+        elif tuple(out.shape) != (2, self.num_edges) or out.dtype != torch.int64 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("`out` must be a contiguous [2, {}] int64 tensor on {}".format(self.num_edges, self.device))
+        else:
+            out._gn_volatile = True          # refilled behind torch's back (`_version` does not move): never a static list
         base = out.data_ptr()
         if self.num_nodes <= 65535 and self.num_edges > 0:
-            packed = torch.empty((self.num_edges,), dtype=torch.int32, device=self.device)
+            # (a refilled `out` keeps its packed words' buffer: a captured step that scores `out` replays on the new draw)
+            held = getattr(out, "_gn_packed", None)
+            packed = held[0] if held is not None else torch.empty((self.num_edges,), dtype=torch.int32, device=self.device)
             _call("gn_negative_sampler_sample_packed", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, base, base + 8 * self.num_edges,
                   ptr(packed), ptr(error_flag(self.device)), stream_ptr(self.device))
             out._gn_packed = (packed, out._version)

@@ -182,14 +182,6 @@ struct gn_rgcn_plan {
     size_t fast_lds_bytes = 0;
     int fast_cols = 32;             // output columns per workgroup of the LDS-resident kernel (32, or 16 = column halves)
     int fast_ok = 0;
-    // register-accumulated path (rgcn_acc.hip): per-wave unit lists and edge streams
-    gn::DevBuf<uint32_t> acc_stream;      // 128-byte blocks: 4 iterations x 16 rows of uint16 source ids
-    gn::DevBuf<int32_t> acc_units;        // 16-byte unit descriptors in wave order
-    gn::DevBuf<int32_t> acc_wave_units;   // [waves + 1] ranges into acc_units
-    gn::DevBuf<uint32_t> acc_wave_stream; // [waves] first stream block of every wave
-    int acc_tiles = 0, acc_q = 0, acc_g = 0;
-    int64_t acc_blocks = 0;
-    int acc_ok = 0;
     // destination-major path (rgcn_pair.hip): a workgroup owns up to three destination rows outright; per wave one
     // flat stream of 64-byte blocks (4 lane groups x 4 edges, each a 32-bit LDS byte offset of a relation's att row)
     gn::DevBuf<uint32_t> pair_stream;     // blocks of 16 words

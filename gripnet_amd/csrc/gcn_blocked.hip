@@ -29,7 +29,6 @@
 // launch took 3.8 + 11.2 + 5.5 us per layer - the 10 MB of partial sums are flushed at one kernel boundary and read back
 // behind the next - against 19.2 / 14.7 us for the wave-per-row kernels.)
 #include "aggregate.cuh"
-#include "rgcn_weights.cuh"
 
 #include <algorithm>
 #include <numeric>
@@ -37,8 +36,8 @@
 
 namespace {
 
-using gn_rw::f32x4;
-using gn_rw::u32x2;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef GN_COL_THREADS

@@ -7,7 +7,6 @@
 // element j  <->  k = 4q + j) identically for A and B, which lets A be read with one 16-byte
 // load per lane instead of four strided dwords.
 #include "common.h"
-#include "rgcn_weights.cuh"
 
 namespace {
 

@@ -376,11 +376,9 @@ __global__ void k_rel_keys(const int64_t* __restrict__ src, const int64_t* __res
 gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
                                       const std::vector<int64_t>& ranges_host, hipStream_t st);
 
-// Implemented in rgcn_acc.hip: per-wave unit lists for the register-accumulated path.
+// Implemented in rgcn_pair.hip: per-workgroup destination rows and per-wave streams of the destination-major path.
 gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
                                   const std::vector<int64_t>& ranges, hipStream_t st);
-gn_status gn_rgcn_build_acc_plan(gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst,
-                                 const std::vector<int64_t>& ranges_host, hipStream_t st);
 
 extern "C" {
 
@@ -571,8 +569,6 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
     for (int64_t i = 0; i < N; ++i) p->max_row_nnz = std::max<int64_t>(p->max_row_nnz, rp[i + 1] - rp[i]);
     gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
     if (fs != GN_OK) return bail(fs);
-    fs = gn_rgcn_build_acc_plan(p, src, dst, ranges, st);
-    if (fs != GN_OK) return bail(fs);
     fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
     if (fs != GN_OK) return bail(fs);
 #undef GN_TRY
@@ -597,10 +593,6 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->pair_wave_units.release();
     p->pair_wave_desc.release();
     p->pair_wg_dst.release();
-    p->acc_stream.release();
-    p->acc_units.release();
-    p->acc_wave_units.release();
-    p->acc_wave_stream.release();
     delete p;
 }
 

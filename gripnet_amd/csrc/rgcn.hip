@@ -10,11 +10,9 @@
 // rgcn_fast.hip
 bool gn_rgcn_fast_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
 size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
-gn_status gn_rgcn_fast_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
-                               int64_t bases, int64_t fout, void* ws, hipStream_t st);
 gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                                const float* basis, const float* att, int64_t bases, const float* root,
-                               const float* bias, int64_t fout, int relu, int partial, int weights_ready, float* out,
+                               const float* bias, int64_t fout, int relu, int partial, float* out,
                                int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
 // rgcn_pair.hip
@@ -23,16 +21,6 @@ gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
                                const void* x_planes, hipStream_t st);
-
-// rgcn_acc.hip
-bool gn_rgcn_acc_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
-size_t gn_rgcn_acc_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
-gn_status gn_rgcn_acc_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
-                              int64_t bases, int64_t fout, void* ws, int exact, hipStream_t st);
-gn_status gn_rgcn_acc_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
-                              const float* basis, const float* att, int64_t bases, const float* root,
-                              const float* bias, int64_t fout, int relu, int partial, int weights_ready, int exact, float* out,
-                              int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st);
 
 bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed);
 gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, const float* x, int64_t ld_x, int64_t fin,
@@ -43,18 +31,16 @@ namespace {
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 
-// Which kernel serves these shapes under these flags (GN_RGCN_PATH_*).  Default arithmetic is fp32-faithful: the
-// destination-major kernel (three-term bf16 splits), else the LDS-resident / general kernels on the fp32 matrix
-// instruction.  GN_RGCN_ARITH_FAST prefers the register-accumulated kernel on two-term splits.
+// Which kernel serves these shapes under these flags (GN_RGCN_PATH_*): the destination-major kernel (three-term bf16
+// splits by default, two-term under GN_RGCN_ARITH_FAST), else the LDS-accumulator / general kernels on the fp32 matrix
+// instruction.  A forced kernel that does not cover the shapes is not taken.
 int select_path(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int flags, const void* basis) {
     const int forced = (flags >> GN_RGCN_PATH_SHIFT) & 7;
     const bool pair_ok = gn_rgcn_pair_applicable(plan, fin, fout, bases) && (reinterpret_cast<uintptr_t>(basis) & 15) == 0;
-    const bool acc_ok = gn_rgcn_acc_applicable(plan, fin, fout, bases), lds_ok = gn_rgcn_fast_applicable(plan, fin, fout, bases);
+    const bool lds_ok = gn_rgcn_fast_applicable(plan, fin, fout, bases);
     if (forced == GN_RGCN_PATH_PAIR && pair_ok) return GN_RGCN_PATH_PAIR;
-    if (forced == GN_RGCN_PATH_ACC && acc_ok) return GN_RGCN_PATH_ACC;
     if (forced == GN_RGCN_PATH_LDS && lds_ok) return GN_RGCN_PATH_LDS;
     if (forced == GN_RGCN_PATH_GENERAL) return GN_RGCN_PATH_GENERAL;
-    if ((flags & GN_RGCN_ARITH_FAST) && acc_ok) return GN_RGCN_PATH_ACC;
     if (pair_ok) return GN_RGCN_PATH_PAIR;
     if (lds_ok) return GN_RGCN_PATH_LDS;
     return GN_RGCN_PATH_GENERAL;
@@ -98,14 +84,18 @@ __global__ void k_rgcn_finalize(const float* __restrict__ summed, int64_t ld_s, 
 
 extern "C" {
 
-size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
-    if (!plan || fin <= 0 || fout <= 0) return 0;
-    // enough for whichever kernel a later call selects (the destination-major kernel needs none)
-    size_t need = 0;
-    if (gn_rgcn_acc_applicable(plan, fin, fout, bases)) need = std::max(need, gn_rgcn_acc_workspace_bytes(plan, fin, fout, bases));
-    if (gn_rgcn_fast_applicable(plan, fin, fout, bases)) need = std::max(need, gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases));
-    if (need == 0 || !gn_rgcn_pair_applicable(plan, fin, fout, bases)) need = std::max(need, general_layout(plan, fin, fout).total);
-    return need;
+// Scratch of ONE kernel for these shapes: what a call that takes `path` writes.
+static size_t path_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int path) {
+    if (path == GN_RGCN_PATH_PAIR) return 0;
+    if (path == GN_RGCN_PATH_LDS) return gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases);
+    return general_layout(plan, fin, fout).total;
+}
+
+size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int flags) {
+    if (!plan || fin <= 0 || fout <= 0 || bases <= 0) return 0;
+    // of the kernel a forward with these flags takes when its `basis` is 16-byte aligned (torch allocations are); a
+    // call that ends up on another kernel - an unaligned basis - is refused with the size it needs, never under-served
+    return path_workspace_bytes(plan, fin, fout, bases, select_path(plan, fin, fout, bases, flags, nullptr));
 }
 
 int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int flags) {
@@ -113,54 +103,35 @@ int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, in
     return select_path(plan, fin, fout, bases, flags, nullptr);
 }
 
-gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att, int64_t bases,
-                              int64_t fout, int flags, void* workspace, size_t workspace_bytes, void* stream) {
-    GN_REQUIRE(plan != nullptr, "plan is null");
-    GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
-    if (plan->num_nodes == 0 || plan->num_relations == 0) return GN_OK;
-    GN_REQUIRE(basis && att, "operand pointer is null");
-    GN_REQUIRE(workspace_bytes >= gn_rgcn_workspace_bytes(plan, fin, fout, bases) && workspace,
-               "workspace too small: need %zu bytes", gn_rgcn_workspace_bytes(plan, fin, fout, bases));
-    hipStream_t st = gn::as_stream(stream);
-    const int path = select_path(plan, fin, fout, bases, flags, basis);
-    if (path == GN_RGCN_PATH_PAIR) return GN_OK;                                  // W_r is never formed there
-    if (path == GN_RGCN_PATH_ACC) return gn_rgcn_acc_weights(plan, fin, basis, att, bases, fout, workspace, !(flags & GN_RGCN_ARITH_FAST), st);
-    if (path == GN_RGCN_PATH_LDS) return gn_rgcn_fast_weights(plan, fin, basis, att, bases, fout, workspace, st);
-    // general path, K7: W[R, fin*fout] = att[R,B] @ basis[B, fin*fout]   (layers.py:172-173)
-    float* W = reinterpret_cast<float*>(static_cast<char*>(workspace) + general_layout(plan, fin, fout).w_off);
-    return gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, plan->num_relations, fin * fout,
-                       bases, 1, nullptr, 0, stream);
-}
-
 gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                               const float* basis, const float* att, int64_t bases, const float* root,
                               const float* bias, int64_t fout, int relu, int flags, float* out, int64_t ld_out,
                               const gn_side_copy* side, const void* x_planes, void* workspace, size_t workspace_bytes,
                               void* stream) {
-    const int partial = flags & GN_RGCN_PARTIAL, weights_ready = (flags & GN_RGCN_WEIGHTS_READY) ? 1 : 0;
+    const int partial = flags & GN_RGCN_PARTIAL;
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
     if (N == 0) return GN_OK;
     GN_REQUIRE(x && basis && att && out && (partial || root), "operand pointer is null");
     GN_REQUIRE(ld_x >= fin && ld_out >= fout, "leading dimension smaller than the row length");
-    GN_REQUIRE((select_path(plan, fin, fout, bases, flags, basis) == GN_RGCN_PATH_PAIR) ||
-                   (workspace_bytes >= gn_rgcn_workspace_bytes(plan, fin, fout, bases) && (workspace || workspace_bytes == 0)),
-               "workspace too small: need %zu bytes", gn_rgcn_workspace_bytes(plan, fin, fout, bases));
+    // the workspace is checked against the kernel THIS call takes (a forced general path, or a basis pointer the
+    // destination-major kernel cannot use, needs the [R, N, out] table whatever gn_rgcn_workspace_bytes said for the
+    // default choice)
+    const int path = select_path(plan, fin, fout, bases, flags, basis);
+    const size_t need = path_workspace_bytes(plan, fin, fout, bases, path);
+    GN_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "workspace too small: this call needs %zu bytes, got %zu",
+               need, workspace_bytes);
     hipStream_t st = gn::as_stream(stream);
     gn_side_copy sc;
     gn_status ss = gn::check_side(side, N, &sc);
     if (ss != GN_OK) return ss;
 
-    const int path = select_path(plan, fin, fout, bases, flags, basis);
     if (path == GN_RGCN_PATH_PAIR)
         return gn_rgcn_pair_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
                                     flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, x_planes, st);
-    if (path == GN_RGCN_PATH_ACC)
-        return gn_rgcn_acc_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, weights_ready,
-                                   !(flags & GN_RGCN_ARITH_FAST), out, ld_out, sc, workspace, workspace_bytes, st);
     if (path == GN_RGCN_PATH_LDS)
-        return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial, weights_ready,
+        return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
                                     out, ld_out, sc, workspace, workspace_bytes, st);
 
     const GeneralWs l = general_layout(plan, fin, fout);
@@ -171,8 +142,7 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     gn_status s;
     if (R > 0) {
         // K7: W[R, fin*fout] = att[R,B] @ basis[B, fin*fout]   (layers.py:172-173)
-        s = weights_ready ? GN_OK : gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, R,
-                                                fin * fout, bases, 1, nullptr, 0, stream);
+        s = gn_gemm_f32(att, bases, 0, nullptr, 0, basis, fin * fout, 0, W, fin * fout, 0, R, fin * fout, bases, 1, nullptr, 0, stream);
         if (s != GN_OK) return s;
         // H[r] = X @ W[r] for all relations; grid.z carries the relation, in slabs of 32768
         for (int64_t r0 = 0; r0 < R; r0 += 32768) {

@@ -867,19 +867,6 @@ gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, c
     return GN_OK;
 }
 
-// Slab reduction + epilogue for the other relational kernels (rgcn_acc.hip): slabs are [n][groups][32].
-gn_status gn_rgcn_slab_finalize_launch(const gn_rgcn_plan* plan, const float* slabs, int groups, const float* x,
-                                       int64_t ld_x, int64_t fin, const float* root, const float* bias, int relu,
-                                       int partial, float* out, int64_t ld_out, const gn_side_copy& side, hipStream_t st) {
-    FinArgs f;
-    f.slabs = slabs; f.groups = groups; f.n = (int)plan->num_nodes; f.indeg = plan->indeg.p; f.x = x; f.ld_x = ld_x;
-    f.fin = (int)fin; f.root = root; f.bias = bias; f.relu = relu; f.partial = partial; f.out = out; f.ld_out = ld_out;
-    f.side = side;
-    k_rgcn_slab_finalize<<<(int)plan->num_nodes, 256, 0, st>>>(f);
-    GN_LAUNCH_CHECK();
-    return GN_OK;
-}
-
 bool gn_rgcn_fast_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     if (!plan->fast_ok || gn::fast_paths_disabled()) return false;
     return fout == kFout && (fin == 16 || fin == 32 || fin == 48 || fin == 64) && bases >= 1;
@@ -890,8 +877,8 @@ size_t gn_rgcn_fast_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64
     return w + (size_t)plan->fast_groups * plan->num_nodes * fout * sizeof(float);
 }
 
-gn_status gn_rgcn_fast_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
-                               int64_t bases, int64_t fout, void* ws, hipStream_t st) {
+static gn_status gn_rgcn_fast_weights(const gn_rgcn_plan* plan, int64_t fin, const float* basis, const float* att,
+                                      int64_t bases, int64_t fout, void* ws, hipStream_t st) {
     GN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
     // K7: W_r = sum_b att[r,b] basis[b], stored transposed per relation   (layers.py:172-173)
     WtArgs wa;
@@ -905,7 +892,7 @@ gn_status gn_rgcn_fast_weights(const gn_rgcn_plan* plan, int64_t fin, const floa
 
 gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin,
                                const float* basis, const float* att, int64_t bases, const float* root,
-                               const float* bias, int64_t fout, int relu, int partial, int weights_ready, float* out,
+                               const float* bias, int64_t fout, int relu, int partial, float* out,
                                int64_t ld_out, const gn_side_copy& side, void* ws, size_t ws_bytes, hipStream_t st) {
     GN_REQUIRE(ld_x % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld_x %% 4 == 0");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
@@ -913,7 +900,7 @@ gn_status gn_rgcn_fast_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     float* Wt = static_cast<float*>(ws);
     const size_t w_bytes = ((size_t)R * fin * fout * sizeof(float) + 255) & ~size_t(255);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + w_bytes);
-    if (!weights_ready) {
+    {
         gn_status ws_status = gn_rgcn_fast_weights(plan, fin, basis, att, bases, fout, ws, st);
         if (ws_status != GN_OK) return ws_status;
     }

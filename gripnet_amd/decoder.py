@@ -105,6 +105,8 @@ class multiRelaInnerProductDecoder(Module):
         Writes that bypass torch (raw pointers, another library) do not move `_version`: such callers either switch
         `auto_static` off (and do not register the buffer), or set `verify_static` and get a RuntimeError instead of
         stale scores."""
+        if getattr(edge_index, "_gn_volatile", False):        # a buffer the device-side sampler refills in place
+            return None
         key = (edge_index._version, edge_type._version)
         entry = self._find(edge_index, edge_type)
         capturing = torch.cuda.is_current_stream_capturing()

@@ -78,7 +78,7 @@ class myGCN(Module):
             self.cached_result = build()
         return self.cached_result
 
-    def _run(self, plan, x, n_out, out, relu, side, cowork=None, planes=None):
+    def _run(self, plan, x, n_out, out, relu, side, planes=None):
         self._planes_written = False                 # did this call's launch leave the split planes it was offered?
         if recording(x, self.weight, self.bias):                                 # training: autograd path
             y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu)
@@ -95,13 +95,8 @@ class myGCN(Module):
         if self.weight.is_contiguous() and (plan.blocked_ok(self.in_channels, self.out_channels, x) or
                                             plan.transform_ok(self.in_channels, self.out_channels, x)):
             # A_norm (x W) = (A_norm x) W: the contraction of layers.py:73 runs on the aggregated row
-            done = cowork.cowork_request() if cowork is not None else None      # W_r of a later relational layer, same launch
-            if done is not None:
-                planes = None
-            y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, cowork=done, planes=planes)
+            y = plan.aggregate(x, self.bias, relu, out, side, weight=self.weight, planes=planes)
             self._planes_written = planes is not None
-            if done is not None:
-                cowork.cowork_done()
             return y
         xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
         _hip.gemm(x, self.weight, xw, fast=self.arithmetic == "fast")               # layers.py:73
@@ -120,13 +115,13 @@ class myGCN(Module):
         return self._run(plan, x, n, _out, _relu, _side)
 
     def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None,
-                          _cowork=None, _planes=None):
+                          _planes=None):
         """The conv as interGraph uses it (layers.py:363-368), in closed form: rows are targets."""
         _hip.require_gpu(x, inter_edge_index, edge_weight, self.weight)
         n_src = x.size(0)
         plan = self._plan(inter_edge_index,
                           lambda: _hip.GraphPlan.bipartite(inter_edge_index, n_src, n_target, edge_weight))
-        return self._run(plan, x, n_target, _out, _relu, _side, _cowork, _planes)
+        return self._run(plan, x, n_target, _out, _relu, _side, _planes)
 
     def __repr__(self):
         return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
@@ -181,39 +176,6 @@ class myRGCN(Module):
             self._plan_key = (edge_index, range_list, key)
         return self._plan
 
-    def cowork_request(self):
-        """(plan, basis, att) for a launch that is asked to compute this layer's W_r on the side, or None (no plan
-        yet, autograd is recording, or the kernel this layer's arithmetic selects never forms W_r)."""
-        if self._plan is None or recording(self.basis, self.att) or not self._fast() or self.kernel != "auto":
-            return None
-        if self._plan.path(self.in_channels, self.out_channels, self.num_bases, fast=True) != "acc":
-            return None
-        return (self._plan, self.basis, self.att)
-
-    def cowork_done(self):
-        """The launch has been queued on the current stream: the next forward on this plan skips its weights kernel."""
-        self._prefetched = (None, self._plan, self.basis._version, self.att._version)
-
-    def prefetch_weights(self):
-        """Start W_r = sum_b att[r,b] basis[b] (layers.py:172-173) on a second HIP stream; the next inference
-        forward on the same plan waits for it with an event instead of computing it in line.  The weights
-        depend on the parameters only, so a caller that still has the layers below to run (the pose
-        pipeline: gg and gd) hides this launch behind them.  No-op before the first forward (no plan yet)
-        and while autograd is recording.  Safe under hipGraph capture (fork here, join in forward)."""
-        plan = self._plan
-        if plan is None or recording(self.basis, self.att):
-            return False
-        if not plan.needs_weights(self.in_channels, self.out_channels, self.num_bases, self._fast(), self.kernel):
-            return False
-        cur = torch.cuda.current_stream(plan.device)
-        side = _hip.side_stream(plan.device)
-        side.wait_stream(cur)                       # the previous forward still reads the workspace; the optimizer may write the parameters
-        with torch.cuda.stream(side):
-            plan.weights(self.basis, self.att, fast=self._fast(), path=self.kernel)
-            event = side.record_event()
-        self._prefetched = (event, plan, self.basis._version, self.att._version)
-        return True
-
     def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False, _side=None):
         # edge_type is accepted and unused, as in the reference (the relation of an edge is the
         # range_list row that contains it, layers.py:171-186)
@@ -230,14 +192,9 @@ class myRGCN(Module):
             return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu)
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
-        ready, pre, self._prefetched = False, getattr(self, "_prefetched", None), None
-        if pre is not None and pre[1] is plan and pre[2:] == (self.basis._version, self.att._version):
-            if pre[0] is not None:                       # computed on another stream (prefetch_weights)
-                torch.cuda.current_stream(x.device).wait_event(pre[0])
-            ready = True
         planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None
-        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, weights_ready=ready,
-                            fast=self._fast(), path=self.kernel, x_planes=planes)
+        return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, fast=self._fast(),
+                            path=self.kernel, x_planes=planes)
 
     def __repr__(self):
         return "{}({}, {}, num_relations={})".format(self.__class__.__name__, self.in_channels,
@@ -330,8 +287,7 @@ class interGraph(Module):
     def reset_parameters(self):
         self.target_feat.data.normal_()
 
-    def forward(self, x, inter_edge_index, edge_weight=None, if_relu=True, mod="cat", *, _cowork=None):
-        # _cowork: a myRGCN whose weights W_r = att . basis are computed by this layer's launch (inference path)
+    def forward(self, x, inter_edge_index, edge_weight=None, if_relu=True, mod="cat"):
         _hip.require_gpu(x, inter_edge_index)
         dev = x.device
         if torch.is_grad_enabled() and recording(x, *self.parameters()):                                     # training: autograd-tracked glue
@@ -356,7 +312,6 @@ class interGraph(Module):
                     planes = self._planes = _hip.SplitPlanes(self.n_target, width // 16, dev)
             self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu,
                                         _side=(self.target_feat, tf, 1),     # |target_feat| slot, same launch
-                                        _cowork=_cowork,
                                         _planes=None if planes is None else (planes, 0, self.target_dim))
             if planes is not None and getattr(self.conv, "_planes_written", False):
                 planes.tag(out)

@@ -34,8 +34,7 @@ class PoseModel(Module):
 
     def encode(self, data):
         z = self.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)    # pose.py:117-119
-        z = self.gd(z, data.gd_edge_index, mod="cat", if_relu=True,                            # pose.py:120
-                    _cowork=self.dd.conv_list[0])        # + W_r of the relational layer below, in the same launch
+        z = self.gd(z, data.gd_edge_index, mod="cat", if_relu=True)                            # pose.py:120
         return self.dd(z, data.train_idx, edge_type=data.train_et, range_list=data.train_range,
                        if_catout=True)                                                         # pose.py:121-127
 
@@ -176,7 +175,6 @@ class PoseStages:
         self._encode = None                          # graphs, decoder timed or nothing timed: genes and drugs as ONE graph
         self.timed_entry, self.graphs = timed_entry, graphs
         self.x = None
-        self._weights_in_genes = False               # did the genes stage's last launch really compute W_r?
         if graphs:
             with torch.no_grad():
                 if timed_entry == "gn_rgcn_forward_f32":
@@ -194,21 +192,13 @@ class PoseStages:
                             self._decode_eager()
 
     def _encode_eager(self):
-        # (myRGCN.prefetch_weights() would fork W_r onto a second stream here; measured on pose0-syn the two
-        # cross-queue dependencies cost more than the 7 us launch they hide: 140.8 vs 118.4 us per step)
         self.x = self._genes_eager()
         return self._drugs_eager()
 
     def _genes_eager(self):
         d = self.data
         z = self.model.gg(None, d.gg_edge_index, edge_weight=d.edge_weight, if_catout=True)
-        self.conv._prefetched = None
-        x = self.model.gd(z, d.gd_edge_index, mod="cat", if_relu=True, _cowork=self.conv)
-        # The launch site (myGCN._run) marks the relational layer's weights as computed only when the external layer
-        # really took the combined launch (fused transform, fp32 table, a relational plan to hand over).  Recorded
-        # here, while the stage is captured or run, so that a replayed genes graph can vouch for it later.
-        self._weights_in_genes = getattr(self.conv, "_prefetched", None) is not None
-        return x
+        return self.model.gd(z, d.gd_edge_index, mod="cat", if_relu=True)    # x, tagged with its bf16 split planes
 
     def _decode_eager(self):
         return self.model.dmt(self.z, self.idx, self.et)
@@ -223,12 +213,6 @@ class PoseStages:
     def _drugs_eager(self):
         fin = self.conv.in_channels
         d = self.data
-        if self._weights_in_genes and self.conv.cowork_request() is not None:
-            # the genes stage always runs first and its last launch computed W_r (see _genes_eager); when the two
-            # stages are separate hipGraphs the hand-over flag set while genes was captured is gone by now.  Any other
-            # configuration (bf16 table storage, a shape the combined launch does not cover) leaves the flag unset and
-            # the layer computes its own weights.
-            self.conv.cowork_done()
         self.conv(self.x, d.train_idx, d.train_et, d.train_range, _out=self.z[:, fin:], _relu=True,
                   _side=(self.x, self.z[:, :fin], 0))
         return self.z

@@ -27,24 +27,6 @@ import torch
 from .utils import shard_edge_ranges
 
 
-class _ShardWeights:
-    """Hands the shard's relational plan to the external layer's launch, which computes W_r = att . basis on the side
-    (gn_graph_aggregate_with_rgcn_weights_f32).  encode_genes always runs before partial, also when it is replayed
-    as a hipGraph, so once the combined launch has been used the weights are known to be in the workspace."""
-
-    def __init__(self, plan, conv):
-        self.plan, self.conv, self.ready = plan, conv, False
-
-    def cowork_request(self):
-        c = self.conv                        # only the two-term ("fast") arithmetic runs on a kernel that reads W_r
-        if not c._fast() or c.kernel != "auto" or self.plan.path(c.in_channels, c.out_channels, c.num_bases, fast=True) != "acc":
-            return None
-        return (self.plan, c.basis, c.att)
-
-    def cowork_done(self):
-        self.ready = True
-
-
 class HipShardKernels:
     """The product arithmetic: HIP kernels behind the C ABI (no CPU fallback)."""
 
@@ -53,22 +35,19 @@ class HipShardKernels:
         self._hip, self.model, self.data = _hip, model, data
         self.conv = model.dd.conv_list[0]
         self.plan = _hip.RgcnPlan(data.train_idx, data.train_range, data.n_d_node, lo, hi)
-        self.weights = _ShardWeights(self.plan, self.conv)
         self.idx = data.train_idx[:, lo:hi].contiguous()
         self.et = data.train_et[lo:hi].contiguous()
 
     def encode_genes(self):
-        self.weights.ready = False            # set again by this call's combined launch, if it takes one (cowork_done)
         z = self.model.gg(None, self.data.gg_edge_index, edge_weight=self.data.edge_weight, if_catout=True)
-        return self.model.gd(z, self.data.gd_edge_index, mod="cat", if_relu=True, _cowork=self.weights)
+        return self.model.gd(z, self.data.gd_edge_index, mod="cat", if_relu=True)
 
     def partial(self, x, out, fresh_weights=False):
-        """`fresh_weights`: compute W_r in this call whatever an earlier launch left in the workspace (training: the
-        parameters move every step)."""
+        """(`fresh_weights` stays in the signature the CPU stand-in kernels of the gloo tests share: every call computes what it needs.)"""
         c = self.conv
-        ready = self.weights.ready and not fresh_weights
-        return self.plan.forward(x, c.basis.detach(), c.att.detach(), None, None, False, out, partial=True, weights_ready=ready,
-                                 fast=c._fast(), path=c.kernel)
+        planes = self._hip.SplitPlanes.of(x, c.in_channels // 16) if c.in_channels % 16 == 0 else None
+        return self.plan.forward(x, c.basis.detach(), c.att.detach(), None, None, False, out, partial=True,
+                                 fast=c._fast(), path=c.kernel, x_planes=planes)
 
     def finalize(self, summed, x, out, slot0):
         c = self.conv                                           # concat slot 0 is copied by the same launch

@@ -231,39 +231,19 @@ GN_API gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, con
 GN_API void gn_rgcn_plan_destroy(gn_rgcn_plan* plan);
 GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
 
-/* Bytes of caller-provided scratch gn_rgcn_forward_f32 needs for these shapes. */
+/* Bytes of caller-provided scratch a gn_rgcn_forward_f32 call with these shapes and flags needs: none on the
+ * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, the [R, N, out] table of the general
+ * path.  (The forward checks the workspace against the kernel IT takes and refuses a smaller one.) */
 GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features,
-                               int64_t num_bases);
-
-/* W_r = sum_b att[r,b] basis[b] for every relation (layers.py:172-173), written into `workspace` in the layout the
- * forward kernels read.  Optional: gn_rgcn_forward_f32 computes it itself unless GN_RGCN_WEIGHTS_READY is set.
- * The weights depend on the parameters only, so a caller can launch this on a second stream while the layers
- * that produce x are still running, and order the forward behind it with an event. */
-GN_API gn_status gn_rgcn_weights_f32(const gn_rgcn_plan* plan, int64_t in_features, const float* basis, const float* att,
-                              int64_t num_bases, int64_t out_features, int flags /* those of the forward call that follows */,
-                              void* workspace, size_t workspace_bytes, void* stream);
-
-/* gn_graph_aggregate_f32 (first eleven arguments, `weight` required) and gn_rgcn_weights_f32 (the rest) as ONE launch:
- * the external layer's aggregation (gripnet/layers.py:363-370) and the weights of the relational layer that follows it
- * (layers.py:172-173) are independent, short and latency-bound, so the launch takes the longer of the two instead of
- * their sum.  The weights are those of the GN_RGCN_ARITH_FAST path: follow it with
- * gn_rgcn_forward_f32(..., GN_RGCN_ARITH_FAST | GN_RGCN_WEIGHTS_READY, ...).  Shapes the combined launch does not
- * cover run as the two entry points, one after the other. */
-GN_API gn_status gn_graph_aggregate_with_rgcn_weights_f32(
-    const gn_graph_plan* plan, const float* x, int64_t ld_x, int64_t num_features, const float* weight, int64_t out_features,
-    const float* bias, int relu, float* out, int64_t ld_out, const gn_side_copy* side /* nullable */,
-    const gn_rgcn_plan* rgcn_plan, int64_t rgcn_in_features, const float* basis, const float* att, int64_t num_bases,
-    int64_t rgcn_out_features, void* rgcn_workspace, size_t rgcn_workspace_bytes, void* stream);
+                               int64_t num_bases, int flags);
 
 #define GN_RGCN_PARTIAL 1        /* flags of gn_rgcn_forward_f32 */
-#define GN_RGCN_WEIGHTS_READY 2  /* `workspace` already holds the output of gn_rgcn_weights_f32 for these parameters */
 #define GN_RGCN_ARITH_FAST 4     /* dense products on two-term bf16 splits (<= 2^-16 relative per product) instead of the
                                   * default fp32-faithful arithmetic (three-term splits / the fp32 matrix instruction) */
 /* Kernel choice, for tests and measurements (0 = the library decides; a kernel that does not cover the shapes is not
  * forced): (GN_RGCN_PATH_x << GN_RGCN_PATH_SHIFT) in flags.  gn_rgcn_forward_path tells which one a call would take. */
 #define GN_RGCN_PATH_SHIFT 8
 #define GN_RGCN_PATH_PAIR 1      /* destination-major in basis space (rgcn_pair.hip): no W_r, no workspace, one launch */
-#define GN_RGCN_PATH_ACC 2       /* relation-major aggregate-then-transform in registers (rgcn_acc.hip) */
 #define GN_RGCN_PATH_LDS 3       /* LDS accumulator rows (rgcn_fast.hip) */
 #define GN_RGCN_PATH_GENERAL 4   /* transform-then-gather through HBM (rgcn.hip), any size */
 GN_API int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features, int64_t num_bases, int flags);

@@ -215,13 +215,14 @@ def use_relational_kernel(module, kernel, arithmetic="fp32"):
     return layers
 
 
-@pytest.fixture(params=["pair", "acc", "acc-fast", "lds", "general"])
+@pytest.fixture(params=["pair", "pair-fast", "lds", "general", "general-forced"])
 def kernel_path(request, monkeypatch):
-    """Run a test once per relational kernel: destination-major (default), register-accumulated (fp32 matrix instruction
-    and two-term splits), LDS-resident accumulator, general; the last two also take the shuffle-based form of the 16-wide
-    GCN gather instead of the quad form."""
+    """Run a test once per relational kernel: destination-major (default; three- and two-term splits), LDS-resident
+    accumulator, general (with every fast path switched off, and FORCED by flag while the fast kernels apply: the
+    workspace then has to be the general path's); the last three also take the shuffle-based form of the 16-wide GCN
+    gather instead of the quad form."""
     monkeypatch.setenv("GN_DISABLE_FAST", "1" if request.param == "general" else "0")
-    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param in ("pair", "acc", "acc-fast") else "1")
+    monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param in ("pair", "pair-fast") else "1")
     return request.param
 
 
@@ -375,7 +376,7 @@ def test_gcn_skewed_degrees_and_empty_rows(gpu, fout):
 
 @pytest.mark.parametrize("n,fin,bases", [(40, 16, 3), (200, 32, 5), (560, 48, 32), (645, 64, 8), (900, 48, 4),
                                          (1000, 32, 2), (1, 16, 1)])
-@pytest.mark.parametrize("path", ["pair", "pair-fast", "acc", "acc-fast", "lds"])
+@pytest.mark.parametrize("path", ["pair", "pair-fast", "lds", "general"])
 def test_rgcn_lds_resident_shapes(gpu, n, fin, bases, path):
     """Every specialisation of the three LDS-resident relational kernels (destination-major: one or two bases per lane,
     one to four feature tiles, one to three rows per workgroup, a pair run longer than one unit; register-accumulated:
@@ -495,11 +496,11 @@ def test_rgcn_destination_major_output_widths(gpu, n, fin, fout, bases):
     close(y, ref.float())
 
 
-@pytest.mark.parametrize("formulation", ["pair", "acc"])
+@pytest.mark.parametrize("formulation", ["pair", "lds"])
 def test_rgcn_sharded_partials_sum_to_full(gpu, formulation):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
-    (the multi-GPU contract, here run sequentially on one device); with either formulation of the
-    LDS-resident relational kernel."""
+    (the multi-GPU contract, here run sequentially on one device); with either LDS-resident
+    relational kernel."""
     data = make_pose("small").to(gpu)
     n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
     conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
@@ -936,53 +937,30 @@ def test_decoder_plan_rejects_out_of_range_edges(gpu):
             dec(z, ei, et)                                            # second sighting validates at plan time
 
 
-def test_rgcn_weights_prefetched_on_a_second_stream(gpu):
-    """gn_rgcn_weights_f32 + GN_RGCN_WEIGHTS_READY: W_r computed ahead of the forward on another stream gives the
-    forward's own result bit for bit; a parameter update between prefetch and forward drops the prefetched weights."""
+def test_forced_general_path_gets_its_own_workspace(gpu):
+    """A kernel forced by flag while the destination-major kernel applies: gn_rgcn_workspace_bytes answers for THAT
+    call (the general path's [R, N, out] table), and a forward handed a smaller workspace is refused instead of writing
+    past it (round-3 advisor finding)."""
     data = make_pose("small").to(gpu)
     n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
     conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
     x = torch.randn(n, fin, device=gpu)
     with torch.no_grad():
-        assert conv.prefetch_weights() is False                         # no plan before the first forward
-        first = conv(x, data.train_idx, None, data.train_range, _relu=True)
-        assert conv.prefetch_weights() is False                         # the default kernel never forms W_r
-        conv.arithmetic = "fast"                                        # the relation-major kernel reads W_r from the workspace
         base = conv(x, data.train_idx, None, data.train_range, _relu=True)
-        close(base, first)
-        assert conv.prefetch_weights() is True
-        again = conv(x, data.train_idx, None, data.train_range, _relu=True)
-        assert torch.equal(base, again)
-        assert conv.prefetch_weights() is True
-        conv.att.mul_(2.0)                                              # stale: the forward recomputes W_r in line
-        changed = conv(x, data.train_idx, None, data.train_range, _relu=True)
-        sd = {k: v.detach().cpu() for k, v in conv.state_dict().items()}
-        ref = torch.relu(orc.rgcn_forward(x.cpu(), data.train_idx.cpu(), data.train_range.cpu(), sd["basis"], sd["att"],
-                                          sd["root"], sd.get("bias")))
-        close(changed, ref)
-
-
-@needs_fast_paths
-def test_external_layer_computes_relational_weights_in_its_launch(gpu):
-    """gn_graph_aggregate_with_rgcn_weights_f32 (interGraph(..., _cowork=conv)): the external layer's output and the
-    relational layer that then skips its weights kernel both equal the separate launches, bit for bit."""
-    data = make_pose("small").to(gpu)
-    torch.manual_seed(5)
-    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
-    conv = model.dd.conv_list[0]
-    conv.arithmetic = "fast"                       # W_r exists only for the relation-major kernel of the two-term arithmetic
-    with torch.no_grad():
-        z_gg = model.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)
-        x_sep = model.gd(z_gg, data.gd_edge_index, mod="cat", if_relu=True)
-        z_sep = model.dd(x_sep, data.train_idx, edge_type=data.train_et, range_list=data.train_range, if_catout=True)
-        assert getattr(conv, "_prefetched", None) is None
-        x_fused = model.gd(z_gg, data.gd_edge_index, mod="cat", if_relu=True, _cowork=conv)
-        assert conv._prefetched is not None and conv._prefetched[0] is None
-        z_fused = model.dd(x_fused, data.train_idx, edge_type=data.train_et, range_list=data.train_range, if_catout=True)
-        assert conv._prefetched is None
-        assert torch.equal(x_sep, x_fused) and torch.equal(z_sep, z_fused)
-        z_all, _ = model(data)                                            # PoseModel.encode uses the combined launch
-        assert torch.equal(z_all, z_sep)
+        plan = conv._plan
+        assert plan.path(fin, fout, 32) == "pair" and plan.path(fin, fout, 32, path="general") == "general"
+        lib = _hip.load()
+        need_default = int(lib.gn_rgcn_workspace_bytes(plan._h, fin, fout, 32, plan.mode_flags()))
+        need_general = int(lib.gn_rgcn_workspace_bytes(plan._h, fin, fout, 32, plan.mode_flags(path="general")))
+        assert need_default == 0 and need_general >= R * n * fout * 4
+        conv.kernel = "general"
+        close(conv(x, data.train_idx, None, data.train_range, _relu=True), base)
+        out = torch.empty(n, fout, device=gpu)
+        small = torch.empty(1024, dtype=torch.uint8, device=gpu)
+        status = lib.gn_rgcn_forward_f32(plan._h, x.data_ptr(), fin, fin, conv.basis.data_ptr(), conv.att.data_ptr(), 32,
+                                         conv.root.data_ptr(), None, fout, 1, plan.mode_flags(path="general"), out.data_ptr(), fout,
+                                         None, None, small.data_ptr(), 1024, _hip.stream_ptr(gpu))
+        assert status == _hip.GN_ERR_INVALID_ARG and b"workspace too small" in lib.gn_last_error()
 
 
 # ---- bf16 storage of the gathered table (SURVEY.md 8f row 4) -----------------------------------
@@ -1042,8 +1020,8 @@ def test_nc_pipeline_with_bf16_tables(gpu, golden):
 @pytest.mark.parametrize("n,fin,bases", [(560, 48, 32), (645, 48, 32), (200, 32, 5), (645, 64, 8)])
 def test_default_relational_arithmetic_is_as_exact_as_fp32(gpu, n, fin, bases):
     """Against the float64 oracle the default relational path (three-term bf16 splits on the matrix cores) is held to the
-    error of the exact fp32 paths (the LDS-accumulator kernel and the relation-major kernel on v_mfma_f32_16x16x4_f32) and
-    of the reference's own fp32 op sequence; the two-term "fast" mode is allowed to be worse and is reported, not held."""
+    error of the exact fp32 paths (the LDS-accumulator and the general kernel on v_mfma_f32_16x16x4_f32) and of the
+    reference's own fp32 op sequence; the two-term "fast" mode is allowed to be worse and is reported, not held."""
     gen = torch.Generator().manual_seed(n * 7 + fin)
     torch.manual_seed(n + fin)
     sizes = [0, 9000, 3, 0, 700, 1, 2500, 0]
@@ -1056,12 +1034,12 @@ def test_default_relational_arithmetic_is_as_exact_as_fp32(gpu, n, fin, bases):
     ref64 = orc.rgcn_forward(x.double(), rei, rl, sd["basis"].double(), sd["att"].double(), sd["root"].double(), sd["bias"].double())
     ref32 = orc.rgcn_forward(x, rei, rl, sd["basis"], sd["att"], sd["root"], sd["bias"])
     err = {}
-    for name, kernel, arith in (("default", "auto", "fp32"), ("lds-exact", "lds", "fp32"), ("acc-exact", "acc", "fp32"), ("fast", "auto", "fast")):
+    for name, kernel, arith in (("default", "auto", "fp32"), ("lds-exact", "lds", "fp32"), ("general-exact", "general", "fp32"), ("fast", "auto", "fast")):
         rg.kernel, rg.arithmetic = kernel, arith
         y = rg(x.to(gpu), rei.to(gpu), None, rl)
         err[name] = (y.cpu().double() - ref64).abs().max().item()
     err["reference-fp32"] = (ref32.double() - ref64).abs().max().item()
-    exact = max(err["lds-exact"], err["acc-exact"], err["reference-fp32"])
+    exact = max(err["lds-exact"], err["general-exact"], err["reference-fp32"])
     assert err["default"] <= 1.5 * exact + 1e-7, err
     assert err["fast"] <= 2e-5, err
 
