@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "gripnet_hip.h"
+#include "host_layout.hpp"
 
 namespace gn {
 
@@ -49,7 +50,6 @@ inline gn_status fail(gn_status code, const char* fmt, ...) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Compute units of the current device (persistent kernels launch one workgroup each); 256 if the query fails.
 inline int compute_units() {
@@ -95,24 +95,6 @@ inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 8) 
     if (g < 1) g = 1;
     if (g > max_blocks) g = max_blocks;
     return static_cast<int>(g);
-}
-
-// Host side of the plan builders: fn(begin, end) over contiguous chunks of [0, n) on up to GN_PLAN_THREADS (default 16:
-// the CPU share of one GPU on the boxes this runs on) threads.  The chunks are fixed by n and the thread count only and
-// every chunk writes its own outputs, so a plan does not depend on scheduling.
-template <typename F>
-inline void parallel_for(int64_t n, int64_t grain, F fn) {
-    int want = 16;
-    if (const char* e = getenv("GN_PLAN_THREADS")) want = std::max(1, atoi(e));
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw > 0) want = std::min<int>(want, (int)hw);
-    const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(want, (n + grain - 1) / std::max<int64_t>(grain, 1)));
-    if (chunks <= 1 || n <= 0) { if (n > 0) fn((int64_t)0, n); return; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)chunks - 1);
-    for (int64_t c = 1; c < chunks; ++c) pool.emplace_back([=]() { fn(n * c / chunks, n * (c + 1) / chunks); });
-    fn((int64_t)0, n / chunks);
-    for (std::thread& t : pool) t.join();
 }
 
 // Opt a kernel in to more than 64 KB of dynamic LDS, once per (kernel, device).

@@ -49,7 +49,7 @@ using namespace gn_dm;
 
 constexpr int kNodeBits = 13;
 constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
-constexpr uint32_t kNoMirror = 0xffffffffu;
+using gn_layout::kNoMirror;
 
 struct DmPlanArgs {
     const float* z; int64_t ld_z; int n;
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(kThreads) void k_distmult_plan(DmPlanArgs a) {
 // fills.  Here a workgroup holds a CLASS of rows with every column: a pair is scored in one go, the sum is split into
 // the same column parts as the phases (so the bits are those of the plan-less kernel), the relation rows of D the
 // workgroup's batches name sit in LDS next to the table, and nothing in the loop needs a clamp or a 64-bit address.
-constexpr int kClsDCache = 64;        // relation rows of D a workgroup keeps in LDS
-constexpr int kClsSlack = 64;         // readable batches behind the last one (the prefetches run ahead unclamped)
+using gn_layout::kClsDCache;          // relation rows of D a workgroup keeps in LDS
+using gn_layout::kClsSlack;           // readable batches behind the last one (the prefetches run ahead unclamped)
 
 struct DmClassArgs {
     const float* z; int64_t ld_z;
@@ -372,247 +372,6 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
 #endif
 }
 
-// Deals the (up to) 64 edges of a batch to its slots.  Lane l of the wave holds slot l; wave step S works on the
-// slots 4 q + S of the 16 quads q, and ds_read_b128 serves the quads in four access groups.  A cell = (step,
-// access group) = four slots that hit the LDS together: its edges should have four different u % 4 and four
-// different v % 4 (the bank slot of a row is (row * odd stride) % 4).
-void deal_batch(const int64_t* u, const int64_t* v, int count, int* slot_of_edge) {
-    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
-    static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
-                                      {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
-                                      {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
-                                      {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
-    std::vector<int> bucket[4][4];                         // edges by (u % 4, v % 4)
-    for (int e = 0; e < count; ++e) bucket[u[e] & 3][v[e] & 3].push_back(e);
-    int left = count;
-    for (int cell = 0; cell < 16; ++cell) {
-        const int S = cell & 3, g = cell >> 2;
-        int chosen[4] = {-1, -1, -1, -1};
-        if (left > 0) {
-            // a full cell: one edge from each (c, sigma(c)) for the permutation whose scarcest bucket is fullest
-            int best = -1, best_min = 0;
-            for (int p = 0; p < 24; ++p) {
-                int mn = 1 << 30;
-                for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
-                if (mn > best_min) { best_min = mn; best = p; }
-            }
-            if (best >= 0) {
-                for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
-            } else {
-                // no conflict-free quadruple left: take edges one by one, preferring unused u and v classes
-                unsigned used_u = 0, used_v = 0;
-                for (int k = 0; k < 4; ++k) {
-                    int bc = -1, bd = -1, bscore = -1;
-                    for (int c = 0; c < 4; ++c)
-                        for (int dd = 0; dd < 4; ++dd) {
-                            if (bucket[c][dd].empty()) continue;
-                            const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
-                            if (score > bscore) { bscore = score; bc = c; bd = dd; }
-                        }
-                    if (bc < 0) break;
-                    chosen[k] = bucket[bc][bd].back();
-                    bucket[bc][bd].pop_back();
-                    used_u |= 1u << bc; used_v |= 1u << bd;
-                }
-            }
-        }
-        for (int k = 0; k < 4; ++k)
-            if (chosen[k] >= 0) { slot_of_edge[chosen[k]] = 4 * kGroupQuads[g][k] + S; --left; }
-    }
-}
-
-// Cells of four pairs for one run of pairs that share class and relation: the four pairs of a cell are read by one
-// 16-lane access group of ds_read_b128, so they should have four different (local row of u) % 4 and four different
-// (local row of v) % 4 - the 64-byte bank slot of a row is (row * odd stride) % 4.  Cells fill whole steps first
-// (step = cell / 4): a run is padded to a multiple of 16 pairs, not 64.  order[cell * 4 + k] = pair of the run, or -1.
-void deal_run(const int* lu, const int* lv, int count, std::vector<int>& order) {
-    static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
-                                      {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
-                                      {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
-                                      {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
-    const int steps = (count + 15) / 16;
-    order.assign((size_t)steps * 16, -1);
-    std::vector<int> bucket[4][4];
-    for (int e = count - 1; e >= 0; --e) bucket[lu[e] & 3][lv[e] & 3].push_back(e);   // (popped from the back: list order)
-    int left = count;
-    for (int cell = 0; cell < steps * 4 && left > 0; ++cell) {
-        int chosen[4] = {-1, -1, -1, -1};
-        int best = -1, best_min = 0;
-        for (int p = 0; p < 24; ++p) {
-            int mn = 1 << 30;
-            for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
-            if (mn > best_min) { best_min = mn; best = p; }
-        }
-        if (best >= 0) {
-            for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
-        } else {
-            unsigned used_u = 0, used_v = 0;
-            for (int k = 0; k < 4; ++k) {
-                int bc = -1, bd = -1, bscore = -1;
-                for (int c = 0; c < 4; ++c)
-                    for (int dd = 0; dd < 4; ++dd) {
-                        if (bucket[c][dd].empty()) continue;
-                        const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
-                        if (score > bscore) { bscore = score; bc = c; bd = dd; }
-                    }
-                if (bc < 0) break;
-                chosen[k] = bucket[bc][bd].back();
-                bucket[bc][bd].pop_back();
-                used_u |= 1u << bc; used_v |= 1u << bd;
-            }
-        }
-        for (int k = 0; k < 4; ++k)
-            if (chosen[k] >= 0) { order[(size_t)cell * 4 + k] = chosen[k]; --left; }
-    }
-}
-
-// The row-class encoding of the scored pairs (see k_distmult_class).  Leaves plan->cls_ok = 0 when a class's rows do
-// not fit the LDS with `features` columns, or a workgroup's batches name more relations than its D cache holds.
-gn_status build_class_encoding(gn_distmult_plan* p, const std::vector<int64_t>& hu, const std::vector<int64_t>& hv,
-                               const std::vector<int64_t>& hr, const std::vector<int64_t>& scored,
-                               const std::vector<int64_t>& mirror_of, int64_t features, hipStream_t st) {
-    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
-    p->cls_ok = 0;
-    const int64_t n = p->num_nodes;
-    if (gn::fast_paths_disabled() || features < 16 || features % 16 != 0 || features > 128 || scored.empty() || n < 1) return GN_OK;
-    const int J = (int)(features / 16), str4 = (J & 1) ? 4 * J : 4 * J + 4;
-    const int64_t rows_fit = ((int64_t)160 * 1024 - (int64_t)kClsDCache * 4 * J * 16) / ((int64_t)str4 * 16);
-    int nblocks = 1;
-    int64_t blk = n;
-    if (n > rows_fit) {
-        blk = gn::ceil_div(n, 3);
-        if (2 * blk > rows_fit) return GN_OK;
-        nblocks = 3;
-    }
-    if (n > 65535) return GN_OK;
-    const int nclasses = nblocks == 1 ? 1 : 3;
-    auto bstart = [&](int b) { return std::min<int64_t>(n, (int64_t)b * blk); };
-    auto bsize = [&](int b) { return bstart(b + 1) - bstart(b); };
-    auto cls_of = [&](int64_t e) {
-        if (nblocks == 1) return 0;
-        const int bu = (int)(hu[e] / blk), bv = (int)(hv[e] / blk);
-        if (bu != bv) return (bu + 1) % 3 == bv ? bu : bv;
-        return (hr[e] & 1) ? (bu + 2) % 3 : bu;                  // a pair inside one block: either class that holds the block
-    };
-    auto local = [&](int64_t node, int k) {
-        const int b = (int)(node / blk);
-        return (int)(b == k ? node - bstart(k) : bsize(k) + node - bstart((k + 1) % 3));
-    };
-    // scored pairs by (class, relation), list order inside
-    const int64_t S = (int64_t)scored.size();
-    std::vector<uint32_t> key((size_t)S);
-    std::vector<int64_t> idx((size_t)S);
-    for (int64_t i = 0; i < S; ++i) { key[i] = (uint32_t)cls_of(scored[i]) << 16 | (uint32_t)hr[scored[i]]; idx[i] = i; }
-    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });
-    // runs -> steps of 16 slots
-    struct Run { int64_t lo, hi; int cls, rel; int64_t step0; };
-    std::vector<Run> runs;
-    std::vector<int64_t> cls_steps(nclasses, 0);
-    for (int64_t i = 0; i < S;) {
-        int64_t j = i;
-        while (j < S && key[idx[j]] == key[idx[i]]) ++j;
-        const int c = (int)(key[idx[i]] >> 16);
-        runs.push_back({i, j, c, (int)(key[idx[i]] & 0xffffu), cls_steps[c]});
-        cls_steps[c] += gn::ceil_div(j - i, 16);
-        i = j;
-    }
-    std::vector<int64_t> cls_batch0(nclasses + 1, 0);
-    for (int c = 0; c < nclasses; ++c) cls_batch0[c + 1] = cls_batch0[c] + gn::ceil_div(cls_steps[c], 4);
-    const int64_t NB = cls_batch0[nclasses], NBA = NB + kClsSlack;
-    std::vector<uint32_t> packed((size_t)NBA * 64, 0u), own((size_t)NBA * 64, kNoMirror), mirror((size_t)NBA * 64, kNoMirror);
-    std::vector<uint16_t> rel16((size_t)NBA * 4, 0);
-    gn::parallel_for((int64_t)runs.size(), 16, [&](int64_t r0, int64_t r1) {
-        std::vector<int> lu, lv, order;
-        for (int64_t ri = r0; ri < r1; ++ri) {
-            const Run& run = runs[ri];
-            const int count = (int)(run.hi - run.lo);
-            lu.resize(count); lv.resize(count);
-            for (int k = 0; k < count; ++k) {
-                const int64_t e = scored[idx[run.lo + k]];
-                lu[k] = local(hu[e], run.cls); lv[k] = local(hv[e], run.cls);
-            }
-            deal_run(lu.data(), lv.data(), count, order);
-            const int steps = (int)(order.size() / 16);
-            for (int t = 0; t < steps; ++t) {
-                const int64_t gstep = cls_batch0[run.cls] * 4 + run.step0 + t;
-                const int64_t bat = gstep >> 2;
-                const int s_in = (int)(gstep & 3);
-                rel16[(size_t)gstep] = (uint16_t)run.rel;
-                for (int gq = 0; gq < 4; ++gq)
-                    for (int k = 0; k < 4; ++k) {
-                        const int pr = order[(size_t)t * 16 + gq * 4 + k];
-                        const size_t slot = (size_t)bat * 64 + 4 * kGroupQuads[gq][k] + s_in;
-                        const int src = pr >= 0 ? pr : 0;                       // padding repeats the run's first pair, writes nothing
-                        packed[slot] = (uint32_t)lu[src] | (uint32_t)lv[src] << 16;
-                        if (pr >= 0) {
-                            const int64_t e = scored[idx[run.lo + pr]];
-                            own[slot] = (uint32_t)e;
-                            mirror[slot] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
-                        }
-                    }
-            }
-        }
-    });
-    // steps that pad a class to whole batches: the relation of the step before them (no reload), pair (0, 0), no positions
-    for (int c = 0; c < nclasses; ++c)
-        for (int64_t gstep = cls_batch0[c] * 4 + cls_steps[c]; gstep < cls_batch0[c + 1] * 4; ++gstep)
-            rel16[(size_t)gstep] = rel16[(size_t)gstep - 1];
-    for (int64_t gstep = NB * 4; gstep < NBA * 4; ++gstep) rel16[(size_t)gstep] = NB > 0 ? rel16[(size_t)NB * 4 - 1] : 0;
-    // workgroups: a share of the compute units per class in proportion to its batches, contiguous batch ranges
-    const int cus = gn::compute_units();
-    int G = (int)std::min<int64_t>(cus, NB);
-    std::vector<int> share(nclasses, 0);
-    {
-        int given = 0, live = 0;
-        for (int c = 0; c < nclasses; ++c) live += cls_batch0[c + 1] > cls_batch0[c];
-        G = std::max(G, live);
-        std::vector<double> frac(nclasses, 0.0);
-        for (int c = 0; c < nclasses; ++c) {
-            const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
-            if (nb == 0) continue;
-            const double want = (double)G * nb / NB;
-            share[c] = std::max(1, (int)want);
-            frac[c] = want - share[c];
-            given += share[c];
-        }
-        while (given < G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] && (best < 0 || frac[c] > frac[best])) best = c; share[best]++; frac[best] -= 1.0; ++given; }
-        while (given > G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] > 1 && (best < 0 || frac[c] < frac[best])) best = c; if (best < 0) break; share[best]--; frac[best] += 1.0; --given; }
-        G = given;
-    }
-    std::vector<int32_t> wg((size_t)G * 8, 0);
-    int gi = 0;
-    for (int c = 0; c < nclasses; ++c) {
-        const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
-        for (int k = 0; k < share[c]; ++k, ++gi) {
-            const int64_t lo = cls_batch0[c] + nb * k / share[c], hi = cls_batch0[c] + nb * (k + 1) / share[c];
-            int rlo = 1 << 30, rhi = -1;
-            for (int64_t gstep = lo * 4; gstep < hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
-            if (hi <= lo) { rlo = 0; rhi = 0; }
-            if (rhi - rlo + 1 > kClsDCache) return GN_OK;                         // (the column-phase kernel serves such a list)
-            int32_t* d = wg.data() + (size_t)gi * 8;
-            if (nblocks == 1) { d[0] = 0; d[1] = (int32_t)n; d[2] = 0; d[3] = 0; }
-            else { d[0] = (int32_t)bstart(c); d[1] = (int32_t)bsize(c); d[2] = (int32_t)bstart((c + 1) % 3); d[3] = (int32_t)bsize((c + 1) % 3); }
-            d[4] = (int32_t)lo; d[5] = (int32_t)hi; d[6] = rlo; d[7] = rhi - rlo + 1;
-        }
-    }
-    std::vector<uint32_t> rel32((size_t)NBA * 2);
-    for (size_t i = 0; i < rel32.size(); ++i) rel32[i] = (uint32_t)rel16[2 * i] | (uint32_t)rel16[2 * i + 1] << 16;
-    GN_HIP(p->cls_packed.alloc(packed.size()));
-    GN_HIP(p->cls_own.alloc(own.size()));
-    GN_HIP(p->cls_mirror.alloc(mirror.size()));
-    GN_HIP(p->cls_rel.alloc(rel32.size()));
-    GN_HIP(p->cls_wg.alloc(wg.size()));
-    GN_HIP(hipMemcpyAsync(p->cls_packed.p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(p->cls_own.p, own.data(), own.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(p->cls_mirror.p, mirror.data(), mirror.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(p->cls_rel.p, rel32.data(), rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipMemcpyAsync(p->cls_wg.p, wg.data(), wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    GN_HIP(hipStreamSynchronize(st));
-    p->cls_features = (int)features; p->cls_groups = G; p->cls_batches = NB;
-    p->cls_ok = 1;
-    return GN_OK;
-}
-
 template <int J, int J1>
 gn_status launch_class(const gn_distmult_plan* plan, const DmClassArgs& a, int64_t n, hipStream_t st) {
     gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_class<J, J1>), 160 * 1024);
@@ -651,32 +410,9 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
             return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
                             (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
                             (long long)num_nodes, (long long)num_relations);
-    // Triples with the same unordered node pair and relation have the same score (the reference's positive list holds
-    // every edge in both directions): they are paired up, the first of a pair is scored and writes both positions.
-    std::vector<int64_t> mirror_of(E, -1);
-    std::vector<char> covered(E, 0);
-    {
-        // open addressing on a power-of-two table (keys are unique per open triple; an erased slot keeps its key with
-        // value -1 so that probe chains stay intact)
-        size_t cap = 1;
-        while (cap < (size_t)E * 2 + 16) cap <<= 1;
-        std::vector<uint64_t> keys(cap, ~(uint64_t)0);
-        std::vector<int64_t> vals(cap, -1);
-        for (int64_t e = 0; e < E; ++e) {
-            const uint64_t lo = (uint64_t)std::min(hu[e], hv[e]), hi = (uint64_t)std::max(hu[e], hv[e]);
-            const uint64_t key = ((uint64_t)hr[e] << (2 * kNodeBits)) | (lo << kNodeBits) | hi;
-            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
-            while (keys[h] != ~(uint64_t)0 && keys[h] != key) h = (h + 1) & (cap - 1);
-            if (keys[h] == key && vals[h] >= 0) {                // the open copy of this triple: pair up
-                mirror_of[vals[h]] = e;
-                covered[e] = 1;
-                vals[h] = -1;
-            } else {                                            // first (or third, fifth, ...) copy: stays open
-                keys[h] = key;
-                vals[h] = e;
-            }
-        }
-    }
+    std::vector<int64_t> mirror_of;
+    std::vector<char> covered;
+    gn_layout::pair_mirrors(hu, hv, hr, kNodeBits, mirror_of, covered);
     // batches: 64 consecutive scored edges each, in list order; a batch's slots are dealt independently of the others
     std::vector<int64_t> scored;
     scored.reserve((size_t)E);
@@ -692,7 +428,7 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         for (int64_t bi = b0; bi < b1; ++bi) {
             const int count = (int)std::min<int64_t>(64, (int64_t)scored.size() - bi * 64);
             for (int k = 0; k < count; ++k) { ce[k] = scored[bi * 64 + k]; cu[k] = hu[ce[k]]; cv[k] = hv[ce[k]]; }
-            deal_batch(cu, cv, count, slot_of_edge);
+            gn_layout::deal_batch(cu, cv, count, slot_of_edge);
             bool uniform = true;
             for (int k = 1; k < count; ++k) uniform = uniform && hr[ce[k]] == hr[ce[0]];
             const size_t s0 = (size_t)bi * 64;
@@ -732,9 +468,23 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         if ((he = hipMemcpyAsync(p->own.p, own.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
         if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);     // host vectors go out of scope after this
     }
-    if (num_features > 0) {
-        const gn_status cs = build_class_encoding(p, hu, hv, hr, scored, mirror_of, num_features, st);
-        if (cs != GN_OK) { gn_distmult_plan_destroy(p); return cs; }
+    if (num_features > 0 && !gn::fast_paths_disabled()) {
+        gn_layout::ClassLayout cl = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, num_nodes, num_features, gn::compute_units());
+        if (cl.ok) {
+            if ((he = p->cls_packed.alloc(cl.packed.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_own.alloc(cl.own.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_mirror.alloc(cl.mirror.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_rel.alloc(cl.rel32.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_wg.alloc(cl.wg.size())) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_packed.p, cl.packed.data(), cl.packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_own.p, cl.own.data(), cl.own.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_mirror.p, cl.mirror.data(), cl.mirror.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_rel.p, cl.rel32.data(), cl.rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_wg.p, cl.wg.data(), cl.wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);
+            p->cls_features = (int)num_features; p->cls_groups = cl.groups; p->cls_batches = cl.batches;
+            p->cls_ok = 1;
+        }
     }
     *out = p;
     return GN_OK;

@@ -45,8 +45,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int kColThreads = GN_COL_THREADS;
 constexpr int kColWaves = kColThreads / 64;
+static_assert(kColWaves == gn_layout::kColLayoutWaves, "the plan cuts a range's tiles into the waves of one workgroup");
 constexpr size_t kColLdsBytes = 160 * 1024;
-constexpr int kColSlack = 32;            // spare iterations behind the id stream: look-ahead loads never leave it
+constexpr int kColSlack = gn_layout::kColLayoutSlack;            // spare iterations behind the id stream: look-ahead loads never leave it
 constexpr int kWaveInts = 12;            // per wave of a range: first tile, end tile, first iteration, end iteration, the ends of its first five tiles, 3 unused
 
 bool blocked_disabled() {
@@ -386,118 +387,12 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     GN_HIP(hipMemcpyAsync(dis_host.data(), plan->dis.p, N * sizeof(float), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
 
-    // destination rows by degree (descending, stable), dealt to the ranges in a snake: every range gets the same number
-    // of edges (to within a row) and rows of every degree; inside a range the rows stay in degree order, so that the 16
-    // rows of a tile have similar lengths
-    std::vector<int32_t> order(N);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
-    std::vector<std::vector<int32_t>> range_rows(R);
-    for (int64_t k = 0; k < N; ++k) {
-        const int64_t lap = k / R, pos = k % R;
-        range_rows[(lap & 1) ? R - 1 - pos : pos].push_back(order[k]);
-    }
-    // tiles of 16 rows; a row's edges are dealt to the 4 lanes of its quad, 4 ids per lane and iteration.  Which edge
-    // goes into which (iteration, slot) is free (the order of a sum), so it is chosen for the LDS: ds_read_b64 (and
-    // b32) serves lanes 0-31 and 32-63 as two access groups, conflict-free when the ids of a group differ mod 32.
-    // (the ranges are scheduled independently of each other, on the plan builders' threads, and concatenated in order)
-    struct RangeOut { std::vector<int32_t> tile_iters, tile_rows; std::vector<uint16_t> ids; bool failed = false; };
-    std::vector<RangeOut> built(R);
-    const uint16_t zero_id = (uint16_t)N;
-    gn::parallel_for(R, 1, [&](int64_t r0, int64_t r1) {
-        std::vector<uint16_t> bucket[16][32];
-        for (int64_t r = r0; r < r1; ++r) {
-            const std::vector<int32_t>& rows = range_rows[r];
-            RangeOut& o = built[r];
-            const int tiles_r = (int)gn::ceil_div((int64_t)rows.size(), 16);
-            for (int tl = 0; tl < tiles_r; ++tl) {
-                int32_t trow[16], rem[16];
-                int iters = 0;
-                for (int qi = 0; qi < 16; ++qi) {
-                    for (int c = 0; c < 32; ++c) bucket[qi][c].clear();
-                    const size_t k = (size_t)tl * 16 + qi;
-                    trow[qi] = k < rows.size() ? rows[k] : -1;
-                    rem[qi] = 0;
-                    if (trow[qi] < 0) continue;
-                    for (int32_t p = rp[trow[qi]]; p < rp[trow[qi] + 1]; ++p) bucket[qi][col[p] & 31].push_back((uint16_t)col[p]);
-                    rem[qi] = rp[trow[qi] + 1] - rp[trow[qi]];
-                    iters = std::max(iters, (rem[qi] + 15) / 16);
-                }
-                for (int qi = 0; qi < 16; ++qi) o.tile_rows.push_back(trow[qi]);
-                const size_t base = o.ids.size();
-                o.ids.resize(base + (size_t)iters * 256, zero_id);
-                for (int itn = 0; itn < iters; ++itn)
-                    for (int s = 0; s < 4; ++s)                               // one LDS instruction: slot s of every lane
-                        for (int half = 0; half < 2; ++half) {                // its two access groups: rows 0-7, rows 8-15
-                            bool used[32] = {false};
-                            int rows_by_need[8];
-                            for (int k = 0; k < 8; ++k) rows_by_need[k] = half * 8 + k;
-                            std::sort(rows_by_need, rows_by_need + 8, [&](int x, int y) { return rem[x] > rem[y]; });
-                            const int left = (iters - itn) * 4 - s;           // instructions left, this one included
-                            for (int k = 0; k < 8; ++k) {
-                                const int qi = rows_by_need[k];
-                                for (int jl = 0; jl < 4; ++jl) {
-                                    if (rem[qi] == 0) break;
-                                    // must this lane take an edge now?  (4 lanes x (left - 1) instructions remain after this one)
-                                    const bool must = rem[qi] > (left - 1) * 4 + (3 - jl);
-                                    int best = -1; size_t bestn = 0;
-                                    for (int c = 0; c < 32; ++c)
-                                        if (!used[c] && bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
-                                    if (best < 0) {
-                                        if (!must) continue;                  // sits this slot out: the zero row
-                                        for (int c = 0; c < 32; ++c)
-                                            if (bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
-                                    }
-                                    o.ids[base + ((size_t)itn * 64 + qi * 4 + jl) * 4 + s] = bucket[qi][best].back();
-                                    bucket[qi][best].pop_back();
-                                    used[best] = true;
-                                    --rem[qi];
-                                }
-                            }
-                        }
-                for (int qi = 0; qi < 16; ++qi)
-                    if (rem[qi] != 0) o.failed = true;
-                o.tile_iters.push_back(iters);
-            }
-        }
-    });
-    std::vector<int32_t> tile_off(1, 0), tile_rows, cell;
-    std::vector<uint16_t> ids;
-    for (int r = 0; r < R; ++r) {
-        RangeOut& o = built[r];
-        if (o.failed) return gn::fail(GN_ERR_UNSUPPORTED, "internal: an edge was not scheduled");
-        const int tiles_r = (int)o.tile_iters.size();
-        const int first_tile = (int)tile_off.size() - 1;
-        for (int tl = 0; tl < tiles_r; ++tl) tile_off.push_back(tile_off.back() + o.tile_iters[tl]);
-        tile_rows.insert(tile_rows.end(), o.tile_rows.begin(), o.tile_rows.end());
-        ids.insert(ids.end(), o.ids.begin(), o.ids.end());
-        // the range's tiles, cut into the contiguous ranges of the workgroup's waves by iterations (+ a cost per tile)
-        auto cost_upto = [&](int tl) { return (int64_t)(tile_off[first_tile + tl] - tile_off[first_tile]) + 2 * (int64_t)tl; };
-        int wt = 0;
-        for (int wv = 0; wv < kColWaves; ++wv) {
-            int wt1 = tiles_r;
-            if (wv < kColWaves - 1) {
-                const int64_t goal = cost_upto(tiles_r) * (wv + 1) / kColWaves;
-                wt1 = wt;
-                while (wt1 < tiles_r && cost_upto(wt1 + 1) <= goal) ++wt1;
-            }
-            cell.push_back(first_tile + wt); cell.push_back(first_tile + wt1);
-            cell.push_back(tile_off[first_tile + wt]); cell.push_back(tile_off[first_tile + wt1]);
-            for (int k = 1; k <= 5; ++k) cell.push_back(tile_off[std::min(first_tile + wt + k, first_tile + tiles_r)]);
-            cell.push_back(0); cell.push_back(0); cell.push_back(0);
-            wt = wt1;
-        }
-        o = RangeOut();
-    }
-    const int64_t iters_total = tile_off.back();
-    for (int k = 0; k < 6; ++k) tile_off.push_back((int32_t)iters_total);
-    for (int k = 0; k < 64; ++k) tile_rows.push_back(-1);
-    std::vector<float> tile_dis(tile_rows.size(), 0.f);
-    for (size_t k = 0; k < tile_rows.size(); ++k)
-        if (tile_rows[k] >= 0) tile_dis[k] = dis_host[tile_rows[k]];
-    ids.resize(ids.size() + (size_t)kColSlack * 256, zero_id);
-    if (ids.size() / 2 >= ((size_t)1 << 31)) return GN_OK;
-
+    gn_layout::BlockedLayout bl = gn_layout::build_blocked_layout(N, R, rp, col, dis_host);
+    if (bl.failed) return gn::fail(GN_ERR_UNSUPPORTED, "internal: an edge was not scheduled");
+    if (!bl.ok) return GN_OK;
+    std::vector<int32_t>& tile_off = bl.tile_off; std::vector<int32_t>& tile_rows = bl.tile_rows; std::vector<int32_t>& cell = bl.cell;
+    std::vector<float>& tile_dis = bl.tile_dis; std::vector<uint16_t>& ids = bl.ids;
+    const int64_t iters_total = bl.iters_total;
     plan->blk_ok = 0;
     plan->blk_dis.release(); plan->blk_tile_off.release(); plan->blk_ids.release(); plan->blk_cell.release();
     plan->blk_tile_rows.release(); plan->blk_tile_dis.release(); plan->blk_table.release();

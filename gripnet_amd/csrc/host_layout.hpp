@@ -1,0 +1,682 @@
+// Pure host-side layout code of the plan builders: which edge goes into which slot of which stream.  No HIP in here -
+// the .hip files copy inputs to the host, call these, and upload what comes back - so that this file also builds with
+// plain g++, where tests/host_layout_san.cpp runs every builder under AddressSanitizer / UBSan and under ThreadSanitizer
+// with GN_PLAN_THREADS=16 (sanitizers; `make -C gripnet_amd/csrc SAN=asan|tsan`).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+namespace gn {
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Host side of the plan builders: fn(begin, end) over contiguous chunks of [0, n) on up to GN_PLAN_THREADS (default 16:
+// the CPU share of one GPU on the boxes this runs on) threads.  The chunks are fixed by n and the thread count only and
+// every chunk writes its own outputs, so a plan does not depend on scheduling.
+template <typename F>
+inline void parallel_for(int64_t n, int64_t grain, F fn) {
+    int want = 16;
+    if (const char* e = getenv("GN_PLAN_THREADS")) want = std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 0) want = std::min<int>(want, (int)hw);
+    const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(want, (n + grain - 1) / std::max<int64_t>(grain, 1)));
+    if (chunks <= 1 || n <= 0) { if (n > 0) fn((int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)chunks - 1);
+    for (int64_t c = 1; c < chunks; ++c) pool.emplace_back([=]() { fn(n * c / chunks, n * (c + 1) / chunks); });
+    fn((int64_t)0, n / chunks);
+    for (std::thread& t : pool) t.join();
+}
+
+}  // namespace gn
+
+namespace gn_layout {
+
+constexpr uint32_t kNoMirror = 0xffffffffu;
+constexpr int kClsDCache = 64;        // relation rows of D a workgroup of k_distmult_class keeps in LDS
+constexpr int kClsSlack = 64;         // readable batches behind the last one (the kernel's prefetches run ahead unclamped)
+
+// ---- DistMult decoder on a static list (distmult_plan.hip) -------------------------------------------------------------
+// Triples with the same unordered node pair and relation have the same score (the reference's positive list holds every
+// edge in both directions, utils.py:132-138): they are paired up, the first of a pair is scored and writes both positions.
+// mirror_of[e] = the later copy that takes e's score (-1: none); covered[e] = e is such a later copy.
+inline void pair_mirrors(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
+                         std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
+    const int64_t E = (int64_t)hu.size();
+    mirror_of.assign((size_t)E, -1);
+    covered.assign((size_t)E, 0);
+    // open addressing on a power-of-two table (keys are unique per open triple; an erased slot keeps its key with
+    // value -1 so that probe chains stay intact)
+    size_t cap = 1;
+    while (cap < (size_t)E * 2 + 16) cap <<= 1;
+    std::vector<uint64_t> keys(cap, ~(uint64_t)0);
+    std::vector<int64_t> vals(cap, -1);
+    for (int64_t e = 0; e < E; ++e) {
+        const uint64_t lo = (uint64_t)std::min(hu[e], hv[e]), hi = (uint64_t)std::max(hu[e], hv[e]);
+        const uint64_t key = ((uint64_t)hr[e] << (2 * node_bits)) | (lo << node_bits) | hi;
+        size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+        while (keys[h] != ~(uint64_t)0 && keys[h] != key) h = (h + 1) & (cap - 1);
+        if (keys[h] == key && vals[h] >= 0) {                // the open copy of this triple: pair up
+            mirror_of[vals[h]] = e;
+            covered[e] = 1;
+            vals[h] = -1;
+        } else {                                            // first (or third, fifth, ...) copy: stays open
+            keys[h] = key;
+            vals[h] = e;
+        }
+    }
+}
+
+// Deals the (up to) 64 edges of a batch to its slots.  Lane l of the wave holds slot l; wave step S works on the
+// slots 4 q + S of the 16 quads q, and ds_read_b128 serves the quads in four access groups.  A cell = (step,
+// access group) = four slots that hit the LDS together: its edges should have four different u % 4 and four
+// different v % 4 (the bank slot of a row is (row * odd stride) % 4).
+inline void deal_batch(const int64_t* u, const int64_t* v, int count, int* slot_of_edge) {
+    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+    static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
+                                      {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
+                                      {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
+                                      {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
+    std::vector<int> bucket[4][4];                         // edges by (u % 4, v % 4)
+    for (int e = 0; e < count; ++e) bucket[u[e] & 3][v[e] & 3].push_back(e);
+    int left = count;
+    for (int cell = 0; cell < 16; ++cell) {
+        const int S = cell & 3, g = cell >> 2;
+        int chosen[4] = {-1, -1, -1, -1};
+        if (left > 0) {
+            // a full cell: one edge from each (c, sigma(c)) for the permutation whose scarcest bucket is fullest
+            int best = -1, best_min = 0;
+            for (int p = 0; p < 24; ++p) {
+                int mn = 1 << 30;
+                for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
+                if (mn > best_min) { best_min = mn; best = p; }
+            }
+            if (best >= 0) {
+                for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
+            } else {
+                // no conflict-free quadruple left: take edges one by one, preferring unused u and v classes
+                unsigned used_u = 0, used_v = 0;
+                for (int k = 0; k < 4; ++k) {
+                    int bc = -1, bd = -1, bscore = -1;
+                    for (int c = 0; c < 4; ++c)
+                        for (int dd = 0; dd < 4; ++dd) {
+                            if (bucket[c][dd].empty()) continue;
+                            const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
+                            if (score > bscore) { bscore = score; bc = c; bd = dd; }
+                        }
+                    if (bc < 0) break;
+                    chosen[k] = bucket[bc][bd].back();
+                    bucket[bc][bd].pop_back();
+                    used_u |= 1u << bc; used_v |= 1u << bd;
+                }
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            if (chosen[k] >= 0) { slot_of_edge[chosen[k]] = 4 * kGroupQuads[g][k] + S; --left; }
+    }
+}
+
+// Cells of four pairs for one run of pairs that share class and relation: the four pairs of a cell are read by one
+// 16-lane access group of ds_read_b128, so they should have four different (local row of u) % 4 and four different
+// (local row of v) % 4 - the 64-byte bank slot of a row is (row * odd stride) % 4.  Cells fill whole steps first
+// (step = cell / 4): a run is padded to a multiple of 16 pairs, not 64.  order[cell * 4 + k] = pair of the run, or -1.
+inline void deal_run(const int* lu, const int* lv, int count, std::vector<int>& order) {
+    static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
+                                      {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
+                                      {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
+                                      {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
+    const int steps = (count + 15) / 16;
+    order.assign((size_t)steps * 16, -1);
+    std::vector<int> bucket[4][4];
+    for (int e = count - 1; e >= 0; --e) bucket[lu[e] & 3][lv[e] & 3].push_back(e);   // (popped from the back: list order)
+    int left = count;
+    for (int cell = 0; cell < steps * 4 && left > 0; ++cell) {
+        int chosen[4] = {-1, -1, -1, -1};
+        int best = -1, best_min = 0;
+        for (int p = 0; p < 24; ++p) {
+            int mn = 1 << 30;
+            for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
+            if (mn > best_min) { best_min = mn; best = p; }
+        }
+        if (best >= 0) {
+            for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
+        } else {
+            unsigned used_u = 0, used_v = 0;
+            for (int k = 0; k < 4; ++k) {
+                int bc = -1, bd = -1, bscore = -1;
+                for (int c = 0; c < 4; ++c)
+                    for (int dd = 0; dd < 4; ++dd) {
+                        if (bucket[c][dd].empty()) continue;
+                        const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
+                        if (score > bscore) { bscore = score; bc = c; bd = dd; }
+                    }
+                if (bc < 0) break;
+                chosen[k] = bucket[bc][bd].back();
+                bucket[bc][bd].pop_back();
+                used_u |= 1u << bc; used_v |= 1u << bd;
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            if (chosen[k] >= 0) { order[(size_t)cell * 4 + k] = chosen[k]; --left; }
+    }
+}
+
+// The row-class encoding of the scored pairs (see k_distmult_class in distmult_plan.hip).  ok = false when a class's
+// rows do not fit the LDS with `features` columns, or a workgroup's batches name more relations than its D cache holds.
+struct ClassLayout {
+    bool ok = false;
+    int groups = 0;
+    int64_t batches = 0;
+    std::vector<uint32_t> packed, own, mirror, rel32;
+    std::vector<int32_t> wg;
+};
+
+inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr,
+                                      const std::vector<int64_t>& scored, const std::vector<int64_t>& mirror_of, int64_t n,
+                                      int64_t features, int cus) {
+    static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+    ClassLayout L;
+    if (features < 16 || features % 16 != 0 || features > 128 || scored.empty() || n < 1) return L;
+    const int J = (int)(features / 16), str4 = (J & 1) ? 4 * J : 4 * J + 4;
+    const int64_t rows_fit = ((int64_t)160 * 1024 - (int64_t)kClsDCache * 4 * J * 16) / ((int64_t)str4 * 16);
+    int nblocks = 1;
+    int64_t blk = n;
+    if (n > rows_fit) {
+        blk = gn::ceil_div(n, 3);
+        if (2 * blk > rows_fit) return L;
+        nblocks = 3;
+    }
+    if (n > 65535) return L;
+    const int nclasses = nblocks == 1 ? 1 : 3;
+    auto bstart = [&](int b) { return std::min<int64_t>(n, (int64_t)b * blk); };
+    auto bsize = [&](int b) { return bstart(b + 1) - bstart(b); };
+    auto cls_of = [&](int64_t e) {
+        if (nblocks == 1) return 0;
+        const int bu = (int)(hu[e] / blk), bv = (int)(hv[e] / blk);
+        if (bu != bv) return (bu + 1) % 3 == bv ? bu : bv;
+        return (hr[e] & 1) ? (bu + 2) % 3 : bu;                  // a pair inside one block: either class that holds the block
+    };
+    auto local = [&](int64_t node, int k) {
+        const int b = (int)(node / blk);
+        return (int)(b == k ? node - bstart(k) : bsize(k) + node - bstart((k + 1) % 3));
+    };
+    // scored pairs by (class, relation), list order inside
+    const int64_t S = (int64_t)scored.size();
+    std::vector<uint32_t> key((size_t)S);
+    std::vector<int64_t> idx((size_t)S);
+    for (int64_t i = 0; i < S; ++i) { key[i] = (uint32_t)cls_of(scored[i]) << 16 | (uint32_t)hr[scored[i]]; idx[i] = i; }
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });
+    // runs -> steps of 16 slots
+    struct Run { int64_t lo, hi; int cls, rel; int64_t step0; };
+    std::vector<Run> runs;
+    std::vector<int64_t> cls_steps(nclasses, 0);
+    for (int64_t i = 0; i < S;) {
+        int64_t j = i;
+        while (j < S && key[idx[j]] == key[idx[i]]) ++j;
+        const int c = (int)(key[idx[i]] >> 16);
+        runs.push_back({i, j, c, (int)(key[idx[i]] & 0xffffu), cls_steps[c]});
+        cls_steps[c] += gn::ceil_div(j - i, 16);
+        i = j;
+    }
+    std::vector<int64_t> cls_batch0(nclasses + 1, 0);
+    for (int c = 0; c < nclasses; ++c) cls_batch0[c + 1] = cls_batch0[c] + gn::ceil_div(cls_steps[c], 4);
+    const int64_t NB = cls_batch0[nclasses], NBA = NB + kClsSlack;
+    std::vector<uint32_t> packed((size_t)NBA * 64, 0u), own((size_t)NBA * 64, kNoMirror), mirror((size_t)NBA * 64, kNoMirror);
+    std::vector<uint16_t> rel16((size_t)NBA * 4, 0);
+    gn::parallel_for((int64_t)runs.size(), 16, [&](int64_t r0, int64_t r1) {
+        std::vector<int> lu, lv, order;
+        for (int64_t ri = r0; ri < r1; ++ri) {
+            const Run& run = runs[ri];
+            const int count = (int)(run.hi - run.lo);
+            lu.resize(count); lv.resize(count);
+            for (int k = 0; k < count; ++k) {
+                const int64_t e = scored[idx[run.lo + k]];
+                lu[k] = local(hu[e], run.cls); lv[k] = local(hv[e], run.cls);
+            }
+            deal_run(lu.data(), lv.data(), count, order);
+            const int steps = (int)(order.size() / 16);
+            for (int t = 0; t < steps; ++t) {
+                const int64_t gstep = cls_batch0[run.cls] * 4 + run.step0 + t;
+                const int64_t bat = gstep >> 2;
+                const int s_in = (int)(gstep & 3);
+                rel16[(size_t)gstep] = (uint16_t)run.rel;
+                for (int gq = 0; gq < 4; ++gq)
+                    for (int k = 0; k < 4; ++k) {
+                        const int pr = order[(size_t)t * 16 + gq * 4 + k];
+                        const size_t slot = (size_t)bat * 64 + 4 * kGroupQuads[gq][k] + s_in;
+                        const int src = pr >= 0 ? pr : 0;                       // padding repeats the run's first pair, writes nothing
+                        packed[slot] = (uint32_t)lu[src] | (uint32_t)lv[src] << 16;
+                        if (pr >= 0) {
+                            const int64_t e = scored[idx[run.lo + pr]];
+                            own[slot] = (uint32_t)e;
+                            mirror[slot] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
+                        }
+                    }
+            }
+        }
+    });
+    // steps that pad a class to whole batches: the relation of the step before them (no reload), pair (0, 0), no positions
+    for (int c = 0; c < nclasses; ++c)
+        for (int64_t gstep = cls_batch0[c] * 4 + cls_steps[c]; gstep < cls_batch0[c + 1] * 4; ++gstep)
+            rel16[(size_t)gstep] = rel16[(size_t)gstep - 1];
+    for (int64_t gstep = NB * 4; gstep < NBA * 4; ++gstep) rel16[(size_t)gstep] = NB > 0 ? rel16[(size_t)NB * 4 - 1] : 0;
+    // workgroups: a share of the compute units per class in proportion to its batches, contiguous batch ranges
+    int G = (int)std::min<int64_t>(cus, NB);
+    std::vector<int> share(nclasses, 0);
+    {
+        int given = 0, live = 0;
+        for (int c = 0; c < nclasses; ++c) live += cls_batch0[c + 1] > cls_batch0[c];
+        G = std::max(G, live);
+        std::vector<double> frac(nclasses, 0.0);
+        for (int c = 0; c < nclasses; ++c) {
+            const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
+            if (nb == 0) continue;
+            const double want = (double)G * nb / NB;
+            share[c] = std::max(1, (int)want);
+            frac[c] = want - share[c];
+            given += share[c];
+        }
+        while (given < G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] && (best < 0 || frac[c] > frac[best])) best = c; share[best]++; frac[best] -= 1.0; ++given; }
+        while (given > G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] > 1 && (best < 0 || frac[c] < frac[best])) best = c; if (best < 0) break; share[best]--; frac[best] += 1.0; --given; }
+        G = given;
+    }
+    std::vector<int32_t> wg((size_t)G * 8, 0);
+    int gi = 0;
+    for (int c = 0; c < nclasses; ++c) {
+        const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
+        for (int k = 0; k < share[c]; ++k, ++gi) {
+            const int64_t lo = cls_batch0[c] + nb * k / share[c], hi = cls_batch0[c] + nb * (k + 1) / share[c];
+            int rlo = 1 << 30, rhi = -1;
+            for (int64_t gstep = lo * 4; gstep < hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
+            if (hi <= lo) { rlo = 0; rhi = 0; }
+            if (rhi - rlo + 1 > kClsDCache) return L;                             // (the column-phase kernel serves such a list)
+            int32_t* d = wg.data() + (size_t)gi * 8;
+            if (nblocks == 1) { d[0] = 0; d[1] = (int32_t)n; d[2] = 0; d[3] = 0; }
+            else { d[0] = (int32_t)bstart(c); d[1] = (int32_t)bsize(c); d[2] = (int32_t)bstart((c + 1) % 3); d[3] = (int32_t)bsize((c + 1) % 3); }
+            d[4] = (int32_t)lo; d[5] = (int32_t)hi; d[6] = rlo; d[7] = rhi - rlo + 1;
+        }
+    }
+    std::vector<uint32_t> rel32((size_t)NBA * 2);
+    for (size_t i = 0; i < rel32.size(); ++i) rel32[i] = (uint32_t)rel16[2 * i] | (uint32_t)rel16[2 * i + 1] << 16;
+    L.packed.swap(packed); L.own.swap(own); L.mirror.swap(mirror); L.rel32.swap(rel32); L.wg.swap(wg);
+    L.groups = G; L.batches = NB;
+    L.ok = true;
+    return L;
+}
+
+
+// ---- relational layer, destination-major kernel (rgcn_pair.hip) -----------------------------------------------------------
+constexpr int kPairWaves = 16;             // waves of a workgroup
+constexpr int kPairRowBytes = 128;         // LDS stride of an att row
+constexpr int kPairMaxD = 3;               // destination rows per workgroup
+constexpr int kPairSectionCap = 64;        // blocks of a section inside one unit
+constexpr int kPairSlackBlocks = 192;      // readable blocks behind the last wave's stream (the window reads ahead)
+
+// The blocks of one section: four lists of relation ids (one per lane group), `nb` blocks of four positions each.
+// Lane groups 0/1 and 2/3 share the 32 lanes of one LDS access: rows of equal parity sit in the same banks, so the
+// lists of a group pair are laid out even rows first / odd rows last against odd rows first / even rows last, and a
+// padded position names the zero row of the parity its partner does not use.
+inline void lay_out_section(const uint32_t* const (&list)[4], const int (&len)[4], int nb, uint32_t R, std::vector<uint32_t>& out) {
+    const int P = 4 * nb;
+    const uint32_t none = 0xffffffffu;
+    std::vector<uint32_t> pos[4];
+    for (int k = 0; k < 4; ++k) {
+        pos[k].assign(P, none);
+        const bool even_first = (k & 1) == 0;
+        int left = 0, right = P - 1;
+        // first the rows of the leading parity, left aligned, in list order; then the others, right aligned
+        for (int i = 0; i < len[k]; ++i)
+            if (((list[k][i] & 1u) == 0u) == even_first) pos[k][left++] = list[k][i];
+        for (int i = len[k] - 1; i >= 0; --i)
+            if (((list[k][i] & 1u) == 0u) != even_first) pos[k][right--] = list[k][i];
+    }
+    const uint32_t zero_even = (R & 1u) ? R + 1 : R, zero_odd = (R & 1u) ? R : R + 1;
+    const size_t base = out.size();
+    out.resize(base + (size_t)nb * 16);
+    for (int k = 0; k < 4; ++k) {
+        const int partner = k ^ 1;
+        for (int i = 0; i < P; ++i) {
+            uint32_t row = pos[k][i];
+            if (row == none) {
+                const uint32_t other = pos[partner][i];
+                row = (other != none && (other & 1u) == 0u) ? zero_odd : zero_even;
+                if (other == none && (k & 1)) row = zero_odd;                  // two padded partners: one of each
+            }
+            out[base + (size_t)(i >> 2) * 16 + k * 4 + (i & 3)] = row * (uint32_t)kPairRowBytes;
+        }
+    }
+}
+
+// Units, per-wave streams and descriptors of the destination-major plan.  rp: [N * kpad + 1] first edge of every
+// (destination, K position) cell of the edge list sorted by that key; rels: the relation of every sorted edge; perm: the
+// source node at every K position (N: none).  G workgroups, up to D rows each.
+struct PairLayout {
+    bool ok = false;
+    int64_t blocks = 0;
+    std::vector<uint32_t> stream, wave_first, desc, wave_units, wave_desc;
+    std::vector<int32_t> wg_dst;
+};
+
+inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, int G, int D, const std::vector<int32_t>& rp,
+                                    const std::vector<uint32_t>& rels, const std::vector<int32_t>& perm) {
+    PairLayout L;
+    // A unit = (destination, chunk, slice j of <= kPairSectionCap blocks per section).  Blocks of a section = the longest of
+    // its four pairs, in fours, at least one; a (destination, chunk) without any edge is no unit at all.
+    // K order PER DESTINATION: its (destination, source) pairs by edge count, longest first, four consecutive ones to the
+    // four lane groups of a section - lock-step partners then have (nearly) equal runs and what is left of the padding is
+    // the rounding to blocks of four (pose0-syn: 1.83 -> 1.32 x the edges, tools/pair_sim.py).  kord[i][pos] = the global
+    // K position (cell of `rp`) that sits at operand position pos = 32 chunk + 8 group + t of destination i; the sources
+    // of a (destination, chunk) are a row of `perm2` (the kernel reads its x rows through it).
+    std::vector<int32_t> kord((size_t)N * kpad);
+    std::vector<int32_t> perm2((size_t)N * kpad);
+    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
+        std::vector<int32_t> idx(kpad);
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t* r = rp.data() + (size_t)i * kpad;
+            std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return r[x + 1] - r[x] > r[y + 1] - r[y]; });
+            for (int q = 0; q < kpad; ++q) {
+                const int ch = q >> 5, t = (q & 31) >> 2, k = q & 3;
+                const size_t pos = (size_t)i * kpad + 32 * ch + 8 * k + t;
+                kord[pos] = idx[q];
+                // a pair without edges names no source: its x row is not read and counts as zero, so a non-finite x[s]
+                // reaches only the destinations s has an edge to (0 . inf would be NaN), as in the reference's edge sum
+                perm2[pos] = r[idx[q] + 1] > r[idx[q]] ? perm[idx[q]] : (int32_t)N;
+            }
+        }
+    });
+    auto cell = [&](int64_t i, int pos) { return (size_t)i * kpad + kord[(size_t)i * kpad + pos]; };
+    auto pair_len = [&](int64_t i, int pos) { const size_t c = cell(i, pos); return rp[c + 1] - rp[c]; };
+    auto chunk_empty = [&](int64_t i, int ch) { return pair_len(i, 32 * ch) == 0; };   // (position 32 ch holds the chunk's longest pair)
+    auto section_blocks = [&](int64_t i, int ch, int t) {
+        int longest = 0;
+        for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
+        return std::max(1, (longest + 3) / 4);
+    };
+    std::vector<int64_t> cost(N, 0);
+    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            int64_t blocks = 0;
+            for (int ch = 0; ch < chunks; ++ch) {
+                if (chunk_empty(i, ch)) continue;
+                int deepest = 1;
+                for (int t = 0; t < 8; ++t) {
+                    const int nb = section_blocks(i, ch, t);
+                    deepest = std::max(deepest, nb);
+                    blocks += nb;
+                }
+                blocks += 12 * gn::ceil_div(deepest, kPairSectionCap);             // a unit's split and matrix products, in block times
+            }
+            cost[i] = blocks;
+        }
+    });
+    // destinations to workgroups: longest first, each to the least loaded workgroup that still has room
+    std::vector<std::vector<int32_t>> wg_rows(G);
+    {
+        std::vector<int32_t> order(N);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
+        std::vector<int64_t> load(G, 0);
+        for (int32_t i : order) {
+            int best = -1;
+            for (int gg = 0; gg < G; ++gg)
+                if ((int)wg_rows[gg].size() < D && (best < 0 || load[gg] < load[best])) best = gg;
+            wg_rows[best].push_back(i);
+            load[best] += cost[i];
+        }
+    }
+    // per workgroup: every destination row gets a share of the sixteen waves in proportion to its cost (at least one), a
+    // wave a contiguous run of its row's units (chunk order) of equal cost; per wave the descriptors (eight dwords a unit,
+    // pages of eight units) and the stream
+    std::vector<std::vector<uint32_t>> wg_stream((size_t)G * kPairWaves), wg_desc((size_t)G * kPairWaves);
+    std::vector<uint32_t> wave_units((size_t)G * kPairWaves, 0u);
+    std::vector<int32_t> wg_dst((size_t)G * 4, -1);
+    gn::parallel_for(G, 1, [&](int64_t b, int64_t e) {
+        struct Unit { int32_t ch, slice; int64_t cost; };
+        std::vector<Unit> units;
+        for (int64_t gg = b; gg < e; ++gg) {
+            const std::vector<int32_t>& rows = wg_rows[gg];
+            const int nd = (int)rows.size();
+            for (int d = 0; d < nd; ++d) wg_dst[gg * 4 + d] = rows[d];
+            // waves per row: largest remainders of the proportional share
+            int share[kPairMaxD] = {0, 0, 0};
+            {
+                int64_t total = 0;
+                for (int d = 0; d < nd; ++d) total += std::max<int64_t>(cost[rows[d]], 1);
+                int given = 0;
+                double frac[kPairMaxD] = {0, 0, 0};
+                for (int d = 0; d < nd; ++d) {
+                    const double want = (double)kPairWaves * std::max<int64_t>(cost[rows[d]], 1) / total;
+                    share[d] = std::max(1, (int)want);
+                    frac[d] = want - share[d];
+                    given += share[d];
+                }
+                while (given < kPairWaves) { int best = 0; for (int d = 1; d < nd; ++d) if (frac[d] > frac[best]) best = d; share[best]++; frac[best] -= 1.0; ++given; }
+                while (given > kPairWaves) { int best = -1; for (int d = 0; d < nd; ++d) if (share[d] > 1 && (best < 0 || frac[d] < frac[best])) best = d; share[best]--; frac[best] += 1.0; --given; }
+            }
+            int wave0 = 0;
+            uint32_t starts = 0;
+            for (int d = 0; d < nd; ++d) {
+                if (d == 1) starts |= (uint32_t)wave0;
+                if (d == 2) starts |= (uint32_t)wave0 << 8;
+                const int64_t i = rows[d];
+                units.clear();
+                int64_t total = 0;
+                for (int ch = 0; ch < chunks; ++ch) {
+                    if (chunk_empty(i, ch)) continue;
+                    int nb[8], deepest = 1;
+                    for (int t = 0; t < 8; ++t) { nb[t] = section_blocks(i, ch, t); deepest = std::max(deepest, nb[t]); }
+                    for (int j = 0; j * kPairSectionCap < deepest; ++j) {
+                        int64_t c = 16;                                        // x chunk, split, matrix products: in block times
+                        for (int t = 0; t < 8; ++t) c += std::max(1, std::min(kPairSectionCap, nb[t] - j * kPairSectionCap));
+                        units.push_back({ch, j, c});
+                        total += c;
+                    }
+                }
+                int64_t seen = 0;
+                for (const Unit& un : units) {
+                    // the wave of this row whose share of the cost line holds this unit's midpoint
+                    const int wv = wave0 + (total > 0 ? (int)std::min<int64_t>(share[d] - 1, (2 * seen + un.cost) * share[d] / (2 * total)) : 0);
+                    seen += un.cost;
+                    std::vector<uint32_t>& out = wg_stream[gg * kPairWaves + wv];
+                    std::vector<uint32_t>& dv = wg_desc[gg * kPairWaves + wv];
+                    const size_t at = dv.size();
+                    dv.resize(at + 32, 0u);
+                    for (int q = 0; q < 16; ++q) {                             // the chunk's sources, 16 bits each (N: none)
+                        const int32_t* ids = perm2.data() + ((size_t)i * chunks + un.ch) * 32 + 2 * q;
+                        dv[at + 8 + q] = (uint32_t)ids[0] | (uint32_t)ids[1] << 16;
+                    }
+                    for (int t = 0; t < 8; ++t) {
+                        const uint32_t* list[4];
+                        int len[4], longest = 0;
+                        for (int k = 0; k < 4; ++k) {
+                            const size_t key_id = cell(i, 32 * un.ch + 8 * k + t);
+                            const int full = rp[key_id + 1] - rp[key_id];
+                            const int from = std::min(full, un.slice * kPairSectionCap * 4);
+                            list[k] = rels.data() + rp[key_id] + from;
+                            len[k] = std::min(full - from, kPairSectionCap * 4);
+                            longest = std::max(longest, len[k]);
+                        }
+                        const int nb = std::max(1, (longest + 3) / 4);
+                        dv[at + (t >> 2)] |= (uint32_t)nb << (8 * (t & 3));
+                        lay_out_section(list, len, nb, (uint32_t)R, out);
+                    }
+                    wave_units[gg * kPairWaves + wv] += 1;
+                }
+                wave0 += share[d];
+            }
+            if (nd < 2) starts |= (uint32_t)kPairWaves;
+            if (nd < 3) starts |= (uint32_t)kPairWaves << 8;
+            wg_dst[gg * 4 + 3] = (int32_t)starts;
+            for (int wv = 0; wv < kPairWaves; ++wv) {                              // whole pages
+                std::vector<uint32_t>& dv = wg_desc[gg * kPairWaves + wv];
+                dv.resize((dv.size() + 63) / 64 * 64, 0u);
+            }
+        }
+    });
+    std::vector<uint32_t> wave_desc((size_t)G * kPairWaves);
+    std::vector<uint32_t> desc;
+    for (size_t i = 0; i < wg_desc.size(); ++i) {
+        wave_desc[i] = (uint32_t)(desc.size() / 32);
+        desc.insert(desc.end(), wg_desc[i].begin(), wg_desc[i].end());
+    }
+    desc.resize(desc.size() + 128, 0u);                                         // a wave without units still reads a page (and the one after)
+    std::vector<uint32_t> first((size_t)G * kPairWaves);
+    size_t total = 0;
+    for (size_t i = 0; i < wg_stream.size(); ++i) { first[i] = (uint32_t)(total / 16); total += wg_stream[i].size(); }
+    if (total / 16 + kPairSlackBlocks >= ((size_t)1 << 31)) return L;
+    std::vector<uint32_t> stream(total + (size_t)kPairSlackBlocks * 16, (uint32_t)R * kPairRowBytes);
+    gn::parallel_for((int64_t)wg_stream.size(), 64, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i)
+            if (!wg_stream[i].empty()) memcpy(stream.data() + (size_t)first[i] * 16, wg_stream[i].data(), wg_stream[i].size() * sizeof(uint32_t));
+    });
+    L.blocks = (int64_t)(total / 16);
+    L.stream.swap(stream); L.wave_first.swap(first); L.desc.swap(desc); L.wave_units.swap(wave_units); L.wave_desc.swap(wave_desc);
+    L.wg_dst.swap(wg_dst);
+    L.ok = true;
+    return L;
+}
+
+
+// ---- gene layers, LDS-staged gather (gcn_blocked.hip) -----------------------------------------------------------------------
+constexpr int kColLayoutWaves = 16;        // waves of a k_col_gather workgroup
+constexpr int kColLayoutSlack = 32;        // spare iterations behind the id stream
+
+// Destination rows -> ranges -> 16-row tiles -> (iteration, slot) of every edge, chosen for conflict-free LDS reads.
+// rp / col: the destination-major CSR; dis: deg^-1/2 per node (zero padded).  R ranges of destination rows.
+struct BlockedLayout {
+    bool ok = false, failed = false;
+    int64_t iters_total = 0;
+    std::vector<int32_t> tile_off, tile_rows, cell;
+    std::vector<float> tile_dis;
+    std::vector<uint16_t> ids;
+};
+
+inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<int32_t>& rp, const std::vector<int32_t>& col,
+                                          const std::vector<float>& dis_host) {
+    BlockedLayout L;
+    // destination rows by degree (descending, stable), dealt to the ranges in a snake: every range gets the same number
+    // of edges (to within a row) and rows of every degree; inside a range the rows stay in degree order, so that the 16
+    // rows of a tile have similar lengths
+    std::vector<int32_t> order(N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
+    std::vector<std::vector<int32_t>> range_rows(R);
+    for (int64_t k = 0; k < N; ++k) {
+        const int64_t lap = k / R, pos = k % R;
+        range_rows[(lap & 1) ? R - 1 - pos : pos].push_back(order[k]);
+    }
+    // tiles of 16 rows; a row's edges are dealt to the 4 lanes of its quad, 4 ids per lane and iteration.  Which edge
+    // goes into which (iteration, slot) is free (the order of a sum), so it is chosen for the LDS: ds_read_b64 (and
+    // b32) serves lanes 0-31 and 32-63 as two access groups, conflict-free when the ids of a group differ mod 32.
+    // (the ranges are scheduled independently of each other, on the plan builders' threads, and concatenated in order)
+    struct RangeOut { std::vector<int32_t> tile_iters, tile_rows; std::vector<uint16_t> ids; bool failed = false; };
+    std::vector<RangeOut> built(R);
+    const uint16_t zero_id = (uint16_t)N;
+    gn::parallel_for(R, 1, [&](int64_t r0, int64_t r1) {
+        std::vector<uint16_t> bucket[16][32];
+        for (int64_t r = r0; r < r1; ++r) {
+            const std::vector<int32_t>& rows = range_rows[r];
+            RangeOut& o = built[r];
+            const int tiles_r = (int)gn::ceil_div((int64_t)rows.size(), 16);
+            for (int tl = 0; tl < tiles_r; ++tl) {
+                int32_t trow[16], rem[16];
+                int iters = 0;
+                for (int qi = 0; qi < 16; ++qi) {
+                    for (int c = 0; c < 32; ++c) bucket[qi][c].clear();
+                    const size_t k = (size_t)tl * 16 + qi;
+                    trow[qi] = k < rows.size() ? rows[k] : -1;
+                    rem[qi] = 0;
+                    if (trow[qi] < 0) continue;
+                    for (int32_t p = rp[trow[qi]]; p < rp[trow[qi] + 1]; ++p) bucket[qi][col[p] & 31].push_back((uint16_t)col[p]);
+                    rem[qi] = rp[trow[qi] + 1] - rp[trow[qi]];
+                    iters = std::max(iters, (rem[qi] + 15) / 16);
+                }
+                for (int qi = 0; qi < 16; ++qi) o.tile_rows.push_back(trow[qi]);
+                const size_t base = o.ids.size();
+                o.ids.resize(base + (size_t)iters * 256, zero_id);
+                for (int itn = 0; itn < iters; ++itn)
+                    for (int s = 0; s < 4; ++s)                               // one LDS instruction: slot s of every lane
+                        for (int half = 0; half < 2; ++half) {                // its two access groups: rows 0-7, rows 8-15
+                            bool used[32] = {false};
+                            int rows_by_need[8];
+                            for (int k = 0; k < 8; ++k) rows_by_need[k] = half * 8 + k;
+                            std::sort(rows_by_need, rows_by_need + 8, [&](int x, int y) { return rem[x] > rem[y]; });
+                            const int left = (iters - itn) * 4 - s;           // instructions left, this one included
+                            for (int k = 0; k < 8; ++k) {
+                                const int qi = rows_by_need[k];
+                                for (int jl = 0; jl < 4; ++jl) {
+                                    if (rem[qi] == 0) break;
+                                    // must this lane take an edge now?  (4 lanes x (left - 1) instructions remain after this one)
+                                    const bool must = rem[qi] > (left - 1) * 4 + (3 - jl);
+                                    int best = -1; size_t bestn = 0;
+                                    for (int c = 0; c < 32; ++c)
+                                        if (!used[c] && bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                    if (best < 0) {
+                                        if (!must) continue;                  // sits this slot out: the zero row
+                                        for (int c = 0; c < 32; ++c)
+                                            if (bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                    }
+                                    o.ids[base + ((size_t)itn * 64 + qi * 4 + jl) * 4 + s] = bucket[qi][best].back();
+                                    bucket[qi][best].pop_back();
+                                    used[best] = true;
+                                    --rem[qi];
+                                }
+                            }
+                        }
+                for (int qi = 0; qi < 16; ++qi)
+                    if (rem[qi] != 0) o.failed = true;
+                o.tile_iters.push_back(iters);
+            }
+        }
+    });
+    std::vector<int32_t> tile_off(1, 0), tile_rows, cell;
+    std::vector<uint16_t> ids;
+    for (int r = 0; r < R; ++r) {
+        RangeOut& o = built[r];
+        if (o.failed) { L.failed = true; return L; }
+        const int tiles_r = (int)o.tile_iters.size();
+        const int first_tile = (int)tile_off.size() - 1;
+        for (int tl = 0; tl < tiles_r; ++tl) tile_off.push_back(tile_off.back() + o.tile_iters[tl]);
+        tile_rows.insert(tile_rows.end(), o.tile_rows.begin(), o.tile_rows.end());
+        ids.insert(ids.end(), o.ids.begin(), o.ids.end());
+        // the range's tiles, cut into the contiguous ranges of the workgroup's waves by iterations (+ a cost per tile)
+        auto cost_upto = [&](int tl) { return (int64_t)(tile_off[first_tile + tl] - tile_off[first_tile]) + 2 * (int64_t)tl; };
+        int wt = 0;
+        for (int wv = 0; wv < kColLayoutWaves; ++wv) {
+            int wt1 = tiles_r;
+            if (wv < kColLayoutWaves - 1) {
+                const int64_t goal = cost_upto(tiles_r) * (wv + 1) / kColLayoutWaves;
+                wt1 = wt;
+                while (wt1 < tiles_r && cost_upto(wt1 + 1) <= goal) ++wt1;
+            }
+            cell.push_back(first_tile + wt); cell.push_back(first_tile + wt1);
+            cell.push_back(tile_off[first_tile + wt]); cell.push_back(tile_off[first_tile + wt1]);
+            for (int k = 1; k <= 5; ++k) cell.push_back(tile_off[std::min(first_tile + wt + k, first_tile + tiles_r)]);
+            cell.push_back(0); cell.push_back(0); cell.push_back(0);
+            wt = wt1;
+        }
+        o = RangeOut();
+    }
+    const int64_t iters_total = tile_off.back();
+    for (int k = 0; k < 6; ++k) tile_off.push_back((int32_t)iters_total);
+    for (int k = 0; k < 64; ++k) tile_rows.push_back(-1);
+    std::vector<float> tile_dis(tile_rows.size(), 0.f);
+    for (size_t k = 0; k < tile_rows.size(); ++k)
+        if (tile_rows[k] >= 0) tile_dis[k] = dis_host[tile_rows[k]];
+    ids.resize(ids.size() + (size_t)kColLayoutSlack * 256, zero_id);
+    if (ids.size() / 2 >= ((size_t)1 << 31)) return L;
+
+    L.iters_total = iters_total;
+    L.tile_off.swap(tile_off); L.tile_rows.swap(tile_rows); L.cell.swap(cell); L.tile_dis.swap(tile_dis); L.ids.swap(ids);
+    L.ok = true;
+    return L;
+}
+
+}  // namespace gn_layout

@@ -34,16 +34,16 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kWaves = 16, kThreads = kWaves * 64;   // four waves per SIMD: 128 registers each, one destination row per wave
-constexpr int kRowBytes = 128;             // LDS stride of an att row (32 bases; fewer: zero padded)
+constexpr int kWaves = gn_layout::kPairWaves, kThreads = kWaves * 64;   // four waves per SIMD: 128 registers each, one destination row per wave
+constexpr int kRowBytes = gn_layout::kPairRowBytes;             // LDS stride of an att row (32 bases; fewer: zero padded)
 constexpr int kRingBlocks = 32;            // per-wave window on its stream: 32 blocks of 64 bytes, refilled a quarter (512 B) at a time
 constexpr int kRingBytes = kRingBlocks * 64;
-constexpr int kMaxD = 3;                   // destination rows per workgroup
+constexpr int kMaxD = gn_layout::kPairMaxD;                   // destination rows per workgroup
 constexpr int kMaxChunks = 255;            // chunks of 32 sources
-constexpr int kSectionCap = 64;            // (<= 255: a descriptor holds a section's blocks in eight bits)
+constexpr int kSectionCap = gn_layout::kPairSectionCap;            // (<= 255: a descriptor holds a section's blocks in eight bits)
                                            // pair becomes several units (running sums stay short: fp32 chains of <= 64)
 constexpr int kLdsBytes = 160 * 1024;
-constexpr int kSlackBlocks = 192;          // readable blocks behind the last wave's stream (the window reads ahead)
+constexpr int kSlackBlocks = gn_layout::kPairSlackBlocks;          // readable blocks behind the last wave's stream (the window reads ahead)
 
 struct PairArgs {
     const float* x;
@@ -709,41 +709,6 @@ bool pair_disabled() {
     return e && e[0] == '1';
 }
 
-// The blocks of one section: four lists of relation ids (one per lane group), `nb` blocks of four positions each.
-// Lane groups 0/1 and 2/3 share the 32 lanes of one LDS access: rows of equal parity sit in the same banks, so the
-// lists of a group pair are laid out even rows first / odd rows last against odd rows first / even rows last, and a
-// padded position names the zero row of the parity its partner does not use.
-void lay_out_section(const uint32_t* const (&list)[4], const int (&len)[4], int nb, uint32_t R, std::vector<uint32_t>& out) {
-    const int P = 4 * nb;
-    const uint32_t none = 0xffffffffu;
-    std::vector<uint32_t> pos[4];
-    for (int k = 0; k < 4; ++k) {
-        pos[k].assign(P, none);
-        const bool even_first = (k & 1) == 0;
-        int left = 0, right = P - 1;
-        // first the rows of the leading parity, left aligned, in list order; then the others, right aligned
-        for (int i = 0; i < len[k]; ++i)
-            if (((list[k][i] & 1u) == 0u) == even_first) pos[k][left++] = list[k][i];
-        for (int i = len[k] - 1; i >= 0; --i)
-            if (((list[k][i] & 1u) == 0u) != even_first) pos[k][right--] = list[k][i];
-    }
-    const uint32_t zero_even = (R & 1u) ? R + 1 : R, zero_odd = (R & 1u) ? R : R + 1;
-    const size_t base = out.size();
-    out.resize(base + (size_t)nb * 16);
-    for (int k = 0; k < 4; ++k) {
-        const int partner = k ^ 1;
-        for (int i = 0; i < P; ++i) {
-            uint32_t row = pos[k][i];
-            if (row == none) {
-                const uint32_t other = pos[partner][i];
-                row = (other != none && (other & 1u) == 0u) ? zero_odd : zero_even;
-                if (other == none && (k & 1)) row = zero_odd;                  // two padded partners: one of each
-            }
-            out[base + (size_t)(i >> 2) * 16 + k * 4 + (i & 3)] = row * (uint32_t)kRowBytes;
-        }
-    }
-}
-
 template <int NT, int BT, int TERMS>
 gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st) {
     static int stamp = 0;
@@ -848,176 +813,12 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
         GN_HIP(hipStreamSynchronize(st));
     }
 
-    // A unit = (destination, chunk, slice j of <= kSectionCap blocks per section).  Blocks of a section = the longest of
-    // its four pairs, in fours, at least one; a (destination, chunk) without any edge is no unit at all.
-    // K order PER DESTINATION: its (destination, source) pairs by edge count, longest first, four consecutive ones to the
-    // four lane groups of a section - lock-step partners then have (nearly) equal runs and what is left of the padding is
-    // the rounding to blocks of four (pose0-syn: 1.83 -> 1.32 x the edges, tools/pair_sim.py).  kord[i][pos] = the global
-    // K position (cell of `rp`) that sits at operand position pos = 32 chunk + 8 group + t of destination i; the sources
-    // of a (destination, chunk) are a row of `perm2` (the kernel reads its x rows through it).
-    std::vector<int32_t> kord((size_t)N * kpad);
-    std::vector<int32_t> perm2((size_t)N * kpad);
-    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
-        std::vector<int32_t> idx(kpad);
-        for (int64_t i = b; i < e; ++i) {
-            const int32_t* r = rp.data() + (size_t)i * kpad;
-            std::iota(idx.begin(), idx.end(), 0);
-            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return r[x + 1] - r[x] > r[y + 1] - r[y]; });
-            for (int q = 0; q < kpad; ++q) {
-                const int ch = q >> 5, t = (q & 31) >> 2, k = q & 3;
-                const size_t pos = (size_t)i * kpad + 32 * ch + 8 * k + t;
-                kord[pos] = idx[q];
-                // a pair without edges names no source: its x row is not read and counts as zero, so a non-finite x[s]
-                // reaches only the destinations s has an edge to (0 . inf would be NaN), as in the reference's edge sum
-                perm2[pos] = r[idx[q] + 1] > r[idx[q]] ? perm[idx[q]] : (int32_t)N;
-            }
-        }
-    });
-    auto cell = [&](int64_t i, int pos) { return (size_t)i * kpad + kord[(size_t)i * kpad + pos]; };
-    auto pair_len = [&](int64_t i, int pos) { const size_t c = cell(i, pos); return rp[c + 1] - rp[c]; };
-    auto chunk_empty = [&](int64_t i, int ch) { return pair_len(i, 32 * ch) == 0; };   // (position 32 ch holds the chunk's longest pair)
-    auto section_blocks = [&](int64_t i, int ch, int t) {
-        int longest = 0;
-        for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
-        return std::max(1, (longest + 3) / 4);
-    };
-    std::vector<int64_t> cost(N, 0);
-    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
-        for (int64_t i = b; i < e; ++i) {
-            int64_t blocks = 0;
-            for (int ch = 0; ch < chunks; ++ch) {
-                if (chunk_empty(i, ch)) continue;
-                int deepest = 1;
-                for (int t = 0; t < 8; ++t) {
-                    const int nb = section_blocks(i, ch, t);
-                    deepest = std::max(deepest, nb);
-                    blocks += nb;
-                }
-                blocks += 12 * gn::ceil_div(deepest, kSectionCap);             // a unit's split and matrix products, in block times
-            }
-            cost[i] = blocks;
-        }
-    });
-    // destinations to workgroups: longest first, each to the least loaded workgroup that still has room
-    std::vector<std::vector<int32_t>> wg_rows(G);
-    {
-        std::vector<int32_t> order(N);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
-        std::vector<int64_t> load(G, 0);
-        for (int32_t i : order) {
-            int best = -1;
-            for (int gg = 0; gg < G; ++gg)
-                if ((int)wg_rows[gg].size() < D && (best < 0 || load[gg] < load[best])) best = gg;
-            wg_rows[best].push_back(i);
-            load[best] += cost[i];
-        }
-    }
-    // per workgroup: every destination row gets a share of the sixteen waves in proportion to its cost (at least one), a
-    // wave a contiguous run of its row's units (chunk order) of equal cost; per wave the descriptors (eight dwords a unit,
-    // pages of eight units) and the stream
-    std::vector<std::vector<uint32_t>> wg_stream((size_t)G * kWaves), wg_desc((size_t)G * kWaves);
-    std::vector<uint32_t> wave_units((size_t)G * kWaves, 0u);
-    std::vector<int32_t> wg_dst((size_t)G * 4, -1);
-    gn::parallel_for(G, 1, [&](int64_t b, int64_t e) {
-        struct Unit { int32_t ch, slice; int64_t cost; };
-        std::vector<Unit> units;
-        for (int64_t gg = b; gg < e; ++gg) {
-            const std::vector<int32_t>& rows = wg_rows[gg];
-            const int nd = (int)rows.size();
-            for (int d = 0; d < nd; ++d) wg_dst[gg * 4 + d] = rows[d];
-            // waves per row: largest remainders of the proportional share
-            int share[kMaxD] = {0, 0, 0};
-            {
-                int64_t total = 0;
-                for (int d = 0; d < nd; ++d) total += std::max<int64_t>(cost[rows[d]], 1);
-                int given = 0;
-                double frac[kMaxD] = {0, 0, 0};
-                for (int d = 0; d < nd; ++d) {
-                    const double want = (double)kWaves * std::max<int64_t>(cost[rows[d]], 1) / total;
-                    share[d] = std::max(1, (int)want);
-                    frac[d] = want - share[d];
-                    given += share[d];
-                }
-                while (given < kWaves) { int best = 0; for (int d = 1; d < nd; ++d) if (frac[d] > frac[best]) best = d; share[best]++; frac[best] -= 1.0; ++given; }
-                while (given > kWaves) { int best = -1; for (int d = 0; d < nd; ++d) if (share[d] > 1 && (best < 0 || frac[d] < frac[best])) best = d; share[best]--; frac[best] += 1.0; --given; }
-            }
-            int wave0 = 0;
-            uint32_t starts = 0;
-            for (int d = 0; d < nd; ++d) {
-                if (d == 1) starts |= (uint32_t)wave0;
-                if (d == 2) starts |= (uint32_t)wave0 << 8;
-                const int64_t i = rows[d];
-                units.clear();
-                int64_t total = 0;
-                for (int ch = 0; ch < chunks; ++ch) {
-                    if (chunk_empty(i, ch)) continue;
-                    int nb[8], deepest = 1;
-                    for (int t = 0; t < 8; ++t) { nb[t] = section_blocks(i, ch, t); deepest = std::max(deepest, nb[t]); }
-                    for (int j = 0; j * kSectionCap < deepest; ++j) {
-                        int64_t c = 16;                                        // x chunk, split, matrix products: in block times
-                        for (int t = 0; t < 8; ++t) c += std::max(1, std::min(kSectionCap, nb[t] - j * kSectionCap));
-                        units.push_back({ch, j, c});
-                        total += c;
-                    }
-                }
-                int64_t seen = 0;
-                for (const Unit& un : units) {
-                    // the wave of this row whose share of the cost line holds this unit's midpoint
-                    const int wv = wave0 + (total > 0 ? (int)std::min<int64_t>(share[d] - 1, (2 * seen + un.cost) * share[d] / (2 * total)) : 0);
-                    seen += un.cost;
-                    std::vector<uint32_t>& out = wg_stream[gg * kWaves + wv];
-                    std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
-                    const size_t at = dv.size();
-                    dv.resize(at + 32, 0u);
-                    for (int q = 0; q < 16; ++q) {                             // the chunk's sources, 16 bits each (N: none)
-                        const int32_t* ids = perm2.data() + ((size_t)i * chunks + un.ch) * 32 + 2 * q;
-                        dv[at + 8 + q] = (uint32_t)ids[0] | (uint32_t)ids[1] << 16;
-                    }
-                    for (int t = 0; t < 8; ++t) {
-                        const uint32_t* list[4];
-                        int len[4], longest = 0;
-                        for (int k = 0; k < 4; ++k) {
-                            const size_t key_id = cell(i, 32 * un.ch + 8 * k + t);
-                            const int full = rp[key_id + 1] - rp[key_id];
-                            const int from = std::min(full, un.slice * kSectionCap * 4);
-                            list[k] = rels.data() + rp[key_id] + from;
-                            len[k] = std::min(full - from, kSectionCap * 4);
-                            longest = std::max(longest, len[k]);
-                        }
-                        const int nb = std::max(1, (longest + 3) / 4);
-                        dv[at + (t >> 2)] |= (uint32_t)nb << (8 * (t & 3));
-                        lay_out_section(list, len, nb, (uint32_t)R, out);
-                    }
-                    wave_units[gg * kWaves + wv] += 1;
-                }
-                wave0 += share[d];
-            }
-            if (nd < 2) starts |= (uint32_t)kWaves;
-            if (nd < 3) starts |= (uint32_t)kWaves << 8;
-            wg_dst[gg * 4 + 3] = (int32_t)starts;
-            for (int wv = 0; wv < kWaves; ++wv) {                              // whole pages
-                std::vector<uint32_t>& dv = wg_desc[gg * kWaves + wv];
-                dv.resize((dv.size() + 63) / 64 * 64, 0u);
-            }
-        }
-    });
-    std::vector<uint32_t> wave_desc((size_t)G * kWaves);
-    std::vector<uint32_t> desc;
-    for (size_t i = 0; i < wg_desc.size(); ++i) {
-        wave_desc[i] = (uint32_t)(desc.size() / 32);
-        desc.insert(desc.end(), wg_desc[i].begin(), wg_desc[i].end());
-    }
-    desc.resize(desc.size() + 128, 0u);                                         // a wave without units still reads a page (and the one after)
-    std::vector<uint32_t> first((size_t)G * kWaves);
-    size_t total = 0;
-    for (size_t i = 0; i < wg_stream.size(); ++i) { first[i] = (uint32_t)(total / 16); total += wg_stream[i].size(); }
-    if (total / 16 + kSlackBlocks >= ((size_t)1 << 31)) return GN_OK;
-    std::vector<uint32_t> stream(total + (size_t)kSlackBlocks * 16, (uint32_t)R * kRowBytes);
-    gn::parallel_for((int64_t)wg_stream.size(), 64, [&](int64_t b, int64_t e) {
-        for (int64_t i = b; i < e; ++i)
-            if (!wg_stream[i].empty()) memcpy(stream.data() + (size_t)first[i] * 16, wg_stream[i].data(), wg_stream[i].size() * sizeof(uint32_t));
-    });
+    gn_layout::PairLayout pl = gn_layout::build_pair_layout(N, R, chunks, kpad, G, D, rp, rels, perm);
+    if (!pl.ok) return GN_OK;
+    std::vector<uint32_t>& stream = pl.stream; std::vector<uint32_t>& first = pl.wave_first; std::vector<uint32_t>& desc = pl.desc;
+    std::vector<uint32_t>& wave_units = pl.wave_units; std::vector<uint32_t>& wave_desc = pl.wave_desc;
+    std::vector<int32_t>& wg_dst = pl.wg_dst;
+    const size_t total = (size_t)pl.blocks * 16;
     GN_HIP(plan->pair_stream.alloc(stream.size()));
     GN_HIP(plan->pair_wave_first.alloc(first.size()));
     GN_HIP(plan->pair_desc.alloc(desc.size()));

@@ -1,0 +1,184 @@
+// Runs the pure host-side layout code of the plan builders (gripnet_amd/csrc/host_layout.hpp) on random inputs, once on one
+// builder thread and once on sixteen, under the sanitizer this file was compiled with (make -C gripnet_amd/csrc SAN=asan
+// or SAN=tsan; tests/test_host_layout.py builds and runs both).  Checks that every edge lands in exactly one slot and that
+// a plan does not depend on the thread count.  No HIP, no GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "host_layout.hpp"
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); std::exit(1); } \
+    } while (0)
+
+namespace {
+
+void set_threads(int n) {
+    char buf[16];
+    std::snprintf(buf, sizeof buf, "%d", n);
+    setenv("GN_PLAN_THREADS", buf, 1);
+}
+
+// ---- decoder: pairing + row classes ------------------------------------------------------------------------------------
+gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t features, unsigned seed, bool check) {
+    std::mt19937_64 rng(seed);
+    std::vector<int64_t> hu, hv, hr;
+    for (int r = 0; r < R; ++r) {
+        const int64_t cnt = std::max<int64_t>(1, e_dir / (r + 1));
+        std::vector<int64_t> u(cnt), v(cnt);
+        for (int64_t k = 0; k < cnt; ++k) { u[k] = (int64_t)(rng() % (uint64_t)n); v[k] = (int64_t)(rng() % (uint64_t)n); }
+        for (int64_t k = 0; k < cnt; ++k) { hu.push_back(u[k]); hv.push_back(v[k]); hr.push_back(r); }
+        for (int64_t k = 0; k < cnt; ++k) { hu.push_back(v[k]); hv.push_back(u[k]); hr.push_back(r); }   // to_bidirection
+    }
+    const int64_t E = (int64_t)hu.size();
+    std::vector<int64_t> mirror_of;
+    std::vector<char> covered;
+    gn_layout::pair_mirrors(hu, hv, hr, 13, mirror_of, covered);
+    std::vector<int64_t> scored;
+    for (int64_t e = 0; e < E; ++e)
+        if (!covered[e]) scored.push_back(e);
+    gn_layout::ClassLayout L = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, n, features, 256);
+    if (!check) return L;
+    CHECK(L.ok);
+    // every edge position is written exactly once: as a scored pair's own position or as its mirror
+    std::vector<int> seen((size_t)E, 0);
+    for (size_t s = 0; s < (size_t)L.batches * 64; ++s) {
+        if (L.own[s] != gn_layout::kNoMirror) { CHECK(L.own[s] < (uint32_t)E); seen[L.own[s]]++; }
+        else CHECK(L.mirror[s] == gn_layout::kNoMirror);
+        if (L.mirror[s] != gn_layout::kNoMirror) { CHECK(L.mirror[s] < (uint32_t)E); seen[L.mirror[s]]++; }
+    }
+    for (int64_t e = 0; e < E; ++e) CHECK(seen[e] == 1);
+    // workgroups: contiguous batch ranges that tile [0, batches); local rows inside the class's rows; relations inside the D cache
+    int64_t at = 0;
+    for (int g = 0; g < L.groups; ++g) {
+        const int32_t* d = L.wg.data() + (size_t)g * 8;
+        CHECK(d[4] == at && d[5] >= d[4]);
+        at = d[5];
+        CHECK(d[7] >= 1 && d[7] <= gn_layout::kClsDCache);
+        const int rows = d[1] + d[3];
+        for (int64_t b = d[4]; b < d[5]; ++b) {
+            for (int s = 0; s < 64; ++s) {
+                const uint32_t w = L.packed[(size_t)b * 64 + s];
+                CHECK((int)(w & 0xffffu) < rows && (int)(w >> 16) < rows);
+            }
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t word = L.rel32[(size_t)b * 2 + (k >> 1)];
+                const int rel = (int)((k & 1) ? word >> 16 : word & 0xffffu);
+                CHECK(rel >= d[6] && rel < d[6] + d[7]);
+            }
+        }
+    }
+    CHECK(at == L.batches);
+    return L;
+}
+
+// ---- relational layer: destination-major streams --------------------------------------------------------------------------
+gn_layout::PairLayout pair_case(int64_t N, int64_t R, int64_t E, unsigned seed, bool check) {
+    std::mt19937_64 rng(seed);
+    const int cus = 256;
+    const int chunks = (int)gn::ceil_div(N, 32), kpad = chunks * 32;
+    const int D = (int)gn::ceil_div(N, cus), G = (int)std::min<int64_t>(N, cus);
+    std::vector<int64_t> src((size_t)E), dst((size_t)E);
+    std::vector<uint32_t> rel((size_t)E);
+    std::vector<int32_t> outdeg((size_t)N, 0);
+    for (int64_t e = 0; e < E; ++e) {
+        src[e] = (int64_t)(rng() % (uint64_t)N);
+        dst[e] = (int64_t)((rng() % (uint64_t)N) * (rng() % 3 ? 1 : 0));   // a third of the edges into node 0: a hub, runs longer than one unit
+        rel[e] = (uint32_t)(rng() % (uint64_t)R);
+        outdeg[src[e]]++;
+    }
+    std::vector<int32_t> order((size_t)N), perm((size_t)kpad, (int32_t)N), kpos((size_t)N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return outdeg[x] > outdeg[y]; });
+    for (int64_t k = 0; k < N; ++k) { perm[k] = order[k]; kpos[order[k]] = (int32_t)k; }
+    std::vector<int64_t> idx((size_t)E);
+    std::iota(idx.begin(), idx.end(), 0);
+    auto key = [&](int64_t e) { return dst[e] * kpad + kpos[src[e]]; };
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
+    std::vector<int32_t> rp((size_t)N * kpad + 1, 0);
+    std::vector<uint32_t> rels((size_t)E);
+    for (int64_t i = 0; i < E; ++i) { rels[i] = rel[idx[i]]; rp[key(idx[i]) + 1]++; }
+    for (size_t i = 1; i < rp.size(); ++i) rp[i] += rp[i - 1];
+    gn_layout::PairLayout L = gn_layout::build_pair_layout(N, R, chunks, kpad, G, D, rp, rels, perm);
+    if (!check) return L;
+    CHECK(L.ok);
+    // every edge is one stream word that names a real att row; everything else names one of the two zero rows
+    int64_t real = 0;
+    std::vector<int64_t> per_rel((size_t)R, 0), want((size_t)R, 0);
+    for (size_t i = 0; i < (size_t)L.blocks * 16; ++i) {
+        const uint32_t row = L.stream[i] / gn_layout::kPairRowBytes;
+        CHECK(L.stream[i] % gn_layout::kPairRowBytes == 0 && row <= (uint32_t)R + 1);
+        if (row < (uint32_t)R) { ++real; per_rel[row]++; }
+    }
+    for (int64_t e = 0; e < E; ++e) want[rel[e]]++;
+    CHECK(real == E);
+    for (int64_t r = 0; r < R; ++r) CHECK(per_rel[r] == want[r]);
+    // every destination row belongs to exactly one workgroup
+    std::vector<int> owner((size_t)N, 0);
+    for (int g = 0; g < G; ++g)
+        for (int d = 0; d < 3; ++d)
+            if (L.wg_dst[(size_t)g * 4 + d] >= 0) owner[L.wg_dst[(size_t)g * 4 + d]]++;
+    for (int64_t i = 0; i < N; ++i) CHECK(owner[i] == 1);
+    return L;
+}
+
+// ---- gene layers: LDS-staged gather ----------------------------------------------------------------------------------------
+gn_layout::BlockedLayout blocked_case(int64_t N, int deg, int R, unsigned seed, bool check) {
+    std::mt19937_64 rng(seed);
+    std::vector<int32_t> rp((size_t)N + 1, 0), col;
+    for (int64_t i = 0; i < N; ++i) {
+        const int d = 1 + (int)(rng() % (uint64_t)(2 * deg));
+        for (int k = 0; k < d; ++k) col.push_back((int32_t)(rng() % (uint64_t)N));
+        rp[i + 1] = (int32_t)col.size();
+    }
+    std::vector<float> dis((size_t)N + 64, 0.f);
+    for (int64_t i = 0; i < N; ++i) dis[i] = 1.0f / std::sqrt((float)(rp[i + 1] - rp[i]));
+    gn_layout::BlockedLayout L = gn_layout::build_blocked_layout(N, R, rp, col, dis);
+    if (!check) return L;
+    CHECK(L.ok && !L.failed);
+    int64_t real = 0;
+    for (uint16_t id : L.ids) real += id != (uint16_t)N;
+    CHECK(real == (int64_t)col.size());
+    std::vector<int> seen((size_t)N, 0);
+    for (int32_t r : L.tile_rows)
+        if (r >= 0) seen[r]++;
+    for (int64_t i = 0; i < N; ++i) CHECK(seen[i] == 1);
+    return L;
+}
+
+template <typename T>
+bool same(const std::vector<T>& a, const std::vector<T>& b) { return a == b; }
+
+}  // namespace
+
+int main() {
+    struct { int64_t n; int R; int64_t e; int64_t f; } dec[] = {{645, 40, 20000, 80}, {200, 7, 3000, 80}, {645, 3, 50000, 48}, {30, 2, 5, 16}};
+    for (auto& c : dec) {
+        set_threads(1);
+        gn_layout::ClassLayout a = decoder_case(c.n, c.R, c.e, c.f, 7, true);
+        set_threads(16);
+        gn_layout::ClassLayout b = decoder_case(c.n, c.R, c.e, c.f, 7, true);
+        CHECK(same(a.packed, b.packed) && same(a.own, b.own) && same(a.mirror, b.mirror) && same(a.rel32, b.rel32) && same(a.wg, b.wg));
+    }
+    struct { int64_t N, R, E; } pr[] = {{645, 30, 60000}, {200, 5, 9000}, {1, 1, 300}, {300, 964, 20000}};
+    for (auto& c : pr) {
+        set_threads(1);
+        gn_layout::PairLayout a = pair_case(c.N, c.R, c.E, 11, true);
+        set_threads(16);
+        gn_layout::PairLayout b = pair_case(c.N, c.R, c.E, 11, true);
+        CHECK(same(a.stream, b.stream) && same(a.desc, b.desc) && same(a.wave_first, b.wave_first) && same(a.wave_units, b.wave_units) &&
+              same(a.wave_desc, b.wave_desc) && same(a.wg_dst, b.wg_dst));
+    }
+    struct { int64_t N; int deg, R; } bk[] = {{5000, 16, 32}, {700, 3, 11}, {19081, 38, 32}};
+    for (auto& c : bk) {
+        set_threads(1);
+        gn_layout::BlockedLayout a = blocked_case(c.N, c.deg, c.R, 13, true);
+        set_threads(16);
+        gn_layout::BlockedLayout b = blocked_case(c.N, c.deg, c.R, 13, true);
+        CHECK(same(a.ids, b.ids) && same(a.tile_off, b.tile_off) && same(a.tile_rows, b.tile_rows) && same(a.cell, b.cell));
+    }
+    std::printf("host layout: all builders ok on 1 and 16 threads\n");
+    return 0;
+}
