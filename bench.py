@@ -99,7 +99,7 @@ def train_step_entry(dev, steps=20):
     from gripnet_amd import _hip
     from gripnet_amd.pipeline import PoseModel
     from gripnet_amd.synth import make_pose
-    from gripnet_amd.utils import EPS
+    from gripnet_amd.utils import link_loss
     data = make_pose("pose0-syn").to(dev)
     torch.manual_seed(1111)
     model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
@@ -117,7 +117,7 @@ def train_step_entry(dev, steps=20):
         z = model.encode(data)
         pos = model.dmt(z, data.train_idx, data.train_et)
         negs = model.dmt(z, neg, data.train_et)
-        loss = -torch.log(pos + EPS).mean() - torch.log(1 - negs + EPS).mean()
+        loss = link_loss(pos, negs)                            # GripNet-pose.py:140-142 in one launch (gn_link_loss_*)
         loss.backward()
         opt.step()
         return loss
@@ -149,7 +149,7 @@ def train_step_entry(dev, steps=20):
     losses.append(float(loss))
     _hip.raise_if_index_errors(dev)
     return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
-            "what": "forward + DistMult on positives and on fresh negatives + loss + backward + fused Adam, one hipGraph replay per step; "
+            "what": "forward + DistMult on positives and on fresh negatives + loss (utils.link_loss) + backward + fused Adam, one hipGraph replay per step; "
                     "the negatives of every step are drawn on the device (typed sampler, 32 us) in front of the replay",
             "loss_after": round(losses[-1], 5)}
 
@@ -401,7 +401,7 @@ def main():
             # graphs: every stage but the one that holds the dominant entry point replays as a hipGraph; that entry
             # point is launched from Python in both modes, with HIP events around it on its stream in EVERY timed step.
             def quick(fn, n=20):                      # under the same event timing as the timed region
-                with _hip.KernelTimer(only=(dom,)):
+                with _hip.KernelTimer(only=(dom,), every=4):
                     for _ in range(5):
                         fn()
                     fence()
@@ -441,13 +441,16 @@ def main():
 
         # the event pool exists before the warm-up, and the W warm-up steps run under the same timer as the K timed ones
         # (their records are dropped): nothing but the fence sits between the last warm-up step and the first timed one
-        timer = _hip.KernelTimer(only=(dom,), pool=2 * (args.steps + max(args.warmup, 1)) + 8)
+        # (every fourth launch of the dominant entry point is bracketed: an event record costs ~4.5 us of stream time, and
+        # two per step would be a tenth of the step; `timed_launches` says how many went into the average)
+        timer = _hip.KernelTimer(only=(dom,), pool=2 * (args.steps + max(args.warmup, 1)) + 8, every=4)
         fence()
         with timer:
             for _ in range(max(args.warmup, 1)):
                 z, score = step()
             fence()
             timer.events.clear()
+            timer._seen.clear()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 z, score = step()

@@ -207,6 +207,42 @@ class DistMultFn(torch.autograd.Function):
         return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
+_loss_ws = {}
+
+
+def _loss_workspace(device):
+    """Per-device scratch of gn_link_loss_forward_f32, zeroed once (the kernel leaves it ready for the next launch)."""
+    key = (device.type, device.index)
+    if key not in _loss_ws:
+        _loss_ws[key] = torch.zeros((int(_hip.load().gn_link_loss_workspace_bytes()),), dtype=torch.uint8, device=device)
+    return _loss_ws[key]
+
+
+class LinkLossFn(torch.autograd.Function):
+    """``-mean(log(pos + eps)) - mean(log(1 - neg + eps))`` (the loss of GripNet-pose.py:140-142) in one launch forward and
+    one backward, instead of the ~20 element-wise and reduction launches of the torch expression."""
+
+    @staticmethod
+    def forward(ctx, pos, neg, eps):
+        p, n = pos.detach().contiguous().float(), neg.detach().contiguous().float()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        ws = _loss_workspace(p.device)
+        _hip._call("gn_link_loss_forward_f32", _hip.ptr(p), p.numel(), _hip.ptr(n), n.numel(), float(eps), _hip.ptr(loss),
+                   _hip.ptr(ws), ws.numel(), _hip.stream_ptr(p.device))
+        ctx.eps = float(eps)
+        ctx.save_for_backward(p, n)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, n = ctx.saved_tensors
+        g = g.contiguous().float()
+        dp, dn = torch.empty_like(p), torch.empty_like(n)
+        _hip._call("gn_link_loss_backward_f32", _hip.ptr(p), p.numel(), _hip.ptr(n), n.numel(), ctx.eps, _hip.ptr(g), _hip.ptr(dp),
+                   _hip.ptr(dn), _hip.stream_ptr(p.device))
+        return (dp if ctx.needs_input_grad[0] else None), (dn if ctx.needs_input_grad[1] else None), None
+
+
 class ClassLogitsFn(torch.autograd.Function):
     """``z[node_list] @ W`` (decoder.py:42); forward on gn_class_scores_f32."""
 

@@ -18,6 +18,8 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import _hip
+
 EPS = 1e-13  # reference: gripnet/utils.py:10
 
 
@@ -220,6 +222,15 @@ def relation_metrics(pos_score: torch.Tensor, neg_score: torch.Tensor, range_lis
     from ._hip import link_metrics, raise_if_index_errors
     raise_if_index_errors(pos_score.device)
     return link_metrics(pos_score, neg_score, range_list)
+
+
+def link_loss(pos_score: torch.Tensor, neg_score: torch.Tensor, eps: float = EPS) -> torch.Tensor:
+    """``-log(pos + EPS).mean() - log(1 - neg + EPS).mean()``: the training loss of GripNet-pose.py:140-142 as one launch
+    forward and one backward (gn_link_loss_*), differentiable.  The reference spells the expression out with torch ops
+    in its driver; that keeps working - this is the same value for callers that want it in two launches instead of ~20."""
+    from .autograd import LinkLossFn
+    _hip.require_gpu(pos_score, neg_score)
+    return LinkLossFn.apply(pos_score, neg_score, float(eps))
 
 
 def set_table_storage(module, storage: str = "bf16"):

@@ -383,6 +383,19 @@ GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, 
 GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
                                             int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
 
+/* The link-prediction loss of the training loop and its gradient (GripNet-pose.py:140-142 with EPS of gripnet/utils.py:10):
+ *   loss = - mean(log(pos + eps)) - mean(log(1 - neg + eps)),
+ *   dpos[i] = - g / (num_pos (pos[i] + eps)),   dneg[i] = g / (num_neg (1 - neg[i] + eps)),   g = *upstream_grad (NULL: 1).
+ * One launch each (written with torch ops: ~20 element-wise and reduction launches per step).  Deterministic: fixed
+ * slices summed in a fixed order, partial sums added in workgroup order by the last workgroup to arrive.  `workspace`:
+ * gn_link_loss_workspace_bytes() bytes, 8-byte aligned, ZEROED ONCE by the caller (the launch leaves it ready for the
+ * next one); calls on one workspace must be stream-ordered. */
+GN_API size_t gn_link_loss_workspace_bytes(void);
+GN_API gn_status gn_link_loss_forward_f32(const float* pos_score, int64_t num_pos, const float* neg_score, int64_t num_neg, float eps,
+                                   float* loss, void* workspace, size_t workspace_bytes, void* stream);
+GN_API gn_status gn_link_loss_backward_f32(const float* pos_score, int64_t num_pos, const float* neg_score, int64_t num_neg, float eps,
+                                    const float* upstream_grad /* device, nullable */, float* dpos, float* dneg, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Per-relation evaluation metrics (replaces the R scikit-learn calls and device -> host copies per epoch
  * of GripNet-pose.py:148-160,188-199 / gripnet/utils.py:28-35).  pos_score / neg_score hold E scores

@@ -526,3 +526,27 @@ def test_short_row_sums_over_a_small_table(gpu, monkeypatch, features, table_row
         assert (out.double() - ref).abs().max().item() <= 1e-4
         outs.append(out)
     assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
+
+
+def test_link_loss_matches_the_torch_expression(gpu):
+    """utils.link_loss (gn_link_loss_forward_f32 / _backward_f32: one launch each) against the expression the reference's
+    driver spells out with torch ops (GripNet-pose.py:140-142): value, both gradients, an upstream factor, run-to-run bits,
+    empty lists."""
+    from gripnet_amd.utils import EPS, link_loss
+    gen = torch.Generator().manual_seed(3)
+    for n_pos, n_neg in ((200003, 150001), (7, 1), (1, 70000)):
+        p = (torch.rand(n_pos, generator=gen) * 0.98 + 0.01).to(gpu).requires_grad_(True)
+        q = (torch.rand(n_neg, generator=gen) * 0.98 + 0.01).to(gpu).requires_grad_(True)
+        p.data[0] = 0.0                                                # log(0 + EPS): the reason EPS exists
+        ref = -torch.log(p.double() + EPS).mean() - torch.log(1 - q.double() + EPS).mean()
+        (3.0 * ref).backward()
+        gp, gq = p.grad.clone(), q.grad.clone()
+        p.grad = q.grad = None
+        loss = link_loss(p, q)
+        (3.0 * loss).backward()
+        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        assert ((p.grad - gp).abs() <= 2e-6 * gp.abs() + 1e-12).all() and ((q.grad - gq).abs() <= 2e-6 * gq.abs() + 1e-12).all()
+        assert torch.equal(link_loss(p, q), loss)
+    empty = torch.empty(0, device=gpu)
+    some = torch.full((5,), 0.5, device=gpu)
+    assert abs(float(link_loss(some, empty)) + float(torch.log(some + EPS).mean())) < 1e-6
