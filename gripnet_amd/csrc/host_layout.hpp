@@ -239,7 +239,19 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
                 const int64_t e = scored[idx[run.lo + k]];
                 lu[k] = local(hu[e], run.cls); lv[k] = local(hv[e], run.cls);
             }
-            deal_run(lu.data(), lv.data(), count, order);
+            // dealt 64 consecutive pairs (one batch, one store instruction per lane) at a time: the 64 scores of a batch then
+            // land inside a window of ~200 list positions.  Dealt over the whole run - more freedom for conflict-free
+            // LDS cells - a batch's scores were spread over the relation's whole block and every lane's store became its own
+            // 32-byte memory write: 207 MB written for the 33.5 MB of scores of pose2-syn (WRITE_SIZE), 72 us instead of 57
+            order.clear();
+            {
+                std::vector<int> part;
+                for (int c0 = 0; c0 < count; c0 += 64) {
+                    const int cn = std::min(64, count - c0);
+                    deal_run(lu.data() + c0, lv.data() + c0, cn, part);
+                    for (int v : part) order.push_back(v >= 0 ? v + c0 : -1);
+                }
+            }
             const int steps = (int)(order.size() / 16);
             for (int t = 0; t < steps; ++t) {
                 const int64_t gstep = cls_batch0[run.cls] * 4 + run.step0 + t;

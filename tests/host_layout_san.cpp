@@ -4,7 +4,9 @@
 // a plan does not depend on the thread count.  No HIP, no GPU.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <random>
+#include <utility>
 
 #include "host_layout.hpp"
 
@@ -50,12 +52,13 @@ gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t fea
         if (L.mirror[s] != gn_layout::kNoMirror) { CHECK(L.mirror[s] < (uint32_t)E); seen[L.mirror[s]]++; }
     }
     for (int64_t e = 0; e < E; ++e) CHECK(seen[e] == 1);
-    // workgroups: contiguous batch ranges that tile [0, batches); local rows inside the class's rows; relations inside the D cache
-    int64_t at = 0;
+    // workgroups: contiguous batch ranges that together tile [0, batches) (with eight position parts workgroup 8 l + x is
+    // the l-th of part x, so they are not in index order); local rows inside the class's rows; relations inside the D cache
+    std::vector<std::pair<int64_t, int64_t>> ranges;
     for (int g = 0; g < L.groups; ++g) {
         const int32_t* d = L.wg.data() + (size_t)g * 8;
-        CHECK(d[4] == at && d[5] >= d[4]);
-        at = d[5];
+        CHECK(d[5] >= d[4] && d[4] >= 0 && d[5] <= L.batches);
+        if (d[5] > d[4]) ranges.push_back({d[4], d[5]});
         CHECK(d[7] >= 1 && d[7] <= gn_layout::kClsDCache);
         const int rows = d[1] + d[3];
         for (int64_t b = d[4]; b < d[5]; ++b) {
@@ -70,6 +73,9 @@ gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t fea
             }
         }
     }
+    std::sort(ranges.begin(), ranges.end());
+    int64_t at = 0;
+    for (auto& r : ranges) { CHECK(r.first == at); at = r.second; }
     CHECK(at == L.batches);
     return L;
 }
