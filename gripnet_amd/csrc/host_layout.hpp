@@ -206,43 +206,53 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
         const int b = (int)(node / blk);
         return (int)(b == k ? node - bstart(k) : bsize(k) + node - bstart((k + 1) % 3));
     };
-    // scored pairs by (class, relation), list order inside
+    // Position parts.  A 64-byte line of the score vector holds sixteen consecutive edges of one relation - pairs of all
+    // three classes - so three workgroups write it, a third each.  The list is cut into eight position ranges, one per
+    // XCD (workgroup b runs on XCD b % 8), and inside a range each class gets its share of that XCD's compute units: the
+    // three writers of a line share an L2, which holds the range's whole share of the scores.
     const int64_t S = (int64_t)scored.size();
+    const int parts = (cus % 8 == 0 && cus >= 24 && S >= (int64_t)64 * 4 * cus) ? 8 : 1;
+    const int ngroups = parts * nclasses;
+    // scored pairs by (part, class, relation), list order inside
     std::vector<uint32_t> key((size_t)S);
     std::vector<int64_t> idx((size_t)S);
-    for (int64_t i = 0; i < S; ++i) { key[i] = (uint32_t)cls_of(scored[i]) << 16 | (uint32_t)hr[scored[i]]; idx[i] = i; }
+    for (int64_t i = 0; i < S; ++i) {
+        const int part = (int)std::min<int64_t>(parts - 1, i * parts / S);
+        key[i] = (uint32_t)(part * nclasses + cls_of(scored[i])) << 16 | (uint32_t)hr[scored[i]];
+        idx[i] = i;
+    }
     std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });
     // runs -> steps of 16 slots
-    struct Run { int64_t lo, hi; int cls, rel; int64_t step0; };
+    struct Run { int64_t lo, hi; int grp, rel; int64_t step0; };
     std::vector<Run> runs;
-    std::vector<int64_t> cls_steps(nclasses, 0);
+    std::vector<int64_t> grp_steps(ngroups, 0);
     for (int64_t i = 0; i < S;) {
         int64_t j = i;
         while (j < S && key[idx[j]] == key[idx[i]]) ++j;
-        const int c = (int)(key[idx[i]] >> 16);
-        runs.push_back({i, j, c, (int)(key[idx[i]] & 0xffffu), cls_steps[c]});
-        cls_steps[c] += gn::ceil_div(j - i, 16);
+        const int g = (int)(key[idx[i]] >> 16);
+        runs.push_back({i, j, g, (int)(key[idx[i]] & 0xffffu), grp_steps[g]});
+        grp_steps[g] += gn::ceil_div(j - i, 16);
         i = j;
     }
-    std::vector<int64_t> cls_batch0(nclasses + 1, 0);
-    for (int c = 0; c < nclasses; ++c) cls_batch0[c + 1] = cls_batch0[c] + gn::ceil_div(cls_steps[c], 4);
-    const int64_t NB = cls_batch0[nclasses], NBA = NB + kClsSlack;
+    std::vector<int64_t> grp_batch0(ngroups + 1, 0);
+    for (int g = 0; g < ngroups; ++g) grp_batch0[g + 1] = grp_batch0[g] + gn::ceil_div(grp_steps[g], 4);
+    const int64_t NB = grp_batch0[ngroups], NBA = NB + kClsSlack;
     std::vector<uint32_t> packed((size_t)NBA * 64, 0u), own((size_t)NBA * 64, kNoMirror), mirror((size_t)NBA * 64, kNoMirror);
     std::vector<uint16_t> rel16((size_t)NBA * 4, 0);
     gn::parallel_for((int64_t)runs.size(), 16, [&](int64_t r0, int64_t r1) {
         std::vector<int> lu, lv, order;
         for (int64_t ri = r0; ri < r1; ++ri) {
             const Run& run = runs[ri];
-            const int count = (int)(run.hi - run.lo);
+            const int count = (int)(run.hi - run.lo), cls = run.grp % nclasses;
             lu.resize(count); lv.resize(count);
             for (int k = 0; k < count; ++k) {
                 const int64_t e = scored[idx[run.lo + k]];
-                lu[k] = local(hu[e], run.cls); lv[k] = local(hv[e], run.cls);
+                lu[k] = local(hu[e], cls); lv[k] = local(hv[e], cls);
             }
             // dealt 64 consecutive pairs (one batch, one store instruction per lane) at a time: the 64 scores of a batch then
             // land inside a window of ~200 list positions.  Dealt over the whole run - more freedom for conflict-free
             // LDS cells - a batch's scores were spread over the relation's whole block and every lane's store became its own
-            // 32-byte memory write: 207 MB written for the 33.5 MB of scores of pose2-syn (WRITE_SIZE), 72 us instead of 57
+            // 32-byte memory write: 202 MB written for the 33.5 MB of scores of pose2-syn (WRITE_SIZE), 71 us instead of 51
             order.clear();
             {
                 std::vector<int> part;
@@ -254,7 +264,7 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
             }
             const int steps = (int)(order.size() / 16);
             for (int t = 0; t < steps; ++t) {
-                const int64_t gstep = cls_batch0[run.cls] * 4 + run.step0 + t;
+                const int64_t gstep = grp_batch0[run.grp] * 4 + run.step0 + t;
                 const int64_t bat = gstep >> 2;
                 const int s_in = (int)(gstep & 3);
                 rel16[(size_t)gstep] = (uint16_t)run.rel;
@@ -273,47 +283,60 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
             }
         }
     });
-    // steps that pad a class to whole batches: the relation of the step before them (no reload), pair (0, 0), no positions
-    for (int c = 0; c < nclasses; ++c)
-        for (int64_t gstep = cls_batch0[c] * 4 + cls_steps[c]; gstep < cls_batch0[c + 1] * 4; ++gstep)
-            rel16[(size_t)gstep] = rel16[(size_t)gstep - 1];
+    // steps that pad a group to whole batches: the relation of the step before them (no reload), pair (0, 0), no positions
+    for (int g = 0; g < ngroups; ++g)
+        for (int64_t gstep = grp_batch0[g] * 4 + grp_steps[g]; gstep < grp_batch0[g + 1] * 4; ++gstep)
+            rel16[(size_t)gstep] = gstep > 0 ? rel16[(size_t)gstep - 1] : 0;
     for (int64_t gstep = NB * 4; gstep < NBA * 4; ++gstep) rel16[(size_t)gstep] = NB > 0 ? rel16[(size_t)NB * 4 - 1] : 0;
-    // workgroups: a share of the compute units per class in proportion to its batches, contiguous batch ranges
-    int G = (int)std::min<int64_t>(cus, NB);
-    std::vector<int> share(nclasses, 0);
-    {
-        int given = 0, live = 0;
-        for (int c = 0; c < nclasses; ++c) live += cls_batch0[c + 1] > cls_batch0[c];
-        G = std::max(G, live);
+    // workgroups: inside a part, a share of the part's compute units per class in proportion to its batches, contiguous
+    // batch ranges; with eight parts workgroup 8 l + x is the l-th of part x
+    const int per_part = parts == 8 ? cus / 8 : (int)std::min<int64_t>(cus, std::max<int64_t>(NB, 1));
+    struct Wg { int cls; int64_t lo, hi; };
+    std::vector<std::vector<Wg>> part_wgs(parts);
+    for (int x = 0; x < parts; ++x) {
+        int64_t nb_part = 0;
+        int live = 0;
+        for (int c = 0; c < nclasses; ++c) { const int g = x * nclasses + c; nb_part += grp_batch0[g + 1] - grp_batch0[g]; live += grp_batch0[g + 1] > grp_batch0[g]; }
+        const int W = parts == 8 ? per_part : std::max(std::min<int>(per_part, (int)std::max<int64_t>(nb_part, 1)), live);
+        if (W < live) return L;
+        std::vector<int> share(nclasses, 0);
         std::vector<double> frac(nclasses, 0.0);
+        int given = 0;
         for (int c = 0; c < nclasses; ++c) {
-            const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
+            const int g = x * nclasses + c;
+            const int64_t nb = grp_batch0[g + 1] - grp_batch0[g];
             if (nb == 0) continue;
-            const double want = (double)G * nb / NB;
+            const double want = (double)W * nb / std::max<int64_t>(nb_part, 1);
             share[c] = std::max(1, (int)want);
             frac[c] = want - share[c];
             given += share[c];
         }
-        while (given < G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] && (best < 0 || frac[c] > frac[best])) best = c; share[best]++; frac[best] -= 1.0; ++given; }
-        while (given > G) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] > 1 && (best < 0 || frac[c] < frac[best])) best = c; if (best < 0) break; share[best]--; frac[best] += 1.0; --given; }
-        G = given;
+        while (given < W && live > 0) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] && (best < 0 || frac[c] > frac[best])) best = c; share[best]++; frac[best] -= 1.0; ++given; }
+        while (given > W) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] > 1 && (best < 0 || frac[c] < frac[best])) best = c; if (best < 0) break; share[best]--; frac[best] += 1.0; --given; }
+        for (int c = 0; c < nclasses; ++c) {
+            const int g = x * nclasses + c;
+            const int64_t nb = grp_batch0[g + 1] - grp_batch0[g];
+            for (int k = 0; k < share[c]; ++k) part_wgs[x].push_back({c, grp_batch0[g] + nb * k / share[c], grp_batch0[g] + nb * (k + 1) / share[c]});
+        }
+        while (parts == 8 && (int)part_wgs[x].size() < W) part_wgs[x].push_back({0, 0, 0});      // (a part without work for all its units)
     }
+    int G = 0;
+    for (int x = 0; x < parts; ++x) G += (int)part_wgs[x].size();
+    if (G < 1) return L;
     std::vector<int32_t> wg((size_t)G * 8, 0);
-    int gi = 0;
-    for (int c = 0; c < nclasses; ++c) {
-        const int64_t nb = cls_batch0[c + 1] - cls_batch0[c];
-        for (int k = 0; k < share[c]; ++k, ++gi) {
-            const int64_t lo = cls_batch0[c] + nb * k / share[c], hi = cls_batch0[c] + nb * (k + 1) / share[c];
+    for (int x = 0; x < parts; ++x)
+        for (size_t l = 0; l < part_wgs[x].size(); ++l) {
+            const Wg& w = part_wgs[x][l];
+            const int c = w.cls;
             int rlo = 1 << 30, rhi = -1;
-            for (int64_t gstep = lo * 4; gstep < hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
-            if (hi <= lo) { rlo = 0; rhi = 0; }
+            for (int64_t gstep = w.lo * 4; gstep < w.hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
+            if (w.hi <= w.lo) { rlo = 0; rhi = 0; }
             if (rhi - rlo + 1 > kClsDCache) return L;                             // (the column-phase kernel serves such a list)
-            int32_t* d = wg.data() + (size_t)gi * 8;
+            int32_t* d = wg.data() + (parts == 8 ? (size_t)(8 * l + x) : l) * 8;
             if (nblocks == 1) { d[0] = 0; d[1] = (int32_t)n; d[2] = 0; d[3] = 0; }
             else { d[0] = (int32_t)bstart(c); d[1] = (int32_t)bsize(c); d[2] = (int32_t)bstart((c + 1) % 3); d[3] = (int32_t)bsize((c + 1) % 3); }
-            d[4] = (int32_t)lo; d[5] = (int32_t)hi; d[6] = rlo; d[7] = rhi - rlo + 1;
+            d[4] = (int32_t)w.lo; d[5] = (int32_t)w.hi; d[6] = rlo; d[7] = rhi - rlo + 1;
         }
-    }
     std::vector<uint32_t> rel32((size_t)NBA * 2);
     for (size_t i = 0; i < rel32.size(); ++i) rel32[i] = (uint32_t)rel16[2 * i] | (uint32_t)rel16[2 * i + 1] << 16;
     L.packed.swap(packed); L.own.swap(own); L.mirror.swap(mirror); L.rel32.swap(rel32); L.wg.swap(wg);
