@@ -703,11 +703,7 @@ int bits_for(int64_t n) {
     return b;
 }
 
-bool pair_disabled() {
-    if (gn::fast_paths_disabled()) return true;
-    const char* e = getenv("GN_DISABLE_PAIR");
-    return e && e[0] == '1';
-}
+bool pair_disabled() { return gn::fast_paths_disabled(); }     // (a kernel is chosen by flag, GN_RGCN_PATH_*; GN_DISABLE_FAST=1 turns every fast path off)
 
 template <int NT, int BT, int TERMS>
 gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st) {

@@ -19,7 +19,7 @@ import json
 import os
 import re
 
-WANT = ("k_rgcn_pair", "k_rgcn_acc", "k_rgcn_weights_frag", "k_aggregate_transform_with_weights", "k_gemm", "k_col_transform", "k_rgcn_lds")
+WANT = ("k_rgcn_pair", "k_gemm", "k_col_transform", "k_rgcn_lds")
 
 
 def main():
