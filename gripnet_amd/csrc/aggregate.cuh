@@ -54,6 +54,8 @@ struct AggArgs {
     int rows;
     gn_side_copy side = {nullptr, 0, nullptr, 0, 0, 0, 0};   // optional fused row copy (dst == nullptr: none)
     gn_split_planes split = {nullptr, 0, 0, 0, 0};           // optional bf16 split planes of what the launch writes
+    const uint32_t* ell_col = nullptr;   // padded rows of the plan (rows of at most 64 entries), or null
+    const float* ell_coef = nullptr;
     int64_t nnz = -1;      // stored coefficients, when the caller knows them (picks the short-row kernel)
     int64_t table_rows = -1;   // rows of the gathered table, when the caller knows them (picks the LDS-table kernel)
 };
@@ -307,23 +309,36 @@ __device__ __forceinline__ void aggregate_transform_body(const AggArgs& a, const
     for (int i = 0; i < KPL; ++i) wreg[i] = w[(kq * KPL + i) * FOUT + c];
     const float bias = a.bias ? a.bias[c] : 0.f;
 
-    if (a.side.dst) {                                          // concat slot: streamed up front by the whole grid
-        const int64_t total = a.side.rows * a.side.cols;
-        for (int64_t t = block * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)n_blocks * blockDim.x) {
-            const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
-            const float v = a.side.src[i * a.side.ld_src + cc];
-            const float o = a.side.mode ? fabsf(v) : v;
-            a.side.dst[i * a.side.ld_dst + cc] = o;
-            if (a.split.planes) write_split(a.split, i, a.split.col_side + (int)cc, o);
-        }
+    // concat slot, by the whole grid: the first element of every thread is REQUESTED here and stored behind the rows (a
+    // load -> store in front of them put its round trip in front of the rows' own three), the rest (slots longer than
+    // the grid) is streamed at the end
+    const int64_t side_total = a.side.dst ? a.side.rows * a.side.cols : 0;
+    const int64_t side_t0 = block * (int64_t)blockDim.x + threadIdx.x;
+    float side_first = 0.f;
+    if (side_t0 < side_total) {
+        const int64_t i = side_t0 / a.side.cols, cc = side_t0 - i * a.side.cols;
+        side_first = a.side.src[i * a.side.ld_src + cc];
     }
     for (int row = wave; row < a.rows; row += n_waves) {
-        const int begin = a.rowptr[row], end = a.rowptr[row + 1];
+        // padded rows: this lane's (column, coefficient) pair sits at row * 64 + lane - no row pointers in front of it
+        int begin, end;
+        uint32_t cl0 = 0u;
+        float v0 = 0.f;
+        if (a.ell_col) {
+            cl0 = a.ell_col[(size_t)row * 64 + lane];
+            v0 = a.ell_coef[(size_t)row * 64 + lane];
+            begin = 0;
+            end = __popcll(__ballot(cl0 != 0xffffffffu));
+            if (lane >= end) cl0 = 0u;
+        } else {
+            begin = a.rowptr[row];
+            end = a.rowptr[row + 1];
+        }
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int base = begin; base < end; base += kWave) {
             const int mine = base + lane;
-            const uint32_t cl = mine < end ? a.col[mine] : 0u;
-            const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+            const uint32_t cl = a.ell_col ? cl0 : (mine < end ? a.col[mine] : 0u);
+            const float v = a.ell_col ? v0 : (mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f);
             const int cnt = min(kWave, end - base);
             // U groups of S neighbour rows are requested before the first one is consumed (see k_aggregate); wide rows
             // (16 lanes each: the external layer, a few hundred destination rows of ~30 edges, latency-bound) ask for
@@ -363,6 +378,13 @@ __device__ __forceinline__ void aggregate_transform_body(const AggArgs& a, const
             a.out[(int64_t)row * a.ld_out + c] = val;
             if (a.split.planes) write_split(a.split, row, a.split.col_main + c, val);
         }
+    }
+    for (int64_t t = side_t0; t < side_total; t += (int64_t)n_blocks * blockDim.x) {
+        const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
+        const float v = t == side_t0 ? side_first : a.side.src[i * a.side.ld_src + cc];
+        const float o = a.side.mode ? fabsf(v) : v;
+        a.side.dst[i * a.side.ld_dst + cc] = o;
+        if (a.split.planes) write_split(a.split, i, a.split.col_side + (int)cc, o);
     }
 }
 

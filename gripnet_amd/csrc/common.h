@@ -117,6 +117,11 @@ struct gn_graph_plan {
     // reference-order copies kept for myGCN.norm parity (GCN plans only)
     gn::DevBuf<int64_t> ref_edge_index;  // [2, nnz]
     gn::DevBuf<float> ref_norm;          // [nnz]
+    // padded rows (bipartite plans whose longest row has at most 64 entries): lane L of the wave that owns row r reads entry
+    // r * 64 + L directly - one dependent round trip less than row pointers -> columns (the external layer is three of them)
+    int ell_ok = 0;
+    gn::DevBuf<uint32_t> ell_col;        // [rows * 64] source row, 0xffffffff beyond the row's end
+    gn::DevBuf<float> ell_coef;          // [rows * 64]
     // source-major CSR of the same coefficients (built on demand for the backward pass)
     int has_transpose = 0;
     gn::DevBuf<int32_t> t_rowptr;        // [table_rows + 1]

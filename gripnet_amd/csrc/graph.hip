@@ -35,6 +35,7 @@ extern "C" gn_status gn_graph_aggregate_f32(const gn_graph_plan* plan, const flo
     a.rows = (int)plan->rows;
     a.nnz = plan->nnz;
     a.table_rows = plan->table_rows;
+    if (plan->ell_ok) { a.ell_col = plan->ell_col.p; a.ell_coef = plan->ell_coef.p; }
     gn_status ss = gn::check_side(side, plan->rows, &a.side);
     if (ss != GN_OK) return ss;
     if (planes && planes->planes) {

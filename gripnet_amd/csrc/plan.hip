@@ -305,7 +305,20 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
     return GN_OK;
 }
 
+__global__ void k_build_ell(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ coef,
+                            int rows, uint32_t* __restrict__ ell_col, float* __restrict__ ell_coef) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rows * 64) return;
+    const int r = (int)(t >> 6), k = (int)(t & 63);
+    const int at = rowptr[r] + k;
+    const bool live = at < rowptr[r + 1];
+    ell_col[t] = live ? (uint32_t)col[at] : 0xffffffffu;
+    ell_coef[t] = live ? (coef ? coef[at] : 1.0f) : 0.f;
+}
+
 void free_graph_plan(gn_graph_plan* p) {
+    p->ell_col.release();
+    p->ell_coef.release();
     p->rowptr.release();
     p->col.release();
     p->coef.release();
@@ -411,6 +424,19 @@ gn_status gn_bipartite_plan_create(const int64_t* src, const int64_t* dst, const
     gn_graph_plan* p = new gn_graph_plan();
     gn_status s = build_graph_plan(src, dst, w, E, n_src, n_tgt, false, 0, gn::as_stream(stream), p);
     if (s != GN_OK) { free_graph_plan(p); delete p; return s; }
+    // short rows (the external layer: 645 targets of ~29 edges): the padded layout as well
+    if (p->rows > 0 && p->rows <= (1 << 20) && p->max_row_nnz <= 64 && p->nnz > 0 && !gn::fast_paths_disabled()) {
+        hipError_t he = p->ell_col.alloc((size_t)p->rows * 64);
+        if (he == hipSuccess) he = p->ell_coef.alloc((size_t)p->rows * 64);
+        if (he != hipSuccess) { free_graph_plan(p); delete p; return gn::fail(GN_ERR_HIP, "padded rows: %s", hipGetErrorString(he)); }
+        k_build_ell<<<(int)gn::ceil_div(p->rows * 64, 256), 256, 0, gn::as_stream(stream)>>>(p->rowptr.p, p->col.p, p->coef.p, (int)p->rows,
+                                                                                            p->ell_col.p, p->ell_coef.p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(gn::as_stream(stream)) != hipSuccess) {
+            free_graph_plan(p); delete p;
+            return gn::fail(GN_ERR_HIP, "padded rows: the layout kernel failed");
+        }
+        p->ell_ok = 1;
+    }
     *out = p;
     return GN_OK;
 }
