@@ -230,7 +230,7 @@ def extra_workloads(dev, budget_s, with_cpu):
             alg_total, alg_per = nc_algorithmic_bytes(model, int(nodes.numel()))
             dom = max(calls, key=calls.get)
             # the same forward as ONE hipGraph replay: what the device needs without the Python loop between the launches
-            from gripnet_amd.pipeline import Graphed
+            from gripnet_amd.pipeline import Graphed, Recorded
             replay = Graphed(lambda: model(data, nodes_dev)).capture()
             for _ in range(3):
                 replay()
@@ -302,11 +302,13 @@ def main():
     ap.add_argument("--workload", default=None, help="pose0-syn (default), pose1-syn, pose2-syn; strong scaling defaults to pose2-syn")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--launch", choices=("auto", "eager", "graphs"), default="auto",
-                    help="eager: every entry point launched from Python (~100-150 us of host work per step, depending "
-                         "on the box, against ~110 us of kernels on pose0-syn); graphs: the stages replayed as hipGraphs, "
-                         "except the dominant entry point, which stays a Python launch between HIP events; auto: "
-                         "whichever of the two runs the step faster on this box, measured before the timed region")
+    ap.add_argument("--launch", choices=("auto", "eager", "graphs", "recorded"), default="auto",
+                    help="eager: every entry point launched through the Python modules (~100-150 us of host work per step, "
+                         "depending on the box, against ~77 us of kernels on pose0-syn); graphs: the stages replayed as "
+                         "hipGraphs, except the dominant entry point, which stays a Python launch between HIP events; "
+                         "recorded: the step's entry-point calls written down once and made again from one loop "
+                         "(gripnet_amd.pipeline.Recorded: ordinary launches, no graph); auto: whichever of the three runs "
+                         "the step fastest on this box, measured before the timed region")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (pose2-syn, aminer-syn, freebase-c-syn)")
     ap.add_argument("--extra-seconds", type=float, default=90.0, help="time budget of the extra workloads")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -411,18 +413,23 @@ def main():
                     fence()
                     return (time.perf_counter() - t) / n
             launch = args.launch
-            graphed = PoseStages(model, data, graphs=True, timed_entry=dom) if launch != "eager" else None
+            modes = {"eager": eager}
+            if launch in ("auto", "graphs"):
+                modes["graphs"] = PoseStages(model, data, graphs=True, timed_entry=dom)
+            if launch in ("auto", "recorded"):
+                modes["recorded"] = PoseStages(model, data, recorded=True)
+            launch_ms = None
             if launch == "auto":
-                # best of three short runs each, alternating: one descheduled launch thread must not decide; a tie goes
-                # to the graphs, whose three launches per step depend least on what else the host is doing
-                tg = min(quick(graphed.step) for _ in range(1))
-                te = min(quick(eager.step) for _ in range(1))
-                for _ in range(2):
-                    tg, te = min(tg, quick(graphed.step)), min(te, quick(eager.step))
-                launch = "graphs" if tg < 1.03 * te else "eager"
-            step = graphed.step if launch == "graphs" else eager.step
+                # best of three short runs each, alternating: one descheduled launch thread must not decide
+                best = {k: float("inf") for k in modes}
+                for _ in range(3):
+                    for k, m in modes.items():
+                        best[k] = min(best[k], quick(m.step))
+                launch = min(best, key=best.get)
+                launch_ms = {k: round(1e3 * v, 5) for k, v in best.items()}
+            step = modes[launch].step
         else:
-            from gripnet_amd.pipeline import Graphed
+            from gripnet_amd.pipeline import Graphed, Recorded
             from gripnet_amd.sharded import ShardedPoseForward
             fwd = sharded = ShardedPoseForward(model, data, rank, world)
             fence()
@@ -434,9 +441,12 @@ def main():
             fast_call, fast_breakdown = {}, {}
             per_call0, breakdown = per_entry_us(fwd, 5)
             dom = max((k for k in CANDIDATES if k != "gn_graph_aggregate_f32[gcn]"), key=lambda k: per_call0.get(k, 0.0))
-            launch = "eager" if args.launch == "eager" else "graphs"
+            launch = "eager" if args.launch == "eager" else "graphs" if args.launch == "graphs" else "recorded"
+            launch_ms = None
             if launch == "graphs":                    # replicated gene layers as one graph; the collective is never captured
                 fwd.kernels.encode_genes = Graphed(fwd.kernels.encode_genes).capture()
+            elif launch == "recorded":                # ... or as their recorded entry-point calls (ordinary launches)
+                fwd.kernels.encode_genes = Recorded(fwd.kernels.encode_genes).capture()
             step = fwd
 
         # the event pool exists before the warm-up, and the W warm-up steps run under the same timer as the K timed ones
@@ -523,6 +533,21 @@ def main():
                                  "(three products instead of six, <= 2^-16 per product); the eager step with it takes {:.1f} us of entry "
                                  "points against {:.1f}".format(sum(fast_breakdown.values()), sum(breakdown.values())))
 
+    if sharded is not None:
+        launch_note = "replicated gene layers replayed as {}, the rest eager; {} HIP-event timed around every fourth launch".format(
+            "one hipGraph" if launch == "graphs" else "their recorded entry-point calls" if launch == "recorded" else "eager launches", dom)
+    elif launch == "eager":
+        launch_note = "eager; {} HIP-event timed around every fourth launch".format(dom)
+    elif launch == "recorded":
+        launch_note = ("the step's {} entry-point calls recorded once and made again from one Python loop (ordinary launches on the "
+                       "recording's buffers; no hipGraph: a graph launch leaves the GPU idle ~9 us in front of its first kernel on this "
+                       "stack); {} HIP-event timed around every fourth launch".format(len(modes["recorded"]._whole.calls), dom))
+    elif dom == "gn_rgcn_forward_f32":
+        launch_note = ("gene and external layers replayed as one hipGraph; {} launched and HIP-event timed from Python, the decoder "
+                       "(one kernel) launched from Python as well".format(dom))
+    else:
+        launch_note = "hipGraph replay of every stage but {}, which is launched and HIP-event timed from Python".format(dom)
+
     result = {
         "metric": "edges aggregated/sec, GripNet forward on pose-0", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -536,13 +561,9 @@ def main():
                    "decoder": "static positive list: every unordered (node pair, relation) scored once, the score written to both "
                               "directions' positions (same bits as scoring both; parity checked on all E scores)",
                    "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
-                   "launch": ("eager; {} HIP-event timed around every launch".format(dom) if launch == "eager" else
-                              ("gene and external layers replayed as one hipGraph; {} launched and HIP-event timed from Python, the "
-                               "decoder (one kernel) launched from Python as well".format(dom) if dom == "gn_rgcn_forward_f32" else
-                               "hipGraph replay of every stage but {}, which is launched and HIP-event timed from Python".format(dom))
-                              if sharded is None else
-                              "replicated gene layers replayed as one hipGraph, the rest eager; {} HIP-event timed around every launch".format(dom))},
+                   "launch": launch_note},
         "spread": spread,
+        "launch_modes_ms_per_step": launch_ms if sharded is None else None,
         "roofline": roofline,
         "roofline_fast": roofline_fast,
         "roofline_all": roofline_all,

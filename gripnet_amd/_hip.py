@@ -238,6 +238,52 @@ class KernelTimer:
 _timer = None
 
 
+class Recorder:
+    """While active, every entry-point call made through this module is also written down - (bound C function, arguments,
+    name, tag) - and the tensors whose pointers it was given are held, so that `replay` can make the same calls again straight
+    from a loop, without the Python layers above them (module forward, plan look-up, pointer extraction: ~15 us per entry
+    point against ~4 us for the call itself).  The calls launch on the stream that was current when they were recorded and
+    read / write the buffers they were recorded with, like a captured hipGraph - but a replay is ordinary launches: it
+    pipelines behind whatever the stream is still running, where a graph launch on this stack leaves the GPU idle for
+    ~9 us in front of its first kernel (tools/launch_modes.py, profiles/r04_counters.md)."""
+
+    def __init__(self):
+        self.calls, self.keep = [], []
+
+    def __enter__(self):
+        global _recorder
+        self._prev, _recorder = _recorder, self
+        return self
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = self._prev
+
+
+_recorder = None
+
+
+def replay(calls):
+    """Make recorded calls again, in order; an active KernelTimer brackets the ones it names (sampled as in _call)."""
+    t = _timer
+    for fn, args, name, tag in calls:
+        if t is not None and (t.only is None or name in t.only):
+            seen = t._seen.get(name, 0)
+            t._seen[name] = seen + 1
+            if seen % t.every == 0:
+                start, stop = t.event(), t.event()
+                start.record()
+                status = fn(*args)
+                stop.record()
+                t.add(tag or name, start, stop)
+                if status:
+                    check(status)
+                continue
+        status = fn(*args)
+        if status:
+            check(status)
+
+
 def _call(name, *args, tag=None):
     """Call an entry point.  Every caller passes `stream_ptr(<device of its operands>)` among the arguments; when that
     device is not the current one the call is made with it current (a launch on a foreign device's stream fails or
@@ -248,6 +294,9 @@ def _call(name, *args, tag=None):
     if dev is not None and dev != torch.cuda.current_device():
         with torch.cuda.device(dev):
             return _call(name, *args, tag=tag)
+    if _recorder is not None:
+        _recorder.calls.append((fn, args, name, tag))
+        _recorder.keep.append(args)
     t = _timer
     if t is None or (t.only is not None and name not in t.only):
         return check(fn(*args))
@@ -343,7 +392,11 @@ def e_count(edge_index):
 
 
 def ptr(t):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if _recorder is not None:
+        _recorder.keep.append(t)             # a recorded call's operands stay alive as long as the recording
+    return t.data_ptr()
 
 
 # ---- thin typed wrappers ---------------------------------------------------------------------

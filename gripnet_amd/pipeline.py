@@ -146,6 +146,31 @@ class Graphed:
         return self.out
 
 
+class Recorded:
+    """A launch-bound stage recorded once as the list of C-ABI calls it makes (gripnet_amd._hip.Recorder) and replayed by
+    making those calls again from one loop: ordinary launches on the stream they were recorded on, on the buffers they
+    were recorded with.  Unlike a hipGraph replay, which on this stack starts ~9 us after the stream's previous work has
+    finished, they queue up behind it - and unlike the eager path they do not pay the Python layers above every entry
+    point.  `fn` must be free of host synchronisation, torch kernels and data-dependent Python decisions (the library's
+    entry points only), and must be replayed with the stream current that was current when it was recorded."""
+
+    def __init__(self, fn):
+        self.fn, self.calls, self.out, self._rec = fn, None, None, None
+
+    def capture(self):
+        for _ in range(2):                            # plans exist, the decoder has seen its list twice
+            self.fn()
+        torch.cuda.synchronize()
+        with _hip.Recorder() as rec:
+            self.out = self.fn()
+        self._rec, self.calls = rec, rec.calls        # (the recorder holds the operands of every call)
+        return self
+
+    def __call__(self):
+        _hip.replay(self.calls)
+        return self.out
+
+
 class PoseStages:
     """The steady-state forward of PoseModel cut into three stages with static buffers, so that the
     launch-bound ones can be replayed as hipGraphs and the relational layer can be bracketed by HIP
@@ -159,7 +184,7 @@ class PoseStages:
     """
 
     def __init__(self, model: PoseModel, data, graphs: bool = True, edge_index=None, edge_type=None,
-                 timed_entry: Optional[str] = None):
+                 timed_entry: Optional[str] = None, recorded: bool = False):
         """`timed_entry` ("gn_rgcn_forward_f32" or "gn_distmult[_plan]_forward_f32"): with graphs, the stage that holds
         that entry point is NOT captured (nor, behind a timed relational layer, the one-kernel decoder): its launches are made from Python, so that an active
         _hip.KernelTimer brackets the entry point itself with HIP events (events around a graph replay would add the
@@ -175,7 +200,11 @@ class PoseStages:
         self._encode = None                          # graphs, decoder timed or nothing timed: genes and drugs as ONE graph
         self.timed_entry, self.graphs = timed_entry, graphs
         self.x = None
-        if graphs:
+        self._whole = None                           # recorded: the whole step as one list of entry-point calls
+        if recorded:
+            with torch.no_grad():
+                self._whole = Recorded(self._step_eager).capture()
+        elif graphs:
             with torch.no_grad():
                 if timed_entry == "gn_rgcn_forward_f32":
                     self._genes = Graphed(self._genes_eager).capture()
@@ -220,7 +249,14 @@ class PoseStages:
     def decode(self):
         return self._decode()
 
+    def _step_eager(self):
+        self.x = self._genes_eager()
+        self._drugs_eager()
+        return self.z, self._decode_eager()
+
     def step(self):
+        if self._whole is not None:
+            return self._whole()
         if self._encode is not None:
             self._encode()
         else:

@@ -263,9 +263,11 @@ def test_staged_forward_follows_parameter_updates(gpu, storage):
     if storage == "bf16":
         set_table_storage(model, "bf16")
     conv = model.dd.conv_list[0]
-    for timed in (None, "gn_rgcn_forward_f32"):
+    for timed in (None, "gn_rgcn_forward_f32", "recorded"):
         with torch.no_grad():
-            stages = PoseStages(model, dg, graphs=True, timed_entry=timed)
+            # ("recorded": the step's entry-point calls written down once and made again from one loop - the same contract)
+            stages = (PoseStages(model, dg, recorded=True) if timed == "recorded" else
+                      PoseStages(model, dg, graphs=True, timed_entry=timed))
             for step in range(3):
                 conv.att.data.mul_(1.25)                       # no _version bump
                 conv.basis.data.add_(0.01)
@@ -277,6 +279,31 @@ def test_staged_forward_follows_parameter_updates(gpu, storage):
                 tol = 2e-5 if storage == "fp32" else 2.0 ** -7 * float(ref["z_dd"].abs().max())
                 close(z, ref["z_dd"], tol, what="{} timed={} step {} z".format(storage, timed, step))
                 close(score, ref["score"], max(tol, 2e-5), what="score")
+
+
+def test_recorded_step_is_the_eager_step(gpu):
+    """PoseStages(recorded=True) makes the eager step's entry-point calls again from one loop: the same bits as the eager
+    modules, on every replay, and a KernelTimer active around a replay brackets the entry points it names."""
+    dg = make_pose("small").to(gpu)
+    torch.manual_seed(5)
+    model = PoseModel(dg.n_g_node, dg.n_d_node, dg.n_dd_edge_type).to(gpu)
+    with torch.no_grad():
+        eager = PoseStages(model, dg, graphs=False)
+        z0, s0 = eager.step()
+        z0, s0 = z0.clone(), s0.clone()
+        rec = PoseStages(model, dg, recorded=True)
+        assert len(rec._whole.calls) >= 4
+        for _ in range(3):
+            z, s = rec.step()
+            assert torch.equal(z, z0) and torch.equal(s, s0)
+        with _hip.KernelTimer(only=("gn_rgcn_forward_f32",), every=2) as t:
+            for _ in range(4):
+                rec.step()
+        calls, ms = t.summary()["gn_rgcn_forward_f32"]
+        assert calls == 2 and ms > 0
+        z, s = rec.step()
+        assert torch.equal(z, z0) and torch.equal(s, s0)
+    _hip.raise_if_index_errors(gpu)
 
 
 @needs_fast_paths

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: the pose0-syn forward step under the launch modes bench.py can choose from, wall clock per step, no event timing:
-eager / genes graph + two Python launches (bench's graphs mode) / two graphs (encode, decode) / ONE graph."""
+eager / genes graph + two Python launches (bench's graphs mode) / two graphs (encode, decode) / ONE graph / the recorded
+entry-point calls replayed from one loop."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gripnet_amd.pipeline import Graphed, PoseModel, PoseStages
@@ -37,3 +38,10 @@ with torch.no_grad():
     print("encode graph + decode graph            {:7.1f} us".format(clock(two.step)))
     one = Graphed(eager.step).capture()
     print("ONE graph                              {:7.1f} us".format(clock(one)))
+    rec = PoseStages(model, data, recorded=True)
+    print("recorded entry-point calls, one loop   {:7.1f} us".format(clock(rec.step)))
+    z0, s0 = eager.step()
+    z0, s0 = z0.clone(), s0.clone()
+    z1, s1 = rec.step()
+    torch.cuda.synchronize()
+    print("recorded == eager:", bool(torch.equal(z0, z1) and torch.equal(s0, s1)), "calls per step:", len(rec._whole.calls))
