@@ -24,7 +24,7 @@ GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 130                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 131                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -81,6 +81,10 @@ SIGNATURES = {
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
     "gn_negative_sampler_sample_packed": (_int, [_p, C.c_uint64, _p, _p, _p, _p, _p]),
+    "gn_rel_grad_plan_create": (_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_rel_grad_plan_destroy": (None, [_p]),
+    "gn_rel_weight_grad_supported": (_int, [_p, _i64, _i64]),
+    "gn_rel_weight_grad_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _p]),
     "gn_link_loss_workspace_bytes": (_sz, []),
     "gn_link_loss_forward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _sz, _p]),
     "gn_link_loss_backward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),
@@ -585,7 +589,7 @@ class RgcnPlan:
         self.num_nodes, self.num_relations, self.num_edges = int(num_nodes), int(rl.shape[0]), e
         self.edge_lo, self.edge_hi = lo, hi
         self._ws = None
-        self._edge_index, self._range_list, self._grad = ei, rl, None
+        self._edge_index, self._range_list, self._grad, self._wgrad = ei, rl, None, None
 
     def grad_plans(self):
         """(reversed-graph relational plan, (relation, source)-major sum plan, in-degree divisor) for the
@@ -603,6 +607,17 @@ class RgcnPlan:
             deg.index_add_(0, ei[1], torch.ones(e_count(ei), dtype=torch.float32, device=self.device))
             self._grad = (rev, pairs, deg.clamp_(min=1.0))
         return self._grad
+
+    def weight_grad_plan(self):
+        """RelGradPlan of this layer's (shard's) edges, or None where the fused kernel does not apply (> 65534 nodes)."""
+        if self._wgrad is None:
+            try:
+                self._wgrad = RelGradPlan(self.grad_plans()[1], self.num_nodes, self.num_relations)
+            except GripNetHipError as err:
+                if err.status != GN_ERR_UNSUPPORTED:
+                    raise
+                self._wgrad = False
+        return self._wgrad or None
 
     def _workspace(self, fin, fout, bases, flags=0):
         need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases, flags))
@@ -763,6 +778,34 @@ class DistMultPlan:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gn_distmult_plan_destroy(h)
+
+
+class RelGradPlan:
+    """Owner of a gn_rel_grad_plan handle: the edge-dependent part of the relational layer's weight gradient
+    (dW_r = X^T Q_r in one launch), built from the layer's (relation, source)-major sum plan."""
+
+    def __init__(self, sums: "GraphPlan", num_nodes, num_relations):
+        lib = load()
+        h = _p()
+        with torch.cuda.device(sums.device):
+            check(lib.gn_rel_grad_plan_create(sums._h, int(num_nodes), int(num_relations), stream_ptr(sums.device), C.byref(h)))
+        self._h, self.device, self.num_relations = h, sums.device, int(num_relations)
+
+    def supported(self, fin, fout) -> bool:
+        return bool(load().gn_rel_weight_grad_supported(self._h, int(fin), int(fout)))
+
+    def weight_grad(self, x, gm, out=None):
+        """dw [R, fin * fout]: dw[r] = sum over the edges e of relation r of x[src_e]^T gm[dst_e]."""
+        fin, fout = x.shape[1], gm.shape[1]
+        if out is None:
+            out = torch.empty((self.num_relations, fin * fout), dtype=torch.float32, device=x.device)
+        _call("gn_rel_weight_grad_f32", self._h, ptr(x), ld(x), fin, ptr(gm), ld(gm), fout, ptr(out), stream_ptr(x.device))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gn_rel_grad_plan_destroy(h)
 
 
 class DistMultBwdPlan:

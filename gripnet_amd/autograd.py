@@ -120,7 +120,10 @@ def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, n
             rev.forward(gm, bt.contiguous(), att, None, None, False, dxe, partial=True)
     if need_basis or need_att:
         # (HIP gather-reduce over (relation, source) rows, then library GEMMs; relation slabs when Q would be huge)
-        if R * n * fout <= Q_BUDGET_FLOATS:
+        wg = plan.weight_grad_plan()
+        if wg is not None and x.stride(1) == 1 and gm.stride(1) == 1 and wg.supported(fin, fout):
+            dw = wg.weight_grad(x, gm)                                       # X^T Q_r in one launch, Q never in memory
+        elif R * n * fout <= Q_BUDGET_FLOATS:
             q = torch.empty((R * n, fout), dtype=torch.float32, device=x.device)
             pairs.aggregate(gm, None, False, q)
             dw = torch.matmul(x.t(), q.view(R, n, fout)).reshape(R, fin * fout)            # [R, fin*fout]

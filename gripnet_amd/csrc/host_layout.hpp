@@ -714,4 +714,141 @@ inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<in
     return L;
 }
 
+// ---- relational weight gradient (rel_grad.hip): dW_r = X^T Q_r, Q_r[s] = sum of the gradient rows of the edges s -> . of
+//      relation r, from the (relation, source)-major CSR of the layer's edges ------------------------------------------
+constexpr int kRelWaves = 16;              // waves of a k_rel_weight_grad workgroup
+constexpr int kRelChunk = 8;               // destination ids of one lane group in one unit
+constexpr int kRelRing = 4;                // units a wave has in flight: the units of a wave in a list entry are padded to a multiple
+constexpr int kRelSlackUnits = 12;         // readable units behind the last one (ids and x are requested four units ahead, sources eight)
+constexpr int kRelCostEntry = 50;          // cost of a list entry in units (the sixteen waves' sums through LDS, four barriers)
+constexpr uint32_t kRelNoSource = 0xffffu;
+
+// A UNIT is four CHUNKS of one relation, a chunk up to eight edges of one (relation, source) row: the source and eight
+// 16-bit destination ids, padded with `n` (the table's zero row).  A row of more than eight edges is several chunks (the
+// sums are linear), so every unit costs the same and nothing in the stream depends on what was loaded before.  A relation
+// whose units exceed half a workgroup's fair share is cut into PARTS (contiguous unit ranges); parts are dealt to the
+// workgroups longest first; the units of a part go round-robin to the sixteen waves, and every wave's units of all its
+// workgroup's parts are contiguous in memory (one stream per wave for the whole launch).
+struct RelGradLayout {
+    std::vector<uint16_t> src;             // [units][4] source of every chunk (kRelNoSource: none)
+    std::vector<uint16_t> ids;             // [units][4][8] destinations
+    std::vector<int32_t> entry;            // 4 per list entry: relation, parts of the relation, part index, first scratch slot of the relation
+    std::vector<int32_t> wave_cnt;         // [entries][16] units of every wave
+    std::vector<int32_t> wg_off;           // [groups + 1] list entries of every workgroup
+    std::vector<int32_t> wave_u0;          // [groups][16] first unit of every wave
+    int groups = 0, scratch_slots = 0;
+    int64_t units = 0;                     // without the slack
+    bool ok = false;
+};
+
+inline RelGradLayout build_rel_grad_layout(const int32_t* rowptr, const int32_t* col, int64_t n, int64_t R, int groups) {
+    RelGradLayout L;
+    if (n < 1 || n >= (int64_t)kRelNoSource || R < 1 || groups < 1) return L;
+    struct Part { int rel, index, parts, u0, u1, slot0; };
+    // chunks of every relation: (source, first edge); units = chunks / 4
+    std::vector<int64_t> chunk_off((size_t)R + 1, 0);
+    for (int64_t r = 0; r < R; ++r) {
+        const int32_t* rp = rowptr + r * n;
+        int64_t c = 0;
+        for (int64_t s = 0; s < n; ++s) c += gn::ceil_div(rp[s + 1] - rp[s], kRelChunk);
+        chunk_off[(size_t)r + 1] = chunk_off[(size_t)r] + c;
+    }
+    std::vector<int32_t> chunk_src((size_t)chunk_off[(size_t)R]), chunk_first((size_t)chunk_off[(size_t)R]);
+    gn::parallel_for(R, 8, [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int32_t* rp = rowptr + r * n;
+            size_t o = (size_t)chunk_off[(size_t)r];
+            for (int64_t s = 0; s < n; ++s)
+                for (int32_t e = rp[s]; e < rp[s + 1]; e += kRelChunk) { chunk_src[o] = (int32_t)s; chunk_first[o] = e; ++o; }
+        }
+    });
+    auto units_of = [&](int64_t r) { return gn::ceil_div(chunk_off[(size_t)r + 1] - chunk_off[(size_t)r], 4); };
+    int64_t total = 0;
+    for (int64_t r = 0; r < R; ++r) total += units_of(r) + kRelCostEntry;
+    const int64_t share = std::max<int64_t>(1, total / groups);
+    std::vector<Part> parts;
+    int slots = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        const int64_t nu = units_of(r);
+        int np = (int)std::min<int64_t>(gn::ceil_div(2 * nu, share), std::max<int64_t>(1, nu / (2 * kRelWaves)));
+        np = std::max(1, std::min(np, 64));
+        const int slot0 = np > 1 ? slots : 0;
+        for (int p = 0; p < np; ++p) parts.push_back(Part{(int)r, p, np, (int)(nu * p / np), (int)(nu * (p + 1) / np), slot0});
+        if (np > 1) slots += np;
+    }
+    // longest first onto the least loaded workgroup
+    std::vector<int> order(parts.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+    auto cost = [&](int k) { return (int64_t)(parts[(size_t)k].u1 - parts[(size_t)k].u0) + kRelCostEntry; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    std::vector<std::vector<int>> mine((size_t)groups);
+    {
+        std::vector<std::pair<int64_t, int>> heap;           // (-load, -group): the max-heap pops the least loaded, lowest index first
+        for (int g = 0; g < groups; ++g) heap.emplace_back(0, -g);
+        std::make_heap(heap.begin(), heap.end());
+        for (int k : order) {
+            std::pop_heap(heap.begin(), heap.end());
+            auto top = heap.back();
+            mine[(size_t)-top.second].push_back(k);
+            top.first -= cost(k);
+            heap.back() = top;
+            std::push_heap(heap.begin(), heap.end());
+        }
+    }
+    // emit: [workgroup][wave][entry][the wave's units of the entry]
+    L.wg_off.assign((size_t)groups + 1, 0);
+    for (int g = 0; g < groups; ++g) L.wg_off[(size_t)g + 1] = L.wg_off[(size_t)g] + (int32_t)mine[(size_t)g].size();
+    const size_t entries = parts.size();
+    L.entry.resize(entries * 4);
+    L.wave_cnt.assign(entries * kRelWaves, 0);
+    L.wave_u0.assign((size_t)groups * kRelWaves, 0);
+    // first unit of every (workgroup, wave): a prefix sum, so that the streams can be written in parallel
+    std::vector<int64_t> wave_first((size_t)groups * kRelWaves + 1, 0);
+    for (int g = 0; g < groups; ++g) {
+        for (size_t k = 0; k < mine[(size_t)g].size(); ++k) {
+            const Part& p = parts[(size_t)mine[(size_t)g][k]];
+            const size_t e = (size_t)L.wg_off[(size_t)g] + k;
+            L.entry[4 * e] = p.rel; L.entry[4 * e + 1] = p.parts; L.entry[4 * e + 2] = p.index; L.entry[4 * e + 3] = p.slot0;
+            for (int w = 0; w < kRelWaves; ++w) {
+                // (padded with empty units to the depth of the kernel's ring of register sets: its loop body is four units)
+                const int cnt = (int)(gn::ceil_div(std::max<int64_t>(0, gn::ceil_div((int64_t)(p.u1 - p.u0) - w, kRelWaves)), kRelRing) * kRelRing);
+                L.wave_cnt[e * kRelWaves + w] = cnt;
+                wave_first[(size_t)g * kRelWaves + w + 1] += cnt;
+            }
+        }
+    }
+    for (size_t k = 1; k < wave_first.size(); ++k) wave_first[k] += wave_first[k - 1];
+    const int64_t units = wave_first.back();
+    if ((units + kRelSlackUnits) * 4 * kRelChunk >= ((int64_t)1 << 31)) return L;
+    L.src.assign((size_t)(units + kRelSlackUnits) * 4, (uint16_t)kRelNoSource);
+    L.ids.assign((size_t)(units + kRelSlackUnits) * 4 * kRelChunk, (uint16_t)n);
+    for (size_t k = 0; k + 1 < wave_first.size(); ++k) L.wave_u0[k] = (int32_t)wave_first[k];
+    gn::parallel_for(groups, 1, [&](int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g)
+            for (int w = 0; w < kRelWaves; ++w) {
+                int64_t u = wave_first[(size_t)g * kRelWaves + w];
+                for (size_t k = 0; k < mine[(size_t)g].size(); ++k) {
+                    const Part& p = parts[(size_t)mine[(size_t)g][k]];
+                    const int32_t* rp = rowptr + (int64_t)p.rel * n;
+                    const int64_t c0 = chunk_off[(size_t)p.rel], c1 = chunk_off[(size_t)p.rel + 1];
+                    const size_t e = (size_t)L.wg_off[(size_t)g] + k;
+                    const int64_t u_next = u + L.wave_cnt[e * kRelWaves + w];
+                    for (int64_t j = p.u0 + w; j < p.u1; j += kRelWaves, ++u)
+                        for (int lg = 0; lg < 4; ++lg) {
+                            const int64_t ch = c0 + 4 * j + lg;
+                            if (ch >= c1) continue;
+                            const int32_t s = chunk_src[(size_t)ch], e0 = chunk_first[(size_t)ch], e1 = std::min(rp[s + 1], e0 + kRelChunk);
+                            L.src[(size_t)u * 4 + lg] = (uint16_t)s;
+                            for (int32_t t = e0; t < e1; ++t) L.ids[((size_t)u * 4 + lg) * kRelChunk + (t - e0)] = (uint16_t)col[t];
+                        }
+                    u = u_next;
+                }
+            }
+    });
+    L.units = units;
+    L.groups = groups; L.scratch_slots = slots;
+    L.ok = true;
+    return L;
+}
+
 }  // namespace gn_layout

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 130 /* 0.1.30 */
+#define GN_VERSION 131 /* 0.1.31 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -264,6 +264,24 @@ GN_API gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* sum
                                int64_t ld_x, int64_t in_features, const float* root, const float* bias,
                                int64_t out_features, int relu, float* out, int64_t ld_out,
                                const gn_side_copy* side /* nullable */, void* stream);
+
+/* Weight gradient of the relational layer (autograd of layers.py:165-197 under the loss of GripNet-pose.py:140-146): with
+ * P = sum_e x[src_e] W_{r(e)} and gm = dL/dP ([n, out_features]),
+ *   dw[r] = sum_{e in r} x[src_e]^T gm[dst_e]      ([num_relations][in_features][out_features], row-major, overwritten),
+ * from which dbasis = att^T dw and datt = dw basis^T (layers.py:172-173).  The plan is built from the plain-sum plan of
+ * the layer's edges keyed dst -> relation * n + src (gn_sum_plan_create with num_relations * n targets over n
+ * sources: one row per (relation, source), its entries the destinations) and holds what depends on the edges only.
+ * One launch: the (relation, source) sums of gm never exist in memory (they were 80 MB per step on PoSE).  No float
+ * atomics: the same bits every run.  GN_ERR_UNSUPPORTED (see gn_rel_weight_grad_supported) for in_features other than
+ * 16 / 32 / 48 / 64, out_features other than 16 / 32, or a gm table that does not fit the LDS: sum the rows with
+ * gn_graph_aggregate_f32 on the plain-sum plan and contract them with x per relation instead. */
+typedef struct gn_rel_grad_plan gn_rel_grad_plan;
+GN_API gn_status gn_rel_grad_plan_create(const gn_graph_plan* relation_source_sums, int64_t num_nodes, int64_t num_relations,
+                                  void* stream, gn_rel_grad_plan** plan);
+GN_API void gn_rel_grad_plan_destroy(gn_rel_grad_plan* plan);
+GN_API int gn_rel_weight_grad_supported(const gn_rel_grad_plan* plan, int64_t in_features, int64_t out_features);
+GN_API gn_status gn_rel_weight_grad_f32(const gn_rel_grad_plan* plan, const float* x, int64_t ld_x, int64_t in_features,
+                                 const float* gm, int64_t ld_gm, int64_t out_features, float* dw, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * DistMult decoder (multiRelaInnerProductDecoder.forward, gripnet/decoder.py:19-23):

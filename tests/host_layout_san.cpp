@@ -154,6 +154,60 @@ gn_layout::BlockedLayout blocked_case(int64_t N, int deg, int R, unsigned seed, 
     return L;
 }
 
+// ---- relational weight gradient: units of four chunks of (relation, source) rows -----------------------------------------
+gn_layout::RelGradLayout rel_grad_case(int64_t n, int64_t R, int64_t E, int groups, unsigned seed, bool check) {
+    std::mt19937_64 rng(seed);
+    // (relation, source)-major CSR with a hub relation (a quarter of the edges), empty relations and empty rows
+    std::vector<std::vector<int32_t>> rows((size_t)(R * n));
+    for (int64_t e = 0; e < E; ++e) {
+        int64_t r = (e % 4 == 0) ? 0 : (int64_t)(rng() % (uint64_t)R);
+        if (R > 3 && r == 2) r = 3;                                       // relation 2 stays empty
+        rows[(size_t)(r * n + (int64_t)(rng() % (uint64_t)n))].push_back((int32_t)(rng() % (uint64_t)n));
+    }
+    std::vector<int32_t> rp((size_t)(R * n) + 1, 0), col;
+    for (size_t k = 0; k < rows.size(); ++k) { col.insert(col.end(), rows[k].begin(), rows[k].end()); rp[k + 1] = (int32_t)col.size(); }
+    gn_layout::RelGradLayout L = gn_layout::build_rel_grad_layout(rp.data(), col.data(), n, R, groups);
+    if (!check) return L;
+    CHECK(L.ok && L.groups == groups);
+    const size_t entries = L.entry.size() / 4;
+    CHECK(L.wg_off.size() == (size_t)groups + 1 && (size_t)L.wg_off.back() == entries && L.wave_cnt.size() == entries * gn_layout::kRelWaves);
+    // every wave's units are one contiguous run, in workgroup / wave / entry order, a multiple of the ring depth per entry
+    int64_t u = 0;
+    std::vector<int64_t> got((size_t)(R * n), 0);                         // edges found per (relation, source) row
+    std::vector<int> parts_seen((size_t)R, 0);
+    for (int g = 0; g < groups; ++g)
+        for (int w = 0; w < gn_layout::kRelWaves; ++w) {
+            CHECK(L.wave_u0[(size_t)g * gn_layout::kRelWaves + w] == u);
+            for (int e = L.wg_off[g]; e < L.wg_off[g + 1]; ++e) {
+                const int rel = L.entry[4 * (size_t)e], cnt = L.wave_cnt[(size_t)e * gn_layout::kRelWaves + w];
+                CHECK(rel >= 0 && rel < R && cnt % gn_layout::kRelRing == 0);
+                if (w == 0) parts_seen[(size_t)rel]++;
+                for (int k = 0; k < cnt; ++k, ++u)
+                    for (int lg = 0; lg < 4; ++lg) {
+                        const uint16_t s = L.src[(size_t)u * 4 + lg];
+                        for (int t = 0; t < gn_layout::kRelChunk; ++t) {
+                            const uint16_t d = L.ids[((size_t)u * 4 + lg) * gn_layout::kRelChunk + t];
+                            if (s == gn_layout::kRelNoSource) { CHECK(d == (uint16_t)n); continue; }
+                            CHECK(s < n && d <= n);
+                            if (d < n) got[(size_t)(rel * n + s)]++;
+                        }
+                    }
+            }
+        }
+    CHECK(u == L.units && L.src.size() == (size_t)(u + gn_layout::kRelSlackUnits) * 4);
+    for (size_t k = 0; k < got.size(); ++k) CHECK(got[k] == rp[k + 1] - rp[k]);
+    // every relation is listed, all its parts exactly once, and the parts' scratch slots do not overlap
+    int slots = 0;
+    for (int64_t r = 0; r < R; ++r) CHECK(parts_seen[(size_t)r] >= 1);
+    for (size_t e = 0; e < entries; ++e) {
+        const int rel = L.entry[4 * e], parts = L.entry[4 * e + 1], index = L.entry[4 * e + 2], slot0 = L.entry[4 * e + 3];
+        CHECK(parts == parts_seen[(size_t)rel] && index >= 0 && index < parts);
+        if (parts > 1) { CHECK(slot0 >= 0 && slot0 + parts <= L.scratch_slots); if (index == 0) slots += parts; }
+    }
+    CHECK(slots == L.scratch_slots);
+    return L;
+}
+
 template <typename T>
 bool same(const std::vector<T>& a, const std::vector<T>& b) { return a == b; }
 
@@ -184,6 +238,14 @@ int main() {
         set_threads(16);
         gn_layout::BlockedLayout b = blocked_case(c.N, c.deg, c.R, 13, true);
         CHECK(same(a.ids, b.ids) && same(a.tile_off, b.tile_off) && same(a.tile_rows, b.tile_rows) && same(a.cell, b.cell));
+    }
+    struct { int64_t n, R, E; int groups; } rg[] = {{645, 40, 200000, 256}, {100, 7, 5000, 256}, {37, 3, 10, 8}, {300, 964, 60000, 64}};
+    for (auto& c : rg) {
+        set_threads(1);
+        gn_layout::RelGradLayout a = rel_grad_case(c.n, c.R, c.E, c.groups, 17, true);
+        set_threads(16);
+        gn_layout::RelGradLayout b = rel_grad_case(c.n, c.R, c.E, c.groups, 17, true);
+        CHECK(same(a.src, b.src) && same(a.ids, b.ids) && same(a.entry, b.entry) && same(a.wave_cnt, b.wave_cnt) && same(a.wave_u0, b.wave_u0));
     }
     std::printf("host layout: all builders ok on 1 and 16 threads\n");
     return 0;

@@ -503,6 +503,38 @@ def test_rgcn_shard_gradient_shares_add_up(gpu):
         close((p + q) / scale, f / scale, 1e-4, what=name)
 
 
+@pytest.mark.parametrize("n,fin,fout,hub", [(645, 48, 32, True), (100, 16, 16, False), (300, 64, 32, True), (37, 32, 16, False),
+                                            (200, 48, 16, True), (1000, 16, 32, False)])
+def test_relational_weight_gradient_in_one_launch(gpu, n, fin, fout, hub):
+    """gn_rel_weight_grad_f32: dW_r = sum over the edges of relation r of x[src]^T gm[dst], against index_add + matmul in
+    float64 - with empty relations, a relation of one edge, sources without edges, a hub relation large enough to be cut
+    into parts that several workgroups add up (the last to arrive, in part order), strided x; the same bits on every
+    launch; and through rgcn_edge_gradients against the unfused path (GN_DISABLE_FAST)."""
+    gen = torch.Generator().manual_seed(n + fin + fout)
+    sizes = [300, 0, 1, 1200, 5, 40, 700, 0] + ([60000 if n > 250 else 9000] if hub else []) + [17] * 40
+    blocks = [torch.randint(0, max(1, n - 3), (2, s), generator=gen) for s in sizes]
+    ei = torch.cat(blocks, dim=1).to(gpu)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    R = len(sizes)
+    wide = torch.randn(n, fin + 8, generator=gen).to(gpu)
+    x = wide[:, 4:4 + fin]                                             # rows 4 floats off, leading dimension fin + 8
+    gm = torch.randn(n, fout, generator=gen).to(gpu)
+    plan = _hip.RgcnPlan(ei, rl, n)
+    wg = plan.weight_grad_plan()
+    assert wg is not None and wg.supported(fin, fout)
+    dw = wg.weight_grad(x, gm)
+    rel = torch.repeat_interleave(torch.arange(R), torch.tensor(sizes)).to(gpu)
+    q = torch.zeros(R * n, fout, dtype=torch.float64, device=gpu)
+    q.index_add_(0, rel * n + ei[0], gm.double().index_select(0, ei[1]))
+    ref = torch.matmul(x.double().t(), q.view(R, n, fout)).reshape(R, fin * fout)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((dw.double() - ref).abs().max()) / scale <= 2e-6
+    for _ in range(3):
+        assert torch.equal(wg.weight_grad(x, gm), dw)
+    assert not wg.supported(fin + 1, fout) and not wg.supported(fin, 24)
+    _hip.raise_if_index_errors(gpu)
+
+
 @pytest.mark.parametrize("features,table_rows", [(32, 645), (16, 1500), (64, 300)])
 def test_short_row_sums_over_a_small_table(gpu, monkeypatch, features, table_rows):
     """The (relation, source) sums of the relational layer's weight gradient at their real shape: ~10^5 rows of a few
