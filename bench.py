@@ -103,7 +103,8 @@ def train_step_entry(dev, steps=20):
     data = make_pose("pose0-syn").to(dev)
     torch.manual_seed(1111)
     model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=True)
+    from gripnet_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=0.01)                    # gn_adam_step_f32: all parameters in one launch
     sampler = _hip.NegativeSampler(data.train_idx, data.n_d_node, data.train_range)
     neg = sampler.sample(seed=0)
     drawn = [1]
@@ -149,7 +150,7 @@ def train_step_entry(dev, steps=20):
     losses.append(float(loss))
     _hip.raise_if_index_errors(dev)
     return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
-            "what": "forward + DistMult on positives and on fresh negatives + loss (utils.link_loss) + backward + fused Adam, one hipGraph replay per step; "
+            "what": "forward + DistMult on positives and on fresh negatives + loss (utils.link_loss) + backward + Adam (gripnet_amd.optim.Adam, one launch), one hipGraph replay per step; "
                     "the negatives of every step are drawn on the device (typed sampler, 32 us) in front of the replay",
             "loss_after": round(losses[-1], 5)}
 

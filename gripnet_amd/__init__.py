@@ -9,8 +9,8 @@ need a GPU, running a layer does.
 """
 from .layers import myGCN, myRGCN, homoGraph, interGraph
 from .decoder import multiRelaInnerProductDecoder, multiClassInnerProductDecoder
-from . import utils, synth
+from . import utils, synth, optim
 
 __all__ = ["myGCN", "myRGCN", "homoGraph", "interGraph", "multiRelaInnerProductDecoder",
-           "multiClassInnerProductDecoder", "utils", "synth"]
+           "multiClassInnerProductDecoder", "utils", "synth", "optim"]
 __version__ = "0.1.0"

@@ -24,7 +24,7 @@ GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 131                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 132                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -85,12 +85,18 @@ SIGNATURES = {
     "gn_rel_grad_plan_destroy": (None, [_p]),
     "gn_rel_weight_grad_supported": (_int, [_p, _i64, _i64]),
     "gn_rel_weight_grad_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _p]),
+    "gn_adam_step_f32": (_int, [_p, _int, _p, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
     "gn_link_loss_workspace_bytes": (_sz, []),
     "gn_link_loss_forward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _sz, _p]),
     "gn_link_loss_backward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),
     "gn_link_metrics_workspace_bytes": (_sz, [_i64, _i64]),
     "gn_link_metrics_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
 }
+
+
+class AdamTensor(C.Structure):
+    """gn_adam_tensor of include/gripnet_hip.h."""
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _i64)]
 
 
 class SideCopy(C.Structure):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 131 /* 0.1.31 */
+#define GN_VERSION 132 /* 0.1.32 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -400,6 +400,25 @@ GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, 
  * of 16.  GN_ERR_UNSUPPORTED for larger graphs. */
 GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
                                             int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
+
+/* One Adam step over all parameter tensors in one launch (torch.optim.Adam(model.parameters(), lr) + optimizer.step(),
+ * GripNet-pose.py:104,146; the update of torch/optim/adam.py without amsgrad / maximize):
+ *   t = *step + 1;  g += weight_decay p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g g;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps);   *step = t.
+ * `tensors` is a HOST array (copied into the launch's arguments, so a captured launch replays with it): device pointers
+ * of parameter, gradient, first and second moment, and the element count.  `step`: one float on the device, the number of
+ * steps taken so far (0 before the first), advanced by the launch.  `workspace`: 4 bytes on the device, 4-byte aligned,
+ * ZEROED ONCE by the caller.  Calls on one (step, workspace) must be stream-ordered. */
+#define GN_ADAM_MAX_TENSORS 64   /* per launch; longer tables take several launches */
+typedef struct gn_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} gn_adam_tensor;
+GN_API gn_status gn_adam_step_f32(const gn_adam_tensor* tensors, int num_tensors, float* step, void* workspace, size_t workspace_bytes,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* The link-prediction loss of the training loop and its gradient (GripNet-pose.py:140-142 with EPS of gripnet/utils.py:10):
  *   loss = - mean(log(pos + eps)) - mean(log(1 - neg + eps)),

@@ -560,6 +560,35 @@ def test_short_row_sums_over_a_small_table(gpu, monkeypatch, features, table_row
     assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adam_step_matches_torch(gpu, wd):
+    """gripnet_amd.optim.Adam (gn_adam_step_f32: all parameters in one launch, step counter on the device) against
+    torch.optim.Adam over several steps: tensors of 1 to ~600 K elements, sizes that are not multiples of four, a parameter
+    without a gradient, new gradient tensors every step."""
+    import gripnet_amd
+    gen = torch.Generator().manual_seed(7)
+    shapes = [(19081, 32), (32, 16), (16,), (1,), (645, 7), (963, 32), (5, 3, 11), (4097,), (64, 48, 32)]
+    ours = [torch.nn.Parameter(torch.randn(s, generator=gen).to(gpu)) for s in shapes]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    idle_a, idle_b = torch.nn.Parameter(torch.ones(3, device=gpu)), torch.nn.Parameter(torch.ones(3, device=gpu))
+    a = gripnet_amd.optim.Adam(ours + [idle_a], lr=0.01, weight_decay=wd)
+    b = torch.optim.Adam(theirs + [idle_b], lr=0.01, weight_decay=wd)
+    for step in range(6):
+        a.zero_grad()
+        b.zero_grad()
+        for p, q in zip(ours, theirs):
+            g = torch.randn(p.shape, generator=gen).to(gpu) * (10.0 ** (step - 3))
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+        for k, (p, q) in enumerate(zip(ours, theirs)):
+            err = float((p - q).abs().max())
+            assert err <= 2e-6 * max(1.0, float(q.abs().max())), (step, k, err)
+    assert float(a.param_groups[0]["step"]) == 6.0
+    assert torch.equal(idle_a, idle_b)
+    _hip.raise_if_index_errors(gpu)
+
+
 def test_link_loss_matches_the_torch_expression(gpu):
     """utils.link_loss (gn_link_loss_forward_f32 / _backward_f32: one launch each) against the expression the reference's
     driver spells out with torch ops (GripNet-pose.py:140-142): value, both gradients, an upstream factor, run-to-run bits,
