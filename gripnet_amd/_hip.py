@@ -24,7 +24,7 @@ GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 132                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 133                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -85,6 +85,8 @@ SIGNATURES = {
     "gn_rel_grad_plan_destroy": (None, [_p]),
     "gn_rel_weight_grad_supported": (_int, [_p, _i64, _i64]),
     "gn_rel_weight_grad_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _p]),
+    "gn_grad_prologue_workspace_bytes": (_sz, []),
+    "gn_grad_prologue_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _sz, _p]),
     "gn_adam_step_f32": (_int, [_p, _int, _p, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
     "gn_link_loss_workspace_bytes": (_sz, []),
     "gn_link_loss_forward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _sz, _p]),
@@ -433,6 +435,29 @@ def xtg(x: torch.Tensor, g: torch.Tensor):
     ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
     _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need, stream_ptr(x.device))
     return out
+
+
+_prologue_ws = {}
+
+
+def grad_prologue(g, saved_out=None, rowdiv=None, want_masked=True, want_colsum=False):
+    """(gm, gd, colsum) of gn_grad_prologue_f32: gm = g masked by saved_out > 0 (None when not wanted), gd = gm / rowdiv
+    (None without rowdiv), colsum = the column sums of gm (None when not wanted).  `g` may be a row-strided view."""
+    g = f32_rows(g)
+    rows, cols = g.shape
+    dev = g.device
+    gm = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_masked else None
+    gd = torch.empty((rows, cols), dtype=torch.float32, device=dev) if rowdiv is not None else None
+    cs = torch.empty((cols,), dtype=torch.float32, device=dev) if want_colsum else None
+    ws = None
+    if want_colsum:
+        key = dev.index
+        if key not in _prologue_ws:
+            _prologue_ws[key] = torch.zeros((int(load().gn_grad_prologue_workspace_bytes()),), dtype=torch.uint8, device=dev)
+        ws = _prologue_ws[key]
+    _call("gn_grad_prologue_f32", ptr(g), ld(g), ptr(saved_out), 0 if saved_out is None else ld(saved_out), ptr(rowdiv), rows, cols,
+          ptr(gm), cols, ptr(gd), cols, ptr(cs), ptr(ws), 0 if ws is None else ws.numel(), stream_ptr(dev))
+    return gm, gd, cs
 
 
 def merge(dst: torch.Tensor, src: torch.Tensor, mode: int, src2=None):

@@ -43,14 +43,16 @@ class GcnConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
-        g = _hip.f32_rows(g.contiguous())
-        if ctx.relu:                                           # gradient passes where the output is positive
-            g = _hip.merge(torch.empty_like(g), g, 5, src2=out)
-        gxw = torch.empty((ctx.plan.n_table, g.shape[1]), dtype=torch.float32, device=g.device)
-        ctx.plan.aggregate_t(g, gxw)                           # A_norm^T g  (HIP, source-major CSR)
+        # one launch: the ReLU mask by the saved output (gradient passes where the output is positive), the bias gradient
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.relu or need_db or g.stride(1) != 1:
+            gm, _, db = _hip.grad_prologue(g, out if ctx.relu else None, None, True, need_db)
+        else:
+            gm, db = _hip.f32_rows(g), None
+        gxw = torch.empty((ctx.plan.n_table, gm.shape[1]), dtype=torch.float32, device=gm.device)
+        ctx.plan.aggregate_t(gm, gxw)                          # A_norm^T g  (HIP, source-major CSR)
         dx = gxw @ w.t() if ctx.needs_input_grad[0] else None
         dw = _hip.xtg(x, gxw) if ctx.needs_input_grad[1] else None
-        db = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None
 
 
@@ -70,16 +72,13 @@ class RgcnConvFn(torch.autograd.Function):
     def backward(ctx, g):
         # out[i] = (sum_{e: dst=i} x[src_e] W_{r(e)}) / deg_i + x[i] root + b,   W_r = sum_b att[r,b] basis[b]
         x, basis, att, root, out = ctx.saved_tensors
-        g = _hip.f32_rows(g.contiguous())
-        if ctx.relu:
-            g = _hip.merge(torch.empty_like(g), g, 5, src2=out)
         deg = ctx.plan.grad_plans()[2]
-        gm = g / deg.view(-1, 1)                                            # gradient of the un-normalised sum
+        # one launch: ReLU mask, gm = g / deg (the gradient of the un-normalised sum), the bias gradient
+        g, gm, dbias = _hip.grad_prologue(g, out if ctx.relu else None, deg, True, bool(ctx.needs_input_grad[4]))
         dxe, dbasis, datt = rgcn_edge_gradients(ctx.plan, x, basis.detach(), att.detach(), gm,
                                                 ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         dx = dxe + g @ root.detach().t() if ctx.needs_input_grad[0] else None
         droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
-        dbias = g.sum(dim=0) if ctx.needs_input_grad[4] else None
         return dx, dbasis, datt, droot, dbias, None, None
 
 

@@ -1,0 +1,120 @@
+// Element-wise glue of the layers' backward passes in one launch per layer (autograd of gripnet/layers.py:71-100,165-197):
+//
+//   gm = (saved_out > 0 ? g : 0)            the ReLU that follows every conv (layers.py:279,305,370), by the saved output
+//   gd = gm / rowdiv                        the mean over the incoming edges of the relational layer (layers.py:191)
+//   colsum[c] = sum_rows gm[row, c]         the bias gradient
+//
+// Written with torch ops these are a strided copy, a mask, a division and a column sum (itself a memset and a two-pass
+// reduction): four to six launches of ~5 us each per layer inside the replayed training step.  Deterministic: a workgroup
+// sums a fixed slice of rows in a fixed order, the last workgroup to arrive adds the slices in workgroup order.
+#include "common.h"
+
+namespace {
+
+constexpr int kGradThreads = 256, kGradGroups = 1024;
+
+template <int CP>     // columns padded to a power of two: thread (tid / CP, tid % CP) keeps its column
+__global__ __launch_bounds__(kGradThreads) void k_grad_prologue(const float* __restrict__ g, int64_t ld_g, const float* __restrict__ saved,
+                                                               int64_t ld_saved, const float* __restrict__ rowdiv, int64_t rows, int cols,
+                                                               float* __restrict__ gm, int64_t ld_gm, float* __restrict__ gd, int64_t ld_gd,
+                                                               float* __restrict__ colsum, float* __restrict__ partial,
+                                                               unsigned int* __restrict__ arrived) {
+    constexpr int RP = kGradThreads / CP;                                  // rows per pass of a workgroup
+    __shared__ float red[kGradThreads];
+    __shared__ bool last;
+    const int tid = threadIdx.x, c = tid % CP, rl = tid / CP;
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+    float sum = 0.f;
+    if (c < cols) {
+        // four rows per trip, their loads requested together (one row per trip waits out a memory round trip per element)
+        for (int64_t r = r0 + rl; r < r1; r += 4 * RP) {
+            float v[4], s[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t rr = min(r + k * RP, r1 - 1);
+                v[k] = g[rr * ld_g + c];
+                s[k] = saved ? saved[rr * ld_saved + c] : 1.f;
+                d[k] = gd ? rowdiv[rr] : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t rr = r + k * RP;
+                if (rr < r1) {
+                    const float x = s[k] > 0.f ? v[k] : 0.f;
+                    if (gm) gm[rr * ld_gm + c] = x;
+                    if (gd) gd[rr * ld_gd + c] = x / d[k];
+                    sum += x;
+                }
+            }
+        }
+    }
+    if (!colsum) return;
+    red[tid] = sum;
+    __syncthreads();
+    if (tid < CP) {                                                        // the workgroup's row lanes, in order
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) s += red[k * CP + tid];
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)blockIdx.x * CP + tid, __float_as_uint(s), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                       // (every storing wave has drained its stores)
+    if (tid == 0) last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    {
+        // row lane k takes workgroups k, k + RP, ... in that order, then the row lanes are added in order: the same association
+        // whatever the arrival order was
+        float s = 0.f;
+        for (unsigned b = rl; b < gridDim.x; b += RP)
+            s += __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(partial) + (size_t)b * CP + c, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();                                                   // (red was read above)
+        red[tid] = s;
+        __syncthreads();
+        if (tid < cols) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < RP; ++k) t += red[k * CP + tid];
+            colsum[tid] = t;
+        }
+    }
+    if (tid == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gn_grad_prologue_workspace_bytes(void) { return (size_t)kGradGroups * 256 * sizeof(float) + 64; }
+
+gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_out, int64_t ld_saved, const float* rowdiv, int64_t rows,
+                               int64_t cols, float* gm, int64_t ld_gm, float* gd, int64_t ld_gd, float* colsum, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(rows >= 0 && cols >= 0 && cols <= 256, "bad size: up to 256 columns");
+    if (rows == 0 || cols == 0) {
+        if (colsum && cols > 0) GN_HIP(hipMemsetAsync(colsum, 0, (size_t)cols * sizeof(float), gn::as_stream(stream)));
+        return GN_OK;
+    }
+    GN_REQUIRE(g && ld_g >= cols && (!saved_out || ld_saved >= cols) && (!gm || ld_gm >= cols) && (!gd || (ld_gd >= cols && rowdiv)),
+               "operand pointer is null or a leading dimension smaller than the row length");
+    GN_REQUIRE(!colsum || (workspace && workspace_bytes >= gn_grad_prologue_workspace_bytes() && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0),
+               "column sums need a workspace of %zu bytes, zeroed once", gn_grad_prologue_workspace_bytes());
+    float* partial = static_cast<float*>(workspace);
+    unsigned int* arrived = workspace ? reinterpret_cast<unsigned int*>(partial + (size_t)kGradGroups * 256) : nullptr;
+    // (a workgroup covers 256 / CP rows per pass and four passes per trip: about two trips each)
+    const int groups = (int)std::min<int64_t>(kGradGroups, gn::ceil_div(rows * std::max<int64_t>(cols, 16), 2048));
+    hipStream_t st = gn::as_stream(stream);
+#define GN_GRAD_LAUNCH(CP) k_grad_prologue<CP><<<groups, kGradThreads, 0, st>>>(g, ld_g, saved_out, ld_saved, rowdiv, rows, (int)cols, gm, ld_gm, gd, ld_gd, colsum, partial, arrived)
+    if (cols <= 16) GN_GRAD_LAUNCH(16);
+    else if (cols <= 32) GN_GRAD_LAUNCH(32);
+    else if (cols <= 64) GN_GRAD_LAUNCH(64);
+    else if (cols <= 128) GN_GRAD_LAUNCH(128);
+    else GN_GRAD_LAUNCH(256);
+#undef GN_GRAD_LAUNCH
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+}  // extern "C"

@@ -15,8 +15,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int kLossGroups = 512, kLossThreads = 256;
 
-// A thread reads its share with 16-byte loads, four of them in flight: one float at a time it waits out a memory round trip per
-// term (60 us for 2 x 2 M scores instead of ~6).
+// A thread reads its share with 16-byte loads, eight of them in flight: one float at a time it waits out a memory round trip
+// per term (60 us for 2 x 2 M scores).
 template <bool VEC>
 __global__ __launch_bounds__(kLossThreads) void k_link_loss(const float* __restrict__ pos, int64_t n_pos, const float* __restrict__ neg,
                                                            int64_t n_neg, float eps, double* __restrict__ partial,
@@ -24,55 +24,37 @@ __global__ __launch_bounds__(kLossThreads) void k_link_loss(const float* __restr
     __shared__ double red[2][kLossThreads / 64];
     __shared__ bool last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // log(pos + eps) and log(1 - neg + eps), the additions in the reference's order (GripNet-pose.py:140-141)
-    float sp, sn;
+    // log(pos + eps) and log(1 - neg + eps), the additions in the reference's order (GripNet-pose.py:140-141).  Four 16-byte
+    // loads of each list are requested before anything is summed, whatever the list's length (clamped index, masked sum): with
+    // 2 M scores a thread's share is under four float4, and a loop that only unrolls when four full trips exist never did.
+    float sp = 0.f, sn = 0.f;
     {
         const int64_t t = (int64_t)blockIdx.x * kLossThreads + tid, stride = (int64_t)gridDim.x * kLossThreads;
-        float sum = 0.f;
-        int64_t done = 0;
         if constexpr (VEC) {
-            const f32x4* __restrict__ v = reinterpret_cast<const f32x4*>(pos);
-            const int64_t nv = n_pos / 4;
-            int64_t i = t;
-            for (; i + 3 * stride < nv; i += 4 * stride) {
-                const f32x4 a = v[i], b = v[i + stride], c = v[i + 2 * stride], d = v[i + 3 * stride];
+            const f32x4* __restrict__ vp = reinterpret_cast<const f32x4*>(pos);
+            const f32x4* __restrict__ vn = reinterpret_cast<const f32x4*>(neg);
+            const int64_t np4 = n_pos / 4, nn4 = n_neg / 4, most = np4 > nn4 ? np4 : nn4;
+            for (int64_t i = t; i < most; i += 4 * stride) {
+                f32x4 a[4], b[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    sum += (__logf(a[k] + eps) + __logf(b[k] + eps)) + (__logf(c[k] + eps) + __logf(d[k] + eps));
-            }
-            for (; i < nv; i += stride) {
-                const f32x4 a = v[i];
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t j = i + k * stride;
+                    a[k] = np4 > 0 ? vp[j < np4 ? j : np4 - 1] : (f32x4){1.f, 1.f, 1.f, 1.f};      // (uniform: an empty list may be null)
+                    b[k] = nn4 > 0 ? vn[j < nn4 ? j : nn4 - 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sum += __logf(a[k] + eps);
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t j = i + k * stride;
+                    if (j < np4) sp += (__logf(a[k][0] + eps) + __logf(a[k][1] + eps)) + (__logf(a[k][2] + eps) + __logf(a[k][3] + eps));
+                    if (j < nn4) sn += (__logf(1.0f - b[k][0] + eps) + __logf(1.0f - b[k][1] + eps)) + (__logf(1.0f - b[k][2] + eps) + __logf(1.0f - b[k][3] + eps));
+                }
             }
-            done = nv * 4;
+            for (int64_t i = np4 * 4 + t; i < n_pos; i += stride) sp += __logf(pos[i] + eps);
+            for (int64_t i = nn4 * 4 + t; i < n_neg; i += stride) sn += __logf(1.0f - neg[i] + eps);
+        } else {
+            for (int64_t i = t; i < n_pos; i += stride) sp += __logf(pos[i] + eps);
+            for (int64_t i = t; i < n_neg; i += stride) sn += __logf(1.0f - neg[i] + eps);
         }
-        for (int64_t i = done + t; i < n_pos; i += stride) sum += __logf(pos[i] + eps);
-        sp = sum;
-    }
-    {
-        const int64_t t = (int64_t)blockIdx.x * kLossThreads + tid, stride = (int64_t)gridDim.x * kLossThreads;
-        float sum = 0.f;
-        int64_t done = 0;
-        if constexpr (VEC) {
-            const f32x4* __restrict__ v = reinterpret_cast<const f32x4*>(neg);
-            const int64_t nv = n_neg / 4;
-            int64_t i = t;
-            for (; i + 3 * stride < nv; i += 4 * stride) {
-                const f32x4 a = v[i], b = v[i + stride], c = v[i + 2 * stride], d = v[i + 3 * stride];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    sum += (__logf(1.0f - a[k] + eps) + __logf(1.0f - b[k] + eps)) + (__logf(1.0f - c[k] + eps) + __logf(1.0f - d[k] + eps));
-            }
-            for (; i < nv; i += stride) {
-                const f32x4 a = v[i];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sum += __logf(1.0f - a[k] + eps);
-            }
-            done = nv * 4;
-        }
-        for (int64_t i = done + t; i < n_neg; i += stride) sum += __logf(1.0f - neg[i] + eps);
-        sn = sum;
     }
     double dp = sp, dn = sn;
 #pragma unroll
@@ -82,23 +64,27 @@ __global__ __launch_bounds__(kLossThreads) void k_link_loss(const float* __restr
     if (tid == 0) {
         double a = 0.0, b = 0.0;
         for (int w = 0; w < kLossThreads / 64; ++w) { a += red[0][w]; b += red[1][w]; }
-        // the partial sums are handed over write-through (sc1), the counter is an agent-scope atomic, the last arriver
-        // reads them with sc1 loads: the form MI355X_MICROARCH.md lists for a last-arriver hand-over of a few bytes
-        __builtin_nontemporal_store(a, partial + 2 * blockIdx.x);
-        __builtin_nontemporal_store(b, partial + 2 * blockIdx.x + 1);
-        __threadfence();
-        const unsigned int arrived = atomicAdd(counter, 1u);
+        // hand-over without fences (a release would write back the XCD's L2 512 times): the two partial sums are stored
+        // write-through (agent-scope relaxed atomic stores), drained, then the ticket is drawn; the last arriver reads them
+        // with agent-scope loads - the form MI355X_MICROARCH.md lists for a last-arriver hand-over of a few bytes
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(partial) + 2 * blockIdx.x, (unsigned long long)__double_as_longlong(a),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(partial) + 2 * blockIdx.x + 1, (unsigned long long)__double_as_longlong(b),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = arrived == gridDim.x - 1;
     }
     __syncthreads();
     if (!last) return;
     // the last workgroup to arrive adds the partial sums: thread t takes workgroups t, t + 256, ... in that order, then a fixed
     // tree over the threads - the same association whatever the arrival order was
-    __threadfence();
     double a = 0.0, b = 0.0;
     for (unsigned g = tid; g < gridDim.x; g += kLossThreads) {
-        a += __builtin_nontemporal_load(partial + 2 * g);
-        b += __builtin_nontemporal_load(partial + 2 * g + 1);
+        a += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(partial) + 2 * g, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+        b += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(partial) + 2 * g + 1, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
@@ -110,7 +96,7 @@ __global__ __launch_bounds__(kLossThreads) void k_link_loss(const float* __restr
         for (int w = 0; w < kLossThreads / 64; ++w) { a += red[0][w]; b += red[1][w]; }
         const double lp = n_pos > 0 ? a / (double)n_pos : 0.0, ln = n_neg > 0 ? b / (double)n_neg : 0.0;
         *loss = (float)(-lp - ln);
-        *counter = 0u;                                             // ready for the next launch (stream-ordered)
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
     }
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 132 /* 0.1.32 */
+#define GN_VERSION 133 /* 0.1.33 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -400,6 +400,17 @@ GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, 
  * of 16.  GN_ERR_UNSUPPORTED for larger graphs. */
 GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
                                             int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
+
+/* The element-wise glue in front of a layer's backward pass, in one launch (autograd of layers.py:71-100,165-197 with the
+ * ReLU of layers.py:279,305,370):  gm = saved_out > 0 ? g : 0 (saved_out NULL: gm = g);  gd = gm / rowdiv[row] (the mean
+ * of the relational layer, layers.py:191);  colsum[c] = sum over the rows of gm[:, c] (the bias gradient).  gm, gd and
+ * colsum are each optional (NULL).  Deterministic (fixed row slices, added in workgroup order by the last workgroup to
+ * arrive).  `workspace` (needed for colsum): gn_grad_prologue_workspace_bytes() bytes, 4-byte aligned, ZEROED ONCE by the
+ * caller; calls on one workspace must be stream-ordered.  Up to 256 columns. */
+GN_API size_t gn_grad_prologue_workspace_bytes(void);
+GN_API gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_out, int64_t ld_saved, const float* rowdiv,
+                               int64_t rows, int64_t cols, float* gm, int64_t ld_gm, float* gd, int64_t ld_gd, float* colsum,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* One Adam step over all parameter tensors in one launch (torch.optim.Adam(model.parameters(), lr) + optimizer.step(),
  * GripNet-pose.py:104,146; the update of torch/optim/adam.py without amsgrad / maximize):

@@ -560,6 +560,31 @@ def test_short_row_sums_over_a_small_table(gpu, monkeypatch, features, table_row
     assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("rows,cols", [(19081, 16), (645, 32), (645, 48), (7, 80), (1, 1), (3000, 200)])
+def test_backward_prologue_in_one_launch(gpu, rows, cols):
+    """gn_grad_prologue_f32: ReLU mask by the saved output, division by the rows' divisor and the column sums of the masked
+    gradient against the torch expressions, on a row-strided gradient (a slot of a concatenated output's gradient); the
+    same bits on every launch; every output optional."""
+    gen = torch.Generator().manual_seed(rows + cols)
+    wide = torch.randn(rows, cols + 24, generator=gen).to(gpu)
+    g = wide[:, 8:8 + cols]
+    out = torch.relu(torch.randn(rows, cols, generator=gen)).to(gpu)
+    div = (1.0 + torch.randint(0, 9, (rows,), generator=gen).float()).to(gpu)
+    gm, gd, cs = _hip.grad_prologue(g, out, div, True, True)
+    ref = g * (out > 0)
+    assert torch.equal(gm, ref)
+    assert float((gd - ref / div.view(-1, 1)).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+    want = ref.double().sum(dim=0)
+    assert float((cs.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    for _ in range(3):
+        assert torch.equal(_hip.grad_prologue(g, out, div, True, True)[2], cs)
+    gm2, gd2, cs2 = _hip.grad_prologue(g, None, None, True, False)
+    assert torch.equal(gm2, g) and gd2 is None and cs2 is None
+    gm3, _, cs3 = _hip.grad_prologue(g, None, None, False, True)
+    assert gm3 is None and float((cs3.double() - g.double().sum(dim=0)).abs().max()) <= 2e-5 * max(1.0, float(g.abs().sum(dim=0).max()))
+    _hip.raise_if_index_errors(gpu)
+
+
 @pytest.mark.parametrize("wd", [0.0, 0.01])
 def test_adam_step_matches_torch(gpu, wd):
     """gripnet_amd.optim.Adam (gn_adam_step_f32: all parameters in one launch, step counter on the device) against
