@@ -22,7 +22,7 @@ GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, G
 GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST = 1, 4                                  # flags of gn_rgcn_forward_f32
 GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
-GN_GEMM_RELU, GN_GEMM_ARITH_FAST = 1, 2                                     # flags of gn_gemm_f32
+GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED = 1, 2, 4, 8, 16                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
 ABI_VERSION = 133                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
@@ -413,15 +413,23 @@ def ptr(t):
 
 # ---- thin typed wrappers ---------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=False, a_rows=None,
-         batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None, fast=False):
-    """`fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic."""
+         batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None, fast=False,
+         b_transposed=False, accumulate=False, a_transposed=False):
+    """`fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic.
+    `b_transposed`: b is [n, k] (out = a b^T); `a_transposed`: a is [k, m] (out = a^T b; m <= 64 or n <= 32 only);
+    `accumulate`: out += a b."""
+    if a_transposed:
+        m = a.shape[1] if m is None else m
+        k = a.shape[0] if k is None else k
     m = (a.shape[0] if a_rows is None else a_rows.shape[0]) if m is None else m
     k = a.shape[1] if k is None else k
-    n = b.shape[-1] if n is None else n
+    n = (b.shape[0] if b_transposed else b.shape[-1]) if n is None else n
     _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
                           ptr(b), ld(b) if ldb is None else ldb, stride_b,
                           ptr(out), ld(out) if ldc is None else ldc, stride_c,
-          m, n, k, batch, ptr(bias), (GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0), stream_ptr(a.device))
+          m, n, k, batch, ptr(bias), (GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0) |
+          (GN_GEMM_B_TRANSPOSED if b_transposed else 0) | (GN_GEMM_ACCUMULATE if accumulate else 0) |
+          (GN_GEMM_A_TRANSPOSED if a_transposed else 0), stream_ptr(a.device))
     return out
 
 

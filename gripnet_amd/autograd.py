@@ -4,8 +4,10 @@ The reference trains full-batch: every epoch calls ``loss.backward()`` through t
 (GripNet-pose.py:140-146).  When autograd is recording, the modules in layers.py / decoder.py route
 through the ``torch.autograd.Function``s below instead of the slot-fused inference path.  The sparse
 parts of every gradient run in HIP kernels behind the C ABI (transposed normalised adjacency,
-DistMult scatter) and so do the tall-skinny weight gradients dW = x^T g (gn_xtg_f32); the remaining small dense
-contractions (dx = g W^T, the basis / attention gradients) are plain library GEMMs (torch.matmul).
+DistMult scatter), and so do the dense contractions: the tall-skinny weight gradients dW = x^T g (gn_xtg_f32), the relational
+dW_r = X^T Q_r (gn_rel_weight_grad_f32), dx = g W^T and the basis / attention gradients (gn_gemm_f32 with operands given
+transposed).  The library GEMM (torch.matmul) is left for shapes outside those kernels only (xtg beyond 4096 outputs, the
+unfused relational path of large graphs).
 """
 from __future__ import annotations
 
@@ -51,7 +53,10 @@ class GcnConvFn(torch.autograd.Function):
             gm, db = _hip.f32_rows(g), None
         gxw = torch.empty((ctx.plan.n_table, gm.shape[1]), dtype=torch.float32, device=gm.device)
         ctx.plan.aggregate_t(gm, gxw)                          # A_norm^T g  (HIP, source-major CSR)
-        dx = gxw @ w.t() if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:                            # gxw W^T (gn_gemm_f32, W given as it is stored)
+            dx = torch.empty((gxw.shape[0], w.shape[0]), dtype=torch.float32, device=gxw.device)
+            _hip.gemm(gxw, w, dx, b_transposed=True)
         dw = _hip.xtg(x, gxw) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None, None
 
@@ -77,7 +82,9 @@ class RgcnConvFn(torch.autograd.Function):
         g, gm, dbias = _hip.grad_prologue(g, out if ctx.relu else None, deg, True, bool(ctx.needs_input_grad[4]))
         dxe, dbasis, datt = rgcn_edge_gradients(ctx.plan, x, basis.detach(), att.detach(), gm,
                                                 ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        dx = dxe + g @ root.detach().t() if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:                            # dx = dxe + g root^T: the product is added onto the edge sums
+            dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True)
         droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
         return dx, dbasis, datt, droot, dbias, None, None
 
@@ -128,10 +135,17 @@ def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, n
             dw = torch.matmul(x.t(), q.view(R, n, fout)).reshape(R, fin * fout)            # [R, fin*fout]
         else:
             dw = _relation_slab_dw(plan, x, gm, R, n, fin, fout)
+        # dbasis = att^T dW, datt = dW basis^T (layers.py:172-173): deep, narrow products (gn_gemm_f32, operands as they are stored)
         if need_basis:
-            dbasis = (att.t() @ dw).view(B, fin, fout)
+            if B <= 64:
+                dbasis = torch.empty((B, fin * fout), dtype=torch.float32, device=x.device)
+                _hip.gemm(att.contiguous(), dw, dbasis, a_transposed=True)
+                dbasis = dbasis.view(B, fin, fout)
+            else:
+                dbasis = (att.t() @ dw).view(B, fin, fout)
         if need_att:
-            datt = dw @ basis.reshape(B, fin * fout).t()
+            datt = torch.empty((R, B), dtype=torch.float32, device=x.device)
+            _hip.gemm(dw, basis.reshape(B, fin * fout), datt, b_transposed=True)
     return dxe, dbasis, datt
 
 

@@ -20,6 +20,9 @@ struct GemmArgs {
     float* __restrict__ c; int64_t ldc, stride_c;
     int m, n, k;
     const float* bias; int relu; int a_vec_ok;
+    int64_t sbk, sbn;                     // element (k, col) of B sits at b[k * sbk + col * sbn]: (ldb, 1), or (1, ldb) for B given transposed
+    int64_t sam, sak;                     // element (row, k) of A at a[row * sam + k * sak]: (lda, 1), or (1, lda) for A given transposed
+    int accumulate;                       // c += a b instead of c = a b
 };
 
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
         for (int t = 0; t < kColTiles; ++t) {
             const int col = min(col0 + 16 * t + r, g.n - 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[t][j] = B[(int64_t)min(kb + j, g.k - 1) * g.ldb + col];
+            for (int j = 0; j < 4; ++j) bv[t][j] = B[(int64_t)min(kb + j, g.k - 1) * g.sbk + (int64_t)col * g.sbn];
         }
     };
     float av[4], bv[kColTiles][4];
@@ -103,9 +106,111 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
             const int row = row0 + 4 * q + i;
             if (row < g.m) {
                 float v = acc[t][i] + bias;
+                if (g.accumulate) v += C[(int64_t)row * g.ldc + col];
                 if (g.relu) v = fmaxf(v, 0.f);
                 C[(int64_t)row * g.ldc + col] = v;
             }
+        }
+    }
+}
+
+// Deep and narrow: one side of the output is a few tiles and K is hundreds to thousands (dbasis = att^T dW and datt =
+// dW basis^T of the relational layer: 32 x 1536 over K = 964 and 964 x 32 over K = 1536).  k_gemm_f32 gives such a shape a
+// handful of waves that each walk the whole K.  Here a workgroup owns a (16 MT) x (16 NT) tile, its sixteen waves take the
+// 16-deep K chunks round-robin, their accumulators meet in LDS and are added in wave order.  Either operand may be given
+// transposed (element strides); a side whose K runs contiguously is read 16 bytes per lane (the K index inside a chunk is
+// permuted identically for A and B, as in k_gemm_f32).
+constexpr int kDeepWaves = 16;
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kDeepWaves * 64) void k_gemm_deep(GemmArgs g) {
+    __shared__ f32x4 part[kDeepWaves][MT * NT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16 * MT, col0 = blockIdx.y * 16 * NT;
+    const int chunks = (g.k + 15) / 16;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // a wave's chunks (wave, wave + 16, ...), the loads of the next one in flight while the MFMAs of the current one run
+    auto load_chunk = [&](int ch, float (&av)[MT][4], float (&bv)[NT][4]) {
+        const int kb = 16 * ch + 4 * q;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int row = min(row0 + 16 * t + r, g.m - 1);
+            const float* __restrict__ p = g.a + (int64_t)row * g.sam;
+            if (g.sak == 1 && g.a_vec_ok && kb + 4 <= g.k) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + kb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[t][j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[t][j] = p[(int64_t)min(kb + j, g.k - 1) * g.sak];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int col = min(col0 + 16 * u + r, g.n - 1);
+            const float* __restrict__ p = g.b + (int64_t)col * g.sbn;
+            if (g.sbk == 1 && ((g.sbn & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.b) & 15) == 0) && kb + 4 <= g.k) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + kb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[u][j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[u][j] = p[(int64_t)min(kb + j, g.k - 1) * g.sbk];
+            }
+        }
+    };
+    float av[MT][4], bv[NT][4];
+    if (wave < chunks) load_chunk(wave, av, bv);
+    for (int ch = wave; ch < chunks; ch += kDeepWaves) {
+        const int kb = 16 * ch + 4 * q;
+        float an[MT][4], bn[NT][4];
+        load_chunk(ch + kDeepWaves < chunks ? ch + kDeepWaves : ch, an, bn);          // (the last trip re-reads its own chunk, unused)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[t][j] = (row0 + 16 * t + r < g.m && kb + j < g.k) ? av[t][j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][j] = (col0 + 16 * u + r < g.n && kb + j < g.k) ? bv[u][j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][j], bv[u][j], acc[t][u], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[t][j] = an[t][j];
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][j] = bn[u][j];
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) part[wave][t * NT + u][lane] = acc[t][u];
+    __syncthreads();
+    // element i of lane l of a tile: row 4 (l >> 4) + i, column l & 15; thread -> (tile, lane, element), the waves in order
+    for (int o = threadIdx.x; o < MT * NT * 256; o += kDeepWaves * 64) {
+        const int tile = o >> 8, l = (o & 255) >> 2, i = o & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kDeepWaves; ++w) v += part[w][tile][l][i];
+        const int row = row0 + 16 * (tile / NT) + 4 * (l >> 4) + i, col = col0 + 16 * (tile % NT) + (l & 15);
+        if (row < g.m && col < g.n) {
+            if (g.bias) v += g.bias[col];
+            float* c = g.c + (int64_t)row * g.ldc + col;
+            if (g.accumulate) v += *c;
+            if (g.relu) v = fmaxf(v, 0.f);
+            *c = v;
         }
     }
 }
@@ -128,7 +233,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles)
         const int col = col0 + 16 * t + (l & 15), kb = 16 * ch + 4 * (l >> 4);
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (col < g.n && kb + j < g.k) ? g.b[(int64_t)(kb + j) * g.ldb + col] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = (col < g.n && kb + j < g.k) ? g.b[(int64_t)(kb + j) * g.sbk + (int64_t)col * g.sbn] : 0.f;
         bfrag[idx] = v;
     }
     __syncthreads();
@@ -182,6 +287,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles)
                 const int row = row0 + 4 * q + i;
                 if (row < g.m) {
                     float v = acc[t][i] + bias;
+                    if (g.accumulate) v += g.c[(int64_t)row * g.ldc + col];
                     if (g.relu) v = fmaxf(v, 0.f);
                     g.c[(int64_t)row * g.ldc + col] = v;
                 }
@@ -303,6 +409,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
                 const int row = row0 + 4 * q + i;
                 if (row < g.m) {
                     float v = acc[t][i] + bias;
+                    if (g.accumulate) v += g.c[(int64_t)row * g.ldc + col];
                     if (g.relu) v = fmaxf(v, 0.f);
                     g.c[(int64_t)row * g.ldc + col] = v;
                 }
@@ -616,10 +723,12 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
                       int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream) {
     const int relu = flags & GN_GEMM_RELU, fast = flags & GN_GEMM_ARITH_FAST;
+    const bool bt = (flags & GN_GEMM_B_TRANSPOSED) != 0, accumulate = (flags & GN_GEMM_ACCUMULATE) != 0, at = (flags & GN_GEMM_A_TRANSPOSED) != 0;
+    GN_REQUIRE(!at || !a_rows, "a row gather of a transposed A is not supported");
     GN_REQUIRE(m >= 0 && n >= 0 && k >= 0 && batch >= 0, "negative GEMM size");
     if (m == 0 || n == 0 || batch == 0) return GN_OK;
     GN_REQUIRE(a && b && c, "GEMM operand pointer is null");
-    GN_REQUIRE(lda >= k && ldb >= n && ldc >= n, "leading dimension smaller than the row length");
+    GN_REQUIRE(lda >= (at ? m : k) && ldb >= (bt ? k : n) && ldc >= n, "leading dimension smaller than the row length");
     GN_REQUIRE(m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31) && batch <= 65535, "GEMM size out of range");
     GemmArgs g;
     g.a = a; g.lda = lda; g.stride_a = stride_a; g.a_rows = a_rows; g.a_table_rows = a_table_rows;
@@ -627,9 +736,27 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     g.c = c; g.ldc = ldc; g.stride_c = stride_c;
     g.m = (int)m; g.n = (int)n; g.k = (int)k; g.bias = bias; g.relu = relu;
     g.a_vec_ok = ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
+    g.sbk = bt ? 1 : ldb; g.sbn = bt ? ldb : 1; g.accumulate = accumulate ? 1 : 0;
+    g.sam = at ? 1 : lda; g.sak = at ? lda : 1;
+    if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
+        // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
+        hipStream_t st = gn::as_stream(stream);
+        if (m <= 64) {
+            dim3 grid(1, (unsigned)gn::ceil_div(n, 16), 1);
+            if (m > 32) k_gemm_deep<4, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+            else if (m > 16) k_gemm_deep<2, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+            else k_gemm_deep<1, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+        } else {
+            dim3 grid((unsigned)gn::ceil_div(m, 16), 1, 1);
+            if (n > 16) k_gemm_deep<1, 2><<<grid, kDeepWaves * 64, 0, st>>>(g); else k_gemm_deep<1, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+        }
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
+    GN_REQUIRE(!at, "A given transposed: at most 64 rows or 32 columns of output (the deep and narrow kernel)");
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
     const int row_tiles = (int)gn::ceil_div(m, 16);
-    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled()) {
+    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !bt && !accumulate && !gn::fast_paths_disabled()) {
         // tall-skinny, one shared B: the bf16 matrix instruction on split operands
         const int terms = fast ? 2 : 3;
         // a wave keeps 64 columns of a row tile, or 128 when the product is wider than 64 (A is then read once per 128)
@@ -643,7 +770,7 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
         if (ct == 8) return fast ? launch_split<2, 8>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3, 8>(g, row_tiles, sgrid, split_bytes, slab, st);
         return fast ? launch_split<2, 4>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3, 4>(g, row_tiles, sgrid, split_bytes, slab, st);
     }
-    if (batch == 1 && m >= 2048 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny on the fp32 instruction
+    if (batch == 1 && m >= 256 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny on the fp32 instruction
         dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
         k_gemm_f32_lds<<<lgrid, 256, lds_bytes, gn::as_stream(stream)>>>(g, row_tiles);
         GN_LAUNCH_CHECK();

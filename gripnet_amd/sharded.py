@@ -211,9 +211,15 @@ class _ShardedRgcnFn(torch.autograd.Function):
         flat = torch.cat([dxe.reshape(-1), dbasis.reshape(-1), datt.reshape(-1)])
         owner.all_reduce(flat)                                             # the one exchange step of the backward
         a, b = dxe.numel(), dxe.numel() + dbasis.numel()
-        dx = flat[:a].view_as(dxe) + g @ root.t()
+        dx = flat[:a].view_as(dxe)
+        if g.is_cuda:                                                      # + g root^T and x^T g on the library's own kernels
+            from . import _hip
+            dx = _hip.gemm(g, root, dx.contiguous(), b_transposed=True, accumulate=True)
+            droot = _hip.xtg(x, g)
+        else:                                                              # (host tensors: the gloo rehearsal with injected kernels)
+            dx, droot = dx + g @ root.t(), x.t() @ g
         has_bias = ctx.needs_input_grad[4]
-        return (dx, flat[a:b].view_as(dbasis), flat[b:].view_as(datt), x.t() @ g,
+        return (dx, flat[a:b].view_as(dbasis), flat[b:].view_as(datt), droot,
                 g.sum(dim=0) if has_bias else None, None)
 
 

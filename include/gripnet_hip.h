@@ -185,6 +185,9 @@ GN_API gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float
  * and three products (<= 2^-16 relative per product). */
 #define GN_GEMM_RELU 1           /* flags of gn_gemm_f32 */
 #define GN_GEMM_ARITH_FAST 2
+#define GN_GEMM_B_TRANSPOSED 4  /* b is given as [n, k] row-major (leading dimension ldb >= k): c = a b^T - the dx = g W^T of the backward passes */
+#define GN_GEMM_ACCUMULATE 8    /* c += a b (+ bias) instead of c = ... */
+#define GN_GEMM_A_TRANSPOSED 16  /* a is given as [k, m] row-major (lda >= m): c = a^T b; m <= 64 or n <= 32 only: dbasis = att^T dW */
 GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
                       int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream);

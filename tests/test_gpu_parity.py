@@ -1082,6 +1082,32 @@ def test_tall_skinny_gemm_shapes(gpu, m, k, n, fast):
     assert err <= (2e-3 if fast else 3 * ref32 + 1e-6), (err, ref32)
 
 
+@pytest.mark.parametrize("m,k,n,at,bt", [(32, 964, 1536, True, False), (964, 1536, 32, False, True), (19081, 16, 64, False, True),
+                                         (645, 32, 48, False, True), (17, 300, 21, True, True), (16, 256, 70, False, False), (64, 6, 1536, True, False), (40, 5, 100, True, True),
+                                         (700, 1000, 9, False, False), (5, 7, 3, False, True)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_with_operands_given_transposed(gpu, m, k, n, at, bt, accumulate):
+    """gn_gemm_f32 with GN_GEMM_A_TRANSPOSED / GN_GEMM_B_TRANSPOSED / GN_GEMM_ACCUMULATE: the backward passes' dx = g W^T,
+    dbasis = att^T dW and datt = dW basis^T with the operands as they are stored - the deep and narrow kernel (K over the
+    waves of a workgroup) and the general kernels, against float64; the same bits on every launch."""
+    gen = torch.Generator().manual_seed(m * 7 + k * 3 + n)
+    a = torch.randn(m, k, generator=gen)
+    b = torch.randn(k, n, generator=gen) * 0.1
+    c0 = torch.randn(m, n, generator=gen)
+    ref64 = a.double() @ b.double() + (c0.double() if accumulate else 0.0)
+    ag = (a.t().contiguous() if at else a).to(gpu)
+    bg = (b.t().contiguous() if bt else b).to(gpu)
+    outs = []
+    for _ in range(2):
+        out = c0.clone().to(gpu) if accumulate else torch.full((m, n), float("nan"), device=gpu)
+        _hip.gemm(ag, bg, out, a_transposed=at, b_transposed=bt, accumulate=accumulate)
+        outs.append(out)
+    err = (outs[0].cpu().double() - ref64).abs().max().item()
+    ref32 = ((a @ b + (c0 if accumulate else 0.0)).double() - ref64).abs().max().item()
+    assert err <= 3 * ref32 + 1e-6, (err, ref32)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("k,n", [(288, 8), (64, 3), (128, 16), (32, 1), (96, 20), (30, 4)])
 @pytest.mark.parametrize("softmax", [True, False])
 def test_class_scores_vs_torch(gpu, k, n, softmax):
