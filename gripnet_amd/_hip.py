@@ -24,7 +24,7 @@ GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED = 1, 2, 4, 8, 16                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 133                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 134                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -69,7 +69,7 @@ SIGNATURES = {
     "gn_distmult_plan_forward_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _int, _p, _p]),
     "gn_distmult_plan_forward_cols_f32": (_int, [_p, _p, _i64, _i64, _i64, _i64, _p, _i64, _int, _p, _p]),
     "gn_xtg_workspace_bytes": (_sz, [_i64, _i64]),
-    "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
+    "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _int, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _p, _sz, _p]),
@@ -433,6 +433,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
     return out
 
 
+_xtg_ws = {}
+GN_XTG_TICKET_ZEROED = 1
+
+
 def xtg(x: torch.Tensor, g: torch.Tensor):
     """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients); torch.matmul beyond 4096 outputs."""
     k1, k2 = x.shape[1], g.shape[1]
@@ -440,8 +444,12 @@ def xtg(x: torch.Tensor, g: torch.Tensor):
         return x.t() @ g
     out = torch.empty((k1, k2), dtype=torch.float32, device=x.device)
     need = int(load().gn_xtg_workspace_bytes(k1, k2))
-    ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
-    _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need, stream_ptr(x.device))
+    key = (x.device.index, need)
+    ws = _xtg_ws.get(key)
+    if ws is None:                                             # one zeroed workspace per device and size: its last 64 bytes are the kernel's ticket
+        ws = _xtg_ws[key] = torch.zeros((need,), dtype=torch.uint8, device=x.device)
+    _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need, GN_XTG_TICKET_ZEROED,
+          stream_ptr(x.device))
     return out
 
 

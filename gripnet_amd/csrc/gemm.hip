@@ -691,6 +691,118 @@ __global__ __launch_bounds__(256) void k_xtg_partial(const float* __restrict__ x
     }
 }
 
+// The same product on the matrix cores in ONE launch, for up to 64 x 32 outputs (every weight gradient of the PoSE model):
+// out = x^T g is a GEMM whose K is the row count.  A workgroup takes a slice of the 16-row chunks, its sixteen waves take
+// them round-robin (A operand = x read down its columns, B = g; loads of the next chunk in flight), the waves' accumulators
+// meet in LDS and are added in wave order, the slice's sums are stored write-through, and the last slice to arrive adds all
+// slices in slice order (no fence: MI355X_MICROARCH.md's form for a few KB).  Deterministic; fp32 MFMA = fp32 FMA chains.
+constexpr int kXtgMfmaSlices = 32;
+
+template <int MT, int NT>
+__global__ __launch_bounds__(1024) void k_xtg_mfma(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ g, int64_t ld_g,
+                                                  int64_t m, int k1, int k2, float* __restrict__ partial, unsigned int* __restrict__ ticket,
+                                                  float* __restrict__ out, int64_t ld_out) {
+    extern __shared__ f32x4 xtg_part[];                                  // [16 waves][MT * NT][64]
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int chunks = (int)((m + 15) / 16), per = (chunks + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * per, c1 = min(chunks, c0 + per);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&](int ch, float (&av)[MT][4], float (&bv)[NT][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = min<int64_t>(16 * (int64_t)ch + 4 * q + j, m - 1);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) av[t][j] = x[row * ld_x + min(16 * t + r, k1 - 1)];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) bv[u][j] = g[row * ld_g + min(16 * u + r, k2 - 1)];
+        }
+    };
+    float av[MT][4], bv[NT][4];
+    if (c0 + wave < c1) load_chunk(c0 + wave, av, bv);
+    for (int ch = c0 + wave; ch < c1; ch += 16) {
+        float an[MT][4], bn[NT][4];
+        load_chunk(ch + 16 < c1 ? ch + 16 : ch, an, bn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool row_ok = 16 * (int64_t)ch + 4 * q + j < m;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float a = (row_ok && 16 * t + r < k1) ? av[t][j] : 0.f;
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, (16 * u + r < k2) ? bv[u][j] : 0.f, acc[t][u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) av[t][j] = an[t][j];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) bv[u][j] = bn[u][j];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) xtg_part[(wave * MT * NT + t * NT + u) * 64 + lane] = acc[t][u];
+    __syncthreads();
+    const bool single = gridDim.x == 1;
+    const int outs = k1 * k2;
+    for (int o = tid; o < MT * NT * 256; o += 1024) {
+        const int tile = o >> 8, l = (o & 255) >> 2, i = o & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += xtg_part[(w * MT * NT + tile) * 64 + l][i];
+        const int row = 16 * (tile / NT) + 4 * (l >> 4) + i, col = 16 * (tile % NT) + (l & 15);
+        if (row < k1 && col < k2) {
+            if (single) out[(int64_t)row * ld_out + col] = v;
+            else __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)blockIdx.x * outs + row * k2 + col, __float_as_uint(v),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (single) return;
+    __syncthreads();                                                       // (every storing wave has drained its stores)
+    if (tid == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    for (int o = tid; o < outs; o += 1024) {
+        // all slices requested before any is added (a load - add chain pays a round trip per slice), added in slice order
+        float p[kXtgMfmaSlices];
+#pragma unroll
+        for (int sl = 0; sl < kXtgMfmaSlices; ++sl)
+            p[sl] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(partial) + (size_t)min(sl, (int)gridDim.x - 1) * outs + o,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < kXtgMfmaSlices; ++sl) v += sl < (int)gridDim.x ? p[sl] : 0.f;
+        out[(int64_t)(o / k2) * ld_out + o % k2] = v;
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+}
+
+template <int MT, int NT>
+gn_status launch_xtg_mfma(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int k1, int k2, float* out, int64_t ld_out,
+                          void* workspace, hipStream_t st) {
+    const size_t lds = (size_t)16 * MT * NT * 64 * sizeof(f32x4);
+    if (lds > 64 * 1024) {
+        const gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_xtg_mfma<MT, NT>), 136 * 1024);   // (+ 4 static bytes)
+        if (ls != GN_OK) return ls;
+    }
+    // about two chunks per wave; the ticket sits behind the slices' sums
+    const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kXtgMfmaSlices, gn::ceil_div(m, 16 * 16 * 2)));
+    float* partial = static_cast<float*>(workspace);
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (size_t)kXtgSlices * k1 * k2 * sizeof(float));
+    k_xtg_mfma<MT, NT><<<slices, 1024, lds, st>>>(x, ld_x, g, ld_g, m, k1, k2, partial, ticket, out, ld_out);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 // 16 outputs per workgroup: 16 groups of threads add 16 slices each (independent loads), then the groups are added
 // in group order.
 __global__ __launch_bounds__(256) void k_xtg_fold(const float* __restrict__ partial, int slices, int outs, int k2,
@@ -828,11 +940,11 @@ gn_status gn_class_scores_f32(const float* z, int64_t ld_z, int64_t table_rows, 
 
 size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2) {
     if (k1 <= 0 || k2 <= 0) return 0;
-    return (size_t)kXtgSlices * k1 * k2 * sizeof(float);
+    return (size_t)kXtgSlices * k1 * k2 * sizeof(float) + 64;           // (+ the ticket of the one-launch kernel)
 }
 
 gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int64_t k1, int64_t k2, float* out,
-                     int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+                     int64_t ld_out, void* workspace, size_t workspace_bytes, int flags, void* stream) {
     GN_REQUIRE(m >= 0 && k1 >= 0 && k2 >= 0, "negative size");
     if (k1 == 0 || k2 == 0) return GN_OK;
     if (k1 * k2 > 4096) return gn::fail(GN_ERR_UNSUPPORTED, "x^T g: %lld x %lld outputs (at most 4096)", (long long)k1, (long long)k2);
@@ -841,6 +953,14 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
     GN_REQUIRE(workspace && workspace_bytes >= gn_xtg_workspace_bytes(k1, k2), "workspace too small: need %zu bytes",
                gn_xtg_workspace_bytes(k1, k2));
     hipStream_t st = gn::as_stream(stream);
+    if (m > 0 && k1 <= 64 && k2 <= 32 && (flags & GN_XTG_TICKET_ZEROED) && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0 &&
+        !gn::fast_paths_disabled()) {
+        const int mt = (int)gn::ceil_div(k1, 16), nt = (int)gn::ceil_div(k2, 16);
+#define GN_XTG_CASE(MT, NT) if (mt == MT && nt == NT) return launch_xtg_mfma<MT, NT>(x, ld_x, g, ld_g, m, (int)k1, (int)k2, out, ld_out, workspace, st)
+        GN_XTG_CASE(1, 1); GN_XTG_CASE(2, 1); GN_XTG_CASE(3, 1); GN_XTG_CASE(4, 1);
+        GN_XTG_CASE(1, 2); GN_XTG_CASE(2, 2); GN_XTG_CASE(3, 2); GN_XTG_CASE(4, 2);
+#undef GN_XTG_CASE
+    }
     const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kXtgSlices, gn::ceil_div(m, 16)));
     const size_t lds = (size_t)kXtgMaxRows * (k1 + 1 + k2) * sizeof(float);
     { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_xtg_partial), 160 * 1024); if (lds_status != GN_OK) return lds_status; }

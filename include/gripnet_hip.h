@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 133 /* 0.1.33 */
+#define GN_VERSION 134 /* 0.1.34 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -194,10 +194,14 @@ GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, cons
 
 /* out[k1, k2] = x^T g over m rows (x [m, k1], g [m, k2]; k1 * k2 <= 4096): the weight gradients dW = x^T (A_norm^T g)
  * of the GCN-style layers and d root = x^T g of the relational one (autograd of layers.py:73,193).  Row slices are
- * reduced in a fixed order: bitwise reproducible.  Scratch is caller-provided. */
+ * reduced in a fixed order: bitwise reproducible.  Scratch is caller-provided (gn_xtg_workspace_bytes).
+ * flags: GN_XTG_TICKET_ZEROED promises that the 64 bytes at offset gn_xtg_workspace_bytes(k1, k2) - 64 of the workspace
+ * were zeroed once by the caller and are touched by nobody else (calls on one workspace stream-ordered): up to 64 x 32 outputs then take ONE launch on the matrix
+ * cores (slices added in slice order by the last slice to arrive) instead of a partial-sum launch and a fold. */
+#define GN_XTG_TICKET_ZEROED 1
 GN_API size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2);
 GN_API gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int64_t k1, int64_t k2,
-                     float* out, int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+                     float* out, int64_t ld_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /* Element-wise merges of the external layer (gripnet/layers.py:375-384) and slot copies of the
  * concat outputs:  mode 0: dst = src;  1: dst = |src|;  2: dst = (dst + |src|) / 2;
