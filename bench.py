@@ -39,14 +39,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s 
 # What in-kernel stamps and the issue-rate probe say bounds each entry point: none of them is HBM-bound;
 # "bound": "hbm" names the roofline the path is priced against, this names what actually limits it.
 LIMITERS = {
-    "gn_rgcn_forward_f32": "instruction issue: ~745 instructions per (destination, 32 sources) unit at ~2.6 cycles per instruction and SIMD "
-                           "(tools/probes/issue_probe.hip) - 415 of them independent of the edges (x chunk, bf16 splits, 36 matrix "
-                           "instructions), 12 blocks x 23 for the gather; 63 units in the three-row workgroups against 52.9 on average, "
-                           "9 us epilogue (196 KB of basis per compute unit); HBM moves less than the algorithmic bytes",
-    "gn_distmult_plan_forward_f32": "LDS bandwidth: 640 B of node rows per scored pair = 640 MB per launch = ~11 us of the 12.8 us of its two "
-                                    "column phases at 128 B/clk/CU; two table fills 5.4 us, phase hand-over 1.5 us (tools/dm_stamps.py)",
+    "gn_rgcn_forward_f32": "instruction issue (7.6 M vector + 2.7 M scalar + 1.3 M LDS instructions per launch; waves wait to be picked 34 % and at "
+                           "s_waitcnt 41 % of their resident cycles); 63 units in the three-row workgroups against 52.9 on average (3.5 us of "
+                           "the loop); 6.3 us epilogue; MFMA pipe 9 % busy; HBM moves 18 MB, less than the algorithmic bytes (DESIGN.md 4.1)",
+    "gn_distmult_plan_forward_f32": "VALU issue (4.1 M instructions = ~6.6 us of the ~10 us loop) next to the LDS array (busy 5.9 us, 21 % of it "
+                                    "bank conflicts); 4.4 us table fill from the Infinity Cache; scores written through one L2 per list range "
+                                    "(8.3 MB = the scores themselves) (DESIGN.md 4.2, profiles/r04_decoder_pmc.md)",
     "gn_distmult_forward_f32": "HBM index stream / LDS reads",
-    "gn_graph_aggregate_f32[gcn]": "launch + LDS fill + id stream latency (two launches per layer)",
+    "gn_graph_aggregate_f32[gcn]": "launch ramp / drain + LDS-DMA fill of the 153 KB table slice from the Infinity Cache (4.5 of 7.6 us in-kernel), "
+                                   "two launches per layer (DESIGN.md 4.3)",
 }
 
 

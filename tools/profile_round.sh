@@ -5,7 +5,7 @@
 tag=${1:-r01}
 root=$PWD; mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $root
-CMD="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --launch eager"
+CMD="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --launch ${LAUNCH:-eager}"
 rm -rf gpurun_out/prof_$tag gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 $CMD > gpurun_out/prof_$tag.log 2>&1; echo "stats rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_fetch -- python3 $CMD > gpurun_out/pmc_${tag}_fetch.log 2>&1; echo "fetch rc=$?"

@@ -8,11 +8,12 @@ Prints start offset, duration and the idle gap before every kernel, so that laun
 between streams are visible."""
 import csv
 import glob
+import os
 import sys
 
 d = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]          # (the newest trace under the directory)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))[-n:]
 t0 = int(rows[0]["Start_Timestamp"])
 prev_end = t0

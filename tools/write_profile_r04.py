@@ -16,7 +16,7 @@ wanted = ("k_rgcn", "k_distmult", "k_aggregate", "k_col_", "fillBuffer", "copyBu
 keep = stats[:2] + [l for l in stats[2:] if any(k in l for k in wanted)][:24]
 md = """# Round 4 - pose0-syn, 1x MI355X (gfx950)
 
-`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --launch eager`
+`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --launch recorded`
 (plan building + per-entry breakdown + the arithmetic-"fast" side pass + warm-up + 3 x 20 forwards of each per-step kernel; plan kernels
 run once.  Kernel durations are those inside the forward, i.e. with nothing of a kernel's inputs left in L2 by its previous launch.)
 
@@ -106,6 +106,60 @@ Gene gather (`tools/blk_stamps.py`):
            blk=rd("gpurun_out/stamps_{}_blk.txt".format(tag)), modes=pick("gpurun_out/launch_modes_{}.txt".format(tag), ("us",)),
            fast=pick("gpurun_out/pair_fast_{}.txt".format(tag), ("rgcn",)))
 open("profiles/{}_counters.md".format(tag), "w").write(counters)
+
+# ---- the training step ----
+import os
+def opt(path):
+    return rd(path) if os.path.exists(path) else "(not collected)"
+train = """# Round 4 - the PoSE training step (pose0-syn, 1x MI355X): forward, both decoder calls, loss, backward, Adam
+
+`tools/train_step.py` = the `train_step_entry` of bench.py: ONE hipGraph replay per step, the negatives drawn on the device in front
+of every replay.  Un-profiled:
+
+```
+{step}
+```
+
+## Kernel stats (`rocprofv3 --kernel-trace --stats -- python3 tools/train_step.py 20`: 3 eager warm-up steps, the capture, 23 replays)
+
+{stats}
+
+## Timeline of the last replayed steps (`tools/timeline.py`; inside a replay a kernel node costs >= ~4.7 us, whatever it does)
+
+```
+{timeline}
+```
+
+## The fused relational weight gradient `k_rel_weight_grad<3,2>` (gn_rel_weight_grad_f32)
+
+Against the path it replaces (`tools/relgrad_probe.py`):
+```
+{probe}
+```
+In-kernel stamps (`tools/rel_stamps.py`, make STAMPS=1):
+```
+{stamps}
+```
+Counters (`tools/pmc_relgrad.sh`, one pass per set; SQ_* cycle counters in units of four clocks, summed over the SIMDs):
+```
+{pmc}
+```
+
+## Do VALU instructions issue in the shadow of fp32 MFMAs?  (`tools/probes/mfma_valu_probe.hip`)
+
+```
+{coissue}
+```
+They do not: with four waves per SIMD the cycles per trip are the SUM of the matrix pipe's (M x 32) and the vector instructions'
+(V x ~5), not their maximum.  The weight-gradient kernel is therefore bound by MFMA + VALU cycles together (DESIGN.md section 7).
+""".format(step=opt("gpurun_out/train_step_{}.txt".format(tag)).split("\n")[-1],
+           stats=opt("gpurun_out/train_stats_{}.md".format(tag)),
+           timeline=opt("gpurun_out/train_timeline_{}.txt".format(tag)),
+           probe="\n".join(l for l in opt("gpurun_out/relgrad_{}.txt".format(tag)).split("\n") if "us" in l or "max" in l),
+           stamps=opt("gpurun_out/stamps_{}_rel.txt".format(tag)),
+           pmc="\n".join(l for l in opt("gpurun_out/pmc_{}_relgrad.txt".format(tag)).split("\n") if "rel_weight" in l),
+           coissue=opt("gpurun_out/mfma_valu_probe_{}.txt".format(tag)))
+open("profiles/{}_train_rocprof.md".format(tag), "w").write(train)
 t = json.load(open("gpurun_out/traffic_{}.json".format(tag)))
 json.dump(t, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
 m = json.load(open("gpurun_out/mfma_{}.json".format(tag)))
