@@ -401,6 +401,46 @@ def test_decoder_backward_plan_matches_planless(gpu):
         _hip.DistMultBwdPlan(ei, et[torch.randperm(e, generator=gen).to(gpu)], n, R)
 
 
+@pytest.mark.parametrize("n,f,R", [(645, 80, 40), (100, 20, 6), (768, 48, 9), (300, 16, 70)])
+@pytest.mark.parametrize("use_probs", [False, True])
+def test_decoder_backward_large_sorted_lists(gpu, n, f, R, use_probs):
+    """The decoder's backward on type-sorted lists of tens of thousands of triples: hub relations, empty relations, a
+    relation of one triple, repeated triples, u == v - the plan-less and the planned call against float64, the same bits
+    on every call."""
+    gen = torch.Generator().manual_seed(n + f + R)
+    sizes = [9000, 0, 1, 4096, 4097, 300] + [int(x) for x in torch.randint(0, 1500, (R - 6,), generator=gen)]
+    half = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    half[0][:, :200] = half[0][:, 200:400]                     # repeated triples
+    half[0][1, 400:450] = half[0][0, 400:450]                  # u == v
+    # the reference's layout (utils.py:168-198): per relation the edges, then the same edges reversed
+    ei = torch.cat([torch.cat([b, b.flip(0)], 1) for b in half], 1).to(gpu)
+    et = torch.cat([torch.full((2 * s,), r, dtype=torch.int64) for r, s in enumerate(sizes)]).to(gpu)
+    e = ei.shape[1]
+    z = (torch.randn(n, f, generator=gen) * 0.5).to(gpu)
+    w = (torch.randn(R, f, generator=gen) * 0.5).to(gpu)
+    g = torch.randn(e, generator=gen).to(gpu)
+    probs = torch.rand(e, generator=gen).to(gpu) if use_probs else None
+    gd = (g * probs * (1 - probs) if use_probs else g).double()
+    zu, zv, wr = z.double()[ei[0]], z.double()[ei[1]], w.double()[et]
+    ref_dz = torch.zeros(n, f, dtype=torch.float64, device=gpu)
+    ref_dz.index_add_(0, ei[0], gd[:, None] * zv * wr)
+    ref_dz.index_add_(0, ei[1], gd[:, None] * zu * wr)
+    ref_dd = torch.zeros(R, f, dtype=torch.float64, device=gpu).index_add_(0, et, gd[:, None] * zu * zv)
+    tol_z, tol_d = 2e-5 * max(1.0, float(ref_dz.abs().max())), 2e-5 * max(1.0, float(ref_dd.abs().max()))
+    outs = []
+    for _ in range(2):
+        dz, dd = torch.full_like(z, 7.0), torch.full_like(w, 7.0)
+        _hip.distmult_backward(z, ei, et, w, g, dz, dd, probs=probs)
+        assert float((dz.double() - ref_dz).abs().max()) <= tol_z and float((dd.double() - ref_dd).abs().max()) <= tol_d
+        outs.append((dz, dd))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    plan = _hip.DistMultBwdPlan(ei, et, n, R)
+    dz, dd = torch.full_like(z, 7.0), torch.full_like(w, 7.0)
+    plan.backward(z, w, g, dz, dd, probs=probs)
+    assert float((dz.double() - ref_dz).abs().max()) <= tol_z and float((dd.double() - ref_dd).abs().max()) <= tol_d
+    _hip.raise_if_index_errors(gpu)
+
+
 def _sharded_hip_worker(rank, world, port, q):
     """One rank of a 2-way sharded training step on the HIP kernels; both ranks share cuda:0, the exchanges travel
     over gloo through host copies (the product uses RCCL on the ranks' own GPUs: gripnet_amd/sharded.py)."""
