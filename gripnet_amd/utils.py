@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional, Sequence, Tuple
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -174,7 +176,7 @@ def negative_sampling(pos_edge_index: torch.Tensor, num_nodes: int,
     return out.to(pos_edge_index.device)
 
 
-_samplers = []          # (pos_edge_index, _version, range_list object, num_nodes, NegativeSampler) of the last few positive lists
+_samplers = []          # (weak reference to pos_edge_index, _version, range_list contents, num_nodes, NegativeSampler) of the last few positive lists
 
 
 def typed_negative_sampling(pos_edge_index: torch.Tensor, num_nodes: int, range_list,
@@ -189,13 +191,24 @@ def typed_negative_sampling(pos_edge_index: torch.Tensor, num_nodes: int, range_
     32-bit words that the decoder scores at 6 instead of 24 bytes per edge.  CPU tensors take the reference's host loop."""
     if pos_edge_index.is_cuda:
         from ._hip import NegativeSampler
+        blocks = tuple((int(s), int(e)) for s, e in torch.as_tensor(range_list).reshape(-1, 2).tolist())   # contents, not identity
+        e_total = int(pos_edge_index.shape[1])
+        tiles = all(a[1] == b[0] for a, b in zip(blocks, blocks[1:])) and (not blocks or (blocks[0][0] == 0 and blocks[-1][1] == e_total)) \
+            and all(s <= e for s, e in blocks)
+        if not tiles:
+            # blocks that overlap, leave gaps or come out of order: the reference samples each [start, end) on its own and
+            # concatenates (utils.py:115-119) - one sampler per block, nothing cached
+            parts = [NegativeSampler(pos_edge_index[:, s:e].contiguous(), num_nodes).sample(
+                seed=int((rng or np.random).randint(0, 2 ** 31 - 1))) for s, e in blocks]
+            return torch.cat(parts, dim=1) if parts else pos_edge_index[:, :0].clone()
         hit = None
         for entry in _samplers:
-            if entry[0] is pos_edge_index and entry[1] == pos_edge_index._version and entry[2] is range_list and entry[3] == num_nodes:
+            if entry[0]() is pos_edge_index and entry[1] == pos_edge_index._version and entry[2] == blocks and entry[3] == num_nodes:
                 hit = entry
                 break
+        _samplers[:] = [en for en in _samplers if en[0]() is not None]     # lists that are gone take their samplers (and bitmaps) with them
         if hit is None:
-            hit = (pos_edge_index, pos_edge_index._version, range_list, num_nodes,
+            hit = (weakref.ref(pos_edge_index), pos_edge_index._version, blocks, num_nodes,
                    NegativeSampler(pos_edge_index, num_nodes, range_list))
             _samplers.insert(0, hit)
             del _samplers[3:]

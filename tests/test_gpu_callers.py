@@ -441,3 +441,16 @@ def test_typed_negative_sampling_draws_on_the_device(gpu):
         assert not np.isin(neg[s:e], pos[s:e]).any()
     host = typed_negative_sampling(data.train_idx.cpu(), n, data.train_range)       # CPU lists: the reference's host loop
     assert not host.is_cuda and host.shape == a.shape
+    # the sampler cache keys on the CONTENTS of range_list: an equal list in another object hits, an edited one does not reuse
+    np.random.seed(5)
+    d = typed_negative_sampling(data.train_idx, n, [list(map(int, row)) for row in data.train_range.tolist()])
+    assert torch.equal(a, d)
+    # blocks that do not tile [0, E) (a subset, out of order): sampled block by block and concatenated, like the reference
+    sub = [[int(rl[2, 0]), int(rl[2, 1])], [int(rl[0, 0]), int(rl[0, 1])]]
+    part = typed_negative_sampling(data.train_idx, n, sub)
+    sizes = [e - s for s, e in sub]
+    assert part.shape == (2, sum(sizes)) and part.is_cuda
+    at = 0
+    for (s, e), m in zip(sub, sizes):
+        assert not np.isin((part[0, at:at + m] * n + part[1, at:at + m]).cpu().numpy(), pos[s:e]).any()
+        at += m
