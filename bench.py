@@ -190,7 +190,7 @@ def extra_workloads(dev, budget_s, with_cpu):
             for _ in range(3):
                 eager.step()
             _, calls, _ = timed(eager.step, 10)
-            stages = PoseStages(model, data, graphs=True, timed_entry=None)
+            stages = PoseStages(model, data, recorded=True)   # the step's entry-point calls recorded once, made again from one loop
             for _ in range(5):
                 stages.step()
             torch.cuda.synchronize()
@@ -205,7 +205,7 @@ def extra_workloads(dev, budget_s, with_cpu):
             rel_us = calls.get("gn_rgcn_forward_f32")
             dec_us = calls.get("gn_distmult_plan_forward_f32", calls.get("gn_distmult_forward_f32"))
             out.append({"workload": "pose2-syn", "E_dd": E, "us_per_step": round(step_us, 1), "edges_per_s": A / (step_us * 1e-6),
-                        "launch": "every stage replayed as a hipGraph",
+                        "launch": "recorded entry-point calls made again from one loop (as the headline)",
                         "relational": {"us": round(rel_us, 1), "frac": round(alg["dd"] / (rel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                         "decoder": {"us": round(dec_us, 1), "frac": round(alg["dmt"] / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}})
             del model, data, eager, stages
@@ -243,13 +243,34 @@ def extra_workloads(dev, budget_s, with_cpu):
             torch.cuda.synchronize()
             graph_us = 1e6 * (time.perf_counter() - t1) / 20
             del replay
+            # ... and as its recorded entry-point calls (ordinary launches: no idle gap in front of a graph's first kernel) - only
+            # if the forward is nothing but entry-point calls, i.e. the replay gives the eager forward's bits
+            launch_mode = "one hipGraph replay per forward"
+            flat = lambda o: [t for t in (o if isinstance(o, (tuple, list)) else (o,)) if torch.is_tensor(t)]
+            want = [t.clone() for t in flat(model(data, nodes_dev))]
+            rec = Recorded(lambda: model(data, nodes_dev)).capture()
+            got = flat(rec())
+            torch.cuda.synchronize()
+            if len(got) == len(want) and all(torch.equal(x, y) for x, y in zip(got, want)):
+                for _ in range(3):
+                    rec()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    rec()
+                torch.cuda.synchronize()
+                rec_us = 1e6 * (time.perf_counter() - t1) / 20
+                if rec_us < graph_us:
+                    graph_us, launch_mode = rec_us, "recorded entry-point calls made again from one loop"
+            del rec
             dom_bytes = alg_per.get(dom)
             dom_calls = {"gn_graph_aggregate_f32[gcn]": sum(len(m.conv_list) for m in model.modules() if hasattr(m, "conv_list")),
                          "gn_graph_aggregate_f32[bipartite]": sum(1 for m in model.modules() if hasattr(m, "if_one_external"))}.get(dom, 1)
             entry = {"workload": name, "table_storage": storage, "forward_us": round(graph_us, 1), "forward_us_entry_points": round(busy, 1),
                      "forward_us_eager_wall": round(1e6 * wall, 1),
                      "algorithmic_bytes": alg_total, "frac": round(alg_total / (graph_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                     "note": "forward_us: one hipGraph replay per forward, wall clock over 20 replays; forward_us_entry_points: sum of the "
+                     "launch": launch_mode,
+                     "note": "forward_us: the faster of one hipGraph replay and the recorded entry-point calls, wall clock over 20 forwards; forward_us_entry_points: sum of the "
                              "HIP-event timed entry points of one eager forward (each pays its events); the wall time of the eager "
                              "Python loop is host-bound",
                      "dominant_entry_point": {"name": dom, "us_per_call": round(calls[dom], 1),
