@@ -306,23 +306,24 @@ def _call(name, *args, tag=None):
     if dev is not None and dev != torch.cuda.current_device():
         with torch.cuda.device(dev):
             return _call(name, *args, tag=tag)
-    if _recorder is not None:
-        _recorder.calls.append((fn, args, name, tag))
-        _recorder.keep.append(args)
     t = _timer
-    if t is None or (t.only is not None and name not in t.only):
-        return check(fn(*args))
-    if t.every > 1:
+    timed = t is not None and (t.only is None or name in t.only)
+    if timed and t.every > 1:
         seen = t._seen.get(name, 0)
         t._seen[name] = seen + 1
-        if seen % t.every:
-            return check(fn(*args))
-    start, stop = t.event(), t.event()
-    start.record()
-    status = fn(*args)
-    stop.record()
-    t.add(tag or name, start, stop)
-    return check(status)
+        timed = seen % t.every == 0
+    if timed:
+        start, stop = t.event(), t.event()
+        start.record()
+        status = fn(*args)
+        stop.record()
+        t.add(tag or name, start, stop)
+    else:
+        status = fn(*args)
+    check(status)
+    if _recorder is not None:                        # (calls that were refused - a path that does not apply - are not part of the recording)
+        _recorder.calls.append((fn, args, name, tag))
+        _recorder.keep.append(args)
 
 
 def require_gpu(*tensors):
