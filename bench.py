@@ -468,9 +468,9 @@ def main():
             launch_ms = None
             if launch == "graphs":                    # replicated gene layers as one graph; the collective is never captured
                 fwd.kernels.encode_genes = Graphed(fwd.kernels.encode_genes).capture()
-            elif launch == "recorded":                # ... or as their recorded entry-point calls (ordinary launches)
-                fwd.kernels.encode_genes = Recorded(fwd.kernels.encode_genes).capture()
             step = fwd
+            if launch == "recorded":                  # ... or everything but the collective as recorded entry-point calls
+                step = fwd.record()
 
         # the event pool exists before the warm-up, and the W warm-up steps run under the same timer as the K timed ones
         # (their records are dropped): nothing but the fence sits between the last warm-up step and the first timed one
@@ -557,8 +557,11 @@ def main():
                                  "points against {:.1f}".format(sum(fast_breakdown.values()), sum(breakdown.values())))
 
     if sharded is not None:
-        launch_note = "replicated gene layers replayed as {}, the rest eager; {} HIP-event timed around every fourth launch".format(
-            "one hipGraph" if launch == "graphs" else "their recorded entry-point calls" if launch == "recorded" else "eager launches", dom)
+        launch_note = ("the forward's entry-point calls recorded once and made again from one loop around the all-reduce (which "
+                       "torch.distributed issues in every step); {} HIP-event timed around every fourth launch".format(dom)
+                       if launch == "recorded" else
+                       "replicated gene layers replayed as {}, the rest eager; {} HIP-event timed around every fourth launch".format(
+                           "one hipGraph" if launch == "graphs" else "eager launches", dom))
     elif launch == "eager":
         launch_note = "eager; {} HIP-event timed around every fourth launch".format(dom)
     elif launch == "recorded":

@@ -166,6 +166,46 @@ class ShardedPoseForward:
         return out, k.score(out, sigmoid=sigmoid)
 
 
+    def record(self, sigmoid: bool = True):
+        """The same forward with its launches recorded once and made again from one loop (gripnet_amd._hip.Recorder; see
+        pipeline.Recorded): three lists of entry-point calls around the exchange - gene / external layers and my partial sums;
+        the decoder's input columns (beside the all-reduce, when it overlaps); finalisation and the rest of the scores.  The
+        collective itself is issued by torch.distributed in every call, as in __call__.  HIP kernels only."""
+        from . import _hip
+        k = self.kernels
+        if not isinstance(k, HipShardKernels):
+            raise TypeError("record() replays the library's entry points: it needs HipShardKernels")
+        for _ in range(2):                                            # plans exist, my edge range is a registered static list
+            self(sigmoid)
+        torch.cuda.synchronize()
+        overlap = (self.overlap_decoder if self.overlap_decoder is not None else self.world_size > 1) and hasattr(k, "score_input_columns")
+        with _hip.Recorder() as first:
+            x = k.encode_genes()
+            k.partial(x, self._partial)
+        out = torch.empty((self.n_d, self.in_dim + self.out_dim), dtype=torch.float32, device=x.device)
+        started, beside = None, None
+        if overlap:
+            with _hip.Recorder() as beside:
+                started = k.score_input_columns(x, sigmoid=sigmoid)
+            if started is None:
+                beside = None
+        with _hip.Recorder() as last:
+            k.finalize(self._partial, x, out[:, self.in_dim:], out[:, :self.in_dim])
+            score = k.score_rest(started, out, sigmoid=sigmoid) if started is not None else k.score(out, sigmoid=sigmoid)
+        torch.cuda.synchronize()
+
+        def run():
+            _hip.replay(first.calls)
+            work = self.all_reduce_begin(self._partial)
+            if beside is not None:
+                _hip.replay(beside.calls)
+            self.all_reduce_end(work)
+            _hip.replay(last.calls)
+            return out, score
+        run._recordings = (first, beside, last, x)                    # (the recorders hold the operands of their calls)
+        return run
+
+
 # ---- training: the same sharding with gradients (SURVEY.md section 8e; the reference trains every epoch,
 #      GripNet-pose.py:140-146) ------------------------------------------------------------------------------------
 class _SumGradAcrossRanks(torch.autograd.Function):

@@ -842,6 +842,17 @@ def test_sharded_forward_on_hip_kernels(gpu):
             close(s2, s1)                                             # (same bits only when the split is a phase boundary of the single launch)
             z3, l3 = over(sigmoid=False)
             close(l3, model(data, sigmoid=False)[1])
+        # the same forward as recorded entry-point calls around the exchange (what bench.py runs at N > 1): the same bits,
+        # replay after replay, with and without the decoder's input columns beside the all-reduce
+        for overlap in (False, True):
+            f = ShardedPoseForward(model, data, 0, 1)
+            f.overlap_decoder = overlap and os.environ.get("GN_DISABLE_FAST") != "1"
+            want_z, want_s = f()
+            want_z, want_s = want_z.clone(), want_s.clone()
+            run = f.record()
+            for _ in range(3):
+                zr, sr = run()
+                assert torch.equal(zr, want_z) and torch.equal(sr, want_s)
     _hip.raise_if_index_errors(gpu)
 
 
