@@ -409,6 +409,21 @@ def main():
             fence()
             plan_build_ms = 1e3 * max(0.0, t_plan - (time.perf_counter() - t_steady))
             per_call0, breakdown = per_entry_us(eager.step, 5)
+            # the two lanes of the two-stream side figure (below the timed region) are made HERE, before any hipGraph is
+            # captured: streams created behind captured graphs came to share a hardware queue and the lanes serialised.
+            # (A second model with the same parameters: the plans' scratch - the gene layers' tables, the split planes of x -
+            # belongs to a model's modules, and two steps in flight must not share it.)
+            lanes = None
+            if args.launch in ("auto", "recorded"):
+                twin = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+                twin.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+                lanes = []
+                for m in (model, twin):
+                    st = torch.cuda.Stream()
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        lanes.append(PoseStages(m, data, recorded=True))
+                fence()
             # side figure: the same step with the dense products on two-term bf16 splits (GN_RGCN_ARITH_FAST /
             # GN_GEMM_ARITH_FAST, flags of the C ABI set per layer): narrower than the reference's fp32, never the headline
             from gripnet_amd.utils import set_arithmetic
@@ -498,6 +513,27 @@ def main():
                 step()
             fence()
             repeats.append(time.perf_counter() - t1)
+    # side figure (never `value`): INDEPENDENT steps on two streams, each a recording with its own buffers - what the device
+    # sustains when forwards do not wait for each other (serving); a step's own latency is `ms_per_step` above
+    two_streams = None
+    if sharded is None and launch == "recorded" and lanes is not None:
+        with torch.no_grad():
+            fence()
+            for _ in range(3):
+                lanes[0].step(); lanes[1].step()
+            fence()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                lanes[0].step(); lanes[1].step()
+            fence()
+            per = (time.perf_counter() - t2) / (2 * args.steps)
+            two_streams = {"ms_per_step": round(1e3 * per, 5), "edges_per_s": pose_edges_aggregated(data) / per,
+                           "note": "throughput of independent forwards, two in flight (two recordings on two HIP streams); not a "
+                                   "step's latency and not the headline"}
+            za, zb = lanes[0].step()[0], lanes[1].step()[0]
+            fence()
+            assert torch.equal(za, zb), "the two lanes disagree"
+            del lanes
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -590,6 +626,7 @@ def main():
                    "launch": launch_note},
         "spread": spread,
         "launch_modes_ms_per_step": launch_ms if sharded is None else None,
+        "two_streams": two_streams,
         "roofline": roofline,
         "roofline_fast": roofline_fast,
         "roofline_all": roofline_all,

@@ -45,3 +45,33 @@ with torch.no_grad():
     z1, s1 = rec.step()
     torch.cuda.synchronize()
     print("recorded == eager:", bool(torch.equal(z0, z1) and torch.equal(s0, s1)), "calls per step:", len(rec._whole.calls))
+    # throughput of INDEPENDENT steps on two streams (two recordings, each with its own buffers): not a step's latency
+    # (a second model with the same parameters: the plans' scratch - the gene layers' tables, the split planes of x - belongs to a
+    # model's modules, and two steps in flight must not share it)
+    import copy
+    twin = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+    twin.load_state_dict(copy.deepcopy(model.state_dict()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    recs = []
+    for st, m in zip(streams, (model, twin)):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            recs.append(PoseStages(m, data, recorded=True))
+    torch.cuda.synchronize()
+
+    def both():
+        recs[0].step()
+        recs[1].step()
+    for _ in range(5):
+        both()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(100):
+        both()
+    torch.cuda.synchronize()
+    print("two streams, independent steps         {:7.1f} us per step (throughput)".format(1e6 * (time.perf_counter() - t0) / 200))
+    za, sa = recs[0].step()
+    zb, sb = recs[1].step()
+    torch.cuda.synchronize()
+    print("both lanes == eager:", bool(torch.equal(za, z0) and torch.equal(sa, s0) and torch.equal(zb, z0) and torch.equal(sb, s0)))
