@@ -195,11 +195,7 @@ __global__ __launch_bounds__(kRelThreads) void k_rel_weight_grad(RelArgs a) {
     };
     gather_issue(ids0);
     vec_t s_cur = gather_finish();                                         // Q of the wave's first unit
-#ifdef GN_REL_NO_MFMA
-#define GN_REL_MFMA(A, B, C) ((C) + (A) * (B))
-#else
 #define GN_REL_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, C, 0, 0, 0)
-#endif
     // the unit of set P (its Q is in s_cur): the next unit's reads go out, the MFMAs, the set is refilled with the unit four
     // further on, the next unit's Q is summed
 #define GN_REL_STEP(P, N)                                                                                      \
