@@ -277,8 +277,11 @@ class ClassLogitsFn(torch.autograd.Function):
         z, w, nodes = ctx.saved_tensors
         g = g.contiguous()
         dz = dw = None
-        if ctx.needs_input_grad[0]:
-            dz = torch.zeros_like(z).index_add_(0, nodes, g @ w.t())
-        if ctx.needs_input_grad[1]:
-            dw = z.index_select(0, nodes).t() @ g
+        g = _hip.f32_rows(g)
+        if ctx.needs_input_grad[0]:                            # rows of g W^T (gn_gemm_f32, W as it is stored) added at the listed nodes
+            gw = torch.empty((g.shape[0], w.shape[0]), dtype=torch.float32, device=g.device)
+            _hip.gemm(g, w, gw, b_transposed=True)
+            dz = torch.zeros_like(z).index_add_(0, nodes, gw)
+        if ctx.needs_input_grad[1]:                            # z[nodes]^T g (gn_xtg_f32)
+            dw = _hip.xtg(z.index_select(0, nodes), g)
         return dz, dw, None
