@@ -95,8 +95,8 @@ def nc_algorithmic_bytes(model, n_nodes_scored):
 
 def train_step_entry(dev, steps=20):
     """One full training step of the PoSE model on pose0-syn (forward, both decoder calls, loss, backward, Adam: the loop
-    body of GripNet-pose.py:112-146) as ONE hipGraph replay per step, with new negative pairs drawn on the device before
-    every replay (gn_negative_sampler_sample_packed into the buffer the captured step scores)."""
+    body of GripNet-pose.py:112-146, negative sampling included) as ONE hipGraph replay per step: the draw
+    (gn_negative_sampler_sample_stepped: its seed moves with a counter on the device) is the graph's first node."""
     from gripnet_amd import _hip
     from gripnet_amd.pipeline import PoseModel
     from gripnet_amd.synth import make_pose
@@ -108,13 +108,10 @@ def train_step_entry(dev, steps=20):
     opt = Adam(model.parameters(), lr=0.01)                    # gn_adam_step_f32: all parameters in one launch
     sampler = _hip.NegativeSampler(data.train_idx, data.n_d_node, data.train_range)
     neg = sampler.sample(seed=0)
-    drawn = [1]
-
-    def resample():
-        sampler.sample(seed=drawn[0], out=neg)
-        drawn[0] += 1
+    drawn = torch.ones((1,), dtype=torch.int64, device=dev)    # draw counter on the device: a replay draws seed + counter
 
     def step():
+        sampler.sample(seed=0, out=neg, step=drawn)            # gn_negative_sampler_sample_stepped
         opt.zero_grad()
         z = model.encode(data)
         pos = model.dmt(z, data.train_idx, data.train_et)
@@ -128,31 +125,31 @@ def train_step_entry(dev, steps=20):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):                                     # plans, relation-order check, optimizer state
-            resample()
             step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad(set_to_none=True)
-    resample()
     with torch.cuda.graph(graph):
         loss = step()
     losses = []
     for _ in range(3):
-        resample()
         graph.replay()
     torch.cuda.synchronize()
+    before = neg.clone()
     t0 = time.perf_counter()
     for _ in range(steps):
-        resample()
         graph.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    losses.append(float(loss))
+    losses.append(float(loss.detach()))
+    if steps > 0 and torch.equal(before, neg):
+        raise RuntimeError("the replayed training step did not draw new negatives")
     _hip.raise_if_index_errors(dev)
     return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
-            "what": "forward + DistMult on positives and on fresh negatives + loss (utils.link_loss) + backward + Adam (gripnet_amd.optim.Adam, one launch), one hipGraph replay per step; "
-                    "the negatives of every step are drawn on the device (typed sampler, 32 us) in front of the replay",
+            "what": "negative sampling + forward + DistMult on positives and on the fresh negatives + loss (utils.link_loss) + backward + Adam (gripnet_amd.optim.Adam, one launch): "
+                    "one hipGraph replay per step and nothing else; the draw (typed sampler, 31 us) is the graph's first node, its seed moves with a counter on the device "
+                    "(as a BRANCH beside the encoder the step is 40 us slower: a forked hipGraph pays more in its joins than the overlap returns)",
             "loss_after": round(losses[-1], 5)}
 
 

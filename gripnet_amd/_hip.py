@@ -24,7 +24,7 @@ GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED = 1, 2, 4, 8, 16                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 134                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 135                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -81,6 +81,7 @@ SIGNATURES = {
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
     "gn_negative_sampler_sample_packed": (_int, [_p, C.c_uint64, _p, _p, _p, _p, _p]),
+    "gn_negative_sampler_sample_stepped": (_int, [_p, C.c_uint64, _p, _p, _p, _p, _p, _p]),
     "gn_rel_grad_plan_create": (_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_rel_grad_plan_destroy": (None, [_p]),
     "gn_rel_weight_grad_supported": (_int, [_p, _i64, _i64]),
@@ -941,10 +942,16 @@ class NegativeSampler:
                                                  stream_ptr(ei.device), C.byref(h)))
         self._h, self.device, self.num_edges, self.num_nodes = h, ei.device, e, int(num_nodes)
 
-    def sample(self, seed: int = 0, out=None) -> torch.Tensor:
+    def sample(self, seed: int = 0, out=None, step=None) -> torch.Tensor:
         """[2, E] int64 negative pairs.  For graphs of up to 65,535 nodes the same launch also leaves every pair as one
         32-bit word; it travels with the returned tensor (`_gn_packed`) and the decoder scores the list from it - 6
-        instead of 24 bytes per edge - as long as the tensor is not modified."""
+        instead of 24 bytes per edge - as long as the tensor is not modified.
+
+        `step`: a one-element int64 tensor on the device.  The draw then is the one of ``seed + step`` and the counter is
+        advanced by one behind it, on the device: a CAPTURED training step that contains this call draws new negatives at
+        every replay (gn_negative_sampler_sample_stepped)."""
+        if step is not None and (step.dtype != torch.int64 or step.numel() != 1 or step.device != self.device):
+            raise ValueError("`step` must be a one-element int64 tensor on {}".format(self.device))
         if out is None:
             out = torch.empty((2, self.num_edges), dtype=torch.int64, device=self.device)
         elif tuple(out.shape) != (2, self.num_edges) or out.dtype != torch.int64 or not out.is_contiguous() or out.device != self.device:
@@ -956,9 +963,18 @@ class NegativeSampler:
             # (a refilled `out` keeps its packed words' buffer: a captured step that scores `out` replays on the new draw)
             held = getattr(out, "_gn_packed", None)
             packed = held[0] if held is not None else torch.empty((self.num_edges,), dtype=torch.int32, device=self.device)
+            if step is not None:
+                _call("gn_negative_sampler_sample_stepped", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(step), base,
+                      base + 8 * self.num_edges, ptr(packed), ptr(error_flag(self.device)), stream_ptr(self.device))
+                out._gn_packed = (packed, out._version)
+                return out
             _call("gn_negative_sampler_sample_packed", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, base, base + 8 * self.num_edges,
                   ptr(packed), ptr(error_flag(self.device)), stream_ptr(self.device))
             out._gn_packed = (packed, out._version)
+            return out
+        if step is not None:
+            _call("gn_negative_sampler_sample_stepped", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(step), base,
+                  base + 8 * self.num_edges, None, ptr(error_flag(self.device)), stream_ptr(self.device))
             return out
         _call("gn_negative_sampler_sample", self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, base, base + 8 * self.num_edges,
               ptr(error_flag(self.device)), stream_ptr(self.device))

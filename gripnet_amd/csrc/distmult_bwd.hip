@@ -41,9 +41,10 @@ struct Rec { uint32_t a, b; float g; };       // 12 bytes: factor rows and the e
 // d loss / d logit of an edge: the caller's gradient, times sigma'(s) = p (1 - p) when the forward returned
 // probabilities p (decoder.py:23) and the caller hands them over instead of folding the factor in itself
 struct GradSrc {
-    const float* g;
+    const float* g;            // null: the "gradient" of triple e is the bit pattern of e (a plan sorts the triples' positions once)
     const float* p;            // nullable
     __device__ __forceinline__ float at(int64_t e) const {
+        if (!g) return __int_as_float((int)e);
         const float v = g[e];
         if (!p) return v;
         const float q = p[e];
@@ -666,6 +667,9 @@ struct gn_distmult_bwd_plan {
     gn::DevBuf<int32_t> offsets;                    // [n * kSortWaves + 1] where every wave's records of every node start
     gn::DevBuf<int32_t> he_taskptr, pr_taskptr;     // [n + 1], [R + 1]
     gn::DevBuf<int32_t> he_tasks, pr_tasks;         // int4 descriptors
+    // The half-edge records in node order and the pair records in list order with the POSITION of their triple (in eu / ev /
+    // er) where the gradient goes: what a step's gradients are placed into (k_place_g), instead of sorting every step.
+    gn::DevBuf<uint64_t> he_static, pr_static;      // [2 e + 64], [e + 64]
 };
 
 namespace {
@@ -674,6 +678,7 @@ void bwd_plan_free(gn_distmult_bwd_plan* p) {
     if (!p) return;
     p->eu.release(); p->ev.release(); p->er.release(); p->own.release(); p->mir.release();
     p->offsets.release(); p->he_taskptr.release(); p->pr_taskptr.release(); p->he_tasks.release(); p->pr_tasks.release();
+    p->he_static.release(); p->pr_static.release();
     delete p;
 }
 
@@ -861,14 +866,40 @@ namespace {
 
 constexpr uint32_t kNoPair = 0xffffffffu;
 
-// g of a pair = the sum of its two triples' gradients (each with its own sigmoid factor)
+// g of a pair = the sum of its two triples' gradients (each with its own sigmoid factor); own == null: no pairing, triple i
+// is pair i.  The pair's record of the dD pass (list order) is completed in the same pass.
 __global__ void k_pair_grad(const uint32_t* __restrict__ own, const uint32_t* __restrict__ mir, int64_t n, GradSrc gs,
-                            float* __restrict__ out) {
+                            float* __restrict__ out, const uint64_t* __restrict__ pr_static, uint64_t* __restrict__ pr) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t m = mir[i];
-        float g = gs.at(own[i]);
-        if (m != kNoPair) g += gs.at(m);
+        const uint64_t rec = pr_static[i];
+        float g;
+        if (own) {
+            const uint32_t m = mir[i];
+            g = gs.at(own[i]);
+            if (m != kNoPair) g += gs.at(m);
+        } else {
+            g = gs.at(i);
+        }
         out[i] = g;
+        pr[i] = (rec & 0xffffffffull) | ((uint64_t)__float_as_uint(g) << 32);
+    }
+}
+
+// he[i] = (the static half of record i, the gradient of the pair it came from): four records per thread and trip, the
+// gathers of all four in flight
+__global__ __launch_bounds__(256) void k_place_g(const uint64_t* __restrict__ he_static, int64_t n, const float* __restrict__ g,
+                                                 uint64_t* __restrict__ he) {
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += 4 * step) {
+        uint64_t rec[4];
+        float gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec[k] = he_static[min(i + k * step, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[k] = g[rec[k] >> 32];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * step < n) he[i + k * step] = (rec[k] & 0xffffffffull) | ((uint64_t)__float_as_uint(gv[k]) << 32);
     }
 }
 
@@ -889,6 +920,35 @@ struct TmpBufs {
         return err;
     }
 };
+
+// The records of the plan's triples, sorted once: the counting sort's scatter pass with the triple's position in place of
+// its gradient (GradSrc index mode).  A step then only places its gradients (k_pair_grad, k_place_g).
+gn_status place_static_records(gn_distmult_bwd_plan* p, const int64_t* u, const int64_t* v, const int64_t* et, TmpBufs& tmp, hipStream_t st) {
+    const int64_t E = p->e, n = p->n, R = p->r;
+    GN_HIP(p->he_static.alloc((size_t)(2 * E + 64)));
+    GN_HIP(p->pr_static.alloc((size_t)(2 * E + 64)));          // (the scatter's spare slots sit at 2 E)
+    const GradSrc index = {nullptr, nullptr};
+    const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
+    const int64_t per_wave = gn::ceil_div(E, kSortWaves);
+    const size_t stage_cap = (size_t)2 * per_wave * kSortWavesPerWg;
+    const size_t staged_bytes = hist_bytes + (2 * (size_t)n + 2 + 1) * sizeof(int32_t) + stage_cap * sizeof(uint64_t);
+    if (staged_bytes <= 127 * 1024) {
+        { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_scatter_staged), 128 * 1024); if (lds_status != GN_OK) return lds_status; }
+        k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(u, v, et, index, E, (int)n, R, p->offsets.p,
+                                                                                                  p->he_static.p, p->pr_static.p, (int)stage_cap);
+    } else {
+        // the unstaged pass advances its offsets in place: it works on a copy
+        const size_t cells = (size_t)n * kSortWaves + 1;
+        int32_t* copy;
+        GN_HIP(tmp.get(&copy, cells));
+        GN_HIP(hipMemcpyAsync(copy, p->offsets.p, cells * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_sort<true>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
+        k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, index, E, (int)n, R, copy, p->he_static.p,
+                                                                                              p->pr_static.p);
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
 
 gn_status build_bwd_plan(gn_distmult_bwd_plan* p, const int64_t* u, const int64_t* v, const int64_t* et, hipStream_t st) {
     const int64_t E = p->e, n = p->n, R = p->r;
@@ -935,6 +995,8 @@ gn_status build_bwd_plan(gn_distmult_bwd_plan* p, const int64_t* u, const int64_
     GN_LAUNCH_CHECK();
     k_task_ptr<<<1, 1024, 0, st>>>(rp, 1, (int)R, p->pr_taskptr.p, reinterpret_cast<int4*>(p->pr_tasks.p));
     GN_LAUNCH_CHECK();
+    const gn_status rc = place_static_records(p, u, v, et, tmp, st);
+    if (rc != GN_OK) return rc;
     GN_HIP(hipStreamSynchronize(st));       // scratch goes out of scope
     return GN_OK;
 }
@@ -1043,25 +1105,9 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
     uint64_t* pr = reinterpret_cast<uint64_t*>(ws + w.pr);
     float* part = reinterpret_cast<float*>(ws + w.partial);
     float* gpair = reinterpret_cast<float*>(ws + w.g);
-    const int64_t* u = plan->eu.p;
-    const int64_t* v = plan->ev.p;
-    const int64_t* et = plan->er.p;
-    k_pair_grad<<<gn::stream_grid(e, 256), 256, 0, st>>>(plan->own.p, plan->mir.p, e, GradSrc{grad_logit, sigmoid_scores}, gpair);
+    k_pair_grad<<<gn::stream_grid(e, 256), 256, 0, st>>>(plan->own.p, plan->mir.p, e, GradSrc{grad_logit, sigmoid_scores}, gpair, plan->pr_static.p, pr);
     GN_LAUNCH_CHECK();
-    const GradSrc grad = {gpair, nullptr};
-    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_sort<true>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
-    { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_scatter_staged), 128 * 1024); if (lds_status != GN_OK) return lds_status; }
-    const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
-    const int64_t per_wave = gn::ceil_div(e, kSortWaves);
-    const size_t stage_cap = (size_t)2 * per_wave * kSortWavesPerWg;
-    const size_t staged_bytes = hist_bytes + (2 * (size_t)n + 2 + 1) * sizeof(int32_t) + stage_cap * sizeof(uint64_t);
-    if (staged_bytes <= 127 * 1024) {
-        k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(u, v, et, grad, e, (int)n, r, plan->offsets.p,
-                                                                                                  he, pr, (int)stage_cap);
-    } else {
-        // the unstaged pass advances its offsets in place: it works on a copy
-        return gn::fail(GN_ERR_UNSUPPORTED, "edge list too long for the staged scatter: use gn_distmult_backward_f32");
-    }
+    k_place_g<<<(unsigned)std::min<int64_t>(gn::ceil_div(2 * e, 4 * 256), 4096), 256, 0, st>>>(plan->he_static.p, 2 * e, gpair, he);
     GN_LAUNCH_CHECK();
     gn_status rc = launch_seg_lds(he, nullptr, 0, plan->he_taskptr.p, reinterpret_cast<int4*>(plan->he_tasks.p), n, z, ld_z, n, d, ld_d, r, f,
                                   part, dz, ld_dz, st, true);

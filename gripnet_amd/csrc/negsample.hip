@@ -64,9 +64,10 @@ __global__ void k_pair_keys(const int64_t* __restrict__ u, const int64_t* __rest
 }
 
 __global__ void k_sample_negatives(const uint64_t* __restrict__ keys, const int64_t* __restrict__ starts, int R,
-                                   int64_t E, int64_t n, uint64_t seed, int64_t* __restrict__ out_u,
+                                   int64_t E, int64_t n, uint64_t seed, const uint64_t* __restrict__ seed_step, int64_t* __restrict__ out_u,
                                    int64_t* __restrict__ out_v, uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
     const uint64_t n2 = (uint64_t)n * (uint64_t)n;
+    if (seed_step) seed += *seed_step;                       // draw number `step` of a captured loop = the draw of seed + step
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int r = relation_of(starts, R, e);
         const int64_t lo0 = starts[r], hi0 = starts[r + 1];
@@ -101,9 +102,10 @@ __global__ void k_narrow_keys(const uint64_t* __restrict__ keys, const int64_t* 
 // The narrow sampler: no 64-bit division (u and v are two multiply-high draws of one 64-bit hash: uniform over the n^2
 // pairs), no search for the relation, 32-bit compares.  Same distribution as k_sample_negatives, another stream.
 __global__ __launch_bounds__(256) void k_sample_negatives_narrow(const uint32_t* __restrict__ keys32, const uint16_t* __restrict__ rel16,
-                                                                 const int64_t* __restrict__ starts, int64_t E, uint32_t n, uint64_t seed,
+                                                                 const int64_t* __restrict__ starts, int64_t E, uint32_t n, uint64_t seed, const uint64_t* __restrict__ seed_step,
                                                                  int64_t* __restrict__ out_u, int64_t* __restrict__ out_v,
                                                                  uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
+    if (seed_step) seed += *seed_step;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int r = rel16[e];
         const int lo0 = (int)starts[r], hi0 = (int)starts[r + 1];
@@ -141,9 +143,10 @@ __global__ void k_fill_bitmap(const uint32_t* __restrict__ keys32, const uint16_
 }
 
 __global__ __launch_bounds__(256) void k_sample_negatives_bitmap(const uint32_t* __restrict__ bitmap, int64_t words,
-                                                                 const uint16_t* __restrict__ rel16, int64_t E, uint32_t n, uint64_t seed,
+                                                                 const uint16_t* __restrict__ rel16, int64_t E, uint32_t n, uint64_t seed, const uint64_t* __restrict__ seed_step,
                                                                  int64_t* __restrict__ out_u, int64_t* __restrict__ out_v,
                                                                  uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
+    if (seed_step) seed += *seed_step;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t* __restrict__ bits = bitmap + (int64_t)rel16[e] * words;
         const uint64_t base = mix64(seed ^ (uint64_t)e * 0xD6E8FEB86659FD93ull);   // the stream of the narrow sampler
@@ -163,18 +166,24 @@ __global__ __launch_bounds__(256) void k_sample_negatives_bitmap(const uint32_t*
     }
 }
 
+__global__ void k_advance_step(uint64_t* step) { *step += 1; }
+
 gn_status launch_sample(const gn_negative_sampler* s, uint64_t seed, int64_t* out_u, int64_t* out_v, uint32_t* packed,
-                        int32_t* error_flag, hipStream_t st) {
+                        int32_t* error_flag, hipStream_t st, uint64_t* seed_step = nullptr) {
     if (s->words > 0)
         k_sample_negatives_bitmap<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
-            s->bitmap.p, s->words, s->rel16.p, s->num_edges, (uint32_t)s->num_nodes, seed, out_u, out_v, packed, error_flag);
+            s->bitmap.p, s->words, s->rel16.p, s->num_edges, (uint32_t)s->num_nodes, seed, seed_step, out_u, out_v, packed, error_flag);
     else if (s->narrow)
         k_sample_negatives_narrow<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
-            s->keys32.p, s->rel16.p, s->starts.p, s->num_edges, (uint32_t)s->num_nodes, seed, out_u, out_v, packed, error_flag);
+            s->keys32.p, s->rel16.p, s->starts.p, s->num_edges, (uint32_t)s->num_nodes, seed, seed_step, out_u, out_v, packed, error_flag);
     else
         k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
-            s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, out_u, out_v, packed, error_flag);
+            s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, seed_step, out_u, out_v, packed, error_flag);
     GN_LAUNCH_CHECK();
+    if (seed_step) {                                          // (stream order: every workgroup of the draw has read it)
+        k_advance_step<<<1, 1, 0, st>>>(seed_step);
+        GN_LAUNCH_CHECK();
+    }
     return GN_OK;
 }
 
@@ -281,6 +290,16 @@ gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* s, uint64
     GN_REQUIRE(out_u && out_v && packed_uv, "output pointers are null");
     if (s->num_nodes > 65535) return gn::fail(GN_ERR_UNSUPPORTED, "packed pairs hold node ids of 16 bits");
     return launch_sample(s, seed, out_u, out_v, packed_uv, error_flag, gn::as_stream(stream));
+}
+
+gn_status gn_negative_sampler_sample_stepped(const gn_negative_sampler* s, uint64_t seed, uint64_t* step, int64_t* out_u, int64_t* out_v,
+                                             uint32_t* packed_uv, int32_t* error_flag, void* stream) {
+    GN_REQUIRE(s != nullptr, "sampler is null");
+    GN_REQUIRE(step != nullptr && (reinterpret_cast<uintptr_t>(step) & 7) == 0, "the step counter is null or not 8-byte aligned");
+    if (s->num_edges == 0) return GN_OK;
+    GN_REQUIRE(out_u && out_v, "output pointers are null");
+    if (packed_uv && s->num_nodes > 65535) return gn::fail(GN_ERR_UNSUPPORTED, "packed pairs hold node ids of 16 bits");
+    return launch_sample(s, seed, out_u, out_v, packed_uv, error_flag, gn::as_stream(stream), step);
 }
 
 }  // extern "C"

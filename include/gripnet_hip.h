@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 134 /* 0.1.34 */
+#define GN_VERSION 135 /* 0.1.34 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -407,6 +407,13 @@ GN_API gn_status gn_negative_sampler_sample(const gn_negative_sampler* sampler, 
  * of 16.  GN_ERR_UNSUPPORTED for larger graphs. */
 GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sampler, uint64_t seed, int64_t* out_u,
                                             int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
+/* The draw of a RECORDED training loop (a hipGraph replays its launch arguments): the seed of the draw is seed + *step, with
+ * `step` a 64-bit counter in device memory (8-byte aligned, set by the caller once) that a one-thread launch behind the draw
+ * advances by one.  Replay k of a captured call therefore writes what gn_negative_sampler_sample(_packed) writes for
+ * seed + step0 + k: new negatives every epoch (GripNet-pose.py:131) without a launch outside the graph.  packed_uv may be
+ * NULL. */
+GN_API gn_status gn_negative_sampler_sample_stepped(const gn_negative_sampler* sampler, uint64_t seed, uint64_t* step, int64_t* out_u,
+                                             int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
 
 /* The element-wise glue in front of a layer's backward pass, in one launch (autograd of layers.py:71-100,165-197 with the
  * ReLU of layers.py:279,305,370):  gm = saved_out > 0 ? g : 0 (saved_out NULL: gm = g);  gd = gm / rowdiv[row] (the mean

@@ -340,6 +340,42 @@ def test_sampled_negatives_are_scored_from_their_packed_pairs(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+def test_sampler_draws_inside_a_captured_step(gpu):
+    """gn_negative_sampler_sample_stepped: the seed of the draw is seed + a counter in device memory that a launch behind
+    the draw advances - replay k of a captured call writes what sample(seed + k) writes (pairs and packed words), for the
+    bitmap sampler (small graphs) and for the searching ones, and the counter counts the draws."""
+    for name, nodes in (("small", None), ("small", 20000), ("small", 70000)):
+        data = make_pose(name).to(gpu)
+        n = data.n_d_node if nodes is None else nodes       # > 65,535 nodes: no packed words, the 64-bit sampler
+        sampler = _hip.NegativeSampler(data.train_idx, n, data.train_range)
+        want = [sampler.sample(seed=5 + k).clone() for k in range(4)]
+        want_packed = _hip.packed_pairs(sampler.sample(seed=5 + 3))
+        step = torch.zeros((1,), dtype=torch.int64, device=gpu)
+        out = sampler.sample(seed=5, step=step).clone()          # eager: draw 0
+        assert torch.equal(out, want[0]) and int(step) == 1
+        buf = torch.empty_like(out)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sampler.sample(seed=5, out=buf, step=step)           # draw 1 (warm-up of the capture)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want[1])
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            sampler.sample(seed=5, out=buf, step=step)
+        for k in (2, 3):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(buf, want[k]), "replay {} of the captured draw".format(k)
+        assert int(step) == 4
+        if want_packed is not None:
+            assert torch.equal(_hip.packed_pairs(buf), want_packed)
+        with pytest.raises(ValueError):
+            sampler.sample(seed=0, step=torch.zeros((1,), dtype=torch.int32, device=gpu))
+    _hip.raise_if_index_errors(gpu)
+
+
 @needs_fast_paths
 def test_plans_do_not_depend_on_the_builder_threads(gpu, monkeypatch):
     """The host side of the plan builders runs on GN_PLAN_THREADS threads; every chunk writes its own slice of a plan,

@@ -91,3 +91,74 @@ def rforked():
 
 print("relational backward  dx {:.0f} us, dW {:.0f} us, one after the other {:.0f} us, on two streams {:.0f} us".format(
     clock(dx), clock(dwf), clock(rserial), clock(rforked)))
+
+# ---- the small dense products behind the big kernels: independent of each other, a few dozen workgroups each ----
+gxw = torch.randn(19081, 16, device=dev)
+xg = torch.randn(19081, 64, device=dev)
+wext = torch.randn(64, 16, device=dev)
+dxg = torch.empty(19081, 64, device=dev)
+streams = [torch.cuda.Stream() for _ in range(3)]
+
+
+def gene_serial():
+    _hip.gemm(gxw, wext, dxg, b_transposed=True)
+    _hip.xtg(xg, gxw)
+
+
+def gene_forked():
+    cur = torch.cuda.current_stream()
+    streams[0].wait_stream(cur)
+    with torch.cuda.stream(streams[0]):
+        _hip.xtg(xg, gxw)
+    _hip.gemm(gxw, wext, dxg, b_transposed=True)
+    cur.wait_stream(streams[0])
+
+
+print("external layer backward  dx = gxw W^T and dW = x^T gxw: one after the other {:.1f} us, on two streams {:.1f} us".format(
+    clock(gene_serial), clock(gene_forked)))
+
+g32 = torch.randn(n, 32, device=dev)
+root = torch.randn(48, 32, device=dev)
+basis = torch.randn(32, 48 * 32, device=dev)
+dbasis, datt = torch.empty(32, 48 * 32, device=dev), torch.empty(R, 32, device=dev)
+
+
+def small_serial():
+    _hip.gemm(att, dw, dbasis, a_transposed=True)
+    _hip.gemm(dw, basis, datt, b_transposed=True)
+    _hip.gemm(g32, root, dxe, b_transposed=True, accumulate=True)
+    _hip.xtg(x, g32)
+
+
+def small_forked():
+    cur = torch.cuda.current_stream()
+    for s in streams:
+        s.wait_stream(cur)
+    with torch.cuda.stream(streams[0]):
+        _hip.gemm(dw, basis, datt, b_transposed=True)
+    with torch.cuda.stream(streams[1]):
+        _hip.gemm(g32, root, dxe, b_transposed=True, accumulate=True)
+    with torch.cuda.stream(streams[2]):
+        _hip.xtg(x, g32)
+    _hip.gemm(att, dw, dbasis, a_transposed=True)
+    for s in streams:
+        cur.wait_stream(s)
+
+
+print("relational layer backward, the four small products: one after the other {:.1f} us, on four streams {:.1f} us".format(
+    clock(small_serial), clock(small_forked)))
+
+
+def captured(fn):
+    fn(); fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(10):
+            fn()
+    return lambda: graph.replay()
+
+
+for name, serial, forked in (("external layer", gene_serial, gene_forked), ("relational layer, small products", small_serial, small_forked)):
+    a, b = clock(captured(serial)) / 10, clock(captured(forked)) / 10
+    print("{} inside a captured graph (ten copies per replay): one after the other {:.1f} us, forked {:.1f} us".format(name, a, b))
