@@ -30,7 +30,13 @@ struct gn_negative_sampler {
     // draw is tested with ONE 4-byte load - a binary search costs ~11 dependent loads whose last steps touch a
     // different cache line in every lane
     gn::DevBuf<uint32_t> bitmap;    // [R][words]
-    int64_t words = 0;              // 32-bit words per relation, 0: no bitmap
+    int64_t words = 0;              // 32-bit words per relation (a multiple of four), 0: no bitmap
+    // and with the bitmap, the draw by TASKS: a workgroup takes a slice of ONE relation's edge positions, four positions per
+    // thread and trip (four tests in flight); a small relation's sorted pair ids are staged in LDS first and the test is a
+    // binary search there, a large relation is tested against its row of the bitmap
+    gn::DevBuf<int32_t> tasks;      // 2 x int4: (relation, first edge position, end, 0 = ids | 1 = bitmap), (first id, ids, -, -)
+    int64_t num_tasks = 0;
+    size_t task_lds = 0;
 };
 
 namespace {
@@ -166,11 +172,119 @@ __global__ __launch_bounds__(256) void k_sample_negatives_bitmap(const uint32_t*
     }
 }
 
+// GN_SAMPLER_TASKS=0 keeps the one-load-per-draw bitmap kernel (the tests compare the two: same draws)
+bool sampler_tasks_disabled() {
+    const char* e = getenv("GN_SAMPLER_TASKS");
+    return e && e[0] == '0';
+}
+
+// Measured on pose0-syn (964 relations of 534 to 130,332 positions, 2 M draws; tools/probes/sampler_probe.py): 28.9 us with one
+// draw per thread and trip against the bitmap, 27.4 us with four in flight, 22.2 us with the ids of the relations of up to 1,024
+// positions staged (half of the relations, a fifth of the positions); staging longer id lists costs more than it returns
+// (2,048: 24.2 us, 8,192: 32.0 us), and so does staging a relation's 52 KB of bits per slice (35 us).  9.5 us without any test.
+constexpr int kTaskSliceIds = 2048, kTaskSliceBits = 2048, kTaskMaxIds = 1024;
+
+// Same draws as k_sample_negatives_bitmap / _narrow (same hashes, same order of attempts), tested against a staged table.
+__global__ __launch_bounds__(256) void k_sample_negatives_tasks(const int4* __restrict__ tasks, const uint32_t* __restrict__ keys32,
+                                                                const int64_t* __restrict__ starts, const uint32_t* __restrict__ bitmap,
+                                                                int64_t words, uint32_t n, uint64_t seed, const uint64_t* __restrict__ seed_step,
+                                                                int64_t* __restrict__ out_u, int64_t* __restrict__ out_v,
+                                                                uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
+    extern __shared__ uint32_t staged[];
+    if (seed_step) seed += *seed_step;
+    const int4 task = tasks[2 * blockIdx.x], block = tasks[2 * blockIdx.x + 1];   // (relation, first position, end, kind), (first id, ids, -, -)
+    const int tid = threadIdx.x;
+    const bool bits = task.w != 0;
+    const int len = bits ? 0 : block.y, shift = bits ? 0 : (block.x & 3);
+    if (!bits) {
+        // the relation's sorted ids from the 16-byte boundary below their first word, 16 bytes per lane, eight loads in flight
+        const uint4* src = reinterpret_cast<const uint4*>(keys32 + (block.x - shift));     // (keys32 is 256-byte aligned)
+        const int quads = (len + shift + 3) >> 2;                                          // may read up to 3 words past the block: inside the array's padding
+        for (int i0 = tid; i0 < quads; i0 += 256 * 8) {
+            uint4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = src[min(i0 + 256 * j, quads - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + 256 * j < quads) reinterpret_cast<uint4*>(staged)[i0 + 256 * j] = q[j];
+        }
+        __syncthreads();
+    }
+    const uint32_t* __restrict__ table = staged + shift;
+    const uint32_t* __restrict__ row = bitmap + (int64_t)task.x * words;                  // a large relation: its bits where they are
+    int top = 1;                                              // smallest power of two > len (uniform)
+    while (top <= len) top <<= 1;
+    auto is_positive = [&](uint32_t key) -> bool {
+        if (bits) return ((row[key >> 5] >> (key & 31)) & 1u) != 0;
+        int lo = 0;                                           // number of ids below `key`
+        for (int step = top >> 1; step > 0; step >>= 1) {
+            const int idx = lo + step;
+            if (idx <= len && table[idx - 1] < key) lo = idx;
+        }
+        return lo < len && table[lo] == key;
+    };
+    // four positions per thread and trip: their first attempts are tested together (four independent chains of LDS reads);
+    // a position whose first attempt hit a positive (0.6 % on PoSE) goes on alone
+    constexpr int U = 4;
+    for (int e0 = task.y + tid; e0 < task.z; e0 += 256 * U) {
+        uint64_t base[U];
+        uint32_t uu[U], vv[U];
+        bool hit[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + 256 * j;
+            base[j] = mix64(seed ^ (uint64_t)e * 0xD6E8FEB86659FD93ull);
+            const uint64_t h = mix64(base[j]);
+            uu[j] = __umulhi((uint32_t)h, n);
+            vv[j] = __umulhi((uint32_t)(h >> 32), n);
+        }
+        if (bits) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) { const uint32_t key = uu[j] * n + vv[j]; hit[j] = ((row[key >> 5] >> (key & 31)) & 1u) != 0; }
+        } else {
+            int lo[U];
+            uint32_t key[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) { lo[j] = 0; key[j] = uu[j] * n + vv[j]; }
+            for (int step = top >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int idx = lo[j] + step;
+                    if (idx <= len && table[idx - 1] < key[j]) lo[j] = idx;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) hit[j] = lo[j] < len && table[lo[j]] == key[j];
+        }
+
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + 256 * j;
+            if (e >= task.z) continue;
+            bool found = !hit[j];
+            for (int k = 1; k < kMaxAttempts && !found; ++k) {
+                const uint64_t h = mix64(base[j] + (uint64_t)k);
+                uu[j] = __umulhi((uint32_t)h, n);
+                vv[j] = __umulhi((uint32_t)(h >> 32), n);
+                found = !is_positive(uu[j] * n + vv[j]);
+            }
+            if (!found && err) atomicOr(err, 2);
+            out_u[e] = (int64_t)uu[j];
+            out_v[e] = (int64_t)vv[j];
+            if (packed) packed[e] = uu[j] | (vv[j] << 16);
+        }
+    }
+}
+
 __global__ void k_advance_step(uint64_t* step) { *step += 1; }
 
 gn_status launch_sample(const gn_negative_sampler* s, uint64_t seed, int64_t* out_u, int64_t* out_v, uint32_t* packed,
                         int32_t* error_flag, hipStream_t st, uint64_t* seed_step = nullptr) {
-    if (s->words > 0)
+    if (s->num_tasks > 0)
+        k_sample_negatives_tasks<<<(unsigned)s->num_tasks, 256, s->task_lds, st>>>(
+            reinterpret_cast<const int4*>(s->tasks.p), s->keys32.p, s->starts.p, s->bitmap.p, s->words, (uint32_t)s->num_nodes, seed, seed_step,
+            out_u, out_v, packed, error_flag);
+    else if (s->words > 0)
         k_sample_negatives_bitmap<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
             s->bitmap.p, s->words, s->rel16.p, s->num_edges, (uint32_t)s->num_nodes, seed, seed_step, out_u, out_v, packed, error_flag);
     else if (s->narrow)
@@ -234,14 +348,14 @@ gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, const i
         if (e3 == hipSuccess) e3 = hipMalloc(&scratch, bytes ? bytes : 1);
         if (e3 == hipSuccess) e3 = rocprim::radix_sort_keys(scratch, bytes, raw, s->keys.p, (size_t)E, 0, 64, st);
         if (e3 == hipSuccess && N < (1ll << 16) && R < (1ll << 16) && E < (1ll << 31) && !gn::fast_paths_disabled()) {
-            e3 = s->keys32.alloc(E);
+            e3 = s->keys32.alloc(E + 8);                     // (the task kernel stages whole 16-byte words)
             if (e3 == hipSuccess) e3 = s->rel16.alloc(E);
             if (e3 == hipSuccess) {
                 k_narrow_keys<<<gn::stream_grid(E, 256), 256, 0, st>>>(s->keys.p, s->starts.p, (int)R, E, s->keys32.p, s->rel16.p);
                 e3 = hipGetLastError();
                 s->narrow = 1;
             }
-            const int64_t words = (N * N + 31) / 32;
+            const int64_t words = ((N * N + 31) / 32 + 3) & ~(int64_t)3;
             if (e3 == hipSuccess && R * words * 4 <= kBitmapBytes) {
                 e3 = s->bitmap.alloc(R * words);
                 if (e3 == hipSuccess) e3 = hipMemsetAsync(s->bitmap.p, 0, (size_t)(R * words) * sizeof(uint32_t), st);
@@ -249,6 +363,30 @@ gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, const i
                     k_fill_bitmap<<<gn::stream_grid(E, 256), 256, 0, st>>>(s->keys32.p, s->rel16.p, E, words, s->bitmap.p);
                     e3 = hipGetLastError();
                     s->words = words;
+                }
+                if (e3 == hipSuccess && !sampler_tasks_disabled()) {
+                    std::vector<int32_t> tasks;
+                    int64_t most = 0;
+                    for (int pass = 1; pass >= 0; --pass)               // the large relations first
+                        for (int64_t r = 0; r < R; ++r) {
+                            const int64_t len = starts[r + 1] - starts[r];
+                            const int kind = len > kTaskMaxIds ? 1 : 0;
+                            if (kind != pass) continue;
+                            if (!kind) most = std::max(most, len);
+                            const int64_t slice = kind ? kTaskSliceBits : kTaskSliceIds;
+                            for (int64_t a = starts[r]; a < starts[r + 1]; a += slice) {
+                                const int32_t d[8] = {(int32_t)r, (int32_t)a, (int32_t)std::min(starts[r + 1], a + slice), kind,
+                                                      (int32_t)starts[r], (int32_t)len, 0, 0};
+                                tasks.insert(tasks.end(), d, d + 8);
+                            }
+                        }
+                    if (!tasks.empty()) {
+                        e3 = s->tasks.alloc(tasks.size());
+                        if (e3 == hipSuccess) e3 = hipMemcpyAsync(s->tasks.p, tasks.data(), tasks.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+                        if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);   // `tasks` leaves scope
+                        s->num_tasks = (int64_t)(tasks.size() / 8);
+                        s->task_lds = (size_t)(most + 8) * 4;                  // (up to three words of alignment in front)
+                    }
                 }
             }
         }
@@ -272,6 +410,7 @@ void gn_negative_sampler_destroy(gn_negative_sampler* s) {
     s->keys32.release();
     s->rel16.release();
     s->bitmap.release();
+    s->tasks.release();
     delete s;
 }
 

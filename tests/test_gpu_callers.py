@@ -340,6 +340,31 @@ def test_sampled_negatives_are_scored_from_their_packed_pairs(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+def test_sampler_kernels_draw_the_same_pairs(gpu, monkeypatch):
+    """The task kernel of the sampler (a workgroup per slice of one relation, four tests in flight, the ids of a small relation
+    staged in LDS) draws exactly what the one-load-per-draw bitmap kernel draws (GN_SAMPLER_TASKS=0): relations below and above
+    the staging limit, an empty one, one that starts at an odd position, a dense one (many redraws)."""
+    gen = torch.Generator().manual_seed(5)
+    n, sizes = 200, [301, 1500, 0, 5000, 37, 1024, 1025, 9000]
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    blocks[4] = torch.randint(0, 6, (2, 37), generator=gen)              # 36 pairs: nearly all of them positives of the block
+    pos = torch.cat(blocks, dim=1).to(gpu)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    tasks = _hip.NegativeSampler(pos, n, rl)
+    monkeypatch.setenv("GN_SAMPLER_TASKS", "0")
+    plain = _hip.NegativeSampler(pos, n, rl)
+    monkeypatch.delenv("GN_SAMPLER_TASKS")
+    for seed in (0, 1, 77):
+        a, b = tasks.sample(seed=seed), plain.sample(seed=seed)
+        assert torch.equal(a, b)
+        assert torch.equal(_hip.packed_pairs(a), _hip.packed_pairs(b))
+    negc, posc = a.cpu(), pos.cpu()
+    for r, (s, e) in enumerate(rl.tolist()):
+        held = set((posc[0, s:e] * n + posc[1, s:e]).tolist())
+        assert not held.intersection((negc[0, s:e] * n + negc[1, s:e]).tolist()), "relation {} drew a positive pair".format(r)
+    _hip.raise_if_index_errors(gpu)
+
+
 def test_sampler_draws_inside_a_captured_step(gpu):
     """gn_negative_sampler_sample_stepped: the seed of the draw is seed + a counter in device memory that a launch behind
     the draw advances - replay k of a captured call writes what sample(seed + k) writes (pairs and packed words), for the
