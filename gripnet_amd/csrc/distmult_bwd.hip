@@ -372,6 +372,77 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
 }
 
 
+// From the (node, wave) counts of the counting sort to its write offsets and to the task list of the node-major reduction,
+// in two small launches (a device-wide exclusive scan over the n x 2048 cells plus the one-workgroup k_task_ptr were 27 us of
+// every backward call on a fresh edge list): k_node_totals adds up a node's 2048 cells; k_he_offsets, a workgroup per node,
+// derives the node's first record and first task from the totals of the nodes before it (every workgroup adds them up itself:
+// n words), scans the node's cells in place and writes the node's task descriptors.  Same values as the scan + k_task_ptr.
+constexpr int kOffsetThreads = kSortWaves / 4;
+static_assert(kOffsetThreads == 512, "a thread per four wave cells");
+
+__global__ __launch_bounds__(kOffsetThreads) void k_node_totals(const int32_t* __restrict__ counts, int32_t* __restrict__ totals) {
+    __shared__ int32_t part[kOffsetThreads / 64];
+    const int tid = threadIdx.x;
+    const int4 v = *reinterpret_cast<const int4*>(counts + (size_t)blockIdx.x * kSortWaves + 4 * tid);
+    int32_t s = v.x + v.y + v.z + v.w;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((tid & 63) == 0) part[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < kOffsetThreads / 64; ++k) t += part[k];
+        totals[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kOffsetThreads) void k_he_offsets(int32_t* __restrict__ counts, const int32_t* __restrict__ totals, int n,
+                                                               int32_t* __restrict__ taskptr, int4* __restrict__ tasks) {
+    __shared__ int32_t part[2][kOffsetThreads / 64];
+    __shared__ int32_t wave_base[kOffsetThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    // records and tasks of the nodes before this one
+    int32_t recs = 0, tks = 0;
+    for (int i = tid; i < b; i += kOffsetThreads) {
+        const int32_t t = totals[i];
+        recs += t;
+        tks += (t + kTaskRecs - 1) / kTaskRecs;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { recs += __shfl_xor(recs, d); tks += __shfl_xor(tks, d); }
+    if (lane == 0) { part[0][wave] = recs; part[1][wave] = tks; }
+    const int4 v = *reinterpret_cast<const int4*>(counts + (size_t)b * kSortWaves + 4 * tid);
+    const int32_t mine = v.x + v.y + v.z + v.w;
+    int32_t incl = mine;                                       // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_base[wave] = incl;
+    __syncthreads();
+    int32_t start = 0, first_task = 0, before = 0;
+#pragma unroll
+    for (int k = 0; k < kOffsetThreads / 64; ++k) {
+        start += part[0][k];
+        first_task += part[1][k];
+        if (k < wave) before += wave_base[k];
+    }
+    const int32_t x = start + before + incl - mine;
+    *reinterpret_cast<int4*>(counts + (size_t)b * kSortWaves + 4 * tid) = make_int4(x, x + v.x, x + v.x + v.y, x + v.x + v.y + v.z);
+    const int32_t total = totals[b], end = start + total, my_tasks = (total + kTaskRecs - 1) / kTaskRecs;
+    if (tid == 0) {
+        taskptr[b] = first_task;
+        if (b == n - 1) {
+            taskptr[n] = first_task + my_tasks;
+            counts[(size_t)n * kSortWaves] = end;              // the cell behind the last node: the record count
+        }
+    }
+    for (int j = tid; j < my_tasks; j += kOffsetThreads)
+        tasks[first_task + j] = make_int4(b, start + j * kTaskRecs, min(end, start + (j + 1) * kTaskRecs), 0);
+}
+
 // The scatter pass with the workgroup's records staged in LDS.  Placed directly (k_he_sort<true>), the 64 lanes of a
 // store hit 64 different cache lines with 8 bytes each: the pass was bound by those partial-line writes (63 us, 18 us
 // without them).  Here the waves of a workgroup own adjacent slices, so for every node the workgroup's records form
@@ -762,11 +833,15 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                 sort_configured = true;
             }
             int32_t* counts = reinterpret_cast<int32_t*>(ws + ll.counts);
-            const size_t cells = (size_t)n * kSortWaves + 1, hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
+            const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
             k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad, e, (int)n, r,
                                                                                                    counts, nullptr, nullptr);
             GN_LAUNCH_CHECK();
-            GN_HIP(rocprim::exclusive_scan(ws + ll.sort_tmp, sort2, counts, counts, 0, cells, rocprim::plus<int32_t>(), st));
+            // offsets of every (node, wave) cell + the reduction's task list (the totals sit in the row-offset scratch, unused on this path)
+            k_node_totals<<<(unsigned)n, kOffsetThreads, 0, st>>>(counts, rp);
+            GN_LAUNCH_CHECK();
+            k_he_offsets<<<(unsigned)n, kOffsetThreads, 0, st>>>(counts, rp, (int)n, tp, tk);
+            GN_LAUNCH_CHECK();
             pairs_done = lds_dd && sorted_types;               // the dD records come out of the same pass
             const int64_t per_wave = gn::ceil_div(e, kSortWaves);
             const size_t stage_cap = (size_t)2 * per_wave * kSortWavesPerWg;
@@ -779,7 +854,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                                                                                                       counts, r2s, pairs_done ? r2 : nullptr);
             }
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(r2s, counts, kSortWaves, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
+            const gn_status rc = launch_seg_lds(r2s, counts, kSortWaves, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st, true);
             if (rc != GN_OK) return rc;
         } else if (lds_dz) {
             k_half_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad, e, n, r, k2, r2);
