@@ -23,8 +23,9 @@ GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST = 1, 4                                  # fl
 GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED = 1, 2, 4, 8, 16                                     # flags of gn_gemm_f32
-GN_DM_TYPES_SORTED = 1                                 # flag of gn_distmult_backward_ex_f32
-ABI_VERSION = 135                                       # GN_VERSION of include/gripnet_hip.h this module binds
+GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
+GN_DM_TYPE_TASKS = 2
+ABI_VERSION = 136                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -71,6 +72,8 @@ SIGNATURES = {
     "gn_xtg_workspace_bytes": (_sz, [_i64, _i64]),
     "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _int, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "gn_distmult_type_tasks_bytes": (_sz, [_i64, _i64]),
+    "gn_distmult_type_tasks": (_int, [_p, _i64, _i64, _p, _sz, _p]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _p, _sz, _p]),
     "gn_distmult_bwd_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
@@ -901,7 +904,13 @@ def type_offsets(et, num_relations):
     off = None
     if et.numel() < 2 or bool((et[1:] >= et[:-1]).all()):
         bounds = torch.arange(num_relations + 1, device=et.device, dtype=et.dtype)
-        off = torch.searchsorted(et.contiguous(), bounds).to(torch.int32)
+        first = torch.searchsorted(et.contiguous(), bounds).to(torch.int32)
+        # the offsets and, behind them, the task list of the decoder gradient's relation-major pass (GN_DM_TYPE_TASKS)
+        lib = load()
+        need = int(lib.gn_distmult_type_tasks_bytes(num_relations, et.numel()))
+        off = torch.empty((need // 4,), dtype=torch.int32, device=et.device)
+        with torch.cuda.device(et.device):
+            _call("gn_distmult_type_tasks", ptr(first), num_relations, et.numel(), ptr(off), need, stream_ptr(et.device))
     _sorted_types.append((et, et._version, num_relations, off))
     del _sorted_types[:-4]
     return off
@@ -912,7 +921,7 @@ def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd, probs=None)
     ei, u, v, e = edge_rows(u_v)
     et = i64_vec(edge_type)
     offsets = type_offsets(edge_type, weight.shape[0])
-    flags = GN_DM_TYPES_SORTED if offsets is not None else 0
+    flags = (GN_DM_TYPES_SORTED | GN_DM_TYPE_TASKS) if offsets is not None else 0
     need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], weight.shape[0], e))
     ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
     _call("gn_distmult_backward_ex_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),

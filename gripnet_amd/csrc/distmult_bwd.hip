@@ -766,6 +766,37 @@ PlanWs plan_ws(const gn_distmult_bwd_plan* p, int64_t f) {
 
 }  // namespace
 
+namespace {
+// a static edge_type's offsets with the task list of the relation-major reduction behind them (GN_DM_TYPE_TASKS)
+struct TypeTasks { size_t taskptr, tasks, total; };           // in int32 words
+TypeTasks type_tasks_layout(int64_t r, int64_t e) {
+    TypeTasks t;
+    t.taskptr = (size_t)((r + 2 + 63) & ~(int64_t)63);
+    t.tasks = t.taskptr + (size_t)((r + 2 + 63) & ~(int64_t)63);
+    t.total = t.tasks + (size_t)lds_max_tasks(e, r) * 4;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t gn_distmult_type_tasks_bytes(int64_t r, int64_t e) {
+    if (r <= 0 || e < 0) return 0;
+    return type_tasks_layout(r, e).total * sizeof(int32_t);
+}
+
+extern "C" gn_status gn_distmult_type_tasks(const int32_t* type_offsets, int64_t r, int64_t e, void* out, size_t out_bytes, void* stream) {
+    GN_REQUIRE(type_offsets && out && r > 0 && e >= 0, "null pointer or bad size");
+    GN_REQUIRE(r < (1ll << 31) && e < (1ll << 31), "too large");
+    GN_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "the buffer is not 16-byte aligned");
+    const TypeTasks t = type_tasks_layout(r, e);
+    GN_REQUIRE(out_bytes >= t.total * sizeof(int32_t), "buffer too small: need %zu bytes", t.total * sizeof(int32_t));
+    hipStream_t st = gn::as_stream(stream);
+    int32_t* o = static_cast<int32_t*>(out);
+    if (o != type_offsets) GN_HIP(hipMemcpyAsync(o, type_offsets, (size_t)(r + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    k_task_ptr<<<1, 1024, 0, st>>>(o, 1, (int)r, o + t.taskptr, reinterpret_cast<int4*>(o + t.tasks));
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 extern "C" size_t gn_distmult_backward_workspace_bytes(int64_t n, int64_t f, int64_t r, int64_t e) {
     if (n <= 0 || f <= 0 || r <= 0 || e <= 0) return 0;
     return std::max(ws_layout(e, std::max(n, r)).total, lds_layout(e, n, r, f).total);
@@ -883,7 +914,15 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                 recs_dd = r2s;
             }
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(recs_dd, rp_dd, 1, tp, tk, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st);
+            int32_t* tp_dd = tp;
+            int4* tk_dd = tk;
+            const bool listed = sorted && type_offsets && (flags & GN_DM_TYPE_TASKS);   // the caller keeps the task list too
+            if (listed) {
+                const TypeTasks t = type_tasks_layout(r, e);
+                tp_dd = const_cast<int32_t*>(type_offsets) + t.taskptr;
+                tk_dd = reinterpret_cast<int4*>(const_cast<int32_t*>(type_offsets) + t.tasks);
+            }
+            const gn_status rc = launch_seg_lds(recs_dd, rp_dd, 1, tp_dd, tk_dd, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st, listed);
             if (rc != GN_OK) return rc;
         }
     }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 135 /* 0.1.34 */
+#define GN_VERSION 136 /* 0.1.34 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -349,9 +349,18 @@ GN_API gn_status gn_distmult_plan_forward_cols_f32(const gn_distmult_plan* plan,
  * reference's layout, utils.py:168-198), which saves the sort of the dD pass.  sigmoid_scores (the probabilities the
  * forward returned, decoder.py:23) makes grad_logit the gradient with respect to those: the factor p (1 - p) is
  * applied where the records are built.  type_offsets ([R + 1] int32 on the device, with GN_DM_TYPES_SORTED): the first
- * edge of every relation, for callers that keep it with a static edge_type instead of having it searched per call.  Node and relation tables that fit
- * the LDS in 16-column blocks ((n + R) * 64 B <= 150 KB) are reduced from there; larger ones from L2. */
+ * edge of every relation, for callers that keep it with a static edge_type instead of having it searched per call.
+ * GN_DM_TYPE_TASKS: type_offsets points at a buffer that gn_distmult_type_tasks filled for this (R, E) - the offsets and,
+ * behind them, the task list of the relation-major reduction, which then is not rebuilt per call (a one-workgroup launch
+ * of 7 us).  Node and relation tables that fit the LDS in 16-column blocks ((n + R) * 64 B <= 150 KB) are reduced from
+ * there; larger ones from L2. */
 #define GN_DM_TYPES_SORTED 1
+#define GN_DM_TYPE_TASKS 2
+GN_API size_t gn_distmult_type_tasks_bytes(int64_t num_relations, int64_t num_edges);
+/* out (16-byte aligned, gn_distmult_type_tasks_bytes bytes; may be where type_offsets already sits): type_offsets [R + 1],
+ * then the task list. */
+GN_API gn_status gn_distmult_type_tasks(const int32_t* type_offsets, int64_t num_relations, int64_t num_edges, void* out,
+                                 size_t out_bytes, void* stream);
 GN_API size_t gn_distmult_backward_workspace_bytes(int64_t num_nodes, int64_t num_features, int64_t num_relations,
                                             int64_t num_edges);
 GN_API gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
