@@ -607,10 +607,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
 // out[key, :] = the key's task partials.  One workgroup per key: eight slices take every eighth task each (four
 // loads in flight), then the slices are added in slice order - a fixed order, whatever the number of tasks (a hub
 // relation has hundreds).
-__global__ __launch_bounds__(256) void k_seg_lds_combine(const int32_t* __restrict__ taskptr, const float* __restrict__ partial,
-                                                         int f, float* __restrict__ out, int64_t ld_out) {
+struct CombineSet { const int32_t* taskptr; const float* partial; float* out; int64_t ld_out; };
+
+__global__ __launch_bounds__(256) void k_seg_lds_combine(CombineSet first, int first_keys, CombineSet second, int f) {
+    // (both reductions of a call in one launch: the node keys, then the relation keys)
+    const bool in_first = (int)blockIdx.x < first_keys;
+    const int32_t* __restrict__ taskptr = in_first ? first.taskptr : second.taskptr;
+    const float* __restrict__ partial = in_first ? first.partial : second.partial;
+    float* __restrict__ out = in_first ? first.out : second.out;
+    const int64_t ld_out = in_first ? first.ld_out : second.ld_out;
     __shared__ f32x4 fold[8][32];
-    const int key = blockIdx.x, slice = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int key = in_first ? (int)blockIdx.x : (int)blockIdx.x - first_keys, slice = threadIdx.x >> 5, j = threadIdx.x & 31;
     const int t0 = taskptr[key], t1 = taskptr[key + 1];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < f; c0 += 128) {                 // 32 float4 lanes per pass
@@ -668,7 +675,7 @@ LdsLayout lds_layout(int64_t e, int64_t n, int64_t r, int64_t f) {
     (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr,
                                     (uint64_t*)nullptr, (size_t)(2 * e), 0, 32, (hipStream_t)0);
     const int64_t rows = std::max(n, r);
-    const int64_t tasks = std::max(lds_max_tasks(2 * e, n), lds_max_tasks(e, r));
+    const int64_t tasks = lds_max_tasks(2 * e, n) + lds_max_tasks(e, r);        // both reductions' partial sums side by side
     l.keys = 0;
     l.keys_sorted = l.keys + align_up(2 * e * sizeof(uint32_t));
     l.recs = l.keys_sorted + align_up(2 * e * sizeof(uint32_t));
@@ -698,7 +705,7 @@ bool lds_dd_fits(int64_t n) { return (size_t)n * 64 <= kLdsTableBudget; }
 gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int64_t rowptr_stride, int32_t* taskptr, int4* tasks, int64_t keys,
                          const float* A, int64_t ld_a,
                          int64_t rows_a, const float* B, int64_t ld_b, int64_t rows_b, int64_t f, float* partial, float* out,
-                         int64_t ld_out, hipStream_t st, bool tasks_ready = false) {
+                         int64_t ld_out, hipStream_t st, bool tasks_ready = false, CombineSet* defer = nullptr) {
     { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_seg_lds), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
     if (!tasks_ready) {
         k_task_ptr<<<1, 1024, 0, st>>>(rowptr, rowptr_stride, (int)keys, taskptr, tasks);
@@ -714,7 +721,18 @@ gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int64_t ro
     a.partial = partial;
     k_seg_lds<<<a.col_blocks * a.workers, kLdsThreads, lds_bytes, st>>>(a);
     GN_LAUNCH_CHECK();
-    k_seg_lds_combine<<<(unsigned)keys, 256, 0, st>>>(taskptr, partial, (int)f, out, ld_out);
+    const CombineSet mine = {taskptr, partial, out, ld_out};
+    if (defer) {                                               // the caller combines two reductions in one launch (combine_both)
+        *defer = mine;
+        return GN_OK;
+    }
+    k_seg_lds_combine<<<(unsigned)keys, 256, 0, st>>>(mine, (int)keys, mine, (int)f);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+gn_status combine_both(const CombineSet& a, int64_t keys_a, const CombineSet& b, int64_t keys_b, int64_t f, hipStream_t st) {
+    k_seg_lds_combine<<<(unsigned)(keys_a + keys_b), 256, 0, st>>>(a, (int)keys_a, b, (int)f);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -760,7 +778,7 @@ PlanWs plan_ws(const gn_distmult_bwd_plan* p, int64_t f) {
     w.he = w.g + align_up((size_t)(p->e + 64) * sizeof(float));
     w.pr = w.he + align_up((size_t)(2 * p->e + 64) * sizeof(uint64_t));
     w.partial = w.pr + align_up((size_t)(2 * p->e + 64) * sizeof(uint64_t));
-    w.total = w.partial + align_up((size_t)std::max(p->he_tasks_max, p->pr_tasks_max) * f * sizeof(float));   // (pr: the spare slots sit at 2 E)
+    w.total = w.partial + align_up((size_t)(p->he_tasks_max + p->pr_tasks_max) * f * sizeof(float));   // both reductions' partial sums (one combine launch)
     return w;
 }
 
@@ -854,6 +872,11 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
         const bool sorted_types = (flags & GN_DM_TYPES_SORTED) != 0;
         bool pairs_done = false;
         float* part = reinterpret_cast<float*>(ws + ll.partial);
+        float* part_dd = part + (size_t)lds_max_tasks(2 * e, n) * f;      // the relation-major reduction's partial sums
+        CombineSet cz, cd;                                                 // both reductions are combined in one launch ...
+        // ... when the relation-major one brings its task list (the scratch holds one list: the node-major one's must outlive its combine)
+        const bool listed = lds_dd && (flags & GN_DM_TYPES_SORTED) && type_offsets && (flags & GN_DM_TYPE_TASKS);
+        const bool both = lds_dz && listed;
         size_t sort2 = ll.sort_tmp_bytes;
         if (lds_dz && n <= kSortMaxKeys) {
             static thread_local bool sort_configured = false;
@@ -885,7 +908,8 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                                                                                                       counts, r2s, pairs_done ? r2 : nullptr);
             }
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(r2s, counts, kSortWaves, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st, true);
+            const gn_status rc = launch_seg_lds(r2s, counts, kSortWaves, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st, true,
+                                                both ? &cz : nullptr);
             if (rc != GN_OK) return rc;
         } else if (lds_dz) {
             k_half_recs<<<gn::stream_grid(e, 256), 256, 0, st>>>(u, v, et, grad, e, n, r, k2, r2);
@@ -893,7 +917,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             GN_HIP(rocprim::radix_sort_pairs(ws + ll.sort_tmp, sort2, k2, k2s, r2, r2s, (size_t)(2 * e), 0, bits_for(n + 1), st));
             k_key_offsets<<<(int)gn::ceil_div(n + 1, 256), 256, 0, st>>>(k2s, 2 * e, (int)n, rp);
             GN_LAUNCH_CHECK();
-            const gn_status rc = launch_seg_lds(r2s, rp, 1, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st);
+            const gn_status rc = launch_seg_lds(r2s, rp, 1, tp, tk, n, z, ld_z, n, d, ld_d, r, f, part, dz, ld_dz, st, false, both ? &cz : nullptr);
             if (rc != GN_OK) return rc;
         }
         if (lds_dd) {
@@ -916,13 +940,14 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             GN_LAUNCH_CHECK();
             int32_t* tp_dd = tp;
             int4* tk_dd = tk;
-            const bool listed = sorted && type_offsets && (flags & GN_DM_TYPE_TASKS);   // the caller keeps the task list too
             if (listed) {
                 const TypeTasks t = type_tasks_layout(r, e);
                 tp_dd = const_cast<int32_t*>(type_offsets) + t.taskptr;
                 tk_dd = reinterpret_cast<int4*>(const_cast<int32_t*>(type_offsets) + t.tasks);
             }
-            const gn_status rc = launch_seg_lds(recs_dd, rp_dd, 1, tp_dd, tk_dd, r, z, ld_z, n, z, ld_z, n, f, part, dd, ld_dd, st, listed);
+            gn_status rc = launch_seg_lds(recs_dd, rp_dd, 1, tp_dd, tk_dd, r, z, ld_z, n, z, ld_z, n, f, part_dd, dd, ld_dd, st, listed,
+                                          both ? &cd : nullptr);
+            if (rc == GN_OK && both) rc = combine_both(cz, n, cd, r, f, st);
             if (rc != GN_OK) return rc;
         }
     }
@@ -1223,9 +1248,12 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
     GN_LAUNCH_CHECK();
     k_place_g<<<(unsigned)std::min<int64_t>(gn::ceil_div(2 * e, 4 * 256), 4096), 256, 0, st>>>(plan->he_static.p, 2 * e, gpair, he);
     GN_LAUNCH_CHECK();
+    CombineSet cz, cd;
     gn_status rc = launch_seg_lds(he, nullptr, 0, plan->he_taskptr.p, reinterpret_cast<int4*>(plan->he_tasks.p), n, z, ld_z, n, d, ld_d, r, f,
-                                  part, dz, ld_dz, st, true);
+                                  part, dz, ld_dz, st, true, &cz);
     if (rc != GN_OK) return rc;
-    return launch_seg_lds(pr, nullptr, 0, plan->pr_taskptr.p, reinterpret_cast<int4*>(plan->pr_tasks.p), r, z, ld_z, n, z, ld_z, n, f, part,
-                          dd, ld_dd, st, true);
+    rc = launch_seg_lds(pr, nullptr, 0, plan->pr_taskptr.p, reinterpret_cast<int4*>(plan->pr_tasks.p), r, z, ld_z, n, z, ld_z, n, f,
+                        part + (size_t)plan->he_tasks_max * f, dd, ld_dd, st, true, &cd);
+    if (rc != GN_OK) return rc;
+    return combine_both(cz, n, cd, r, f, st);
 }
