@@ -117,10 +117,11 @@ def train_step_entry(dev, steps=20):
         pos = model.dmt(z, data.train_idx, data.train_et)
         negs = model.dmt(z, neg, data.train_et)
         loss = link_loss(pos, negs)                            # GripNet-pose.py:140-142 in one launch (gn_link_loss_*)
-        loss.backward()
+        loss.backward(one)                                     # (the seed gradient is kept: backward() would fill a new 1 per step)
         opt.step()
         return loss
 
+    one = torch.ones((), dtype=torch.float32, device=dev)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
