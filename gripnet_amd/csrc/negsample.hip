@@ -187,7 +187,8 @@ constexpr int kTaskSliceIds = 2048, kTaskSliceBits = 2048, kTaskMaxIds = 1024;
 // Same draws as k_sample_negatives_bitmap / _narrow (same hashes, same order of attempts), tested against a staged table.
 __global__ __launch_bounds__(256) void k_sample_negatives_tasks(const int4* __restrict__ tasks, const uint32_t* __restrict__ keys32,
                                                                 const int64_t* __restrict__ starts, const uint32_t* __restrict__ bitmap,
-                                                                int64_t words, uint32_t n, uint64_t seed, const uint64_t* __restrict__ seed_step,
+                                                                int64_t words, uint32_t n, uint64_t seed, uint64_t* seed_step,
+                                                                unsigned int* __restrict__ arrived,
                                                                 int64_t* __restrict__ out_u, int64_t* __restrict__ out_v,
                                                                 uint32_t* __restrict__ packed, int32_t* __restrict__ err) {
     extern __shared__ uint32_t staged[];
@@ -274,6 +275,17 @@ __global__ __launch_bounds__(256) void k_sample_negatives_tasks(const int4* __re
             if (packed) packed[e] = uu[j] | (vv[j] << 16);
         }
     }
+    // the step counter moves when every workgroup has read it (each reads it first thing): the last one to arrive writes it
+    if (seed_step) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int seen = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen == gridDim.x - 1) {
+                *seed_step += 1;
+                __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next draw (stream-ordered)
+            }
+        }
+    }
 }
 
 __global__ void k_advance_step(uint64_t* step) { *step += 1; }
@@ -283,7 +295,7 @@ gn_status launch_sample(const gn_negative_sampler* s, uint64_t seed, int64_t* ou
     if (s->num_tasks > 0)
         k_sample_negatives_tasks<<<(unsigned)s->num_tasks, 256, s->task_lds, st>>>(
             reinterpret_cast<const int4*>(s->tasks.p), s->keys32.p, s->starts.p, s->bitmap.p, s->words, (uint32_t)s->num_nodes, seed, seed_step,
-            out_u, out_v, packed, error_flag);
+            reinterpret_cast<unsigned int*>(s->tasks.p + 8 * s->num_tasks), out_u, out_v, packed, error_flag);
     else if (s->words > 0)
         k_sample_negatives_bitmap<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
             s->bitmap.p, s->words, s->rel16.p, s->num_edges, (uint32_t)s->num_nodes, seed, seed_step, out_u, out_v, packed, error_flag);
@@ -294,7 +306,7 @@ gn_status launch_sample(const gn_negative_sampler* s, uint64_t seed, int64_t* ou
         k_sample_negatives<<<gn::stream_grid(s->num_edges, 256), 256, 0, st>>>(
             s->keys.p, s->starts.p, (int)s->num_relations, s->num_edges, s->num_nodes, seed, seed_step, out_u, out_v, packed, error_flag);
     GN_LAUNCH_CHECK();
-    if (seed_step) {                                          // (stream order: every workgroup of the draw has read it)
+    if (seed_step && s->num_tasks == 0) {                     // (stream order: every workgroup of the draw has read it; the task kernel moves it itself)
         k_advance_step<<<1, 1, 0, st>>>(seed_step);
         GN_LAUNCH_CHECK();
     }
@@ -381,10 +393,12 @@ gn_status gn_negative_sampler_create(const int64_t* u, const int64_t* v, const i
                             }
                         }
                     if (!tasks.empty()) {
+                        const size_t described = tasks.size();
+                        tasks.push_back(0);                                   // the arrival counter of the stepped draw
                         e3 = s->tasks.alloc(tasks.size());
                         if (e3 == hipSuccess) e3 = hipMemcpyAsync(s->tasks.p, tasks.data(), tasks.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
                         if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);   // `tasks` leaves scope
-                        s->num_tasks = (int64_t)(tasks.size() / 8);
+                        s->num_tasks = (int64_t)(described / 8);
                         s->task_lds = (size_t)(most + 8) * 4;                  // (up to three words of alignment in front)
                     }
                 }

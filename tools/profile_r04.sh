@@ -20,6 +20,9 @@ tools/pmc_relgrad.sh > gpurun_out/pmc_${tag}_relgrad.txt 2>&1
 python3 tools/relgrad_probe.py > gpurun_out/relgrad_$tag.txt 2>&1
 hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_valu_probe.hip -o /tmp/mfma_valu_probe > /dev/null 2>&1 && /tmp/mfma_valu_probe > gpurun_out/mfma_valu_probe_$tag.txt 2>&1
 python3 tools/train_step.py 40 > gpurun_out/train_step_$tag.txt 2>&1
+# the sampler's two kernels, the rate of LDS atomics (why the decoder's backward sorts instead of scattering)
+python3 tools/probes/sampler_probe.py > gpurun_out/sampler_probe_$tag.txt 2>&1
+mkdir -p tools/probes/bin && hipcc -O3 --offload-arch=gfx950 tools/probes/lds_atomic_probe.hip -o tools/probes/bin/lds_atomic_probe > /dev/null 2>&1 && tools/probes/bin/lds_atomic_probe > gpurun_out/lds_atomic_probe_$tag.txt 2>&1
 python3 tools/launch_modes.py > gpurun_out/launch_modes_$tag.txt 2>&1
 python3 tools/bench_kernels.py --what rgcn --arith fast --rgcn-kernel pair --iters 40 > gpurun_out/pair_fast_$tag.txt 2>&1
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_$tag.log 2>&1
