@@ -21,23 +21,77 @@ def recording(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+class Slot:
+    """Columns [lo, hi) of a concat buffer (not a tensor argument: autograd sees the view a Function makes of it as that
+    Function's own output)."""
+    __slots__ = ("buf", "lo", "hi")
+
+    def __init__(self, buf, lo, hi):
+        self.buf, self.lo, self.hi = buf, lo, hi
+
+    def view(self):
+        return self.buf[:, self.lo:self.hi]
+
+
+def cat_slots(widths, n_rows, device):
+    buf = torch.empty((n_rows, int(sum(widths))), dtype=torch.float32, device=device)
+    slots, lo = [], 0
+    for w in widths:
+        slots.append(Slot(buf, lo, lo + int(w)))
+        lo += int(w)
+    return buf, slots
+
+
+class SlotsCatFn(torch.autograd.Function):
+    """``torch.cat(parts, dim=1)`` (layers.py:309,376) for parts that already sit in their columns of one buffer - written
+    there by the launches that produced them (GcnConvFn / RgcnConvFn with a slot, their side copies): no copy forward, column
+    slices of the gradient backward."""
+
+    @staticmethod
+    def forward(ctx, slots, *parts):
+        ctx.bounds = [(s.lo, s.hi) for s in slots]
+        return slots[0].buf.view_as(slots[0].buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[:, lo:hi] if need else None for (lo, hi), need in zip(ctx.bounds, ctx.needs_input_grad[1:]))
+
+
+class AbsSlotFn(torch.autograd.Function):
+    """``torch.abs(t)`` (layers.py:376) whose value a side copy of another launch already left in `slot`."""
+
+    @staticmethod
+    def forward(ctx, t, slot):
+        ctx.save_for_backward(t)
+        return slot.view()
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        return g * torch.sign(t), None
+
+
 class GcnConvFn(torch.autograd.Function):
     """``act(A_norm (x W) + b)`` over a cached plan (myGCN.forward, gripnet/layers.py:71-100, with the ReLU
     that follows it at layers.py:279,305,370).  ``n_out`` rows: N for a square graph, n_target for the
     external layer's closed form."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, plan, n_out, relu):
+    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None):
+        # slot: a Slot of a concat buffer the output is written into (the concat of layers.py:309,376 without a copy, SlotsCatFn);
+        # side: (tensor, Slot, mode) copied by the same launch, as on the inference path
         x = _hip.f32_rows(x.detach())
         w = weight.detach()
-        out = torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=x.device)
+        out = slot.view() if slot is not None else torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=x.device)
+        if side is not None:
+            side = (side[0].detach(), side[1].view(), side[2])
         b = None if bias is None else bias.detach()
         if _hip.transform_fusable(w.shape[0], w.shape[1], x) and w.is_contiguous():
-            plan.aggregate(x, b, relu, out, weight=w)          # (A_norm x) W in one launch, as the inference path
+            plan.aggregate(x, b, relu, out, side, weight=w)    # (A_norm x) W in one launch, as the inference path
         else:
             xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
             _hip.gemm(x, w, xw)
-            plan.aggregate(xw, b, relu, out)
+            plan.aggregate(xw, b, relu, out, side)
         ctx.plan, ctx.relu, ctx.has_bias = plan, bool(relu), bias is not None
         ctx.save_for_backward(x, w, out if relu else None)
         return out
@@ -58,17 +112,19 @@ class GcnConvFn(torch.autograd.Function):
             dx = torch.empty((gxw.shape[0], w.shape[0]), dtype=torch.float32, device=gxw.device)
             _hip.gemm(gxw, w, dx, b_transposed=True)
         dw = _hip.xtg(x, gxw) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class RgcnConvFn(torch.autograd.Function):
     """``act(mean_{e: dst=i} x[src_e] W_{r(e)} + x[i] root + b)`` (myRGCN.forward, layers.py:165-197)."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, bias, plan, relu):
+    def forward(ctx, x, basis, att, root, bias, plan, relu, slot=None, side=None):
         xc = _hip.f32_rows(x.detach())
-        out = torch.empty((xc.shape[0], basis.shape[2]), dtype=torch.float32, device=xc.device)
-        plan.forward(xc, basis.detach(), att.detach(), root.detach(), None if bias is None else bias.detach(), relu, out)
+        out = slot.view() if slot is not None else torch.empty((xc.shape[0], basis.shape[2]), dtype=torch.float32, device=xc.device)
+        if side is not None:
+            side = (side[0].detach(), side[1].view(), side[2])
+        plan.forward(xc, basis.detach(), att.detach(), root.detach(), None if bias is None else bias.detach(), relu, out, side=side)
         ctx.plan, ctx.relu = plan, bool(relu)
         ctx.save_for_backward(xc, basis, att, root, out if relu else None)
         return out
@@ -86,7 +142,7 @@ class RgcnConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:                            # dx = dxe + g root^T: the product is added onto the edge sums
             dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True)
         droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
-        return dx, dbasis, datt, droot, dbias, None, None
+        return dx, dbasis, datt, droot, dbias, None, None, None, None
 
 
 # (relation, source) sums Q of more than this many floats are reduced per slab of relations (the dense Q of a graph

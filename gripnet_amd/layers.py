@@ -20,7 +20,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import _hip
-from .autograd import GcnConvFn, RgcnConvFn, recording
+from .autograd import AbsSlotFn, GcnConvFn, RgcnConvFn, SlotsCatFn, cat_slots, recording
 
 
 def _cat_slots(widths, n_rows, device):
@@ -80,11 +80,8 @@ class myGCN(Module):
 
     def _run(self, plan, x, n_out, out, relu, side, planes=None):
         self._planes_written = False                 # did this call's launch leave the split planes it was offered?
-        if recording(x, self.weight, self.bias):                                 # training: autograd path
-            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu)
-            if side is not None or out is not None:
-                raise RuntimeError("slot-fused outputs are an inference path; autograd builds its own concat")
-            return y
+        if recording(x, self.weight, self.bias):                                 # training: autograd path (out / side: Slots)
+            return GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side)
         x = _hip.f32_rows(x)
         if out is None:
             out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
@@ -187,9 +184,7 @@ class myRGCN(Module):
             raise ValueError("range_list has {} rows for {} relations".format(range_list.shape[0], self.num_relations))
         plan = self.plan_for(edge_index, range_list, x.shape[0])
         if recording(x, self.basis, self.att, self.root, self.bias):             # training: autograd path
-            if _out is not None or _side is not None:
-                raise RuntimeError("slot-fused outputs are an inference path; autograd builds its own concat")
-            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu)
+            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu, _out, _side)   # (Slots)
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
         planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None
@@ -236,15 +231,21 @@ class homoGraph(Module):
             assert edge_type is not None
             assert range_list is not None
         _hip.require_gpu(x, homo_edge_index)
-        if torch.is_grad_enabled() and recording(x, *self.parameters()):                                     # training: plain concat, autograd-tracked
+        if torch.is_grad_enabled() and recording(x, *self.parameters()):         # training: autograd-tracked
+            # the concat of layers.py:309 without a copy: every layer writes its columns of one buffer, the first layer's launch
+            # copies the input into its columns (as on the inference path); SlotsCatFn hands the gradient's columns back
+            slots = [None] * (len(self.conv_list) + 1)
+            if if_catout:
+                _, slots = cat_slots([x.shape[1]] + [c.out_channels for c in self.conv_list], x.shape[0], x.device)
             outs, h = [x], x
-            for net in self.conv_list:
+            for i, net in enumerate(self.conv_list):
+                side = (x, slots[0], 0) if if_catout and i == 0 else None
                 if self.multi_relational:
-                    h = net(h, homo_edge_index, edge_type, range_list, _relu=True)
+                    h = net(h, homo_edge_index, edge_type, range_list, _relu=True, _out=slots[i + 1], _side=side)
                 else:
-                    h = net(h, homo_edge_index, edge_weight, _relu=True)
+                    h = net(h, homo_edge_index, edge_weight, _relu=True, _out=slots[i + 1], _side=side)
                 outs.append(h)
-            return torch.cat(outs, dim=1) if if_catout else h
+            return SlotsCatFn.apply(slots, *outs) if if_catout else h
         x = _hip.f32_rows(x)
         n = x.shape[0]
         side = None
@@ -291,11 +292,15 @@ class interGraph(Module):
         _hip.require_gpu(x, inter_edge_index)
         dev = x.device
         if torch.is_grad_enabled() and recording(x, *self.parameters()):                                     # training: autograd-tracked glue
+            if self.if_one_external and mod == "cat":
+                # [y | |target_feat|] (layers.py:376) in one launch: both written into their columns, no concat, no abs
+                _, (ys, ts) = cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
+                y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu, _out=ys,
+                                                _side=(self.target_feat, ts, 1))
+                return SlotsCatFn.apply([ys, ts], y, AbsSlotFn.apply(self.target_feat, ts))
             y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
             if not self.if_one_external:
                 return y
-            if mod == "cat":
-                return torch.cat([y, torch.abs(self.target_feat)], dim=1)
             if y.shape[1] == self.target_feat.shape[1]:
                 return (y + torch.abs(self.target_feat)) / 2
             return (y + torch.relu(self.target_feat @ self.target_feat_down)) / 2
