@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # k
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED = 1, 2, 4, 8, 16                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 136                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 137                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -72,6 +72,8 @@ SIGNATURES = {
     "gn_xtg_workspace_bytes": (_sz, [_i64, _i64]),
     "gn_xtg_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _int, _p]),
     "gn_distmult_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "gn_dense_batch_begin": (_int, []),
+    "gn_dense_batch_end": (_int, [_p]),
     "gn_distmult_type_tasks_bytes": (_sz, [_i64, _i64]),
     "gn_distmult_type_tasks": (_int, [_p, _i64, _i64, _p, _sz, _p]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
@@ -429,6 +431,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
     m = (a.shape[0] if a_rows is None else a_rows.shape[0]) if m is None else m
     k = a.shape[1] if k is None else k
     n = (b.shape[0] if b_transposed else b.shape[-1]) if n is None else n
+    if _open_batch is not None:                              # a queued product reads its operands when the batch leaves
+        _open_batch.keep.extend((a, b, out, bias, a_rows))
     _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
                           ptr(b), ld(b) if ldb is None else ldb, stride_b,
                           ptr(out), ld(out) if ldc is None else ldc, stride_c,
@@ -453,6 +457,8 @@ def xtg(x: torch.Tensor, g: torch.Tensor):
     ws = _xtg_ws.get(key)
     if ws is None:                                             # one zeroed workspace per device and size: its last 64 bytes are the kernel's ticket
         ws = _xtg_ws[key] = torch.zeros((need,), dtype=torch.uint8, device=x.device)
+    if _open_batch is not None:
+        _open_batch.keep.extend((x, g, out))
     _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need, GN_XTG_TICKET_ZEROED,
           stream_ptr(x.device))
     return out
@@ -892,6 +898,35 @@ class DistMultBwdPlan:
 
 
 _sorted_types = []          # (tensor, _version, relations, offsets or None) of the last few edge_type tensors asked about
+
+
+_open_batch = None
+
+
+class dense_batch:
+    """``with dense_batch(device):`` - the deep-and-narrow `gemm` calls and the one-launch `xtg` calls inside leave as ONE
+    launch at the end of the block (gn_dense_batch_begin / _end); they must not depend on each other.  The operands of
+    every `gemm` / `xtg` call inside are kept alive until the batch has been launched (a temporary freed in between could
+    be handed out again and overwritten before the queued product reads it)."""
+
+    def __init__(self, device):
+        self.device, self.keep = device, []
+
+    def __enter__(self):
+        global _open_batch
+        _call("gn_dense_batch_begin")
+        _open_batch = self
+        return self
+
+    def __exit__(self, *exc):
+        global _open_batch
+        _open_batch = None
+        try:
+            with torch.cuda.device(self.device):
+                _call("gn_dense_batch_end", stream_ptr(self.device))
+        finally:
+            self.keep = []
+        return False
 
 
 def type_offsets(et, num_relations):

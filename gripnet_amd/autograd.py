@@ -136,12 +136,14 @@ class RgcnConvFn(torch.autograd.Function):
         deg = ctx.plan.grad_plans()[2]
         # one launch: ReLU mask, gm = g / deg (the gradient of the un-normalised sum), the bias gradient
         g, gm, dbias = _hip.grad_prologue(g, out if ctx.relu else None, deg, True, bool(ctx.needs_input_grad[4]))
-        dxe, dbasis, datt = rgcn_edge_gradients(ctx.plan, x, basis.detach(), att.detach(), gm,
-                                                ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        dx = None
-        if ctx.needs_input_grad[0]:                            # dx = dxe + g root^T: the product is added onto the edge sums
-            dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True)
-        droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
+        # dbasis, datt and droot are independent, deep and small: they leave as ONE launch at the end of the block
+        with _hip.dense_batch(x.device):
+            dxe, dbasis, datt = rgcn_edge_gradients(ctx.plan, x, basis.detach(), att.detach(), gm,
+                                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            dx = None
+            if ctx.needs_input_grad[0]:                        # dx = dxe + g root^T: the product is added onto the edge sums
+                dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True)
+            droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
         return dx, dbasis, datt, droot, dbias, None, None, None, None
 
 

@@ -123,11 +123,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 constexpr int kDeepWaves = 16;
 
 template <int MT, int NT>
-__global__ __launch_bounds__(kDeepWaves * 64) void k_gemm_deep(GemmArgs g) {
-    __shared__ f32x4 part[kDeepWaves][MT * NT][64];
+__device__ __forceinline__ void gemm_deep_body(const GemmArgs& g, int bx, int by, f32x4* __restrict__ part) {   // part: [16 waves][MT * NT][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * 16 * MT, col0 = blockIdx.y * 16 * NT;
+    const int row0 = bx * 16 * MT, col0 = by * 16 * NT;
     const int chunks = (g.k + 15) / 16;
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -196,14 +195,14 @@ __global__ __launch_bounds__(kDeepWaves * 64) void k_gemm_deep(GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int u = 0; u < NT; ++u) part[wave][t * NT + u][lane] = acc[t][u];
+        for (int u = 0; u < NT; ++u) part[(wave * MT * NT + t * NT + u) * 64 + lane] = acc[t][u];
     __syncthreads();
     // element i of lane l of a tile: row 4 (l >> 4) + i, column l & 15; thread -> (tile, lane, element), the waves in order
     for (int o = threadIdx.x; o < MT * NT * 256; o += kDeepWaves * 64) {
         const int tile = o >> 8, l = (o & 255) >> 2, i = o & 3;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kDeepWaves; ++w) v += part[w][tile][l][i];
+        for (int w = 0; w < kDeepWaves; ++w) v += part[(w * MT * NT + tile) * 64 + l][i];
         const int row = row0 + 16 * (tile / NT) + 4 * (l >> 4) + i, col = col0 + 16 * (tile % NT) + (l & 15);
         if (row < g.m && col < g.n) {
             if (g.bias) v += g.bias[col];
@@ -213,6 +212,12 @@ __global__ __launch_bounds__(kDeepWaves * 64) void k_gemm_deep(GemmArgs g) {
             *c = v;
         }
     }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kDeepWaves * 64) void k_gemm_deep(GemmArgs g) {
+    __shared__ f32x4 part[kDeepWaves * MT * NT * 64];
+    gemm_deep_body<MT, NT>(g, blockIdx.x, blockIdx.y, part);
 }
 
 // Tall-skinny form (one shared B of at most 64 KB per 64-column block: every layer's x @ W): B is laid out ONCE per
@@ -698,16 +703,24 @@ __global__ __launch_bounds__(256) void k_xtg_partial(const float* __restrict__ x
 // slices in slice order (no fence: MI355X_MICROARCH.md's form for a few KB).  Deterministic; fp32 MFMA = fp32 FMA chains.
 constexpr int kXtgMfmaSlices = 32;
 
+struct XtgArgs {
+    const float* x; int64_t ld_x; const float* g; int64_t ld_g; int64_t m; int k1, k2;
+    float* partial; unsigned int* ticket; float* out; int64_t ld_out;
+};
+
 template <int MT, int NT>
-__global__ __launch_bounds__(1024) void k_xtg_mfma(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ g, int64_t ld_g,
-                                                  int64_t m, int k1, int k2, float* __restrict__ partial, unsigned int* __restrict__ ticket,
-                                                  float* __restrict__ out, int64_t ld_out) {
-    extern __shared__ f32x4 xtg_part[];                                  // [16 waves][MT * NT][64]
-    __shared__ int last;
+__device__ __forceinline__ void xtg_mfma_body(const XtgArgs& a, int bx, int nblocks, f32x4* __restrict__ xtg_part, int* last_flag) {
+    const float* __restrict__ x = a.x;
+    const float* __restrict__ g = a.g;
+    const int64_t ld_x = a.ld_x, ld_g = a.ld_g, m = a.m, ld_out = a.ld_out;
+    const int k1 = a.k1, k2 = a.k2;
+    float* __restrict__ partial = a.partial;
+    unsigned int* __restrict__ ticket = a.ticket;
+    float* __restrict__ out = a.out;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int chunks = (int)((m + 15) / 16), per = (chunks + gridDim.x - 1) / gridDim.x;
-    const int c0 = blockIdx.x * per, c1 = min(chunks, c0 + per);
+    const int chunks = (int)((m + 15) / 16), per = (chunks + nblocks - 1) / nblocks;
+    const int c0 = bx * per, c1 = min(chunks, c0 + per);
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -752,7 +765,7 @@ __global__ __launch_bounds__(1024) void k_xtg_mfma(const float* __restrict__ x, 
 #pragma unroll
         for (int u = 0; u < NT; ++u) xtg_part[(wave * MT * NT + t * NT + u) * 64 + lane] = acc[t][u];
     __syncthreads();
-    const bool single = gridDim.x == 1;
+    const bool single = nblocks == 1;
     const int outs = k1 * k2;
     for (int o = tid; o < MT * NT * 256; o += 1024) {
         const int tile = o >> 8, l = (o & 255) >> 2, i = o & 3;
@@ -762,28 +775,35 @@ __global__ __launch_bounds__(1024) void k_xtg_mfma(const float* __restrict__ x, 
         const int row = 16 * (tile / NT) + 4 * (l >> 4) + i, col = 16 * (tile % NT) + (l & 15);
         if (row < k1 && col < k2) {
             if (single) out[(int64_t)row * ld_out + col] = v;
-            else __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)blockIdx.x * outs + row * k2 + col, __float_as_uint(v),
+            else __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)bx * outs + row * k2 + col, __float_as_uint(v),
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (single) return;
     __syncthreads();                                                       // (every storing wave has drained its stores)
-    if (tid == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (tid == 0) *last_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
     __syncthreads();
-    if (!last) return;
+    if (!*last_flag) return;
     for (int o = tid; o < outs; o += 1024) {
         // all slices requested before any is added (a load - add chain pays a round trip per slice), added in slice order
         float p[kXtgMfmaSlices];
 #pragma unroll
         for (int sl = 0; sl < kXtgMfmaSlices; ++sl)
-            p[sl] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(partial) + (size_t)min(sl, (int)gridDim.x - 1) * outs + o,
+            p[sl] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(partial) + (size_t)min(sl, nblocks - 1) * outs + o,
                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         float v = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < kXtgMfmaSlices; ++sl) v += sl < (int)gridDim.x ? p[sl] : 0.f;
+        for (int sl = 0; sl < kXtgMfmaSlices; ++sl) v += sl < nblocks ? p[sl] : 0.f;
         out[(int64_t)(o / k2) * ld_out + o % k2] = v;
     }
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(1024) void k_xtg_mfma(XtgArgs a) {
+    extern __shared__ f32x4 xtg_part[];                                  // [16 waves][MT * NT][64]
+    __shared__ int last;
+    xtg_mfma_body<MT, NT>(a, blockIdx.x, gridDim.x, xtg_part, &last);
 }
 
 template <int MT, int NT>
@@ -798,8 +818,122 @@ gn_status launch_xtg_mfma(const float* x, int64_t ld_x, const float* g, int64_t 
     const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kXtgMfmaSlices, gn::ceil_div(m, 16 * 16 * 2)));
     float* partial = static_cast<float*>(workspace);
     unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (size_t)kXtgSlices * k1 * k2 * sizeof(float));
-    k_xtg_mfma<MT, NT><<<slices, 1024, lds, st>>>(x, ld_x, g, ld_g, m, k1, k2, partial, ticket, out, ld_out);
+    const XtgArgs a = {x, ld_x, g, ld_g, m, k1, k2, partial, ticket, out, ld_out};
+    k_xtg_mfma<MT, NT><<<slices, 1024, lds, st>>>(a);
     GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+// ---- independent small products in ONE launch ------------------------------------------------------------------------
+// The weight gradients of a layer's backward are a handful of products of a few dozen workgroups and ~10 us each (latency
+// chains of a few round trips), independent of each other: dbasis = att^T dW, datt = dW basis^T and droot = x^T g of the
+// relational layer.  Between gn_dense_batch_begin() and gn_dense_batch_end(stream) the calls of gn_gemm_f32 that take the
+// deep-and-narrow kernel and of gn_xtg_f32 that take the one-launch kernel are QUEUED (per host thread) and leave as one grid
+// whose workgroups pick their product from a table in the launch's arguments; every other call inside the bracket launches
+// as usual.  The caller promises that the queued products do not depend on each other.
+constexpr int kBatchMax = 4;
+struct BatchOp {
+    int kind;                        // 0: gemm_deep_body, 1: xtg_mfma_body
+    int mt, nt;                      // the body's tile template
+    int first, blocks, gx;           // workgroups [first, first + blocks) of the launch; deep: grid (gx, blocks / gx)
+    GemmArgs g;
+    XtgArgs x;
+};
+struct BatchTable { BatchOp op[kBatchMax]; int n; };
+
+__global__ __launch_bounds__(1024) void k_dense_batch(BatchTable tab) {
+    extern __shared__ f32x4 batch_lds[];
+    __shared__ int last;
+    int k = 0;
+    while (k + 1 < tab.n && (int)blockIdx.x >= tab.op[k + 1].first) ++k;   // (uniform: scalar registers)
+    const BatchOp& op = tab.op[k];
+    const int vb = (int)blockIdx.x - op.first;
+    if (op.kind == 0) {
+        const int bx = vb % op.gx, by = vb / op.gx;
+        if (op.mt == 1 && op.nt == 1) gemm_deep_body<1, 1>(op.g, bx, by, batch_lds);
+        else if (op.mt == 2 && op.nt == 1) gemm_deep_body<2, 1>(op.g, bx, by, batch_lds);
+        else if (op.mt == 4 && op.nt == 1) gemm_deep_body<4, 1>(op.g, bx, by, batch_lds);
+        else gemm_deep_body<1, 2>(op.g, bx, by, batch_lds);
+        return;
+    }
+#define GN_XTG_BODY(MT, NT) if (op.mt == MT && op.nt == NT) { xtg_mfma_body<MT, NT>(op.x, vb, op.blocks, batch_lds, &last); return; }
+    GN_XTG_BODY(1, 1) GN_XTG_BODY(2, 1) GN_XTG_BODY(3, 1) GN_XTG_BODY(4, 1)
+    GN_XTG_BODY(1, 2) GN_XTG_BODY(2, 2) GN_XTG_BODY(3, 2) GN_XTG_BODY(4, 2)
+#undef GN_XTG_BODY
+}
+
+thread_local bool batch_open = false;
+thread_local std::vector<BatchOp> batch_queue;
+
+void deep_shape(const GemmArgs& g, BatchOp& op) {
+    if (g.m <= 64) {
+        op.mt = g.m > 32 ? 4 : g.m > 16 ? 2 : 1; op.nt = 1;
+        op.gx = 1; op.blocks = (int)gn::ceil_div(g.n, 16);
+    } else {
+        op.mt = 1; op.nt = g.n > 16 ? 2 : 1;
+        op.gx = (int)gn::ceil_div(g.m, 16); op.blocks = op.gx;
+    }
+}
+
+gn_status launch_deep(const GemmArgs& g, hipStream_t st) {
+    BatchOp op;
+    deep_shape(g, op);
+    dim3 grid((unsigned)op.gx, (unsigned)(op.blocks / op.gx), 1);
+    if (op.mt == 4) k_gemm_deep<4, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+    else if (op.mt == 2) k_gemm_deep<2, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+    else if (op.nt == 2) k_gemm_deep<1, 2><<<grid, kDeepWaves * 64, 0, st>>>(g);
+    else k_gemm_deep<1, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+XtgArgs xtg_args(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int k1, int k2, float* out, int64_t ld_out, void* workspace) {
+    float* partial = static_cast<float*>(workspace);
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (size_t)kXtgSlices * k1 * k2 * sizeof(float));
+    return XtgArgs{x, ld_x, g, ld_g, m, k1, k2, partial, ticket, out, ld_out};
+}
+int xtg_slices(int64_t m) { return (int)std::max<int64_t>(1, std::min<int64_t>(kXtgMfmaSlices, gn::ceil_div(m, 16 * 16 * 2))); }
+
+gn_status launch_xtg_op(const BatchOp& op, hipStream_t st) {
+    const XtgArgs& a = op.x;
+    void* ws = a.partial;
+#define GN_XTG_CASE(MT, NT) if (op.mt == MT && op.nt == NT) return launch_xtg_mfma<MT, NT>(a.x, a.ld_x, a.g, a.ld_g, a.m, a.k1, a.k2, a.out, a.ld_out, ws, st)
+    GN_XTG_CASE(1, 1); GN_XTG_CASE(2, 1); GN_XTG_CASE(3, 1); GN_XTG_CASE(4, 1);
+    GN_XTG_CASE(1, 2); GN_XTG_CASE(2, 2); GN_XTG_CASE(3, 2); GN_XTG_CASE(4, 2);
+#undef GN_XTG_CASE
+    return gn::fail(GN_ERR_INVALID_ARG, "x^T g tile shape %d x %d", op.mt, op.nt);
+}
+
+gn_status flush_batch(hipStream_t st) {
+    std::vector<BatchOp> ops;
+    ops.swap(batch_queue);
+    for (size_t done = 0; done < ops.size();) {
+        const size_t take = std::min<size_t>(kBatchMax, ops.size() - done);
+        if (take == 1) {                                      // alone: its own kernel
+            const BatchOp& op = ops[done];
+            const gn_status rc = op.kind == 0 ? launch_deep(op.g, st) : launch_xtg_op(op, st);
+            if (rc != GN_OK) return rc;
+            done += 1;
+            continue;
+        }
+        BatchTable tab;
+        tab.n = (int)take;
+        int blocks = 0;
+        size_t lds = 0;
+        for (size_t i = 0; i < take; ++i) {
+            tab.op[i] = ops[done + i];
+            tab.op[i].first = blocks;
+            blocks += tab.op[i].blocks;
+            lds = std::max(lds, (size_t)16 * tab.op[i].mt * tab.op[i].nt * 64 * sizeof(f32x4));
+        }
+        if (lds > 64 * 1024) {
+            const gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_dense_batch), 136 * 1024);   // (+ 4 static bytes)
+            if (ls != GN_OK) return ls;
+        }
+        k_dense_batch<<<blocks, 1024, lds, st>>>(tab);
+        GN_LAUNCH_CHECK();
+        done += take;
+    }
     return GN_OK;
 }
 
@@ -852,18 +986,14 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     g.sam = at ? 1 : lda; g.sak = at ? lda : 1;
     if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
-        hipStream_t st = gn::as_stream(stream);
-        if (m <= 64) {
-            dim3 grid(1, (unsigned)gn::ceil_div(n, 16), 1);
-            if (m > 32) k_gemm_deep<4, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
-            else if (m > 16) k_gemm_deep<2, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
-            else k_gemm_deep<1, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
-        } else {
-            dim3 grid((unsigned)gn::ceil_div(m, 16), 1, 1);
-            if (n > 16) k_gemm_deep<1, 2><<<grid, kDeepWaves * 64, 0, st>>>(g); else k_gemm_deep<1, 1><<<grid, kDeepWaves * 64, 0, st>>>(g);
+        if (batch_open) {                                     // between gn_dense_batch_begin / _end: leaves with the others
+            BatchOp op;
+            op.kind = 0; op.g = g; op.first = 0;
+            deep_shape(g, op);
+            batch_queue.push_back(op);
+            return GN_OK;
         }
-        GN_LAUNCH_CHECK();
-        return GN_OK;
+        return launch_deep(g, gn::as_stream(stream));
     }
     GN_REQUIRE(!at, "A given transposed: at most 64 rows or 32 columns of output (the deep and narrow kernel)");
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
@@ -956,6 +1086,15 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
     if (m > 0 && k1 <= 64 && k2 <= 32 && (flags & GN_XTG_TICKET_ZEROED) && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0 &&
         !gn::fast_paths_disabled()) {
         const int mt = (int)gn::ceil_div(k1, 16), nt = (int)gn::ceil_div(k2, 16);
+        bool ws_free = true;                                  // a queued product owns its workspace until the batch has left
+        for (const BatchOp& q : batch_queue) ws_free = ws_free && !(q.kind == 1 && q.x.partial == workspace);
+        if (batch_open && ws_free) {
+            BatchOp op;
+            op.kind = 1; op.mt = mt; op.nt = nt; op.first = 0; op.gx = 1; op.blocks = xtg_slices(m);
+            op.x = xtg_args(x, ld_x, g, ld_g, m, (int)k1, (int)k2, out, ld_out, workspace);
+            batch_queue.push_back(op);
+            return GN_OK;
+        }
 #define GN_XTG_CASE(MT, NT) if (mt == MT && nt == NT) return launch_xtg_mfma<MT, NT>(x, ld_x, g, ld_g, m, (int)k1, (int)k2, out, ld_out, workspace, st)
         GN_XTG_CASE(1, 1); GN_XTG_CASE(2, 1); GN_XTG_CASE(3, 1); GN_XTG_CASE(4, 1);
         GN_XTG_CASE(1, 2); GN_XTG_CASE(2, 2); GN_XTG_CASE(3, 2); GN_XTG_CASE(4, 2);
@@ -970,6 +1109,19 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
                                                                   out, ld_out);
     GN_LAUNCH_CHECK();
     return GN_OK;
+}
+
+gn_status gn_dense_batch_begin(void) {
+    GN_REQUIRE(!batch_open, "gn_dense_batch_begin inside an open batch");
+    batch_queue.clear();
+    batch_open = true;
+    return GN_OK;
+}
+
+gn_status gn_dense_batch_end(void* stream) {
+    GN_REQUIRE(batch_open, "gn_dense_batch_end without gn_dense_batch_begin");
+    batch_open = false;
+    return flush_batch(gn::as_stream(stream));
 }
 
 }  // extern "C"

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 136 /* 0.1.34 */
+#define GN_VERSION 137 /* 0.1.34 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -423,6 +423,17 @@ GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sa
  * NULL. */
 GN_API gn_status gn_negative_sampler_sample_stepped(const gn_negative_sampler* sampler, uint64_t seed, uint64_t* step, int64_t* out_u,
                                              int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
+
+/* Independent small products in ONE launch.  Between gn_dense_batch_begin() and gn_dense_batch_end(stream) (per host thread,
+ * not nested) the calls of gn_gemm_f32 that take the deep-and-narrow kernel (a single product with at most 64 rows or 32 columns
+ * of output and A given transposed or K >= 256) and of gn_xtg_f32 that take the one-launch kernel are queued instead of launched,
+ * and leave together at _end as one grid (up to four per launch; a product alone in its batch launches as usual); every other
+ * call inside the bracket launches at once.  The caller promises that the queued products neither depend on each other nor
+ * share a workspace (a second gn_xtg_f32 on a queued workspace launches at once), and that their operands stay valid until
+ * _end.  The weight gradients of the relational layer's backward (dbasis, datt, droot: layers.py:165-197 under autograd) are
+ * three ~11 us launches, or one of 13 us. */
+GN_API gn_status gn_dense_batch_begin(void);
+GN_API gn_status gn_dense_batch_end(void* stream);
 
 /* The element-wise glue in front of a layer's backward pass, in one launch (autograd of layers.py:71-100,165-197 with the
  * ReLU of layers.py:279,305,370):  gm = saved_out > 0 ? g : 0 (saved_out NULL: gm = g);  gd = gm / rowdiv[row] (the mean

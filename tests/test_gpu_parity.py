@@ -1119,6 +1119,51 @@ def test_gemm_with_operands_given_transposed(gpu, m, k, n, at, bt, accumulate):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_independent_products_in_one_launch(gpu):
+    """gn_dense_batch_begin / _end: the deep-and-narrow products and the one-launch x^T g products called inside the bracket
+    leave as one grid (four at most per launch) and give the bits of their own launches; a product of another kind inside the
+    bracket launches at once; a batch of one is the product's own kernel; a second x^T g on a queued workspace is not queued;
+    a bracket cannot be nested."""
+    gen = torch.Generator().manual_seed(11)
+    R, B, K = 964, 32, 48 * 32
+    att = torch.randn(R, B, generator=gen).to(gpu)
+    dw = torch.randn(R, K, generator=gen).to(gpu)
+    basis = torch.randn(B, K, generator=gen).to(gpu)
+    x = torch.randn(645, 48, generator=gen).to(gpu)
+    g = torch.randn(645, 32, generator=gen).to(gpu)
+    wide = torch.randn(K, 40, generator=gen).to(gpu)          # 964 x 40 output: not the deep kernel
+
+    def products(count=None):
+        outs = [torch.full((B, K), float("nan"), device=gpu), torch.full((R, B), float("nan"), device=gpu), None,
+                torch.full((R, 40), float("nan"), device=gpu), torch.full((B, K), float("nan"), device=gpu),
+                torch.full((R, B), float("nan"), device=gpu), None]
+        _hip.gemm(att, dw, outs[0], a_transposed=True)
+        _hip.gemm(dw, basis, outs[1], b_transposed=True)
+        outs[2] = _hip.xtg(x, g)
+        _hip.gemm(dw, wide, outs[3])
+        _hip.gemm(att, dw * 2, outs[4], a_transposed=True)
+        _hip.gemm(dw * 3, basis, outs[5], b_transposed=True)
+        outs[6] = _hip.xtg(x, g)                              # same shape, same workspace as outs[2]
+        return outs
+
+    alone = products()
+    with _hip.dense_batch(gpu):
+        together = products()
+    for a, b in zip(alone, together):
+        assert torch.equal(a, b)
+    assert torch.equal(alone[2], alone[6])
+    close(alone[0], att.t().double().cpu() @ dw.double().cpu(), atol=2e-3)
+    with _hip.dense_batch(gpu):                               # a batch of one
+        single = torch.full((R, B), float("nan"), device=gpu)
+        _hip.gemm(dw, basis, single, b_transposed=True)
+    assert torch.equal(single, alone[1])
+    with pytest.raises(ValueError):
+        _hip.check(_hip.load().gn_dense_batch_end(None))      # no open batch
+    with _hip.dense_batch(gpu):
+        with pytest.raises(ValueError):
+            _hip.check(_hip.load().gn_dense_batch_begin())    # not nested
+
+
 @pytest.mark.parametrize("k,n", [(288, 8), (64, 3), (128, 16), (32, 1), (96, 20), (30, 4)])
 @pytest.mark.parametrize("softmax", [True, False])
 def test_class_scores_vs_torch(gpu, k, n, softmax):
