@@ -22,7 +22,7 @@ GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, G
 GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST = 1, 4                                  # flags of gn_rgcn_forward_f32
 GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # kernel choice (tests, measurements)
-GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED = 1, 2, 4, 8, 16                                     # flags of gn_gemm_f32
+GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
 ABI_VERSION = 137                                       # GN_VERSION of include/gripnet_hip.h this module binds
@@ -421,8 +421,9 @@ def ptr(t):
 # ---- thin typed wrappers ---------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=False, a_rows=None,
          batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None, fast=False,
-         b_transposed=False, accumulate=False, a_transposed=False):
-    """`fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic.
+         b_transposed=False, accumulate=False, a_transposed=False, join_batch=False):
+    """`join_batch`: inside ``with dense_batch(...)`` the product may be queued and leave with the batch (it must not depend
+    on another queued product).  `fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic.
     `b_transposed`: b is [n, k] (out = a b^T); `a_transposed`: a is [k, m] (out = a^T b; m <= 64 or n <= 32 only);
     `accumulate`: out += a b."""
     if a_transposed:
@@ -431,23 +432,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
     m = (a.shape[0] if a_rows is None else a_rows.shape[0]) if m is None else m
     k = a.shape[1] if k is None else k
     n = (b.shape[0] if b_transposed else b.shape[-1]) if n is None else n
-    if _open_batch is not None:                              # a queued product reads its operands when the batch leaves
+    join_batch = join_batch and _open_batch is not None
+    if join_batch:                                           # a queued product reads its operands when the batch leaves
         _open_batch.keep.extend((a, b, out, bias, a_rows))
     _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
                           ptr(b), ld(b) if ldb is None else ldb, stride_b,
                           ptr(out), ld(out) if ldc is None else ldc, stride_c,
           m, n, k, batch, ptr(bias), (GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0) |
           (GN_GEMM_B_TRANSPOSED if b_transposed else 0) | (GN_GEMM_ACCUMULATE if accumulate else 0) |
-          (GN_GEMM_A_TRANSPOSED if a_transposed else 0), stream_ptr(a.device))
+          (GN_GEMM_A_TRANSPOSED if a_transposed else 0) | (GN_GEMM_JOIN_BATCH if join_batch else 0), stream_ptr(a.device))
     return out
 
 
 _xtg_ws = {}
-GN_XTG_TICKET_ZEROED = 1
+GN_XTG_TICKET_ZEROED, GN_XTG_JOIN_BATCH = 1, 2
 
 
-def xtg(x: torch.Tensor, g: torch.Tensor):
-    """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients); torch.matmul beyond 4096 outputs."""
+def xtg(x: torch.Tensor, g: torch.Tensor, join_batch=False):
+    """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients); torch.matmul beyond 4096 outputs.  `join_batch`: as in
+    `gemm`."""
     k1, k2 = x.shape[1], g.shape[1]
     if k1 * k2 > 4096 or k1 * k2 == 0:
         return x.t() @ g
@@ -457,9 +460,11 @@ def xtg(x: torch.Tensor, g: torch.Tensor):
     ws = _xtg_ws.get(key)
     if ws is None:                                             # one zeroed workspace per device and size: its last 64 bytes are the kernel's ticket
         ws = _xtg_ws[key] = torch.zeros((need,), dtype=torch.uint8, device=x.device)
-    if _open_batch is not None:
+    join_batch = join_batch and _open_batch is not None
+    if join_batch:
         _open_batch.keep.extend((x, g, out))
-    _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need, GN_XTG_TICKET_ZEROED,
+    _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need,
+          GN_XTG_TICKET_ZEROED | (GN_XTG_JOIN_BATCH if join_batch else 0),
           stream_ptr(x.device))
     return out
 
@@ -914,12 +919,17 @@ class dense_batch:
 
     def __enter__(self):
         global _open_batch
+        self.off = os.environ.get("GN_DENSE_BATCH") == "0"     # (development switch: every product launches on its own)
+        if self.off:
+            return self
         _call("gn_dense_batch_begin")
         _open_batch = self
         return self
 
     def __exit__(self, *exc):
         global _open_batch
+        if self.off:
+            return False
         _open_batch = None
         try:
             with torch.cuda.device(self.device):

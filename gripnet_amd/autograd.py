@@ -108,10 +108,11 @@ class GcnConvFn(torch.autograd.Function):
         gxw = torch.empty((ctx.plan.n_table, gm.shape[1]), dtype=torch.float32, device=gm.device)
         ctx.plan.aggregate_t(gm, gxw)                          # A_norm^T g  (HIP, source-major CSR)
         dx = None
-        if ctx.needs_input_grad[0]:                            # gxw W^T (gn_gemm_f32, W given as it is stored)
-            dx = torch.empty((gxw.shape[0], w.shape[0]), dtype=torch.float32, device=gxw.device)
-            _hip.gemm(gxw, w, dx, b_transposed=True)
-        dw = _hip.xtg(x, gxw) if ctx.needs_input_grad[1] else None
+        with _hip.dense_batch(gxw.device):                     # dx and dW do not depend on each other: one launch
+            if ctx.needs_input_grad[0]:                        # gxw W^T (gn_gemm_f32, W given as it is stored)
+                dx = torch.empty((gxw.shape[0], w.shape[0]), dtype=torch.float32, device=gxw.device)
+                _hip.gemm(gxw, w, dx, b_transposed=True, join_batch=True)
+            dw = _hip.xtg(x, gxw, join_batch=True) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None, None, None, None
 
 
@@ -142,8 +143,8 @@ class RgcnConvFn(torch.autograd.Function):
                                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
             dx = None
             if ctx.needs_input_grad[0]:                        # dx = dxe + g root^T: the product is added onto the edge sums
-                dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True)
-            droot = _hip.xtg(x, g) if ctx.needs_input_grad[3] else None
+                dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True, join_batch=True)
+            droot = _hip.xtg(x, g, join_batch=True) if ctx.needs_input_grad[3] else None
         return dx, dbasis, datt, droot, dbias, None, None, None, None
 
 
@@ -197,13 +198,13 @@ def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, n
         if need_basis:
             if B <= 64:
                 dbasis = torch.empty((B, fin * fout), dtype=torch.float32, device=x.device)
-                _hip.gemm(att.contiguous(), dw, dbasis, a_transposed=True)
+                _hip.gemm(att.contiguous(), dw, dbasis, a_transposed=True, join_batch=True)
                 dbasis = dbasis.view(B, fin, fout)
             else:
                 dbasis = (att.t() @ dw).view(B, fin, fout)
         if need_att:
             datt = torch.empty((R, B), dtype=torch.float32, device=x.device)
-            _hip.gemm(dw, basis.reshape(B, fin * fout), datt, b_transposed=True)
+            _hip.gemm(dw, basis.reshape(B, fin * fout), datt, b_transposed=True, join_batch=True)
     return dxe, dbasis, datt
 
 

@@ -225,15 +225,15 @@ __global__ __launch_bounds__(kDeepWaves * 64) void k_gemm_deep(GemmArgs g) {
 // 16-byte global load (A) and kColTiles ds_read_b128 per lane instead of 16 four-byte global loads whose issue - not
 // the MFMAs - bounded k_gemm_f32 (17 load instructions of 16 cycles per 16 MFMAs of 8 cycles of the CU).  Workgroups
 // are persistent over the row tiles; A is read one chunk ahead.
-__global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles) {
-    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][64]
+// (bx of nbx workgroups of `waves` waves each walk the row tiles; by: the 64-column block)
+__device__ __forceinline__ void gemm_lds_body(const GemmArgs& g, int row_tiles, int bx, int by, int nbx, int waves, f32x4* __restrict__ bfrag) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int col0 = blockIdx.y * (16 * kColTiles);
+    const int col0 = by * (16 * kColTiles);
     const int chunks = (g.k + 15) / 16;
     const int n_tiles = min(kColTiles, (g.n - col0 + 15) / 16);
-    for (int idx = threadIdx.x; idx < chunks * kColTiles * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < chunks * kColTiles * 64; idx += 64 * waves) {
         const int l = idx & 63, t = (idx >> 6) % kColTiles, ch = idx / (64 * kColTiles);
         const int col = col0 + 16 * t + (l & 15), kb = 16 * ch + 4 * (l >> 4);
         f32x4 v;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles)
         bfrag[idx] = v;
     }
     __syncthreads();
-    for (int tile = blockIdx.x * 4 + wave; tile < row_tiles; tile += gridDim.x * 4) {
+    for (int tile = bx * waves + wave; tile < row_tiles; tile += nbx * waves) {
         const int row0 = tile * 16;
         const int arow = row0 + r;
         int64_t a_src_row = min(arow, g.m - 1);
@@ -299,6 +299,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles)
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_f32_lds(GemmArgs g, int row_tiles) {
+    extern __shared__ f32x4 bfrag[];                          // [chunks][kColTiles][64]
+    gemm_lds_body(g, row_tiles, blockIdx.x, blockIdx.y, gridDim.x, 4, bfrag);
 }
 
 
@@ -827,14 +832,16 @@ gn_status launch_xtg_mfma(const float* x, int64_t ld_x, const float* g, int64_t 
 // ---- independent small products in ONE launch ------------------------------------------------------------------------
 // The weight gradients of a layer's backward are a handful of products of a few dozen workgroups and ~10 us each (latency
 // chains of a few round trips), independent of each other: dbasis = att^T dW, datt = dW basis^T and droot = x^T g of the
-// relational layer.  Between gn_dense_batch_begin() and gn_dense_batch_end(stream) the calls of gn_gemm_f32 that take the
-// deep-and-narrow kernel and of gn_xtg_f32 that take the one-launch kernel are QUEUED (per host thread) and leave as one grid
-// whose workgroups pick their product from a table in the launch's arguments; every other call inside the bracket launches
-// as usual.  The caller promises that the queued products do not depend on each other.
+// relational layer.  Between gn_dense_batch_begin() and gn_dense_batch_end(stream) the calls of gn_gemm_f32 / gn_xtg_f32 that
+// carry GN_GEMM_JOIN_BATCH / GN_XTG_JOIN_BATCH and take the deep-and-narrow, the tall-skinny fp32 or the one-launch x^T g kernel
+// are QUEUED (per host thread) and leave as one grid whose workgroups pick their product from a table in the launch's
+// arguments; every other call inside the bracket - the library's own products inside other entry points among them -
+// launches as usual.  The caller promises that the queued products do not depend on each other.
 constexpr int kBatchMax = 4;
 struct BatchOp {
-    int kind;                        // 0: gemm_deep_body, 1: xtg_mfma_body
-    int mt, nt;                      // the body's tile template
+    int kind;                        // 0: gemm_deep_body, 1: xtg_mfma_body, 2: gemm_lds_body
+    int mt, nt;                      // the body's tile template (kind 2: mt = row tiles)
+    int lds;                         // dynamic LDS bytes of the body
     int first, blocks, gx;           // workgroups [first, first + blocks) of the launch; deep: grid (gx, blocks / gx)
     GemmArgs g;
     XtgArgs x;
@@ -848,6 +855,10 @@ __global__ __launch_bounds__(1024) void k_dense_batch(BatchTable tab) {
     while (k + 1 < tab.n && (int)blockIdx.x >= tab.op[k + 1].first) ++k;   // (uniform: scalar registers)
     const BatchOp& op = tab.op[k];
     const int vb = (int)blockIdx.x - op.first;
+    if (op.kind == 2) {                                          // tall-skinny, B in LDS: sixteen waves per workgroup here
+        gemm_lds_body(op.g, op.mt, vb % op.gx, vb / op.gx, op.gx, 16, batch_lds);
+        return;
+    }
     if (op.kind == 0) {
         const int bx = vb % op.gx, by = vb / op.gx;
         if (op.mt == 1 && op.nt == 1) gemm_deep_body<1, 1>(op.g, bx, by, batch_lds);
@@ -887,6 +898,15 @@ gn_status launch_deep(const GemmArgs& g, hipStream_t st) {
     return GN_OK;
 }
 
+gn_status launch_lds(const GemmArgs& g, hipStream_t st) {
+    const size_t lds_bytes = (size_t)gn::ceil_div(g.k, 16) * kColTiles * 64 * sizeof(f32x4);
+    const int row_tiles = (int)gn::ceil_div(g.m, 16);
+    dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(g.n, 16 * kColTiles), 1);
+    k_gemm_f32_lds<<<lgrid, 256, lds_bytes, st>>>(g, row_tiles);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 XtgArgs xtg_args(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int k1, int k2, float* out, int64_t ld_out, void* workspace) {
     float* partial = static_cast<float*>(workspace);
     unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (size_t)kXtgSlices * k1 * k2 * sizeof(float));
@@ -911,7 +931,7 @@ gn_status flush_batch(hipStream_t st) {
         const size_t take = std::min<size_t>(kBatchMax, ops.size() - done);
         if (take == 1) {                                      // alone: its own kernel
             const BatchOp& op = ops[done];
-            const gn_status rc = op.kind == 0 ? launch_deep(op.g, st) : launch_xtg_op(op, st);
+            const gn_status rc = op.kind == 0 ? launch_deep(op.g, st) : op.kind == 1 ? launch_xtg_op(op, st) : launch_lds(op.g, st);
             if (rc != GN_OK) return rc;
             done += 1;
             continue;
@@ -924,7 +944,7 @@ gn_status flush_batch(hipStream_t st) {
             tab.op[i] = ops[done + i];
             tab.op[i].first = blocks;
             blocks += tab.op[i].blocks;
-            lds = std::max(lds, (size_t)16 * tab.op[i].mt * tab.op[i].nt * 64 * sizeof(f32x4));
+            lds = std::max(lds, (size_t)tab.op[i].lds);
         }
         if (lds > 64 * 1024) {
             const gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_dense_batch), 136 * 1024);   // (+ 4 static bytes)
@@ -986,10 +1006,11 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     g.sam = at ? 1 : lda; g.sak = at ? lda : 1;
     if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
-        if (batch_open) {                                     // between gn_dense_batch_begin / _end: leaves with the others
+        if (batch_open && (flags & GN_GEMM_JOIN_BATCH)) {         // between gn_dense_batch_begin / _end: leaves with the others
             BatchOp op;
             op.kind = 0; op.g = g; op.first = 0;
             deep_shape(g, op);
+            op.lds = (int)((size_t)16 * op.mt * op.nt * 64 * sizeof(f32x4));
             batch_queue.push_back(op);
             return GN_OK;
         }
@@ -1013,10 +1034,15 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
         return fast ? launch_split<2, 4>(g, row_tiles, sgrid, split_bytes, slab, st) : launch_split<3, 4>(g, row_tiles, sgrid, split_bytes, slab, st);
     }
     if (batch == 1 && m >= 256 && lds_bytes <= 64 * 1024 && !gn::fast_paths_disabled()) {      // tall-skinny on the fp32 instruction
-        dim3 lgrid((unsigned)std::min<int64_t>(gn::ceil_div(row_tiles, 4), 1024), (unsigned)gn::ceil_div(n, 16 * kColTiles), 1);
-        k_gemm_f32_lds<<<lgrid, 256, lds_bytes, gn::as_stream(stream)>>>(g, row_tiles);
-        GN_LAUNCH_CHECK();
-        return GN_OK;
+        if (batch_open && (flags & GN_GEMM_JOIN_BATCH) && !a_rows) {   // between gn_dense_batch_begin / _end: leaves with the others
+            BatchOp op;
+            op.kind = 2; op.g = g; op.first = 0; op.mt = row_tiles; op.nt = 0; op.lds = (int)lds_bytes;
+            op.gx = (int)std::min<int64_t>(gn::ceil_div(row_tiles, 16), 256);
+            op.blocks = op.gx * (int)gn::ceil_div(n, 16 * kColTiles);
+            batch_queue.push_back(op);
+            return GN_OK;
+        }
+        return launch_lds(g, gn::as_stream(stream));
     }
     dim3 grid((unsigned)gn::ceil_div(m, 64), (unsigned)gn::ceil_div(n, 16 * kColTiles), (unsigned)batch);
     k_gemm_f32<<<grid, 256, 0, gn::as_stream(stream)>>>(g);
@@ -1088,9 +1114,10 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
         const int mt = (int)gn::ceil_div(k1, 16), nt = (int)gn::ceil_div(k2, 16);
         bool ws_free = true;                                  // a queued product owns its workspace until the batch has left
         for (const BatchOp& q : batch_queue) ws_free = ws_free && !(q.kind == 1 && q.x.partial == workspace);
-        if (batch_open && ws_free) {
+        if (batch_open && (flags & GN_XTG_JOIN_BATCH) && ws_free) {
             BatchOp op;
             op.kind = 1; op.mt = mt; op.nt = nt; op.first = 0; op.gx = 1; op.blocks = xtg_slices(m);
+            op.lds = (int)((size_t)16 * mt * nt * 64 * sizeof(f32x4));
             op.x = xtg_args(x, ld_x, g, ld_g, m, (int)k1, (int)k2, out, ld_out, workspace);
             batch_queue.push_back(op);
             return GN_OK;

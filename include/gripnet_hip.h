@@ -188,6 +188,7 @@ GN_API gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float
 #define GN_GEMM_B_TRANSPOSED 4  /* b is given as [n, k] row-major (leading dimension ldb >= k): c = a b^T - the dx = g W^T of the backward passes */
 #define GN_GEMM_ACCUMULATE 8    /* c += a b (+ bias) instead of c = ... */
 #define GN_GEMM_A_TRANSPOSED 16  /* a is given as [k, m] row-major (lda >= m): c = a^T b; m <= 64 or n <= 32 only: dbasis = att^T dW */
+#define GN_GEMM_JOIN_BATCH 32   /* the product may leave with the open batch (gn_dense_batch_begin / _end, below) */
 GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
                       int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream);
@@ -199,6 +200,7 @@ GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, cons
  * were zeroed once by the caller and are touched by nobody else (calls on one workspace stream-ordered): up to 64 x 32 outputs then take ONE launch on the matrix
  * cores (slices added in slice order by the last slice to arrive) instead of a partial-sum launch and a fold. */
 #define GN_XTG_TICKET_ZEROED 1
+#define GN_XTG_JOIN_BATCH 2      /* the product may leave with the open batch (gn_dense_batch_begin / _end) */
 GN_API size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2);
 GN_API gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int64_t k1, int64_t k2,
                      float* out, int64_t ld_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
@@ -425,13 +427,14 @@ GN_API gn_status gn_negative_sampler_sample_stepped(const gn_negative_sampler* s
                                              int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
 
 /* Independent small products in ONE launch.  Between gn_dense_batch_begin() and gn_dense_batch_end(stream) (per host thread,
- * not nested) the calls of gn_gemm_f32 that take the deep-and-narrow kernel (a single product with at most 64 rows or 32 columns
- * of output and A given transposed or K >= 256) and of gn_xtg_f32 that take the one-launch kernel are queued instead of launched,
+ * not nested) the calls that carry GN_GEMM_JOIN_BATCH / GN_XTG_JOIN_BATCH - those of gn_gemm_f32 that take the deep-and-narrow kernel (a single product with at most 64 rows or 32 columns
+ * of output and A given transposed or K >= 256) or the tall-skinny fp32 kernel (a single product of >= 256 rows whose B fits 64 KB
+ * of LDS, no row gather) and of gn_xtg_f32 that take the one-launch kernel are queued instead of launched,
  * and leave together at _end as one grid (up to four per launch; a product alone in its batch launches as usual); every other
- * call inside the bracket launches at once.  The caller promises that the queued products neither depend on each other nor
+ * call inside the bracket (without the flag, of another shape, or made by the library inside another entry point) launches at once.  The caller promises that the queued products neither depend on each other nor
  * share a workspace (a second gn_xtg_f32 on a queued workspace launches at once), and that their operands stay valid until
- * _end.  The weight gradients of the relational layer's backward (dbasis, datt, droot: layers.py:165-197 under autograd) are
- * three ~11 us launches, or one of 13 us. */
+ * _end.  The dense products of the relational layer's backward (dbasis, datt, droot, dx += g root^T: layers.py:165-197 under
+ * autograd) are four ~10 us launches, or one of 13 us; a GCN layer's dx and dW (layers.py:71-100) two, or one. */
 GN_API gn_status gn_dense_batch_begin(void);
 GN_API gn_status gn_dense_batch_end(void* stream);
 

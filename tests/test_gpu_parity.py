@@ -1131,31 +1131,32 @@ def test_independent_products_in_one_launch(gpu):
     basis = torch.randn(B, K, generator=gen).to(gpu)
     x = torch.randn(645, 48, generator=gen).to(gpu)
     g = torch.randn(645, 32, generator=gen).to(gpu)
-    wide = torch.randn(K, 40, generator=gen).to(gpu)          # 964 x 40 output: not the deep kernel
+    wide = torch.randn(K, 40, generator=gen).to(gpu)          # 964 x 40 output over K = 1536: the tall-skinny kernel
+    dw2, dw3 = dw * 2, dw * 3
 
-    def products(count=None):
+    def products(join=False):
         outs = [torch.full((B, K), float("nan"), device=gpu), torch.full((R, B), float("nan"), device=gpu), None,
                 torch.full((R, 40), float("nan"), device=gpu), torch.full((B, K), float("nan"), device=gpu),
                 torch.full((R, B), float("nan"), device=gpu), None]
-        _hip.gemm(att, dw, outs[0], a_transposed=True)
-        _hip.gemm(dw, basis, outs[1], b_transposed=True)
-        outs[2] = _hip.xtg(x, g)
-        _hip.gemm(dw, wide, outs[3])
-        _hip.gemm(att, dw * 2, outs[4], a_transposed=True)
-        _hip.gemm(dw * 3, basis, outs[5], b_transposed=True)
-        outs[6] = _hip.xtg(x, g)                              # same shape, same workspace as outs[2]
+        _hip.gemm(att, dw, outs[0], a_transposed=True, join_batch=join)
+        _hip.gemm(dw, basis, outs[1], b_transposed=True, join_batch=join)
+        outs[2] = _hip.xtg(x, g, join_batch=join)
+        _hip.gemm(dw, wide, outs[3], join_batch=join)
+        _hip.gemm(att, dw2, outs[4], a_transposed=True, join_batch=join)
+        _hip.gemm(dw3, basis, outs[5], b_transposed=True)       # without the flag: at once
+        outs[6] = _hip.xtg(x, g, join_batch=join)             # same shape, same workspace as outs[2]: at once
         return outs
 
     alone = products()
     with _hip.dense_batch(gpu):
-        together = products()
+        together = products(True)
     for a, b in zip(alone, together):
         assert torch.equal(a, b)
     assert torch.equal(alone[2], alone[6])
     close(alone[0], att.t().double().cpu() @ dw.double().cpu(), atol=2e-3)
     with _hip.dense_batch(gpu):                               # a batch of one
         single = torch.full((R, B), float("nan"), device=gpu)
-        _hip.gemm(dw, basis, single, b_transposed=True)
+        _hip.gemm(dw, basis, single, b_transposed=True, join_batch=True)
     assert torch.equal(single, alone[1])
     with pytest.raises(ValueError):
         _hip.check(_hip.load().gn_dense_batch_end(None))      # no open batch
