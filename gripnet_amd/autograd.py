@@ -337,10 +337,14 @@ class ClassLogitsFn(torch.autograd.Function):
         g = g.contiguous()
         dz = dw = None
         g = _hip.f32_rows(g)
-        if ctx.needs_input_grad[0]:                            # rows of g W^T (gn_gemm_f32, W as it is stored) added at the listed nodes
-            gw = torch.empty((g.shape[0], w.shape[0]), dtype=torch.float32, device=g.device)
-            _hip.gemm(g, w, gw, b_transposed=True)
+        zsel = z.index_select(0, nodes) if ctx.needs_input_grad[1] else None
+        gw = None
+        with _hip.dense_batch(g.device):                       # the two products do not depend on each other: one launch
+            if ctx.needs_input_grad[0]:                        # rows of g W^T (gn_gemm_f32, W as it is stored) ...
+                gw = torch.empty((g.shape[0], w.shape[0]), dtype=torch.float32, device=g.device)
+                _hip.gemm(g, w, gw, b_transposed=True, join_batch=True)
+            if zsel is not None:                               # z[nodes]^T g (gn_xtg_f32)
+                dw = _hip.xtg(zsel, g, join_batch=True)
+        if gw is not None:                                     # ... added at the listed nodes
             dz = torch.zeros_like(z).index_add_(0, nodes, gw)
-        if ctx.needs_input_grad[1]:                            # z[nodes]^T g (gn_xtg_f32)
-            dw = _hip.xtg(z.index_select(0, nodes), g)
         return dz, dw, None
