@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4}                  # k
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 137                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 138                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "gn_distmult_type_tasks": (_int, [_p, _i64, _i64, _p, _sz, _p]),
     "gn_distmult_backward_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_ex_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _p, _sz, _p]),
+    "gn_distmult_backward_packed_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _int, _p, _p, _p, _sz, _p]),
     "gn_distmult_bwd_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_distmult_bwd_plan_destroy": (None, [_p]),
     "gn_distmult_bwd_plan_workspace_bytes": (_sz, [_p, _i64]),
@@ -969,6 +970,17 @@ def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd, probs=None)
     flags = (GN_DM_TYPES_SORTED | GN_DM_TYPE_TASKS) if offsets is not None else 0
     need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], weight.shape[0], e))
     ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
+    packed = packed_pairs(u_v)
+    if packed is not None and offsets is not None and z.shape[0] <= 65535 and weight.shape[0] <= 32767:
+        # the sampler's 32-bit pairs + the static edge_type's 16-bit ids: 6 instead of 24 bytes per edge and sort pass
+        try:
+            _call("gn_distmult_backward_packed_f32", ptr(z), ld(z), z.shape[0], z.shape[1], ptr(packed), ptr(relation_ids16(edge_type)),
+                  ptr(weight), ld(weight), weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), flags, ptr(probs),
+                  ptr(offsets), ptr(ws), need, stream_ptr(z.device))
+            return dz, dd
+        except GripNetHipError as err:                     # tables too large for the counting-sort path: the int64 call
+            if err.status != GN_ERR_UNSUPPORTED:
+                raise
     _call("gn_distmult_backward_ex_f32", ptr(z), ld(z), z.shape[0], z.shape[1], u, v, ptr(et), ptr(weight), ld(weight),
           weight.shape[0], e, ptr(grad_logit), ptr(dz), ld(dz), ptr(dd), ld(dd), flags, ptr(probs), ptr(offsets), ptr(ws),
           need, stream_ptr(z.device))

@@ -52,6 +52,22 @@ struct GradSrc {
     }
 };
 
+// Where a call's triples come from: the int64 arrays of the reference's tensors, or - the negative samples as the sampler
+// leaves them next to its int64 output - one 32-bit word per pair (u | v << 16) and a 16-bit relation id per position:
+// 6 instead of 24 bytes per edge in each of the counting sort's two passes.
+struct EdgeSrc {
+    const int64_t* u; const int64_t* v; const int64_t* et;
+    const uint32_t* packed; const uint16_t* rel16;
+    __device__ __forceinline__ void load(int64_t e, int64_t& uu, int64_t& vv, int64_t& rr) const {
+        if (packed) {
+            const uint32_t w = packed[e];
+            uu = w & 0xffffu; vv = w >> 16; rr = rel16[e];
+        } else {
+            uu = u[e]; vv = v[e]; rr = et[e];
+        }
+    }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -315,8 +331,7 @@ static_assert(kSortWavesPerWg == 4, "k_he_scatter_staged reads the four wave off
 constexpr int64_t kSortMaxKeys = 4096;        // 4 waves x 16 KB of histogram
 
 template <bool SCATTER>
-__global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
-                                                                   const int64_t* __restrict__ et, GradSrc gs,
+__global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(EdgeSrc src, GradSrc gs,
                                                                    int64_t E, int n, int64_t R, int32_t* __restrict__ counts,
                                                                    uint64_t* __restrict__ recs, uint64_t* __restrict__ pair_recs) {
     extern __shared__ int32_t he_hist[];
@@ -332,14 +347,15 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_sort(const int64_t*
     if (SCATTER && e0 >= e1) return;
     const size_t dump = (size_t)2 * E;                   // 64 spare records behind the 2 E real ones
     int64_t at = max<int64_t>(0, min(e0 + lane, e1 - 1));
-    int64_t nu = u[at], nv = v[at], nr = et[at];
+    int64_t nu, nv, nr;
+    src.load(at, nu, nv, nr);
     float ng = SCATTER ? gs.at(at) : 0.f;
     for (int64_t base = e0; base < e1; base += 64) {
         const int64_t uu = nu, vv = nv, rr = nr;
         const float g = ng;
         const bool have = base + lane < e1;
         at = min(base + 64 + lane, e1 - 1);
-        nu = u[at]; nv = v[at]; nr = et[at];
+        src.load(at, nu, nv, nr);
         if (SCATTER) ng = gs.at(at);
         const bool ok = have && (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
         if (SCATTER) {
@@ -448,8 +464,7 @@ __global__ __launch_bounds__(kOffsetThreads) void k_he_offsets(int32_t* __restri
 // without them).  Here the waves of a workgroup own adjacent slices, so for every node the workgroup's records form
 // one contiguous run of the output; they are placed in an LDS copy of that layout first (same wave-private offsets,
 // shifted to the workgroup's base) and then copied out in order: consecutive lanes write consecutive records.
-__global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_scatter_staged(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
-                                                                             const int64_t* __restrict__ et, GradSrc gs,
+__global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_scatter_staged(EdgeSrc src, GradSrc gs,
                                                                              int64_t E, int n, int64_t R, const int32_t* __restrict__ offsets,
                                                                              uint64_t* __restrict__ recs, uint64_t* __restrict__ pair_recs,
                                                                              int stage_cap) {
@@ -502,14 +517,15 @@ __global__ __launch_bounds__(kSortWavesPerWg * 64) void k_he_scatter_staged(cons
         const size_t dump = (size_t)2 * E;
         if (e0 < e1) {
             int64_t at = min(e0 + lane, e1 - 1);
-            int64_t nu = u[at], nv = v[at], nr = et[at];
+            int64_t nu, nv, nr;
+            src.load(at, nu, nv, nr);
             float ng = gs.at(at);
             for (int64_t base = e0; base < e1; base += 64) {
                 const int64_t uu = nu, vv = nv, rr = nr;
                 const float g = ng;
                 const bool have = base + lane < e1;
                 at = min(base + 64 + lane, e1 - 1);
-                nu = u[at]; nv = v[at]; nr = et[at]; ng = gs.at(at);
+                src.load(at, nu, nv, nr); ng = gs.at(at);
                 const bool ok = have && (uint64_t)uu < (uint64_t)n && (uint64_t)vv < (uint64_t)n && (uint64_t)rr < (uint64_t)R;
                 if (ok) {
                     const int pu = atomicAdd(&mine[uu], 1);
@@ -822,12 +838,16 @@ extern "C" size_t gn_distmult_backward_workspace_bytes(int64_t n, int64_t f, int
     return std::max(ws_layout(e, std::max(n, r)).total, lds_layout(e, n, r, f).total);
 }
 
-extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
-                                                 const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
-                                                 int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
-                                                 float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
-                                                 const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
-                                                 void* stream) {
+namespace {
+gn_status backward_impl(const float* z, int64_t ld_z, int64_t n, int64_t f, const EdgeSrc& edges, const float* d, int64_t ld_d,
+                        int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
+                        float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
+                        const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    const int64_t* u = edges.u;
+    const int64_t* v = edges.v;
+    const int64_t* et = edges.et;
+    const bool from_words = edges.packed != nullptr;           // no int64 arrays: the counting-sort / LDS path or nothing
     GN_REQUIRE(n >= 0 && f >= 0 && r >= 0 && e >= 0, "negative size");
     GN_REQUIRE(f < (1ll << 31) && n < (1ll << 31) && r < (1ll << 31) && e < (1ll << 31), "table or edge list too large");
     GN_REQUIRE((n == 0 || f == 0 || dz) && (r == 0 || f == 0 || dd), "gradient output pointer is null");
@@ -839,7 +859,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
         GN_REQUIRE(e == 0 || f == 0 || (n > 0 && r > 0), "edges given but the node or relation table is empty");
         return GN_OK;
     }
-    GN_REQUIRE(z && u && v && et && d && grad_logit, "operand pointer is null");
+    GN_REQUIRE(z && d && grad_logit && (from_words ? edges.rel16 != nullptr : (u && v && et)), "operand pointer is null");
     const GradSrc grad = {grad_logit, sigmoid_scores};
     GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
     const WsLayout l = ws_layout(e, std::max(n, r));
@@ -863,6 +883,8 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
                             ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) |
                               reinterpret_cast<uintptr_t>(dd)) & 15) == 0;
     const bool lds_dz = lds_shapes && lds_dz_fits(n, r), lds_dd = lds_shapes && lds_dd_fits(n);
+    if (from_words && !(lds_dz && lds_dd && n <= kSortMaxKeys && (flags & GN_DM_TYPES_SORTED) && type_offsets))
+        return gn::fail(GN_ERR_UNSUPPORTED, "packed pairs: only the counting-sort path (tables in LDS, sorted edge_type with its offsets); use gn_distmult_backward_ex_f32");
     if (lds_dz || lds_dd) {
         uint32_t* k2 = reinterpret_cast<uint32_t*>(ws + ll.keys);
         uint32_t* k2s = reinterpret_cast<uint32_t*>(ws + ll.keys_sorted);
@@ -890,7 +912,7 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             }
             int32_t* counts = reinterpret_cast<int32_t*>(ws + ll.counts);
             const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
-            k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad, e, (int)n, r,
+            k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(edges, grad, e, (int)n, r,
                                                                                                    counts, nullptr, nullptr);
             GN_LAUNCH_CHECK();
             // offsets of every (node, wave) cell + the reduction's task list (the totals sit in the row-offset scratch, unused on this path)
@@ -904,9 +926,9 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
             const size_t staged_bytes = hist_bytes + (2 * (size_t)n + 2 + 1) * sizeof(int32_t) + stage_cap * sizeof(uint64_t);
             if (staged_bytes <= 127 * 1024) {                  // (78 KB on pose0-syn: two workgroups per CU)
                 k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(
-                    u, v, et, grad, e, (int)n, r, counts, r2s, pairs_done ? r2 : nullptr, (int)stage_cap);
+                    edges, grad, e, (int)n, r, counts, r2s, pairs_done ? r2 : nullptr, (int)stage_cap);
             } else {
-                k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, grad, e, (int)n, r,
+                k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(edges, grad, e, (int)n, r,
                                                                                                       counts, r2s, pairs_done ? r2 : nullptr);
             }
             GN_LAUNCH_CHECK();
@@ -993,6 +1015,28 @@ extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, i
     }
     return GN_OK;
 }
+}  // namespace
+
+extern "C" gn_status gn_distmult_backward_ex_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
+                                                 const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
+                                                 int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
+                                                 float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
+                                                 const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
+                                                 void* stream) {
+    return backward_impl(z, ld_z, n, f, EdgeSrc{u, v, et, nullptr, nullptr}, d, ld_d, r, e, grad_logit, dz, ld_dz, dd, ld_dd, flags,
+                         sigmoid_scores, type_offsets, workspace, workspace_bytes, stream);
+}
+
+extern "C" gn_status gn_distmult_backward_packed_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const uint32_t* packed_uv,
+                                                     const uint16_t* rel16, const float* d, int64_t ld_d, int64_t r, int64_t e,
+                                                     const float* grad_logit, float* dz, int64_t ld_dz, float* dd, int64_t ld_dd,
+                                                     int flags, const float* sigmoid_scores, const int32_t* type_offsets,
+                                                     void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(e == 0 || (packed_uv && rel16), "packed pairs or relation ids are null");
+    GN_REQUIRE(n <= 65536 && r <= 65536, "packed pairs hold ids of 16 bits");
+    return backward_impl(z, ld_z, n, f, EdgeSrc{nullptr, nullptr, nullptr, packed_uv, rel16}, d, ld_d, r, e, grad_logit, dz, ld_dz, dd,
+                         ld_dd, flags, sigmoid_scores, type_offsets, workspace, workspace_bytes, stream);
+}
 
 extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
                                               const int64_t* v, const int64_t* et, const float* d, int64_t ld_d,
@@ -1075,7 +1119,7 @@ gn_status place_static_records(gn_distmult_bwd_plan* p, const int64_t* u, const 
     const size_t staged_bytes = hist_bytes + (2 * (size_t)n + 2 + 1) * sizeof(int32_t) + stage_cap * sizeof(uint64_t);
     if (staged_bytes <= 127 * 1024) {
         { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_scatter_staged), 128 * 1024); if (lds_status != GN_OK) return lds_status; }
-        k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(u, v, et, index, E, (int)n, R, p->offsets.p,
+        k_he_scatter_staged<<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, staged_bytes, st>>>(EdgeSrc{u, v, et, nullptr, nullptr}, index, E, (int)n, R, p->offsets.p,
                                                                                                   p->he_static.p, p->pr_static.p, (int)stage_cap);
     } else {
         // the unstaged pass advances its offsets in place: it works on a copy
@@ -1084,7 +1128,7 @@ gn_status place_static_records(gn_distmult_bwd_plan* p, const int64_t* u, const 
         GN_HIP(tmp.get(&copy, cells));
         GN_HIP(hipMemcpyAsync(copy, p->offsets.p, cells * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_he_sort<true>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
-        k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, index, E, (int)n, R, copy, p->he_static.p,
+        k_he_sort<true><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(EdgeSrc{u, v, et, nullptr, nullptr}, index, E, (int)n, R, copy, p->he_static.p,
                                                                                               p->pr_static.p);
     }
     GN_LAUNCH_CHECK();
@@ -1110,7 +1154,7 @@ gn_status build_bwd_plan(gn_distmult_bwd_plan* p, const int64_t* u, const int64_
     GN_HIP(p->offsets.alloc(cells));
     const GradSrc none = {nullptr, nullptr};
     const size_t hist_bytes = (size_t)kSortWavesPerWg * n * sizeof(int32_t);
-    k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(u, v, et, none, E, (int)n, R, p->offsets.p, nullptr,
+    k_he_sort<false><<<kSortWaves / kSortWavesPerWg, kSortWavesPerWg * 64, hist_bytes, st>>>(EdgeSrc{u, v, et, nullptr, nullptr}, none, E, (int)n, R, p->offsets.p, nullptr,
                                                                                            nullptr);
     GN_LAUNCH_CHECK();
     GN_HIP(rocprim::exclusive_scan(scratch, scan_bytes, p->offsets.p, p->offsets.p, 0, cells, rocprim::plus<int32_t>(), st));

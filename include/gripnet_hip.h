@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 137 /* 0.1.34 */
+#define GN_VERSION 138 /* 0.1.34 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -363,6 +363,16 @@ GN_API size_t gn_distmult_type_tasks_bytes(int64_t num_relations, int64_t num_ed
  * then the task list. */
 GN_API gn_status gn_distmult_type_tasks(const int32_t* type_offsets, int64_t num_relations, int64_t num_edges, void* out,
                                  size_t out_bytes, void* stream);
+/* The same gradients from the triples as the negative sampler leaves them next to its int64 output
+ * (gn_negative_sampler_sample_packed / _stepped): packed_uv[e] = u | v << 16 and a 16-bit relation id per position (the
+ * static edge_type, narrowed once by the caller) - 6 instead of 24 bytes per edge in each pass of the counting sort.  Takes
+ * the counting-sort / LDS path only: GN_DM_TYPES_SORTED with type_offsets, tables that fit the LDS, at most 4,096 nodes;
+ * GN_ERR_UNSUPPORTED otherwise (call gn_distmult_backward_ex_f32 on the int64 arrays).  Same bits as the int64 call. */
+GN_API gn_status gn_distmult_backward_packed_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
+                                          const uint32_t* packed_uv, const uint16_t* rel16, const float* d, int64_t ld_d,
+                                          int64_t num_relations, int64_t num_edges, const float* grad_logit, float* dz,
+                                          int64_t ld_dz, float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
+                                          const int32_t* type_offsets, void* workspace, size_t workspace_bytes, void* stream);
 GN_API size_t gn_distmult_backward_workspace_bytes(int64_t num_nodes, int64_t num_features, int64_t num_relations,
                                             int64_t num_edges);
 GN_API gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
