@@ -149,7 +149,7 @@ def train_step_entry(dev, steps=20):
     _hip.raise_if_index_errors(dev)
     return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
             "what": "negative sampling + forward + DistMult on positives and on the fresh negatives + loss (utils.link_loss) + backward + Adam (gripnet_amd.optim.Adam, one launch): "
-                    "one hipGraph replay per step and nothing else; the draw (typed sampler, 31 us) is the graph's first node, its seed moves with a counter on the device "
+                    "one hipGraph replay per step and nothing else; the draw (typed sampler, 22 us) is the graph's first node, its seed moves with a counter on the device "
                     "(as a BRANCH beside the encoder the step is 40 us slower: a forked hipGraph pays more in its joins than the overlap returns)",
             "loss_after": round(losses[-1], 5)}
 
