@@ -432,7 +432,8 @@ GN_API gn_status gn_negative_sampler_sample_packed(const gn_negative_sampler* sa
  * `step` a 64-bit counter in device memory (8-byte aligned, set by the caller once) that a one-thread launch behind the draw
  * advances by one.  Replay k of a captured call therefore writes what gn_negative_sampler_sample(_packed) writes for
  * seed + step0 + k: new negatives every epoch (GripNet-pose.py:131) without a launch outside the graph.  packed_uv may be
- * NULL. */
+ * NULL.  Stepped draws of ONE sampler must not run concurrently (they share the sampler's arrival counter): one stream, or
+ * one sampler per stream. */
 GN_API gn_status gn_negative_sampler_sample_stepped(const gn_negative_sampler* sampler, uint64_t seed, uint64_t* step, int64_t* out_u,
                                              int64_t* out_v, uint32_t* packed_uv, int32_t* error_flag, void* stream);
 
