@@ -577,22 +577,40 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
     __syncthreads();
     const char* ta = reinterpret_cast<const char*>(seg_lds4) + l4 * 16;
     const char* tb = same ? ta : ta + (size_t)a.rows_a * 64;
-    const int tasks = *a.n_tasks;
+    const int tasks = __builtin_amdgcn_readfirstlane(*a.n_tasks);
     const int t_step = a.workers * (kLdsThreads / 64);
-    int t = worker * (kLdsThreads / 64) + wave;
-    int4 desc = a.tasks[t < tasks ? t : 0];
-    for (; t < tasks; t += t_step) {
-        const int begin = desc.y, end = desc.z;
-        desc = a.tasks[t + t_step < tasks ? t + t_step : 0];        // the next task's descriptor: a task ahead
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        uint64_t next = begin + lane < end ? a.recs[begin + lane] : 0ull;
-        for (int base = begin; base < end; base += 64) {
-            const uint64_t rec = next;
-            const int nidx = base + 64 + lane;
-            next = nidx < end ? a.recs[nidx] : 0ull;      // a batch ahead
-            const int ab = (int)(uint32_t)rec, gb = (int)(uint32_t)(rec >> 32);
-            f32x4 va[4], vb[4];
-            float gs[4];
+    // The wave's tasks (t, t + t_step, ...) are ONE stream of 64-record batches, requested FOUR batches ahead of the arithmetic and
+    // across task boundaries: with one batch ahead a wave waited a memory round trip (~0.8 us) per batch - 126 clocks per batch
+    // and CU where the LDS reads need ~70 - and once more at every task's start.  Four fixed register sets (a rotation of
+    // registers with loads in flight makes hipcc wait for all of them); what a batch belongs to travels in scalars.
+    // (the descriptors are uniform: read through the scalar cache - as vector loads they would share the records' counter and
+    // every use of one would wait for all record loads in flight)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) i32x4* scalar_desc_t;
+    const scalar_desc_t descs = (scalar_desc_t)(uintptr_t)a.tasks;
+    int ft = worker * (kLdsThreads / 64) + wave;             // fetch cursor: the task, its descriptor, the next one's, the position
+    bool fvalid = ft < tasks;
+    i32x4 fdesc = descs[fvalid ? ft : 0];
+    i32x4 fnext = descs[ft + t_step < tasks ? ft + t_step : 0];
+    int fpos = fdesc.y;
+    if (!fvalid) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // (unconditional loads at a clamped index: past the wave's last task the cursor stays on that task and the batch is not used)
+#define GN_SEG_FETCH(REC, CNT, TASK, LAST, VALID)                                                              \
+    {                                                                                                         \
+        VALID = fvalid; TASK = ft;                                                                            \
+        REC = a.recs[min(fpos + lane, fdesc.z - 1)];          /* (masked where it is used: not here, behind the load) */ \
+        CNT = fdesc.z - fpos;                                                                                 \
+        LAST = fpos + 64 >= fdesc.z;                                                                          \
+        if (!LAST) {                                                                                          \
+            fpos += 64;                                                                                       \
+        } else if (ft + t_step < tasks) {                                                                     \
+            ft += t_step; fdesc = fnext; fpos = fdesc.y;                                                      \
+            fnext = descs[ft + t_step < tasks ? ft + t_step : 0];                                             \
+        } else {                                                                                              \
+            fvalid = false;                                                                                   \
+        }                                                                                                     \
+    }
 #define GN_SEG_STEP(S)                                                                                    \
             {                                                                                             \
                 const uint32_t x = (uint32_t)__builtin_amdgcn_mov_dpp(ab, (S) * 0x55, 0xf, 0xf, true);    \
@@ -600,24 +618,52 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
                 va[S] = *reinterpret_cast<const f32x4*>(ta + ((x & 0xffffu) << 6));                       \
                 vb[S] = *reinterpret_cast<const f32x4*>(tb + ((x >> 16) << 6));                           \
             }
-            GN_SEG_STEP(0) GN_SEG_STEP(1) GN_SEG_STEP(2) GN_SEG_STEP(3)
-#undef GN_SEG_STEP
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc += gs[s] * (va[s] * vb[s]);
-        }
-        // the 16 quads of the wave, in a fixed order: inside the rows of 16 lanes, then across the four rows
-        // (ds_bpermute: once per task; hipcc folds the four DPP row rotations of a float4 into one, wrongly)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x = acc[c];
-            x += __shfl_xor(x, 4);
-            x += __shfl_xor(x, 8);
-            x += __shfl_xor(x, 16);
-            x += __shfl_xor(x, 32);
-            acc[c] = x;
-        }
-        if (lane < w4) *reinterpret_cast<f32x4*>(a.partial + (size_t)t * a.f + c0 + 4 * lane) = acc;
+#define GN_SEG_CONSUME(REC, CNT, TASK, LAST)                                                              \
+    {                                                                                                         \
+        const uint64_t rec_ = lane < CNT ? REC : 0ull;                                                        \
+        const int ab = (int)(uint32_t)rec_, gb = (int)(uint32_t)(rec_ >> 32);                                 \
+        f32x4 va[4], vb[4];                                                                                   \
+        float gs[4];                                                                                          \
+        GN_SEG_STEP(0) GN_SEG_STEP(1) GN_SEG_STEP(2) GN_SEG_STEP(3)                                           \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) acc += gs[s_] * (va[s_] * vb[s_]);                   \
+        if (LAST) {                                                                                           \
+            /* the 16 quads of the wave, in a fixed order: inside the rows of 16 lanes, then across the four rows */ \
+            /* (ds_bpermute: once per task; hipcc folds the four DPP row rotations of a float4 into one, wrongly) */ \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                   \
+                float x = acc[c];                                                                             \
+                x += __shfl_xor(x, 4);                                                                        \
+                x += __shfl_xor(x, 8);                                                                        \
+                x += __shfl_xor(x, 16);                                                                       \
+                x += __shfl_xor(x, 32);                                                                       \
+                acc[c] = x;                                                                                   \
+            }                                                                                                 \
+            if (lane < w4) *reinterpret_cast<f32x4*>(a.partial + (size_t)TASK * a.f + c0 + 4 * lane) = acc;  \
+            acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                \
+        }                                                                                                     \
     }
+    uint64_t r0, r1, r2, r3;
+    int k0, k1, k2, k3, c0_, c1_, c2_, c3_;
+    bool l0, l1, l2, l3, v0, v1, v2, v3;
+    GN_SEG_FETCH(r0, c0_, k0, l0, v0)
+    GN_SEG_FETCH(r1, c1_, k1, l1, v1)
+    GN_SEG_FETCH(r2, c2_, k2, l2, v2)
+    GN_SEG_FETCH(r3, c3_, k3, l3, v3)
+    while (v0) {
+        GN_SEG_CONSUME(r0, c0_, k0, l0)
+        GN_SEG_FETCH(r0, c0_, k0, l0, v0)
+        if (!v1) break;
+        GN_SEG_CONSUME(r1, c1_, k1, l1)
+        GN_SEG_FETCH(r1, c1_, k1, l1, v1)
+        if (!v2) break;
+        GN_SEG_CONSUME(r2, c2_, k2, l2)
+        GN_SEG_FETCH(r2, c2_, k2, l2, v2)
+        if (!v3) break;
+        GN_SEG_CONSUME(r3, c3_, k3, l3)
+        GN_SEG_FETCH(r3, c3_, k3, l3, v3)
+    }
+#undef GN_SEG_CONSUME
+#undef GN_SEG_STEP
+#undef GN_SEG_FETCH
 }
 
 // out[key, :] = the key's task partials.  One workgroup per key: eight slices take every eighth task each (four
@@ -1135,6 +1181,40 @@ gn_status place_static_records(gn_distmult_bwd_plan* p, const int64_t* u, const 
     return GN_OK;
 }
 
+// The node-major records of a static list, batch by batch of their tasks, in the bank-balanced order (host_layout.hpp): the
+// partner's row of z and the relation's row of D have four different indices mod 4 in every lane group where the batch allows it.
+gn_status balance_static_records(gn_distmult_bwd_plan* p, hipStream_t st) {
+    const int64_t n_rec = 2 * p->e;
+    int32_t n_tasks = 0;
+    GN_HIP(hipMemcpyAsync(&n_tasks, p->he_taskptr.p + p->n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    if (n_tasks <= 0 || n_rec <= 0) return GN_OK;
+    std::vector<uint64_t> recs((size_t)n_rec);
+    std::vector<int32_t> tasks((size_t)n_tasks * 4);
+    GN_HIP(hipMemcpyAsync(recs.data(), p->he_static.p, recs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipMemcpyAsync(tasks.data(), p->he_tasks.p, tasks.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    uint64_t tmp[64];
+    for (int32_t t = 0; t < n_tasks; ++t) {
+        const int64_t begin = tasks[(size_t)t * 4 + 1], end = tasks[(size_t)t * 4 + 2];
+        if (begin < 0 || end > n_rec) return gn::fail(GN_ERR_INVALID_ARG, "task %d of the decoder gradient plan lies outside its records", (int)t);
+        for (int64_t b0 = begin; b0 + 64 <= end; b0 += 64) {
+            uint8_t cls[64];
+            int order[64];
+            for (int i = 0; i < 64; ++i) {
+                const uint32_t w = (uint32_t)recs[(size_t)(b0 + i)];
+                cls[i] = (uint8_t)((w & 3u) | (((w >> 16) & 3u) << 2));
+            }
+            gn_layout::balance_batch64(cls, order);
+            for (int i = 0; i < 64; ++i) tmp[i] = recs[(size_t)(b0 + order[i])];
+            for (int i = 0; i < 64; ++i) recs[(size_t)(b0 + i)] = tmp[i];
+        }
+    }
+    GN_HIP(hipMemcpyAsync(p->he_static.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    GN_HIP(hipStreamSynchronize(st));
+    return GN_OK;
+}
+
 gn_status build_bwd_plan(gn_distmult_bwd_plan* p, const int64_t* u, const int64_t* v, const int64_t* et, hipStream_t st) {
     const int64_t E = p->e, n = p->n, R = p->r;
     TmpBufs tmp;
@@ -1234,6 +1314,33 @@ extern "C" gn_status gn_distmult_bwd_plan_create(const int64_t* u, const int64_t
             }
         }
     }
+    // The pairs of a relation may stand in any order: inside every full 64-record batch of the relation-major reduction's tasks
+    // they are placed so that the four rows of an LDS lane group have four different indices mod 4, for u and for v (host_layout.hpp)
+    {
+        const int64_t P = (int64_t)eu.size();
+        std::vector<int64_t> tu(64), tv(64);
+        std::vector<uint32_t> to(64), tm(64);
+        for (int64_t s0 = 0; s0 < P;) {
+            int64_t s1 = s0;
+            while (s1 < P && er[(size_t)s1] == er[(size_t)s0]) ++s1;
+            for (int64_t t0 = s0; t0 < s1; t0 += kTaskRecs)
+                for (int64_t b0 = t0; b0 + 64 <= std::min(s1, t0 + kTaskRecs); b0 += 64) {
+                    uint8_t cls[64];
+                    int order[64];
+                    for (int i = 0; i < 64; ++i) cls[i] = (uint8_t)((eu[(size_t)(b0 + i)] & 3) | ((ev[(size_t)(b0 + i)] & 3) << 2));
+                    gn_layout::balance_batch64(cls, order);
+                    for (int i = 0; i < 64; ++i) {
+                        const size_t from = (size_t)(b0 + order[i]);
+                        tu[i] = eu[from]; tv[i] = ev[from]; to[i] = own[from]; tm[i] = mir[from];
+                    }
+                    for (int i = 0; i < 64; ++i) {
+                        const size_t at = (size_t)(b0 + i);
+                        eu[at] = tu[i]; ev[at] = tv[i]; own[at] = to[i]; mir[at] = tm[i];
+                    }
+                }
+            s0 = s1;
+        }
+    }
     gn_distmult_bwd_plan* p = new (std::nothrow) gn_distmult_bwd_plan();
     GN_REQUIRE(p != nullptr, "out of host memory");
     p->e_list = E; p->e = (int64_t)eu.size(); p->n = num_nodes; p->r = num_relations;
@@ -1250,7 +1357,8 @@ extern "C" gn_status gn_distmult_bwd_plan_create(const int64_t* u, const int64_t
             bwd_plan_free(p);
             return gn::fail(GN_ERR_HIP, "decoder gradient plan upload failed: %s", hipGetErrorString(err));
         }
-        const gn_status rc = build_bwd_plan(p, p->eu.p, p->ev.p, p->er.p, st);
+        gn_status rc = build_bwd_plan(p, p->eu.p, p->ev.p, p->er.p, st);
+        if (rc == GN_OK) rc = balance_static_records(p, st);
         if (rc != GN_OK) { bwd_plan_free(p); return rc; }
     }
     *out = p;

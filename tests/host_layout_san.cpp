@@ -213,7 +213,38 @@ bool same(const std::vector<T>& a, const std::vector<T>& b) { return a == b; }
 
 }  // namespace
 
+// balance_batch64: a permutation of the batch, never more access cycles than the input order, close to the 32 of a perfect split
+void balance_case(unsigned seed) {
+    std::mt19937 rng(seed);
+    for (int round = 0; round < 200; ++round) {
+        uint8_t cls[64];
+        const int skew = round % 5;                      // 0: uniform classes; else: one class rare / absent
+        for (int i = 0; i < 64; ++i) {
+            int c = (int)(rng() % 16);
+            if (skew == 1 && (c & 3) == 3) c &= 12;
+            if (skew == 2) c &= 5;
+            if (skew == 3) c = 6;
+            cls[i] = (uint8_t)c;
+        }
+        int order[64], ident[64];
+        for (int i = 0; i < 64; ++i) { order[i] = -1; ident[i] = i; }
+        gn_layout::balance_batch64(cls, order);
+        bool seen[64] = {false};
+        for (int i = 0; i < 64; ++i) {
+            if (order[i] < 0 || order[i] >= 64 || seen[order[i]]) { std::fprintf(stderr, "balance_batch64: not a permutation\n"); std::exit(1); }
+            seen[order[i]] = true;
+        }
+        const int before = gn_layout::batch64_access_cycles(cls, ident), after = gn_layout::batch64_access_cycles(cls, order);
+        if (round < 5 && seed == 5) std::printf("balance_batch64 (class mix %d): %d -> %d LDS cycles per batch (32 = no conflict)\n", skew, before, after);
+        if (after > before || (skew == 0 && after > 56)) {
+            std::fprintf(stderr, "balance_batch64: %d -> %d cycles (round %d)\n", before, after, round);
+            std::exit(1);
+        }
+    }
+}
+
 int main() {
+    balance_case(5);
     struct { int64_t n; int R; int64_t e; int64_t f; } dec[] = {{645, 40, 20000, 80}, {200, 7, 3000, 80}, {645, 3, 50000, 48}, {30, 2, 5, 16}};
     for (auto& c : dec) {
         set_threads(1);

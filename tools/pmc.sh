@@ -14,6 +14,6 @@ for f in glob.glob("gpurun_out/pmc_$tag/**/*counter_collection.csv", recursive=T
         k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0][-44:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items():
-        if any(s in k for s in ("distmult","rgcn","aggregate","gemm","merge","rel_weight")):
+        if any(s in k for s in ("distmult","rgcn","aggregate","gemm","merge","rel_weight","seg_lds","dense_batch","he_s","place_g","sample_neg")):
             print(k, {c: round(sum(x)/len(x)) for c,x in sorted(v.items())}, "n=",len(next(iter(v.values()))))
 PY
