@@ -563,7 +563,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
     extern __shared__ float4 seg_lds4[];
     const int tid = threadIdx.x, lane = tid & 63, l4 = lane & 3;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cb = blockIdx.x % a.col_blocks, worker = blockIdx.x / a.col_blocks;
+    // The column blocks of one worker read the SAME records: they sit on one XCD (workgroup i runs on XCD i % 8), so that one of
+    // them pulls a batch from the memory side and the others find it in that XCD's L2 - spread over the XCDs every column block
+    // streamed all records again (8 bytes x 5 blocks per record: more time than the LDS reads and the arithmetic together)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cb = slot % a.col_blocks, worker = (slot / a.col_blocks) * 8 + xcd;
     const int c0 = cb * 16, w4 = min(4, (a.f - c0) / 4);
     const bool same = a.B == a.A;
     {
@@ -611,12 +615,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
             fvalid = false;                                                                                   \
         }                                                                                                     \
     }
+#if defined(GN_SEG_EXPERIMENT_NOLDS)
+#define GN_SEG_READ(DST, ADDR) { const uint32_t w_ = (uint32_t)(uintptr_t)(ADDR); DST = (f32x4){__uint_as_float(w_), 1.f, 2.f, 3.f}; }
+#else
+#define GN_SEG_READ(DST, ADDR) DST = *reinterpret_cast<const f32x4*>(ADDR);
+#endif
+#if defined(GN_SEG_EXPERIMENT_NOMATH)
+#define GN_SEG_MATH acc[0] += gs[0] + va[0][0] + vb[0][1] + va[1][2] + vb[1][3] + gs[1] + va[2][0] + vb[2][1] + va[3][2] + vb[3][3] + gs[2] + gs[3];
+#else
+#define GN_SEG_MATH _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) acc += gs[s_] * (va[s_] * vb[s_]);
+#endif
 #define GN_SEG_STEP(S)                                                                                    \
             {                                                                                             \
                 const uint32_t x = (uint32_t)__builtin_amdgcn_mov_dpp(ab, (S) * 0x55, 0xf, 0xf, true);    \
                 gs[S] = __int_as_float(__builtin_amdgcn_mov_dpp(gb, (S) * 0x55, 0xf, 0xf, true));         \
-                va[S] = *reinterpret_cast<const f32x4*>(ta + ((x & 0xffffu) << 6));                       \
-                vb[S] = *reinterpret_cast<const f32x4*>(tb + ((x >> 16) << 6));                           \
+                GN_SEG_READ(va[S], ta + ((x & 0xffffu) << 6))                                             \
+                GN_SEG_READ(vb[S], tb + ((x >> 16) << 6))                                                 \
             }
 #define GN_SEG_CONSUME(REC, CNT, TASK, LAST)                                                              \
     {                                                                                                         \
@@ -625,7 +639,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
         f32x4 va[4], vb[4];                                                                                   \
         float gs[4];                                                                                          \
         GN_SEG_STEP(0) GN_SEG_STEP(1) GN_SEG_STEP(2) GN_SEG_STEP(3)                                           \
-        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) acc += gs[s_] * (va[s_] * vb[s_]);                   \
+        GN_SEG_MATH                                                                                           \
         if (LAST) {                                                                                           \
             /* the 16 quads of the wave, in a fixed order: inside the rows of 16 lanes, then across the four rows */ \
             /* (ds_bpermute: once per task; hipcc folds the four DPP row rotations of a float4 into one, wrongly) */ \
@@ -663,6 +677,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
     }
 #undef GN_SEG_CONSUME
 #undef GN_SEG_STEP
+#undef GN_SEG_READ
+#undef GN_SEG_MATH
 #undef GN_SEG_FETCH
 }
 
@@ -779,7 +795,7 @@ gn_status launch_seg_lds(const uint64_t* recs, const int32_t* rowptr, int64_t ro
     a.f = (int)f; a.col_blocks = (int)gn::ceil_div(f, 16);
     const size_t lds_bytes = (size_t)(rows_a + (B == A ? 0 : rows_b)) * 64;
     const int per_cu = lds_bytes * 2 <= 156 * 1024 ? 2 : 1;           // 1024-thread workgroups: two per CU at most
-    a.workers = std::max(1, 256 * per_cu / a.col_blocks);
+    a.workers = 8 * std::max(1, 32 * per_cu / a.col_blocks);  // per XCD: as many workers as its 32 CUs hold, all column blocks of a worker together
     a.partial = partial;
     k_seg_lds<<<a.col_blocks * a.workers, kLdsThreads, lds_bytes, st>>>(a);
     GN_LAUNCH_CHECK();
