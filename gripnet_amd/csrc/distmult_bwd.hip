@@ -615,16 +615,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
             fvalid = false;                                                                                   \
         }                                                                                                     \
     }
-#if defined(GN_SEG_EXPERIMENT_NOLDS)
-#define GN_SEG_READ(DST, ADDR) { const uint32_t w_ = (uint32_t)(uintptr_t)(ADDR); DST = (f32x4){__uint_as_float(w_), 1.f, 2.f, 3.f}; }
-#else
+// (Measured with variants of this loop, decoder backward of pose0-syn, static list / fresh list: 79 / 157 us as it is, 74 / 136 us
+// without the LDS row reads, 77 / 148 us without the arithmetic, 61 / 114 us without both: more than half of the reductions' time is
+// neither - the record stream, the quad broadcasts, the bookkeeping of the batches in flight, the per-task folds.)
 #define GN_SEG_READ(DST, ADDR) DST = *reinterpret_cast<const f32x4*>(ADDR);
-#endif
-#if defined(GN_SEG_EXPERIMENT_NOMATH)
-#define GN_SEG_MATH acc[0] += gs[0] + va[0][0] + vb[0][1] + va[1][2] + vb[1][3] + gs[1] + va[2][0] + vb[2][1] + va[3][2] + vb[3][3] + gs[2] + gs[3];
-#else
 #define GN_SEG_MATH _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) acc += gs[s_] * (va[s_] * vb[s_]);
-#endif
 #define GN_SEG_STEP(S)                                                                                    \
             {                                                                                             \
                 const uint32_t x = (uint32_t)__builtin_amdgcn_mov_dpp(ab, (S) * 0x55, 0xf, 0xf, true);    \
