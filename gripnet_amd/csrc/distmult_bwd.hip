@@ -579,8 +579,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
         }
     }
     __syncthreads();
-    const char* ta = reinterpret_cast<const char*>(seg_lds4) + l4 * 16;
-    const char* tb = same ? ta : ta + (size_t)a.rows_a * 64;
+    const char* lds_base = reinterpret_cast<const char*>(seg_lds4);
+    const uint32_t ta32 = (uint32_t)l4 * 16u, tb32 = same ? ta32 : ta32 + (uint32_t)a.rows_a * 64u;   // byte offsets of the lane's chunk in the tables
     const int tasks = __builtin_amdgcn_readfirstlane(*a.n_tasks);
     const int t_step = a.workers * (kLdsThreads / 64);
     // The wave's tasks (t, t + t_step, ...) are ONE stream of 64-record batches, requested FOUR batches ahead of the arithmetic and
@@ -618,24 +618,26 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
 // (Measured with variants of this loop, decoder backward of pose0-syn, static list / fresh list: 79 / 157 us as it is, 74 / 136 us
 // without the LDS row reads, 77 / 148 us without the arithmetic, 61 / 114 us without both: more than half of the reductions' time is
 // neither - the record stream, the quad broadcasts, the bookkeeping of the batches in flight, the per-task folds.)
-#define GN_SEG_READ(DST, ADDR) DST = *reinterpret_cast<const f32x4*>(ADDR);
 #define GN_SEG_MATH _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) acc += gs[s_] * (va[s_] * vb[s_]);
 #define GN_SEG_STEP(S)                                                                                    \
             {                                                                                             \
-                const uint32_t x = (uint32_t)__builtin_amdgcn_mov_dpp(ab, (S) * 0x55, 0xf, 0xf, true);    \
+                const uint32_t pa_ = (uint32_t)__builtin_amdgcn_mov_dpp((int)ra_, (S) * 0x55, 0xf, 0xf, true) + ta32;   \
+                const uint32_t pb_ = (uint32_t)__builtin_amdgcn_mov_dpp((int)rb_, (S) * 0x55, 0xf, 0xf, true) + tb32;   \
                 gs[S] = __int_as_float(__builtin_amdgcn_mov_dpp(gb, (S) * 0x55, 0xf, 0xf, true));         \
-                GN_SEG_READ(va[S], ta + ((x & 0xffffu) << 6))                                             \
-                GN_SEG_READ(vb[S], tb + ((x >> 16) << 6))                                                 \
+                va[S] = *reinterpret_cast<const f32x4*>(lds_base + pa_);                                  \
+                vb[S] = *reinterpret_cast<const f32x4*>(lds_base + pb_);                                  \
             }
 #define GN_SEG_CONSUME(REC, CNT, TASK, LAST)                                                              \
     {                                                                                                         \
         const uint64_t rec_ = lane < CNT ? REC : 0ull;                                                        \
-        const int ab = (int)(uint32_t)rec_, gb = (int)(uint32_t)(rec_ >> 32);                                 \
+        const int gb = (int)(uint32_t)(rec_ >> 32);                                                           \
+        /* the byte offsets of this lane's record's two rows, once; the quad broadcast rides on the address add */ \
+        const uint32_t ra_ = ((uint32_t)rec_ & 0xffffu) << 6, rb_ = ((uint32_t)rec_ >> 16) << 6;              \
         f32x4 va[4], vb[4];                                                                                   \
         float gs[4];                                                                                          \
         GN_SEG_STEP(0) GN_SEG_STEP(1) GN_SEG_STEP(2) GN_SEG_STEP(3)                                           \
         GN_SEG_MATH                                                                                           \
-        if (LAST) {                                                                                           \
+        if (LAST) {                                                                                \
             /* the 16 quads of the wave, in a fixed order: inside the rows of 16 lanes, then across the four rows */ \
             /* (ds_bpermute: once per task; hipcc folds the four DPP row rotations of a float4 into one, wrongly) */ \
             _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                   \
@@ -672,7 +674,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
     }
 #undef GN_SEG_CONSUME
 #undef GN_SEG_STEP
-#undef GN_SEG_READ
 #undef GN_SEG_MATH
 #undef GN_SEG_FETCH
 }
