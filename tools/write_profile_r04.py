@@ -152,13 +152,29 @@ Counters (`tools/pmc_relgrad.sh`, one pass per set; SQ_* cycle counters in units
 ```
 They do not: with four waves per SIMD the cycles per trip are the SUM of the matrix pipe's (M x 32) and the vector instructions'
 (V x ~5), not their maximum.  The weight-gradient kernel is therefore bound by MFMA + VALU cycles together (DESIGN.md section 7).
+
+## The rate of LDS atomics (`tools/probes/lds_atomic_probe.hip`): why the decoder's backward sorts instead of scattering
+
+```
+{atomics}
+```
+`ds_add_f32` retires about one lane per three clocks per CU whatever the addresses (193 clocks per wave instruction); `ds_add_u32`
+and `ds_add_u64` run at the rate of plain LDS writes.
+
+## The negative sampler's two kernels (`tools/probes/sampler_probe.py`)
+
+```
+{sampler}
+```
 """.format(step=opt("gpurun_out/train_step_{}.txt".format(tag)).split("\n")[-1],
            stats=opt("gpurun_out/train_stats_{}.md".format(tag)),
            timeline=opt("gpurun_out/train_timeline_{}.txt".format(tag)),
            probe="\n".join(l for l in opt("gpurun_out/relgrad_{}.txt".format(tag)).split("\n") if "us" in l or "max" in l),
            stamps=opt("gpurun_out/stamps_{}_rel.txt".format(tag)),
            pmc="\n".join(l for l in opt("gpurun_out/pmc_{}_relgrad.txt".format(tag)).split("\n") if "rel_weight" in l),
-           coissue=opt("gpurun_out/mfma_valu_probe_{}.txt".format(tag)))
+           coissue=opt("gpurun_out/mfma_valu_probe_{}.txt".format(tag)),
+           atomics=opt("gpurun_out/lds_atomic_probe_{}.txt".format(tag)),
+           sampler="\n".join(l for l in opt("gpurun_out/sampler_probe_{}.txt".format(tag)).split("\n") if "amdgpu.ids" not in l))
 open("profiles/{}_train_rocprof.md".format(tag), "w").write(train)
 t = json.load(open("gpurun_out/traffic_{}.json".format(tag)))
 json.dump(t, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
