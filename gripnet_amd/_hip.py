@@ -433,9 +433,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
     m = (a.shape[0] if a_rows is None else a_rows.shape[0]) if m is None else m
     k = a.shape[1] if k is None else k
     n = (b.shape[0] if b_transposed else b.shape[-1]) if n is None else n
-    join_batch = join_batch and _open_batch is not None
+    join_batch = join_batch and getattr(_batch_tls, 'open', None) is not None
     if join_batch:                                           # a queued product reads its operands when the batch leaves
-        _open_batch.keep.extend((a, b, out, bias, a_rows))
+        _batch_tls.open.keep.extend((a, b, out, bias, a_rows))
     _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
                           ptr(b), ld(b) if ldb is None else ldb, stride_b,
                           ptr(out), ld(out) if ldc is None else ldc, stride_c,
@@ -461,9 +461,9 @@ def xtg(x: torch.Tensor, g: torch.Tensor, join_batch=False):
     ws = _xtg_ws.get(key)
     if ws is None:                                             # one zeroed workspace per device and size: its last 64 bytes are the kernel's ticket
         ws = _xtg_ws[key] = torch.zeros((need,), dtype=torch.uint8, device=x.device)
-    join_batch = join_batch and _open_batch is not None
+    join_batch = join_batch and getattr(_batch_tls, 'open', None) is not None
     if join_batch:
-        _open_batch.keep.extend((x, g, out))
+        _batch_tls.open.keep.extend((x, g, out))
     _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need,
           GN_XTG_TICKET_ZEROED | (GN_XTG_JOIN_BATCH if join_batch else 0),
           stream_ptr(x.device))
@@ -906,7 +906,8 @@ class DistMultBwdPlan:
 _sorted_types = []          # (tensor, _version, relations, offsets or None) of the last few edge_type tensors asked about
 
 
-_open_batch = None
+_batch_tls = threading.local()      # the open batch of THIS thread: the library's queue is thread_local too (autograd runs a
+                                    # device's backward on its own thread; two GPUs in one process must not see each other's batch)
 
 
 class dense_batch:
@@ -919,19 +920,17 @@ class dense_batch:
         self.device, self.keep = device, []
 
     def __enter__(self):
-        global _open_batch
         self.off = os.environ.get("GN_DENSE_BATCH") == "0"     # (development switch: every product launches on its own)
         if self.off:
             return self
         _call("gn_dense_batch_begin")
-        _open_batch = self
+        _batch_tls.open = self
         return self
 
     def __exit__(self, *exc):
-        global _open_batch
         if self.off:
             return False
-        _open_batch = None
+        _batch_tls.open = None
         try:
             with torch.cuda.device(self.device):
                 _call("gn_dense_batch_end", stream_ptr(self.device))

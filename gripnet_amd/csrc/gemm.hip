@@ -785,7 +785,8 @@ __device__ __forceinline__ void xtg_mfma_body(const XtgArgs& a, int bx, int nblo
         }
     }
     if (single) return;
-    __syncthreads();                                                       // (every storing wave has drained its stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's write-through stores have reached L2 ...
+    __syncthreads();                                                       // ... and so have every other wave's when the ticket is drawn
     if (tid == 0) *last_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
     __syncthreads();
     if (!*last_flag) return;

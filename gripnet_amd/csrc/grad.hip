@@ -59,7 +59,8 @@ __global__ __launch_bounds__(kGradThreads) void k_grad_prologue(const float* __r
         __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)blockIdx.x * CP + tid, __float_as_uint(s), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                                       // (every storing wave has drained its stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's write-through stores have reached L2 ...
+    __syncthreads();                                                       // ... and so have every other wave's when the ticket is drawn
     if (tid == 0) last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!last) return;
@@ -92,7 +93,7 @@ size_t gn_grad_prologue_workspace_bytes(void) { return (size_t)kGradGroups * 256
 gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_out, int64_t ld_saved, const float* rowdiv, int64_t rows,
                                int64_t cols, float* gm, int64_t ld_gm, float* gd, int64_t ld_gd, float* colsum, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    GN_REQUIRE(rows >= 0 && cols >= 0 && cols <= 256, "bad size: up to 256 columns");
+    GN_REQUIRE(rows >= 0 && cols >= 0, "bad size");
     if (rows == 0 || cols == 0) {
         if (colsum && cols > 0) GN_HIP(hipMemsetAsync(colsum, 0, (size_t)cols * sizeof(float), gn::as_stream(stream)));
         return GN_OK;
@@ -103,17 +104,23 @@ gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_
                "column sums need a workspace of %zu bytes, zeroed once", gn_grad_prologue_workspace_bytes());
     float* partial = static_cast<float*>(workspace);
     unsigned int* arrived = workspace ? reinterpret_cast<unsigned int*>(partial + (size_t)kGradGroups * 256) : nullptr;
-    // (a workgroup covers 256 / CP rows per pass and four passes per trip: about two trips each)
-    const int groups = (int)std::min<int64_t>(kGradGroups, gn::ceil_div(rows * std::max<int64_t>(cols, 16), 2048));
     hipStream_t st = gn::as_stream(stream);
-#define GN_GRAD_LAUNCH(CP) k_grad_prologue<CP><<<groups, kGradThreads, 0, st>>>(g, ld_g, saved_out, ld_saved, rowdiv, rows, (int)cols, gm, ld_gm, gd, ld_gd, colsum, partial, arrived)
-    if (cols <= 16) GN_GRAD_LAUNCH(16);
-    else if (cols <= 32) GN_GRAD_LAUNCH(32);
-    else if (cols <= 64) GN_GRAD_LAUNCH(64);
-    else if (cols <= 128) GN_GRAD_LAUNCH(128);
-    else GN_GRAD_LAUNCH(256);
+    // a launch covers up to 256 columns (a thread keeps its column); wider layers take one launch per block of 256 columns, the
+    // operands being row-strided already.  The launches share the workspace: they are ordered by the stream, and the last
+    // workgroup of a launch leaves the ticket at zero.
+    for (int64_t c0 = 0; c0 < cols; c0 += 256) {
+        const int cw = (int)std::min<int64_t>(256, cols - c0);
+        // (a workgroup covers 256 / CP rows per pass and four passes per trip: about two trips each)
+        const int groups = (int)std::min<int64_t>(kGradGroups, gn::ceil_div(rows * std::max<int64_t>(cw, 16), 2048));
+#define GN_GRAD_LAUNCH(CP) k_grad_prologue<CP><<<groups, kGradThreads, 0, st>>>(g + c0, ld_g, saved_out ? saved_out + c0 : nullptr, ld_saved, rowdiv, rows, cw, gm ? gm + c0 : nullptr, ld_gm, gd ? gd + c0 : nullptr, ld_gd, colsum ? colsum + c0 : nullptr, partial, arrived)
+        if (cw <= 16) GN_GRAD_LAUNCH(16);
+        else if (cw <= 32) GN_GRAD_LAUNCH(32);
+        else if (cw <= 64) GN_GRAD_LAUNCH(64);
+        else if (cw <= 128) GN_GRAD_LAUNCH(128);
+        else GN_GRAD_LAUNCH(256);
 #undef GN_GRAD_LAUNCH
-    GN_LAUNCH_CHECK();
+        GN_LAUNCH_CHECK();
+    }
     return GN_OK;
 }
 

@@ -273,12 +273,13 @@ __global__ __launch_bounds__(kRelThreads) void k_rel_weight_grad(RelArgs a) {
             if (tid < FF / 4) reinterpret_cast<f32x4*>(dst)[tid] = reinterpret_cast<const f32x4*>(whole)[tid];
         } else {
             // hand-over (the form of MI355X_MICROARCH.md for a few KB): every handed-over dword is stored write-through
-            // (agent-scope relaxed atomic store = sc1), every storing wave drains its stores in front of the barrier, ONE lane
-            // draws the ticket; the part that draws the last one reads all parts with sc1 loads and adds them in part order.
+            // (agent-scope relaxed atomic store = sc1), every storing wave drains its stores (an EXPLICIT s_waitcnt vmcnt(0): the
+            // barrier alone waits for nothing that is in flight to memory) in front of the barrier, ONE lane draws the ticket; the part that draws the last one reads all parts with sc1 loads and adds them in part order.
             // No fence: a release here writes back the XCD's whole L2 (all the dW rows its workgroups have stored so far).
             uint32_t* __restrict__ mine = reinterpret_cast<uint32_t*>(dst);
             for (int o = tid; o < FF; o += kRelThreads) __hip_atomic_store(mine + o, __float_as_uint(whole[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();                                               // (s_waitcnt vmcnt(0) of every wave, then the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have reached L2
+            __syncthreads();
             if (tid == 0) {
                 const uint32_t drawn = __hip_atomic_fetch_add(a.ticket + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *last_part = drawn == (uint32_t)parts - 1;

@@ -7,9 +7,10 @@ Mirrors gripnet/layers.py of the reference:
   homoGraph  layers.py:208-319  internal layer stack of one supervertex
   interGraph layers.py:322-387  external (inter-supervertex) layer
 
-Forward only; all tensors must be fp32 / int64 on the GPU (no CPU fallback).  What the
-reference caches on first use (normalised edge list) is a *plan* here; the cache protocol
-(keyed by edge count, RuntimeError on mismatch) is the reference's (layers.py:75-90).
+Forward and backward: under ``torch.no_grad()`` (or with nothing that requires grad) a module runs the slot-fused inference
+launches, otherwise it routes through the ``torch.autograd.Function``s of autograd.py (same forward kernels, HIP backward).
+All tensors must be fp32 / int64 on the GPU (no CPU fallback).  What the reference caches on first use (normalised edge
+list) is a *plan* here; the cache protocol (keyed by edge count, RuntimeError on mismatch) is the reference's (layers.py:75-90).
 """
 from __future__ import annotations
 
@@ -20,7 +21,17 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import _hip
-from .autograd import AbsSlotFn, GcnConvFn, RgcnConvFn, SlotsCatFn, cat_slots, recording
+from .autograd import AbsSlotFn, GcnConvFn, RgcnConvFn, Slot, SlotsCatFn, cat_slots, recording
+
+
+def _unslot(out, side):
+    """A frozen layer inside a model that trains (homoGraph / interGraph hand Slots down whenever ANY of their tensors
+    requires grad): the inference launches take the Slots' views."""
+    if isinstance(out, Slot):
+        out = out.view()
+    if side is not None and isinstance(side[1], Slot):
+        side = (side[0].detach(), side[1].view(), side[2])
+    return out, side
 
 
 def _cat_slots(widths, n_rows, device):
@@ -82,7 +93,8 @@ class myGCN(Module):
         self._planes_written = False                 # did this call's launch leave the split planes it was offered?
         if recording(x, self.weight, self.bias):                                 # training: autograd path (out / side: Slots)
             return GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side)
-        x = _hip.f32_rows(x)
+        out, side = _unslot(out, side)
+        x = _hip.f32_rows(x.detach())
         if out is None:
             out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
         if self.table_storage == "bf16" and self.out_channels % 8 == 0 and _hip.ld(out) % 4 == 0 and out.data_ptr() % 16 == 0:
@@ -185,6 +197,7 @@ class myRGCN(Module):
         plan = self.plan_for(edge_index, range_list, x.shape[0])
         if recording(x, self.basis, self.att, self.root, self.bias):             # training: autograd path
             return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu, _out, _side)   # (Slots)
+        _out, _side = _unslot(_out, _side)
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
         planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None

@@ -454,7 +454,7 @@ GN_API gn_status gn_dense_batch_end(void* stream);
  * of the relational layer, layers.py:191);  colsum[c] = sum over the rows of gm[:, c] (the bias gradient).  gm, gd and
  * colsum are each optional (NULL).  Deterministic (fixed row slices, added in workgroup order by the last workgroup to
  * arrive).  `workspace` (needed for colsum): gn_grad_prologue_workspace_bytes() bytes, 4-byte aligned, ZEROED ONCE by the
- * caller; calls on one workspace must be stream-ordered.  Up to 256 columns. */
+ * caller; calls on one workspace must be stream-ordered.  Any width (one launch per block of 256 columns). */
 GN_API size_t gn_grad_prologue_workspace_bytes(void);
 GN_API gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_out, int64_t ld_saved, const float* rowdiv,
                                int64_t rows, int64_t cols, float* gm, int64_t ld_gm, float* gd, int64_t ld_gd, float* colsum,

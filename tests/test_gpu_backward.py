@@ -676,3 +676,226 @@ def test_link_loss_matches_the_torch_expression(gpu):
     empty = torch.empty(0, device=gpu)
     some = torch.full((5,), 0.5, device=gpu)
     assert abs(float(link_loss(some, empty)) + float(torch.log(some + EPS).mean())) < 1e-6
+
+
+def test_wide_layer_backward(gpu):
+    """A layer wider than the 256 columns one launch of gn_grad_prologue_f32 covers (the reference accepts any width,
+    layers.py:16-24): the prologue runs per block of 256 columns, the gradients match torch autograd through the oracle."""
+    gen = torch.Generator().manual_seed(83)
+    n, fin, fout, e = 120, 12, 520, 900
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    x = torch.randn(n, fin, generator=gen)
+    proj = torch.randn(n, fout, generator=gen)
+    torch.manual_seed(85)
+    conv = gripnet_amd.myGCN(fin, fout).to(gpu)
+    conv.bias.data.normal_()
+    xg = leaf(x.to(gpu))
+    y = conv(xg, ei.to(gpu), None, _relu=True)
+    (y * proj.to(gpu)).sum().backward()
+    xr, wr, br = leaf(x), leaf(conv.weight.cpu()), leaf(conv.bias.cpu())
+    yr = torch.relu(orc.gcn_forward(xr, wr, br, ei, None))
+    (yr * proj).sum().backward()
+    close(y, yr, what="forward")
+    close(xg.grad, xr.grad, 1e-4, what="dx")
+    close(conv.weight.grad, wr.grad, 1e-4, what="dW")
+    close(conv.bias.grad, br.grad, 1e-4, what="db")
+    wide = torch.randn(300, 700, generator=gen).to(gpu)
+    out = torch.relu(torch.randn(300, 700, generator=gen)).to(gpu)
+    div = (1.0 + torch.randint(0, 9, (300,), generator=gen).float()).to(gpu)
+    gm, gd, cs = _hip.grad_prologue(wide, out, div, True, True)
+    ref = wide * (out > 0)
+    assert torch.equal(gm, ref)
+    assert float((gd - ref / div.view(-1, 1)).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+    assert float((cs.double() - ref.double().sum(0)).abs().max()) <= 2e-5 * max(1.0, float(ref.double().sum(0).abs().max()))
+    _hip.raise_if_index_errors(gpu)
+
+
+def test_adam_resumes_from_a_cpu_checkpoint(gpu, tmp_path):
+    """save -> torch.load(map_location="cpu") -> load_state_dict -> step: the step counter a loader leaves on the CPU is moved
+    to the parameters' device, the address table is rebuilt for the loaded moments (an optimizer that had stepped before
+    the load must not keep updating its old ones); the resumed run equals torch.optim.Adam resumed the same way."""
+    gen = torch.Generator().manual_seed(89)
+    shapes = [(300, 7), (16,), (33, 5)]
+    ours = [torch.nn.Parameter(torch.randn(s, generator=gen).to(gpu)) for s in shapes]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a, b = gripnet_amd.optim.Adam(ours, lr=0.01), torch.optim.Adam(theirs, lr=0.01)
+
+    def one_step(oa, ob, pa, pb):
+        for p, q in zip(pa, pb):
+            g = torch.randn(p.shape, generator=gen).to(gpu)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for _ in range(3):
+        one_step(a, b, ours, theirs)
+    torch.save(a.state_dict(), tmp_path / "a.pt")
+    torch.save(b.state_dict(), tmp_path / "b.pt")
+    # new optimizers over the same parameters; the first has already stepped once (its address table exists)
+    a2, b2 = gripnet_amd.optim.Adam(ours, lr=0.01), torch.optim.Adam(theirs, lr=0.01)
+    keep = [p.detach().clone() for p in ours]
+    for p in ours:
+        p.grad = torch.zeros_like(p)
+    a2.step()
+    for p, k in zip(ours, keep):
+        p.data.copy_(k)
+    a2.load_state_dict(torch.load(tmp_path / "a.pt", map_location="cpu"))
+    b2.load_state_dict(torch.load(tmp_path / "b.pt", map_location="cpu"))
+    for _ in range(3):
+        one_step(a2, b2, ours, theirs)
+    assert float(a2.param_groups[0]["step"]) == 6.0 and a2.param_groups[0]["step"].device.type == "cuda"
+    for p, q in zip(ours, theirs):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
+    _hip.raise_if_index_errors(gpu)
+
+
+def test_frozen_layers_inside_a_training_model(gpu):
+    """A frozen first layer (its parameters do not require grad) under a trainable second one, and a frozen external conv
+    under a trainable target_feat: the stacks hand their concat Slots to a layer that takes the inference launches."""
+    gen = torch.Generator().manual_seed(97)
+    n, e = 150, 1200
+    a = torch.randint(0, n, (2, e), generator=gen)
+    ei = torch.cat([a, a.flip(0)], dim=1)
+    x = torch.randn(n, 10, generator=gen)
+    torch.manual_seed(99)
+    m = gripnet_amd.homoGraph([10, 8, 6]).to(gpu)
+    for p in m.conv_list[0].parameters():
+        p.requires_grad_(False)
+    y = m(x.to(gpu), ei.to(gpu), None, if_catout=True)
+    proj = torch.randn(y.shape, generator=gen)
+    (y * proj.to(gpu)).sum().backward()
+    sd = {"h." + k: leaf(v.cpu()) for k, v in m.state_dict().items()}
+    yr = orc.homo_forward(sd, "h.", x, ei, None, if_catout=True)
+    (yr * proj).sum().backward()
+    close(y, yr, what="forward")
+    assert m.conv_list[0].weight.grad is None
+    close(m.conv_list[1].weight.grad, sd["h.conv_list.1.weight"].grad, 1e-4, what="dW of the trainable layer")
+    n_src, n_tgt = 200, 60
+    gd = torch.stack([torch.randint(0, n_src, (900,), generator=gen), torch.randint(0, n_tgt, (900,), generator=gen)])
+    xs = torch.randn(n_src, 18, generator=gen)
+    ig = gripnet_amd.interGraph(18, 12, n_tgt, target_feat_dim=20).to(gpu)
+    for p in ig.conv.parameters():
+        p.requires_grad_(False)
+    y = ig(xs.to(gpu), gd.to(gpu))
+    proj = torch.randn(y.shape, generator=gen)
+    (y * proj.to(gpu)).sum().backward()
+    sd = {"g." + k: leaf(v.cpu()) for k, v in ig.state_dict().items()}
+    yr = orc.inter_forward(sd, "g.", xs, gd, None, if_relu=True, mod="cat", n_target=n_tgt)
+    (yr * proj).sum().backward()
+    close(y, yr, what="external forward")
+    close(ig.target_feat.grad, sd["g.target_feat"].grad, 1e-4, what="d target_feat")
+    assert ig.conv.weight.grad is None
+
+
+def test_last_arriver_hand_overs_replayed(gpu):
+    """The kernels whose last workgroup to arrive adds partial sums that other workgroups left in a REUSED scratch
+    (gn_xtg_f32, gn_grad_prologue_f32, gn_rel_weight_grad_f32): thousands of back-to-back launches with different inputs,
+    every result against float64 - a hand-over that lets the ticket overtake a store reads the previous launch's partials."""
+    gen = torch.Generator().manual_seed(101)
+    m, k1, k2 = 19081, 64, 16
+    xs = [torch.randn(m, k1, generator=gen).to(gpu) for _ in range(4)]
+    gs = [torch.randn(m, k2, generator=gen).to(gpu) for _ in range(4)]
+    want = [[(x.double().t() @ g.double()) for g in gs] for x in xs]
+    outs = []
+    for it in range(1500):
+        outs.append((it % 4, (it // 4) % 4, _hip.xtg(xs[it % 4], gs[(it // 4) % 4])))
+    for i, j, got in outs:
+        assert float((got.double() - want[i][j]).abs().max()) <= 1e-4 * float(want[i][j].abs().max())
+    outs = []
+    sav = torch.relu(torch.randn(m, k2, generator=gen)).to(gpu)
+    wantc = [(g * (sav > 0)).double().sum(0) for g in gs]
+    for it in range(1500):
+        outs.append((it % 4, _hip.grad_prologue(gs[it % 4], sav, None, False, True)[2]))
+    for j, got in outs:
+        assert float((got.double() - wantc[j]).abs().max()) <= 2e-5 * float(wantc[j].abs().max())
+    n, fin, fout = 645, 48, 32
+    sizes = [60000, 300, 0, 1, 1200] + [17] * 30                       # a hub relation cut into parts
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    ei = torch.cat(blocks, dim=1).to(gpu)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    R = len(sizes)
+    wg = _hip.RgcnPlan(ei, rl, n).weight_grad_plan()
+    x = torch.randn(n, fin, generator=gen).to(gpu)
+    gms = [torch.randn(n, fout, generator=gen).to(gpu) for _ in range(3)]
+    rel = torch.repeat_interleave(torch.arange(R), torch.tensor(sizes)).to(gpu)
+    refs = []
+    for gm in gms:
+        q = torch.zeros(R * n, fout, dtype=torch.float64, device=gpu)
+        q.index_add_(0, rel * n + ei[0], gm.double().index_select(0, ei[1]))
+        refs.append(torch.matmul(x.double().t(), q.view(R, n, fout)).reshape(R, fin * fout))
+    outs = [(it % 3, wg.weight_grad(x, gms[it % 3])) for it in range(600)]
+    for j, got in outs:
+        assert float((got.double() - refs[j]).abs().max()) <= 2e-6 * max(1.0, float(refs[j].abs().max()))
+    _hip.raise_if_index_errors(gpu)
+
+
+@pytest.mark.parametrize("workload", ["pose0-syn", "pose2-syn"])
+def test_decoder_gradients_at_full_size(gpu, workload):
+    """The decoder's backward on the whole type-sorted list of a BASELINE configuration (2.0 M / 8.4 M triples: pose2-syn
+    takes the unstaged scatter) against index_add_ in float64 (decoder.py:19-23 under autograd)."""
+    from gripnet_amd.synth import make_pose
+    data = make_pose(workload).to(gpu)
+    n, R, f = data.n_d_node, data.n_dd_edge_type, 80
+    torch.manual_seed(3)
+    z, D = torch.randn(n, f, device=gpu) * 0.3, torch.randn(R, f, device=gpu) * 0.3
+    ei, et = data.train_idx, data.train_et
+    g = torch.randn(ei.shape[1], device=gpu)
+    dz, dd = torch.empty_like(z), torch.empty_like(D)
+    _hip.distmult_backward(z, ei, et, D, g, dz, dd)
+    u, v = ei[0], ei[1]
+    rz = torch.zeros(n, f, device=gpu, dtype=torch.float64)
+    rd = torch.zeros(R, f, device=gpu, dtype=torch.float64)
+    zz, DD, gg = z.double(), D.double(), g.double()
+    step = 1 << 20
+    for a in range(0, ei.shape[1], step):
+        s = slice(a, a + step)
+        rz.index_add_(0, u[s], gg[s, None] * zz[v[s]] * DD[et[s]])
+        rz.index_add_(0, v[s], gg[s, None] * zz[u[s]] * DD[et[s]])
+        rd.index_add_(0, et[s], gg[s, None] * zz[u[s]] * zz[v[s]])
+    assert float((dz.double() - rz).abs().max() / rz.abs().max()) <= 1e-5
+    assert float((dd.double() - rd).abs().max() / rd.abs().max()) <= 1e-5
+    dz2, dd2 = torch.empty_like(z), torch.empty_like(D)
+    _hip.distmult_backward(z, ei, et, D, g, dz2, dd2)
+    assert torch.equal(dz, dz2) and torch.equal(dd, dd2)
+    _hip.raise_if_index_errors(gpu)
+
+
+@pytest.mark.timeout(900)
+def test_pose0_syn_training_step_gradients(gpu):
+    """The training step of GripNet-pose.py:117-146 at the size the driver's training entry is timed on (pose0-syn): ONE
+    oracle forward + backward under torch autograd on the host against the HIP step - loss <= 1e-6 relative, every parameter
+    gradient <= 1e-4 of its largest entry."""
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.synth import make_pose
+    from gripnet_amd.utils import link_loss
+    data = make_pose("pose0-syn")
+    torch.manual_seed(59)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type)
+    sd = {k: leaf(v) for k, v in model.state_dict().items()}
+    neg = torch.randint(0, data.n_d_node, data.train_idx.shape, generator=torch.Generator().manual_seed(61))
+    model = model.to(gpu)
+    dg = make_pose("pose0-syn").to(gpu)
+    for _ in range(2):                                          # the second pass runs on the static list's plans
+        model.zero_grad()
+        z = model.encode(dg)
+        loss = link_loss(model.dmt(z, dg.train_idx, dg.train_et), model.dmt(z, neg.to(gpu), dg.train_et))
+        loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = orc.pose_forward(sd, data.gg_edge_index, data.edge_weight, data.gd_edge_index, data.train_idx,
+                           data.train_et, data.train_range)
+    neg_ref = orc.distmult(ref["z_dd"], neg, data.train_et, sd["dmt.weight"])
+    eps = gripnet_amd.utils.EPS
+    loss_ref = -torch.log(ref["score"] + eps).mean() - torch.log(1 - neg_ref + eps).mean()      # GripNet-pose.py:140-142
+    loss_ref.backward()
+    # the expression summed in float64 over the oracle's fp32 scores (the fp32 `.mean()` of two million terms carries ~1e-6 itself)
+    loss_64 = -torch.log(ref["score"].detach().double() + eps).mean() - torch.log(1 - neg_ref.detach().double() + eps).mean()
+    assert abs(float(loss) - float(loss_64)) <= 1e-6 * abs(float(loss_64)), (float(loss), float(loss_64))
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:                                 # gd.target_feat_down is unused in cat mode
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale_k = float(sd[k].grad.abs().max())
+        assert scale_k > 0, k
+        close(p.grad / scale_k, sd[k].grad / scale_k, 1e-4, what=k)
+    _hip.raise_if_index_errors(gpu)
