@@ -303,6 +303,83 @@ def replay(calls):
             check(status)
 
 
+# Test hooks the library reads from the environment at call time (common.h, aggregate.cuh, gcn_blocked.hip): part of every
+# memo key, so that a shortcut recorded under one setting is not replayed under another.
+_ENV_HOOKS = ("GN_DISABLE_FAST", "GN_DISABLE_QUAD", "GN_DISABLE_BLOCKED", "GN_BLOCKED_ANY", "GN_DISABLE_LDS_TABLE")
+_ENV_DATA = getattr(os.environ, "_data", None)
+_ENV_KEYS = tuple(k.encode() for k in _ENV_HOOKS) if isinstance(_ENV_DATA, dict) and all(isinstance(k, bytes) for k in list(_ENV_DATA)[:1]) else None
+
+
+def env_stamp():
+    """The current values of the library's environment hooks (plain dict look-ups on CPython's POSIX `os.environ`)."""
+    if _ENV_KEYS is not None:
+        d = _ENV_DATA
+        return tuple([d.get(k) for k in _ENV_KEYS])
+    return tuple([os.environ.get(k) for k in _ENV_HOOKS])
+
+
+def launch_context(device):
+    """(current device, raw stream) a memoised call sequence is bound to."""
+    index = device.index
+    return torch.cuda.current_device(), (_raw_stream(index) if _raw_stream is not None else torch.cuda.current_stream(index).cuda_stream)
+
+
+class CallMemo:
+    """Steady-state shortcut of ONE module's inference forward (the reference-shaped API of layers.py / decoder.py as a
+    caller of GripNet-pose.py:117-138 uses it): the C-ABI calls a forward makes are a function of a few pointers, shapes
+    and versions - the module computes that key, and when the key repeats the calls are made again straight from the
+    recording (`replay`), without the Python between the module's `forward` and the library (~20 us per entry point:
+    module dispatch, plan look-ups, layout checks, ctypes structures).  The OUTPUT is allocated fresh by the module on
+    every call (the reference returns fresh tensors) and its address is part of the key: under torch's caching allocator
+    a loop's outputs cycle through one or two addresses.  A key is recorded the second time in a row it is seen (one-shot
+    inputs - fresh negative samples - never fill the table).  An entry keeps alive what its calls read besides the
+    caller's input and the output (plans' scratch, temporaries the slow path allocated, the by-reference structures), and
+    the objects whose `id` is part of the key."""
+
+    DEPTH = 8
+
+    def __init__(self):
+        self.entries = {}                    # key -> (calls, keep, post)
+        self.last = None
+
+    def get(self, key):
+        return self.entries.get(key)
+
+    def second_sighting(self, guard):
+        seen, self.last = self.last == guard, guard
+        return seen
+
+    def record(self, key, run, drop, hold=(), post=None):
+        """Run `run()` with every entry-point call written down, store the recording under `key`; `drop`: tensors (the
+        caller's input, the fresh output) the entry must NOT keep alive; `hold`: objects it must."""
+        global _recorder
+        if _recorder is not None:
+            return run()
+        drop_ptrs = {t.untyped_storage().data_ptr() for t in drop if t is not None}
+        with Recorder() as rec:
+            result = run()
+        keep = list(hold)
+        for item in rec.keep:
+            if torch.is_tensor(item):
+                if item.untyped_storage().data_ptr() not in drop_ptrs:
+                    keep.append(item)
+                continue
+            if isinstance(item, tuple):      # an argument tuple: its by-reference structures stay, what THEY held is filtered too
+                for a in item:
+                    obj = getattr(a, "_obj", None)
+                    held = getattr(obj, "_keep", None) if obj is not None else None
+                    if held is not None:
+                        for t in (held if isinstance(held, tuple) else (held,)):
+                            if torch.is_tensor(t) and t.untyped_storage().data_ptr() not in drop_ptrs:
+                                keep.append(t)
+                        obj._keep = None
+            keep.append(item)
+        while len(self.entries) >= self.DEPTH:
+            self.entries.pop(next(iter(self.entries)))
+        self.entries[key] = (rec.calls, keep, post)
+        return result
+
+
 def _call(name, *args, tag=None):
     """Call an entry point.  Every caller passes `stream_ptr(<device of its operands>)` among the arguments; when that
     device is not the current one the call is made with it current (a launch on a foreign device's stream fails or

@@ -261,12 +261,49 @@ class homoGraph(Module):
             return SlotsCatFn.apply(slots, *outs) if if_catout else h
         x = _hip.f32_rows(x)
         n = x.shape[0]
+        widths = [x.shape[1]] + [c.out_channels for c in self.conv_list]
+        # the output is a fresh tensor on every call (as the reference's); with if_catout the layers write their columns of it
+        out = torch.empty((n, sum(widths) if if_catout else widths[-1]), dtype=torch.float32, device=x.device)
+        if torch.is_grad_enabled() or _hip._recorder is not None:
+            return self._infer(x, homo_edge_index, edge_weight, edge_type, range_list, if_catout, widths, out)
+        # steady state: the same graph tensors, the same input and output addresses -> the recorded calls (_hip.CallMemo)
+        convs = self.conv_list
+        planes = _hip.SplitPlanes.of(x, widths[0] // 16) if self.multi_relational and widths[0] % 16 == 0 else None
+        guard = (x.data_ptr(), n, widths[0], x.stride(0), id(homo_edge_index), homo_edge_index._version,
+                 id(edge_weight), 0 if edge_weight is None else edge_weight._version,
+                 id(range_list), getattr(range_list, "_version", 0), if_catout, id(planes),
+                 tuple([(id(c._plan) if self.multi_relational else id(c.cached_result), c.arithmetic,
+                         c.kernel if self.multi_relational else c.table_storage) +
+                        tuple([0 if p is None else p.data_ptr() for p in c._parameters.values()]) for c in convs]),
+                 _hip.launch_context(x.device), _hip.env_stamp())
+        memo = self.__dict__.get("_memo")
+        if memo is None:
+            memo = self.__dict__["_memo"] = _hip.CallMemo()
+        key = guard + (out.data_ptr(),)
+        hit = memo.get(key)
+        if hit is not None:
+            _hip.replay(hit[0])
+            return out
+        run = lambda: self._infer(x, homo_edge_index, edge_weight, edge_type, range_list, if_catout, widths, out)
+        if not memo.second_sighting(guard):
+            return run()
+        result = memo.record(key, run, drop=(x, out), hold=(homo_edge_index, edge_weight, range_list, planes))
+        # (the key names the plans the recording ran on by id: the entry holds them, so that an id cannot be reused)
+        memo.entries[key][1].extend([c._plan if self.multi_relational else c.cached_result for c in convs])
+        return result
+
+    def _infer(self, x, homo_edge_index, edge_weight, edge_type, range_list, if_catout, widths, out):
+        """The inference launches: conv + ReLU fused, every layer; the last layer (every layer and the input, with
+        if_catout) writes into `out`."""
         side = None
         if if_catout:
-            out, slots = _cat_slots([x.shape[1]] + [c.out_channels for c in self.conv_list], n, x.device)
+            slots, lo = [], 0
+            for w in widths:
+                slots.append(out[:, lo:lo + w])
+                lo += w
             side = (x, slots[0], 0)                          # slot 0 <- input, copied by the first layer's launch
         else:
-            out, slots = None, [None] * (len(self.conv_list) + 1)
+            slots = [None] * len(self.conv_list) + [out]
         h = x
         for i, net in enumerate(self.conv_list):                                 # conv + ReLU fused, every layer
             if self.multi_relational:
@@ -274,7 +311,7 @@ class homoGraph(Module):
             else:
                 h = net(h, homo_edge_index, edge_weight, _out=slots[i + 1], _relu=True, _side=side)
             side = None
-        return out if if_catout else h
+        return out
 
 
 class interGraph(Module):
@@ -320,23 +357,59 @@ class interGraph(Module):
         if not self.if_one_external:                                             # layers.py:372-373
             return self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if mod == "cat":                                                         # layers.py:375-376
-            out, (y, tf) = _cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
-            # the same launch leaves [y | |target_feat|] as bf16 split planes: a relational layer that takes this
-            # output as its input (GripNet-pose.py:120-127) contracts with them instead of splitting x in every unit
-            width, planes = self.target_dim + self.target_feat_dim, None
-            if width % 16 == 0 and width <= 64 and self.conv.table_storage == "fp32":
-                planes = getattr(self, "_planes", None)
-                if planes is None or planes.device != dev:
-                    planes = self._planes = _hip.SplitPlanes(self.n_target, width // 16, dev)
-            self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu,
-                                        _side=(self.target_feat, tf, 1),     # |target_feat| slot, same launch
-                                        _planes=None if planes is None else (planes, 0, self.target_dim))
-            if planes is not None and getattr(self.conv, "_planes_written", False):
-                planes.tag(out)
-            return out
+            x = _hip.f32_rows(x)
+            out = torch.empty((self.n_target, self.target_dim + self.target_feat_dim), dtype=torch.float32, device=dev)
+            conv, tf = self.conv, self.target_feat
+            if torch.is_grad_enabled() or _hip._recorder is not None or not tf.is_contiguous():
+                return self._infer_cat(x, inter_edge_index, edge_weight, if_relu, out)
+            # steady state: the recorded calls (_hip.CallMemo; see homoGraph.forward)
+            guard = (x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), id(inter_edge_index), inter_edge_index._version,
+                     id(edge_weight), 0 if edge_weight is None else edge_weight._version, bool(if_relu),
+                     id(conv.cached_result), conv.table_storage, conv.arithmetic, tf.data_ptr(),
+                     tuple([0 if p is None else p.data_ptr() for p in conv._parameters.values()]),
+                     _hip.launch_context(dev), _hip.env_stamp())
+            memo = self.__dict__.get("_memo")
+            if memo is None:
+                memo = self.__dict__["_memo"] = _hip.CallMemo()
+            key = guard + (out.data_ptr(),)
+            hit = memo.get(key)
+            if hit is not None:
+                _hip.replay(hit[0])
+                planes = hit[2]
+                if planes is not None:                       # the launch rewrote the split planes: they describe THIS output now
+                    planes.generation += 1
+                    planes.tag(out)
+                return out
+            run = lambda: self._infer_cat(x, inter_edge_index, edge_weight, if_relu, out)
+            if not memo.second_sighting(guard):
+                return run()
+            result = memo.record(key, run, drop=(x, out), hold=(inter_edge_index, edge_weight))
+            entry = memo.entries[key]
+            entry[1].append(conv.cached_result)
+            memo.entries[key] = (entry[0], entry[1], _hip.SplitPlanes.of(out, (self.target_dim + self.target_feat_dim) // 16)
+                                 if (self.target_dim + self.target_feat_dim) % 16 == 0 else None)
+            return result
         y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if y.shape[1] == self.target_feat.shape[1]:                              # layers.py:378-379
             return _hip.merge(y, self.target_feat, 2)
         down = torch.empty_like(y)                                               # layers.py:381-384
         _hip.gemm(self.target_feat, self.target_feat_down, down)
         return _hip.merge(y, down, 3)
+
+    def _infer_cat(self, x, inter_edge_index, edge_weight, if_relu, out):
+        """[y | |target_feat|] (layers.py:375-376) written into the columns of `out` by ONE launch, which also leaves the
+        row as bf16 split planes: a relational layer that takes this output as its input (GripNet-pose.py:120-127)
+        contracts with them instead of splitting x in every unit."""
+        dev = x.device
+        y, tf = out[:, :self.target_dim], out[:, self.target_dim:]
+        width, planes = self.target_dim + self.target_feat_dim, None
+        if width % 16 == 0 and width <= 64 and self.conv.table_storage == "fp32":
+            planes = getattr(self, "_planes", None)
+            if planes is None or planes.device != dev:
+                planes = self._planes = _hip.SplitPlanes(self.n_target, width // 16, dev)
+        self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _out=y, _relu=if_relu,
+                                    _side=(self.target_feat, tf, 1),     # |target_feat| slot, same launch
+                                    _planes=None if planes is None else (planes, 0, self.target_dim))
+        if planes is not None and getattr(self.conv, "_planes_written", False):
+            planes.tag(out)
+        return out

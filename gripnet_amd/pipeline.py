@@ -195,7 +195,7 @@ class PoseStages:
         n_d = int(data.n_d_node)
         self.idx = data.train_idx if edge_index is None else edge_index      # decoder's edge list (a shard's slice)
         self.et = data.train_et if edge_type is None else edge_type
-        self.z = torch.empty((n_d, self.conv.in_channels + self.conv.out_channels), dtype=torch.float32, device=dev)
+        self.z = None                                # [n_d, 80]: the drug stack's output of the last step
         self._genes, self._drugs, self._decode = self._genes_eager, self._drugs_eager, self._decode_eager
         self._encode = None                          # graphs, decoder timed or nothing timed: genes and drugs as ONE graph
         self.timed_entry, self.graphs = timed_entry, graphs
@@ -240,10 +240,8 @@ class PoseStages:
         return self._drugs()
 
     def _drugs_eager(self):
-        fin = self.conv.in_channels
         d = self.data
-        self.conv(self.x, d.train_idx, d.train_et, d.train_range, _out=self.z[:, fin:], _relu=True,
-                  _side=(self.x, self.z[:, :fin], 0))
+        self.z = self.model.dd(self.x, d.train_idx, edge_type=d.train_et, range_list=d.train_range, if_catout=True)
         return self.z
 
     def decode(self):

@@ -306,6 +306,80 @@ def test_recorded_step_is_the_eager_step(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+def test_memoised_module_calls_are_the_eager_calls(gpu):
+    """The reference-shaped API in a loop (`model(data)` under no_grad, GripNet-pose.py:117-138 / :185): from the third
+    call on the modules make their recorded entry-point calls again (_hip.CallMemo).  The results stay the eager ones, bit
+    for bit, through: outputs the caller keeps alive (fresh tensors every call, never aliased), a parameter update in
+    place, an in-place edit of an edge list, a parameter moved to new storage, a module switch, and an environment hook."""
+    dg = make_pose("small").to(gpu)
+    torch.manual_seed(5)
+    model = PoseModel(dg.n_g_node, dg.n_d_node, dg.n_dd_edge_type).to(gpu)
+
+    def fresh_reference():
+        """The same forward through modules that have never memoised anything: a new model with the same parameters and
+        switches, run under an active recorder (which keeps modules on their slow path)."""
+        twin = PoseModel(dg.n_g_node, dg.n_d_node, dg.n_dd_edge_type).to(gpu)
+        twin.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        twin.dd.conv_list[0].kernel = model.dd.conv_list[0].kernel
+        with torch.no_grad(), _hip.Recorder():
+            z, s = twin(dg)
+        return z.clone(), s.clone()
+
+    with torch.no_grad():
+        kept = [model(dg) for _ in range(6)]                  # every output stays alive: six distinct buffers
+        assert len({z.data_ptr() for z, _ in kept}) == 6 and len({s.data_ptr() for _, s in kept}) == 6
+        z0, s0 = fresh_reference()
+        for z, s in kept:
+            assert torch.equal(z, z0) and torch.equal(s, s0)
+        del kept
+        for _ in range(4):                                    # the steady state of a loop: addresses repeat, calls are replayed
+            z, s = model(dg)
+        assert any(m.__dict__.get("_memo") is not None and m.__dict__["_memo"].entries for m in model.modules())
+        assert torch.equal(z, z0) and torch.equal(s, s0)
+        # a parameter update in place (an optimizer step): same addresses, new values
+        for p in model.parameters():
+            p.mul_(1.01)
+        z1, s1 = fresh_reference()
+        assert not torch.equal(z1, z0)
+        for _ in range(3):
+            z, s = model(dg)
+            assert torch.equal(z, z1) and torch.equal(s, s1)
+        # an in-place edit of the relational edge list (its `_version` moves: new plans, new recordings)
+        dg.train_idx[:, :40] = dg.train_idx[:, 40:80].clone()
+        z2, s2 = fresh_reference()
+        assert not torch.equal(s2, s1)
+        for _ in range(4):
+            z, s = model(dg)
+            assert torch.equal(z, z2) and torch.equal(s, s2)
+        # a parameter moved to new storage, a switch of a module, an environment hook of the library
+        model.dd.conv_list[0].root.data = model.dd.conv_list[0].root.data.clone() * 0.5
+        z3, s3 = fresh_reference()
+        for _ in range(3):
+            z, s = model(dg)
+            assert torch.equal(z, z3) and torch.equal(s, s3)
+        model.dd.conv_list[0].kernel = "lds"
+        zl, sl = fresh_reference()
+        for _ in range(3):
+            z, s = model(dg)
+            assert torch.equal(z, zl) and torch.equal(s, sl)
+        model.dd.conv_list[0].kernel = "auto"
+        os.environ["GN_DISABLE_FAST"] = "1"
+        try:
+            zs, ss = fresh_reference()
+            for _ in range(3):
+                z, s = model(dg)
+                assert torch.equal(z, zs) and torch.equal(s, ss)
+        finally:
+            del os.environ["GN_DISABLE_FAST"]
+        for _ in range(3):
+            z, s = model(dg)
+            assert torch.equal(z, z3) and torch.equal(s, s3)
+    # training afterwards takes the autograd path as before
+    z = model.encode(dg)
+    assert z.requires_grad
+    _hip.raise_if_index_errors(gpu)
+
+
 @needs_fast_paths
 def test_sampled_negatives_are_scored_from_their_packed_pairs(gpu):
     """NegativeSampler.sample leaves every pair as one 32-bit word next to the int64 tensor; the decoder scores the list

@@ -1,16 +1,40 @@
-import os, sys, cProfile, pstats, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from gripnet_amd.pipeline import PoseModel, PoseStages
+#!/usr/bin/env python3
+"""Host-side cost of the reference-shaped API: `model(data)` under no_grad, as a caller of GripNet-pose.py:117-138 makes it.
+Prints the wall time per forward (eager; host-bound when the Python above the launches is slower than the kernels) and the
+cProfile table of 300 forwards.  `--train` profiles the eager training step instead."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gripnet_amd.pipeline import PoseModel
 from gripnet_amd.synth import make_pose
+
 dev = torch.device("cuda:0")
 data = make_pose("pose0-syn").to(dev)
 torch.manual_seed(1111)
 model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+n = 300
 with torch.no_grad():
-    st = PoseStages(model, data, graphs=False)
-    for _ in range(10): st.step()
+    for _ in range(10):
+        model(data)
     torch.cuda.synchronize()
-    pr = cProfile.Profile(); pr.enable()
-    for _ in range(300): st.step()
-    pr.disable(); torch.cuda.synchronize()
-ps = pstats.Stats(pr); ps.sort_stats("tottime").print_stats(22)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model(data)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        print("eager model(data): {:.1f} us per forward (host loop alone {:.1f} us)".format(1e6 * t_all / n, 1e6 * t_host / n))
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(n):
+        model(data)
+    pr.disable()
+    torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
