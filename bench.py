@@ -208,8 +208,49 @@ def extra_workloads(dev, budget_s, with_cpu):
                         "decoder": {"us": round(dec_us, 1), "frac": round(alg["dmt"] / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}})
             del model, data, eager, stages
             torch.cuda.empty_cache()
-        # ---- the node-classification models (configs 3 and 5) ----
+        # ---- rgcn-pose-syn: the reference's all-nodes relational baseline (baselines/LP_baselines/rgcn_pose.py:53-106):
+        #      N = 19,726, R = 964, 64 -> 32 -> 32, 16 bases - the O(E)-memory general relational path (rgcn_basis.hip) ----
         from oracle import gripnet_oracle as orc
+        if left() > 25:
+            from gripnet_amd.pipeline import RgcnPoseModel
+            from gripnet_amd.synth import make_rgcn_pose
+            data_cpu = make_rgcn_pose("pose0-syn")
+            torch.manual_seed(1111)
+            model = RgcnPoseModel(data_cpu.n_node, data_cpu.n_edge_type)
+            sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            model = model.to(dev)
+            data = Data(**data_cpu.__dict__).to(dev)
+            for _ in range(3):
+                model(data)
+            wall, calls, busy = timed(lambda: model(data), 10)
+            E, N, R = int(data.train_idx.shape[1]), int(data.n_node), int(data.n_edge_type)
+            rel_bytes = [E * 16 + N * 4 * (fi + fo) + 4 * (16 * fi * fo + R * 16 + fi * fo) for fi, fo in ((64, 32), (32, 32))]
+            dec_bytes = E * 28 + N * 32 * 4 + R * 32 * 4
+            rel_us = calls.get("gn_rgcn_forward_f32")
+            plan = model.rgcn1._plan
+            ws = int(_hip.load().gn_rgcn_workspace_bytes(plan._h, 64, 32, 16, 0))
+            entry = {"workload": "rgcn-pose-syn", "nodes": N, "relations": R, "edges": E, "layers": "64 -> 32 -> 32, 16 bases",
+                     "forward_us_entry_points": round(busy, 1), "forward_us_eager_wall": round(1e6 * wall, 1),
+                     "algorithmic_bytes": sum(rel_bytes) + dec_bytes,
+                     "frac": round((sum(rel_bytes) + dec_bytes) / (busy * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "relational": {"kernel": plan.path(64, 32, 16), "us_per_call": round(rel_us, 1),
+                                    "algorithmic_bytes_per_call": sum(rel_bytes) // 2,
+                                    "frac": round(sum(rel_bytes) / 2 / (rel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "workspace_bytes": ws, "table_path_workspace_bytes": R * N * 32 * 4},
+                     "note": "us_per_call: average over the two relational layers (HIP events around the entry point: the gather "
+                             "launches and the dense products of its slabs of rows); workspace independent of R and N"}
+            if with_cpu and left() > 20:
+                d = data_cpu
+                t1 = time.perf_counter()
+                h = orc.rgcn_forward(sd["embedding"], d.train_idx, d.train_range, sd["rgcn1.basis"], sd["rgcn1.att"], sd["rgcn1.root"])
+                zr = orc.rgcn_forward(h, d.train_idx, d.train_range, sd["rgcn2.basis"], sd["rgcn2.att"], sd["rgcn2.root"])
+                entry["cpu_oracle_encoder_s"] = round(time.perf_counter() - t1, 3)
+                entry["cpu_threads"] = torch.get_num_threads()
+                entry["parity_max_abs_err_z"] = float((model.encode(data).cpu() - zr).abs().max())
+            out.append(entry)
+            del model, data
+            torch.cuda.empty_cache()
+        # ---- the node-classification models (configs 3 and 5) ----
         from gripnet_amd.utils import set_table_storage
         for name, cls, storage in (("aminer-syn", AminerModel, "fp32"), ("freebase-c-syn", FreebaseCModel, "fp32"),
                                    ("freebase-c-syn, bf16 table storage", FreebaseCModel, "bf16")):
@@ -570,7 +611,7 @@ def main():
     traffic = traffic_all.get(dom)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (PMC passes of tools/profile_round.sh, not counters of this run)" if traffic else None,
+                "traffic_source": "profiles/traffic.json (PMC passes of tools/prof.sh step r05: warm-up + recorded steps of tools/step_only.py and nothing else, same round; not counters of this run)" if traffic else None,
                 "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_us": round(dom_us, 2),
                 "timed_launches": calls,
                 "limiter": LIMITERS.get(dom)}
@@ -629,7 +670,7 @@ def main():
         "roofline_fast": roofline_fast,
         "roofline_all": roofline_all,
         "mfma_util": mfma,
-        "mfma_util_source": "profiles/mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES pass of tools/mfma_util.sh, not a counter of this run)" if mfma else None,
+        "mfma_util_source": "profiles/mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES pass of tools/prof.sh step r05, same command as the traffic passes; not a counter of this run)" if mfma else None,
         "plan_build_ms": round(plan_build_ms, 1),
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
         "edges_scored_per_sec": (hi - lo) / (per_call0.get("gn_distmult_plan_forward_f32",

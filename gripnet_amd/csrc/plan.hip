@@ -593,6 +593,17 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
     GN_TRY(hipStreamSynchronize(st));
     if (bad) return bail(gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld)", (long long)N));
     for (int64_t i = 0; i < N; ++i) p->max_row_nnz = std::max<int64_t>(p->max_row_nnz, rp[i + 1] - rp[i]);
+    if (N > 0) {
+        // rows by in-degree, largest first (a counting sort on the host: the row pointers are here anyway), ties by row id
+        std::vector<int64_t> first(p->max_row_nnz + 2, 0);
+        for (int64_t i = 0; i < N; ++i) ++first[p->max_row_nnz - (rp[i + 1] - rp[i]) + 1];
+        for (size_t d = 1; d < first.size(); ++d) first[d] += first[d - 1];
+        std::vector<int32_t> order(N);
+        for (int64_t i = 0; i < N; ++i) order[first[p->max_row_nnz - (rp[i + 1] - rp[i])]++] = (int32_t)i;
+        GN_TRY(p->row_order.alloc(N));
+        GN_TRY(hipMemcpyAsync(p->row_order.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        GN_TRY(hipStreamSynchronize(st));
+    }
     gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
     if (fs != GN_OK) return bail(fs);
     fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
@@ -607,6 +618,7 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->indeg.release();
     p->rowptr.release();
     p->key.release();
+    p->row_order.release();
     p->seg_rel.release();
     p->item_tile.release();
     p->seg_begin.release();

@@ -1,10 +1,13 @@
-// Multi-relational internal layer (myRGCN, gripnet/layers.py:165-197): general path.
+// Multi-relational internal layer (myRGCN, gripnet/layers.py:165-197): the entry point, its choice of kernel, and the
+// TABLE path.
 //
-// Transform-then-gather ordering: W_r = att[r,:] . basis, H_r = X W_r for
-// every relation (two MFMA GEMMs), then one destination-major gather-reduce over the
-// [R*N, out] table with the global mean, the root term and the activation in the epilogue.
-// Works for any shape; the table lives in HBM / Infinity Cache (sized for 288 GB parts).
-// The LDS-resident specialisation for small supervertices is in rgcn_fast.hip.
+// Kernels: destination-major in basis space for small supervertices (rgcn_pair.hip), LDS accumulator rows
+// (rgcn_fast.hip), and for everything else the O(E)-memory basis-space path of rgcn_basis.hip (GN_RGCN_PATH_GENERAL).
+// The table path below (GN_RGCN_PATH_TABLE) is the transform-then-gather ordering: W_r = att[r,:] .
+// basis, H_r = X W_r for every relation (two MFMA GEMMs), then one destination-major gather-reduce over the [R*N, out]
+// table with the global mean, the root term and the activation in the epilogue.  It works for any shape but needs
+// R * N * out floats of workspace: kept for the shapes the basis-space path does not cover (> 64 bases, > 128 input
+// features) and as an independent cross-check in the tests.
 #include "aggregate.cuh"
 
 // rgcn_fast.hip
@@ -27,6 +30,14 @@ gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, c
                                 const float* root, const float* bias, int relu, float* out, int64_t ld_out,
                                 const gn_side_copy& side, hipStream_t st);
 
+// rgcn_basis.hip
+bool gn_rgcn_basis_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+size_t gn_rgcn_basis_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases);
+gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
+                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout, int relu,
+                                int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side, void* ws,
+                                size_t ws_bytes, hipStream_t st);
+
 namespace {
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -40,10 +51,12 @@ int select_path(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bas
     const bool lds_ok = gn_rgcn_fast_applicable(plan, fin, fout, bases);
     if (forced == GN_RGCN_PATH_PAIR && pair_ok) return GN_RGCN_PATH_PAIR;
     if (forced == GN_RGCN_PATH_LDS && lds_ok) return GN_RGCN_PATH_LDS;
-    if (forced == GN_RGCN_PATH_GENERAL) return GN_RGCN_PATH_GENERAL;
+    const bool basis_ok = gn_rgcn_basis_applicable(plan, fin, fout, bases);
+    if (forced == GN_RGCN_PATH_TABLE) return GN_RGCN_PATH_TABLE;
+    if (forced == GN_RGCN_PATH_GENERAL) return basis_ok ? GN_RGCN_PATH_GENERAL : GN_RGCN_PATH_TABLE;
     if (pair_ok) return GN_RGCN_PATH_PAIR;
     if (lds_ok) return GN_RGCN_PATH_LDS;
-    return GN_RGCN_PATH_GENERAL;
+    return basis_ok ? GN_RGCN_PATH_GENERAL : GN_RGCN_PATH_TABLE;
 }
 
 struct GeneralWs {
@@ -88,6 +101,7 @@ extern "C" {
 static size_t path_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int path) {
     if (path == GN_RGCN_PATH_PAIR) return 0;
     if (path == GN_RGCN_PATH_LDS) return gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases);
+    if (path == GN_RGCN_PATH_GENERAL) return gn_rgcn_basis_workspace_bytes(plan, fin, fout, bases);
     return general_layout(plan, fin, fout).total;
 }
 
@@ -115,8 +129,8 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     if (N == 0) return GN_OK;
     GN_REQUIRE(x && basis && att && out && (partial || root), "operand pointer is null");
     GN_REQUIRE(ld_x >= fin && ld_out >= fout, "leading dimension smaller than the row length");
-    // the workspace is checked against the kernel THIS call takes (a forced general path, or a basis pointer the
-    // destination-major kernel cannot use, needs the [R, N, out] table whatever gn_rgcn_workspace_bytes said for the
+    // the workspace is checked against the kernel THIS call takes (a forced general or table path, or a basis pointer the
+    // destination-major kernel cannot use, needs its own scratch whatever gn_rgcn_workspace_bytes said for the
     // default choice)
     const int path = select_path(plan, fin, fout, bases, flags, basis);
     const size_t need = path_workspace_bytes(plan, fin, fout, bases, path);
@@ -133,6 +147,9 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     if (path == GN_RGCN_PATH_LDS)
         return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
                                     out, ld_out, sc, workspace, workspace_bytes, st);
+    if (path == GN_RGCN_PATH_GENERAL)
+        return gn_rgcn_basis_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
+                                     flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, workspace, workspace_bytes, st);
 
     const GeneralWs l = general_layout(plan, fin, fout);
     char* ws = static_cast<char*>(workspace);

@@ -114,6 +114,28 @@ class FreebaseCModel(Module):
         return z, self.mcip(z, node_list, softmax=softmax)
 
 
+class RgcnPoseModel(Module):
+    """embedding -> myRGCN -> myRGCN -> DistMult over ALL nodes of the homogenised graph: the reference's improved-RGCN
+    baseline (baselines/LP_baselines/rgcn_pose.py:53-77 model, :91-106 call order; `sparse_id(n) @ embedding` is the
+    embedding itself).  The relational layers run far beyond the LDS-resident kernels (N ~ 2 x 10^4, R ~ 10^3)."""
+
+    def __init__(self, n_node, n_edge_type, dims=(64, 32, 32), n_bases=16):
+        super().__init__()
+        from .layers import myRGCN
+        self.embedding = torch.nn.Parameter(torch.empty(n_node, dims[0]).normal_())            # rgcn_pose.py:64-65
+        self.rgcn1 = myRGCN(dims[0], dims[1], n_edge_type, n_bases, after_relu=False)           # rgcn_pose.py:73
+        self.rgcn2 = myRGCN(dims[1], dims[2], n_edge_type, n_bases, after_relu=True)            # rgcn_pose.py:74
+        self.dmt = multiRelaInnerProductDecoder(dims[2], n_edge_type)                           # rgcn_pose.py:75
+
+    def encode(self, data):
+        z = self.rgcn1(self.embedding, data.train_idx, data.train_et, data.train_range)        # rgcn_pose.py:95-97
+        return self.rgcn2(z, data.train_idx, data.train_et, data.train_range)
+
+    def forward(self, data, sigmoid=True):
+        z = self.encode(data)
+        return z, self.dmt(z, data.train_idx, data.train_et, sigmoid=sigmoid)                   # rgcn_pose.py:110
+
+
 def load_reference_state(model: Module, state: Dict[str, torch.Tensor], strict: bool = True):
     """Load a state dict saved by the reference (GripNet-pose.py:236; keys of SURVEY App. B.2)."""
     return model.load_state_dict(state, strict=strict)

@@ -113,6 +113,28 @@ def pose_edges_aggregated(data: Data) -> int:
             + int(data.gd_edge_index.shape[1]) + int(data.train_idx.shape[1]))
 
 
+def make_rgcn_pose(name: str = "pose0-syn", seed: int = 7, n_rel: int = None, **override) -> Data:
+    """The homogenised graph of the reference's all-nodes baselines (baselines/LP_baselines/rgcn_pose.py:28-35,91-106,
+    `pose-*-combl.pt`): ONE node set of n_d drugs followed by n_g genes, relations = the drug-drug relations, then the
+    gene-gene edges, then the gene-drug edges as the LAST TWO relations (the caller slices `train_range[:-2]` for the
+    drug-only negatives), every relation bidirectional and type-sorted.  Built from the PoSE ladder's graph; `n_rel`
+    keeps the total at that many relations (default: the ladder's count, so that R matches the GripNet runs)."""
+    base = make_pose(name, seed=seed, **override)
+    n_d, n_g = int(base.n_d_node), int(base.n_g_node)
+    R = int(base.n_dd_edge_type) if n_rel is None else int(n_rel)
+    rng = base.train_range
+    keep = R - 2                                          # drug-drug relations kept (the largest ones: the ladder is Zipf-ordered)
+    blocks = [base.train_idx[:, int(rng[r, 0]):int(rng[r, 1])] for r in range(keep)]
+    blocks.append(base.gg_edge_index + n_d)               # gene ids follow the drug ids
+    gd = torch.stack([base.gd_edge_index[0] + n_d, base.gd_edge_index[1]])
+    blocks.append(to_bidirection(gd))
+    train_idx = torch.cat(blocks, dim=1)
+    train_range = get_range_list(blocks)
+    train_et = torch.repeat_interleave(torch.arange(R, dtype=torch.long), train_range[:, 1] - train_range[:, 0])
+    return Data(name="rgcn-" + name, n_node=n_d + n_g, n_drug=n_d, n_edge_type=R,
+                train_idx=train_idx.long(), train_et=train_et, train_range=train_range)
+
+
 NC_LADDER = {
     "tiny": dict(n_p=60, e_pp=150, n_q=40, e_qq=90, n_a=25, e_pa=80, e_qa=60, e_aa=50, n_class=4),
     "aminer-syn": dict(n_p=50_000, e_pp=250_000, n_q=30_000, e_qq=150_000, n_a=20_000,

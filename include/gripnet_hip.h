@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 138 /* 0.1.34 */
+#define GN_VERSION 139 /* 0.1.35 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -241,8 +241,8 @@ GN_API void gn_rgcn_plan_destroy(gn_rgcn_plan* plan);
 GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
 
 /* Bytes of caller-provided scratch a gn_rgcn_forward_f32 call with these shapes and flags needs: none on the
- * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, the [R, N, out] table of the general
- * path.  (The forward checks the workspace against the kernel IT takes and refuses a smaller one.) */
+ * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, a slab of rows (<= 64 MB) and the stacked
+ * weights on the general path (independent of R and N), the [R, N, out] table on the table path.  (The forward checks the workspace against the kernel IT takes and refuses a smaller one.) */
 GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features,
                                int64_t num_bases, int flags);
 
@@ -254,7 +254,10 @@ GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_featu
 #define GN_RGCN_PATH_SHIFT 8
 #define GN_RGCN_PATH_PAIR 1      /* destination-major in basis space (rgcn_pair.hip): no W_r, no workspace, one launch */
 #define GN_RGCN_PATH_LDS 3       /* LDS accumulator rows (rgcn_fast.hip) */
-#define GN_RGCN_PATH_GENERAL 4   /* transform-then-gather through HBM (rgcn.hip), any size */
+#define GN_RGCN_PATH_GENERAL 4   /* any size, O(E) memory: basis-space sums per destination on the fp32 matrix instruction, one dense
+                                 * product per slab of rows with [basis ; root] (rgcn_basis.hip); up to 64 bases and 128 input
+                                 * features, else the table path */
+#define GN_RGCN_PATH_TABLE 5     /* transform-then-gather through an [R, N, out] table in HBM (rgcn.hip): any shape */
 GN_API int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features, int64_t num_bases, int flags);
 
 /* flags & GN_RGCN_PARTIAL == 0:  out[i,:] = act( (sum_{e: dst=i} x[src_e] W_{r(e)}) / max(1, indeg_i) + x[i] root + bias )

@@ -306,6 +306,36 @@ def test_recorded_step_is_the_eager_step(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+def test_rgcn_pose_model_on_the_homogenised_graph(gpu):
+    """pipeline.RgcnPoseModel on synth.make_rgcn_pose (the reference's all-nodes baseline, baselines/LP_baselines/
+    rgcn_pose.py:53-110): the last two relations are the gene-gene and gene-drug edges, the layers take the general
+    relational path, scores against the oracle."""
+    from gripnet_amd.pipeline import RgcnPoseModel
+    from gripnet_amd.synth import make_rgcn_pose
+    d = make_rgcn_pose("small")
+    assert d.n_node == 2128 and d.n_edge_type == 32 and int(d.train_range[-1, 1]) == d.train_idx.shape[1]
+    gg = d.train_idx[:, int(d.train_range[-2, 0]):int(d.train_range[-2, 1])]
+    gd = d.train_idx[:, int(d.train_range[-1, 0]):]
+    assert int(d.train_idx[:, :int(d.train_range[-3, 1])].max()) < d.n_drug <= int(gg.min())        # drug-drug, then gene-gene
+    assert int(gd.min()) < d.n_drug <= int(gd.max()) < d.n_node                                    # gene-drug, both directions
+    torch.manual_seed(3)
+    model = RgcnPoseModel(d.n_node, d.n_edge_type)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    h = orc.rgcn_forward(sd["embedding"], d.train_idx, d.train_range, sd["rgcn1.basis"], sd["rgcn1.att"], sd["rgcn1.root"])
+    zr = orc.rgcn_forward(h, d.train_idx, d.train_range, sd["rgcn2.basis"], sd["rgcn2.att"], sd["rgcn2.root"])
+    ref = orc.distmult(zr, d.train_idx, d.train_et, sd["dmt.weight"])
+    model, dg = model.to(gpu), make_rgcn_pose("small").to(gpu)
+    for kernel in ("auto", "general"):
+        model.rgcn1.kernel = model.rgcn2.kernel = kernel
+        with torch.no_grad():
+            for _ in range(3):
+                z, score = model(dg)
+        close(z, zr, what="z " + kernel)
+        close(score, ref, what="score " + kernel)
+    assert model.rgcn1._plan.path(64, 32, 16, path="general") == "general"
+    _hip.raise_if_index_errors(gpu)
+
+
 def test_memoised_module_calls_are_the_eager_calls(gpu):
     """The reference-shaped API in a loop (`model(data)` under no_grad, GripNet-pose.py:117-138 / :185): from the third
     call on the modules make their recorded entry-point calls again (_hip.CallMemo).  The results stay the eager ones, bit

@@ -215,12 +215,12 @@ def use_relational_kernel(module, kernel, arithmetic="fp32"):
     return layers
 
 
-@pytest.fixture(params=["pair", "pair-fast", "lds", "general", "general-forced"])
+@pytest.fixture(params=["pair", "pair-fast", "lds", "general", "general-forced", "table"])
 def kernel_path(request, monkeypatch):
     """Run a test once per relational kernel: destination-major (default; three- and two-term splits), LDS-resident
-    accumulator, general (with every fast path switched off, and FORCED by flag while the fast kernels apply: the
-    workspace then has to be the general path's); the last three also take the shuffle-based form of the 16-wide GCN
-    gather instead of the quad form."""
+    accumulator, general = the O(E) basis-space path (with every fast path switched off, and FORCED by flag while the fast
+    kernels apply: the workspace then has to be the general path's), table = the [R, N, out] table path forced by flag;
+    the last four also take the shuffle-based form of the 16-wide GCN gather instead of the quad form."""
     monkeypatch.setenv("GN_DISABLE_FAST", "1" if request.param == "general" else "0")
     monkeypatch.setenv("GN_DISABLE_QUAD", "0" if request.param in ("pair", "pair-fast") else "1")
     return request.param
@@ -376,7 +376,7 @@ def test_gcn_skewed_degrees_and_empty_rows(gpu, fout):
 
 @pytest.mark.parametrize("n,fin,bases", [(40, 16, 3), (200, 32, 5), (560, 48, 32), (645, 64, 8), (900, 48, 4),
                                          (1000, 32, 2), (1, 16, 1)])
-@pytest.mark.parametrize("path", ["pair", "pair-fast", "lds", "general"])
+@pytest.mark.parametrize("path", ["pair", "pair-fast", "lds", "general", "table"])
 def test_rgcn_lds_resident_shapes(gpu, n, fin, bases, path):
     """Every specialisation of the three LDS-resident relational kernels (destination-major: one or two bases per lane,
     one to four feature tiles, one to three rows per workgroup, a pair run longer than one unit; register-accumulated:
@@ -804,6 +804,64 @@ def test_rgcn_improved_baseline_caller(gpu):
     close(score, ref, TOL)
 
 
+@pytest.mark.parametrize("n,fin,fout,bases,R", [(20000, 64, 32, 16, 600), (5000, 40, 24, 5, 520), (3000, 128, 16, 20, 7),
+                                                 (2500, 20, 8, 64, 3), (70000, 16, 32, 2, 501)])
+def test_rgcn_general_path_is_linear_in_the_edges(gpu, n, fin, fout, bases, R):
+    """The O(E)-memory relational path (rgcn_basis.hip: basis-space sums per destination on the fp32 matrix instruction, one
+    dense product per slab of rows) where the reference's per-relation loop is the only other O(E) formulation
+    (layers.py:171-189; the all-nodes caller baselines/LP_baselines/rgcn_pose.py:53-106 has N = 2 x 10^4, R ~ 10^3): graphs
+    with >= 500 relations and up to 7 x 10^4 nodes, skewed relation sizes, empty relations, hub destinations, nodes without
+    edges, input widths that are no multiple of 16, 2..64 bases, an x that is a column slice (no vector loads); against the
+    float64 oracle; workspace independent of R and N; bias, ReLU, concat slot and the un-normalised partial sums of a shard."""
+    gen = torch.Generator().manual_seed(n + fin + R)
+    torch.manual_seed(n * 3 + R)
+    ranks = torch.arange(1, R + 1, dtype=torch.float64)
+    sizes = [int(s) for s in torch.floor(300000 * ranks.pow(-0.9) / ranks.pow(-0.9).sum())]
+    sizes[R // 2] = 0
+    blocks = [torch.randint(0, n - n // 9, (2, s), generator=gen) for s in sizes]          # the top ids have no edges
+    blocks[0][1, :4000] = 7                                                               # a hub destination
+    ei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    wide = torch.randn(n, fin + 5, generator=gen)
+    conv = gripnet_amd.myRGCN(fin, fout, R, bases, False, bias=True).to(gpu)
+    conv.bias.data.normal_()
+    sd = {k: v.detach().cpu().double() for k, v in conv.state_dict().items()}
+    eig = ei.to(gpu)
+    for x in (wide[:, :fin].contiguous(), wide[:, 3:3 + fin]):
+        xg = x.to(gpu) if x.is_contiguous() else wide.to(gpu)[:, 3:3 + fin]
+        ref = torch.relu(orc.rgcn_forward(x.double(), ei, rl, sd["basis"], sd["att"], sd["root"], sd["bias"])).float()
+        with torch.no_grad():
+            slot = torch.full((n, fin + fout), float("nan"), device=gpu)
+            y = conv(xg, eig, None, rl, _relu=True, _out=slot[:, fin:], _side=(xg, slot[:, :fin], 0))
+        plan = conv._plan
+        assert plan.path(fin, fout, bases) == "general"
+        close(y, ref, TOL * max(1.0, float(ref.abs().max())))
+        assert torch.equal(slot[:, :fin], xg)
+        with torch.no_grad():
+            assert torch.equal(conv(xg, eig, None, rl, _relu=True), y)                    # the same bits on every call
+    need = int(_hip.load().gn_rgcn_workspace_bytes(plan._h, fin, fout, bases, 0))
+    assert need <= (66 << 20) and (R < 500 or need < R * n * fout * 4)
+    # a shard's un-normalised partial sums (GN_RGCN_PARTIAL) over two edge ranges add up to deg * (out - root term)
+    E = ei.shape[1]
+    xg = wide[:, :fin].contiguous().to(gpu)
+    parts = []
+    for lo, hi in ((0, E // 3), (E // 3, E)):
+        p = torch.empty(n, fout, device=gpu)
+        _hip.RgcnPlan(eig, rl, n, lo, hi).forward(xg, conv.basis.detach(), conv.att.detach(), None, None, False, p, partial=True)
+        parts.append(p)
+    whole = torch.empty(n, fout, device=gpu)
+    plan.forward(xg, conv.basis.detach(), conv.att.detach(), None, None, False, whole, partial=True)
+    scale = max(1.0, float(whole.abs().max()))
+    close((parts[0] + parts[1]) / scale, whole / scale, TOL)
+    if n <= 5000:                                                                         # the table path, where its table is small
+        conv.kernel = "table"
+        with torch.no_grad():
+            close(conv(xg, eig, None, rl, _relu=True), ref if x.is_contiguous() else
+                  torch.relu(orc.rgcn_forward(wide[:, :fin].double(), ei, rl, sd["basis"], sd["att"], sd["root"], sd["bias"])).float(),
+                  TOL * max(1.0, float(ref.abs().max())))
+    _hip.raise_if_index_errors(gpu)
+
+
 def test_sharded_forward_on_hip_kernels(gpu):
     """gripnet_amd.sharded with the product kernels: world_size 1 end to end, and the two ranks of a
     world_size-2 job run one after the other on this device with the all-reduce done by hand
@@ -950,8 +1008,8 @@ def test_decoder_plan_rejects_out_of_range_edges(gpu):
 
 def test_forced_general_path_gets_its_own_workspace(gpu):
     """A kernel forced by flag while the destination-major kernel applies: gn_rgcn_workspace_bytes answers for THAT
-    call (the general path's [R, N, out] table), and a forward handed a smaller workspace is refused instead of writing
-    past it (round-3 advisor finding)."""
+    call (the general path's slab of rows and stacked weights - independent of R; the table path's [R, N, out] table), and
+    a forward handed a smaller workspace is refused instead of writing past it (round-3 advisor finding)."""
     data = make_pose("small").to(gpu)
     n, fin, fout, R = data.n_d_node, 48, 32, data.n_dd_edge_type
     conv = gripnet_amd.myRGCN(fin, fout, R, 32, False, bias=True).to(gpu)
@@ -963,9 +1021,13 @@ def test_forced_general_path_gets_its_own_workspace(gpu):
         lib = _hip.load()
         need_default = int(lib.gn_rgcn_workspace_bytes(plan._h, fin, fout, 32, plan.mode_flags()))
         need_general = int(lib.gn_rgcn_workspace_bytes(plan._h, fin, fout, 32, plan.mode_flags(path="general")))
-        assert need_default == 0 and need_general >= R * n * fout * 4
+        need_table = int(lib.gn_rgcn_workspace_bytes(plan._h, fin, fout, 32, plan.mode_flags(path="table")))
+        kp = (33 * fin + 31) // 32 * 32                                # [U_i | x_i] padded to the dense product's K step
+        assert need_default == 0 and need_table >= R * n * fout * 4 and kp * (n + fout) * 4 <= need_general <= kp * (n + fout) * 4 + 512
+        for forced in ("general", "table"):
+            conv.kernel = forced
+            close(conv(x, data.train_idx, None, data.train_range, _relu=True), base)
         conv.kernel = "general"
-        close(conv(x, data.train_idx, None, data.train_range, _relu=True), base)
         out = torch.empty(n, fout, device=gpu)
         small = torch.empty(1024, dtype=torch.uint8, device=gpu)
         status = lib.gn_rgcn_forward_f32(plan._h, x.data_ptr(), fin, fin, conv.basis.data_ptr(), conv.att.data_ptr(), 32,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""MFMA utilisation per kernel from one rocprofv3 PMC pass (tools/mfma_util.sh).
+"""MFMA utilisation per kernel from one rocprofv3 PMC pass (tools/prof.sh step).
 
     python tools/summarize_mfma.py <pmc_dir> [--json profiles/mfma_util.json --workload pose0-syn]
 

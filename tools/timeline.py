@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device timeline of the last steps of a rocprofv3 kernel trace (development tool).
 
-    tools/prof_stats.sh tl bench.py --steps 20 --warmup 3 --no-cpu-baseline [--graphs]
+    tools/prof.sh stats tl bench.py --steps 20 --warmup 3 --no-cpu-baseline [--graphs]
     python tools/timeline.py gpurun_out/prof_tl [n_kernels]
 
 Prints start offset, duration and the idle gap before every kernel, so that launch gaps and overlap

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """dev helper: device-busy share of the training steps in a rocprofv3 kernel trace of tools/bench_train.py.
-    tools/prof_stats.sh train tools/bench_train.py --steps 10 && python tools/train_busy.py gpurun_out/prof_train"""
+    tools/prof.sh stats train tools/bench_train.py --steps 10 && python tools/train_busy.py gpurun_out/prof_train"""
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The training-step entry of bench.py on its own (development tool; for rocprofv3 traces of the replayed step:
-tools/prof_stats.sh ts tools/train_step.py 20 && python tools/timeline.py gpurun_out/prof_ts 140)."""
+tools/prof.sh train <tag> 20))."""
 import json
 import os
 import sys
