@@ -527,23 +527,29 @@ GN_XTG_TICKET_ZEROED, GN_XTG_JOIN_BATCH = 1, 2
 
 
 def xtg(x: torch.Tensor, g: torch.Tensor, join_batch=False):
-    """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients); torch.matmul beyond 4096 outputs.  `join_batch`: as in
-    `gemm`."""
+    """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients) on gn_xtg_f32: up to 64 x 32 outputs in one launch; wider
+    products (the 128 x 64 ... 256 x 128 layers of the node-classification models) in tiles of 64 x 32 outputs over column
+    slices of x and g, every tile with a workspace of its own.  `join_batch`: as in `gemm`."""
     k1, k2 = x.shape[1], g.shape[1]
-    if k1 * k2 > 4096 or k1 * k2 == 0:
-        return x.t() @ g
     out = torch.empty((k1, k2), dtype=torch.float32, device=x.device)
-    need = int(load().gn_xtg_workspace_bytes(k1, k2))
-    key = (x.device.index, need)
-    ws = _xtg_ws.get(key)
-    if ws is None:                                             # one zeroed workspace per device and size: its last 64 bytes are the kernel's ticket
-        ws = _xtg_ws[key] = torch.zeros((need,), dtype=torch.uint8, device=x.device)
-    join_batch = join_batch and getattr(_batch_tls, 'open', None) is not None
-    if join_batch:
-        _batch_tls.open.keep.extend((x, g, out))
-    _call("gn_xtg_f32", ptr(x), ld(x), ptr(g), ld(g), x.shape[0], k1, k2, ptr(out), ld(out), ptr(ws), need,
-          GN_XTG_TICKET_ZEROED | (GN_XTG_JOIN_BATCH if join_batch else 0),
-          stream_ptr(x.device))
+    if k1 * k2 == 0:
+        return out
+    if x.shape[0] == 0:
+        return out.zero_()
+    tiles = [(c0, min(64, k1 - c0), d0, min(32, k2 - d0)) for c0 in range(0, k1, 64) for d0 in range(0, k2, 32)] \
+        if (k1 > 64 or k2 > 32) else [(0, k1, 0, k2)]
+    batched = join_batch and getattr(_batch_tls, 'open', None) is not None
+    for t, (c0, w1, d0, w2) in enumerate(tiles):
+        need = int(load().gn_xtg_workspace_bytes(w1, w2))
+        key = (x.device.index, need, t)
+        ws = _xtg_ws.get(key)
+        if ws is None:                                         # one zeroed workspace per device, size and tile: its last 64 bytes are the kernel's ticket
+            ws = _xtg_ws[key] = torch.zeros((need,), dtype=torch.uint8, device=x.device)
+        xs, gs, os_ = (x, g, out) if len(tiles) == 1 else (x[:, c0:c0 + w1], g[:, d0:d0 + w2], out[c0:c0 + w1, d0:d0 + w2])
+        if batched:
+            _batch_tls.open.keep.extend((xs, gs, os_))
+        _call("gn_xtg_f32", ptr(xs), ld(xs), ptr(gs), ld(gs), x.shape[0], w1, w2, ptr(os_), ld(os_), ptr(ws), need,
+              GN_XTG_TICKET_ZEROED | (GN_XTG_JOIN_BATCH if batched else 0), stream_ptr(x.device))
     return out
 
 

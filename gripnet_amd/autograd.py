@@ -6,8 +6,11 @@ through the ``torch.autograd.Function``s below instead of the slot-fused inferen
 parts of every gradient run in HIP kernels behind the C ABI (transposed normalised adjacency,
 DistMult scatter), and so do the dense contractions: the tall-skinny weight gradients dW = x^T g (gn_xtg_f32), the relational
 dW_r = X^T Q_r (gn_rel_weight_grad_f32), dx = g W^T and the basis / attention gradients (gn_gemm_f32 with operands given
-transposed).  The library GEMM (torch.matmul) is left for shapes outside those kernels only (xtg beyond 4096 outputs, the
-unfused relational path of large graphs).
+transposed; x^T g wider than 64 x 32 outputs in tiles), the class decoder's row gather / scatter-add through a one-edge-per-node
+plan, the merges of the external layer's mod="add" branches and of freebase-c.  torch arithmetic is left in ONE place: the
+relational weight gradient of graphs too large for the fused kernel (rgcn_edge_gradients: more than 65,534 nodes or a
+gradient table beyond the LDS - the all-nodes baseline of rgcn_pose.py), where the (relation, source) sums are scattered with
+index_add_ and contracted with a batched matmul per slab of relations.
 """
 from __future__ import annotations
 
@@ -322,8 +325,27 @@ class LinkLossFn(torch.autograd.Function):
         return (dp if ctx.needs_input_grad[0] else None), (dn if ctx.needs_input_grad[1] else None), None
 
 
+_node_plans = []            # (node_list tensor, _version, rows of z, plan): the row-gather plans of the last few node lists
+
+
+def node_gather_plan(nodes: torch.Tensor, num_rows: int):
+    """Plain-sum plan with ONE edge per listed node (table row nodes[i] -> output row i): its aggregation is the row gather
+    z[node_list] (decoder.py:42), its transposed aggregation the scatter-add of the gathered rows' gradients.  Built once
+    per node list (the label splits of a training loop are static, GripNet-aminer.py:124-147)."""
+    for t, ver, rows, plan in _node_plans:
+        if t is nodes and ver == nodes._version and rows == num_rows:
+            return plan
+    ei = torch.stack([nodes, torch.arange(nodes.shape[0], dtype=torch.int64, device=nodes.device)])
+    plan = _hip.GraphPlan.plain_sum(ei, num_rows, nodes.shape[0])
+    _node_plans.append((nodes, nodes._version, num_rows, plan))
+    del _node_plans[:-4]
+    return plan
+
+
 class ClassLogitsFn(torch.autograd.Function):
-    """``z[node_list] @ W`` (decoder.py:42); forward on gn_class_scores_f32."""
+    """``z[node_list] @ W`` (decoder.py:42); forward on gn_class_scores_f32, backward on the library's own kernels: the
+    gathered rows and the scatter-add of their gradients through a one-edge-per-node plan (gn_graph_aggregate_f32 /
+    gn_graph_aggregate_t_f32), the two products on gn_gemm_f32 / gn_xtg_f32."""
 
     @staticmethod
     def forward(ctx, z, weight, node_list):
@@ -332,16 +354,23 @@ class ClassLogitsFn(torch.autograd.Function):
         nodes = _hip.i64_vec(node_list)
         out = torch.empty((nodes.shape[0], w.shape[1]), dtype=torch.float32, device=zc.device)
         _hip.class_scores(zc, w, nodes, out, False)
-        ctx.save_for_backward(zc, w, nodes)
+        ctx.nodes = node_list if nodes is node_list else nodes     # (the caller's tensor keys the gather plan's cache)
+        ctx.save_for_backward(zc, w)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        z, w, nodes = ctx.saved_tensors
-        g = g.contiguous()
+        z, w = ctx.saved_tensors
+        nodes = ctx.nodes
         dz = dw = None
-        g = _hip.f32_rows(g)
-        zsel = z.index_select(0, nodes) if ctx.needs_input_grad[1] else None
+        g = _hip.f32_rows(g.contiguous())
+        plan = node_gather_plan(nodes, z.shape[0]) if nodes.shape[0] > 0 else None
+        if plan is None:
+            return (torch.zeros_like(z) if ctx.needs_input_grad[0] else None), (torch.zeros_like(w) if ctx.needs_input_grad[1] else None), None
+        zsel = None
+        if ctx.needs_input_grad[1]:                            # z[nodes]: a one-edge-per-row aggregation
+            zsel = torch.empty((nodes.shape[0], z.shape[1]), dtype=torch.float32, device=z.device)
+            plan.aggregate(z, None, False, zsel)
         gw = None
         with _hip.dense_batch(g.device):                       # the two products do not depend on each other: one launch
             if ctx.needs_input_grad[0]:                        # rows of g W^T (gn_gemm_f32, W as it is stored) ...
@@ -349,6 +378,85 @@ class ClassLogitsFn(torch.autograd.Function):
                 _hip.gemm(g, w, gw, b_transposed=True, join_batch=True)
             if zsel is not None:                               # z[nodes]^T g (gn_xtg_f32)
                 dw = _hip.xtg(zsel, g, join_batch=True)
-        if gw is not None:                                     # ... added at the listed nodes
-            dz = torch.zeros_like(z).index_add_(0, nodes, gw)
+        if gw is not None:                                     # ... added at the listed nodes (rows named twice add up)
+            dz = torch.empty_like(z)
+            plan.aggregate_t(gw, dz)
         return dz, dw, None
+
+
+class MergeMeanFn(torch.autograd.Function):
+    """``(a + b + c) / 3`` (the three-way merge of GripNet-freebase-c.py:158-162) in two launches forward (a slot copy and
+    gn_merge_f32 mode 4) and one backward (every operand's gradient is g / 3: mode 7)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+        _hip.merge(out, _hip.f32_rows(a.detach()), 0)
+        _hip.merge(out, _hip.f32_rows(b.detach()), 4, src2=_hip.f32_rows(c.detach()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        share = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+        _hip.merge(share, _hip.f32_rows(g), 7)
+        return tuple(share if need else None for need in ctx.needs_input_grad)
+
+
+class HalfSumAbsFn(torch.autograd.Function):
+    """``(y + |t|) / 2`` (interGraph with mod != "cat" and equal widths, layers.py:378-379)."""
+
+    @staticmethod
+    def forward(ctx, y, t):
+        tc = _hip.f32_rows(t.detach())
+        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        _hip.merge(out, _hip.f32_rows(y.detach()), 0)
+        _hip.merge(out, tc, 2)
+        ctx.save_for_backward(tc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        g = _hip.f32_rows(g)
+        gy = gt = None
+        if ctx.needs_input_grad[0]:
+            gy = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+            _hip.merge(gy, g, 8)
+        if ctx.needs_input_grad[1]:
+            gt = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+            _hip.merge(gt, g, 9, t)
+        return gy, gt
+
+
+class HalfSumDownFn(torch.autograd.Function):
+    """``(y + relu(t @ down)) / 2`` (interGraph with mod != "cat" and unequal widths, layers.py:381-384): the product on
+    gn_gemm_f32, its gradients on gn_gemm_f32 / gn_xtg_f32."""
+
+    @staticmethod
+    def forward(ctx, y, t, down):
+        tc, dc = _hip.f32_rows(t.detach()), _hip.f32_rows(down.detach())
+        proj = torch.empty((tc.shape[0], dc.shape[1]), dtype=torch.float32, device=tc.device)
+        _hip.gemm(tc, dc, proj)
+        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        _hip.merge(out, _hip.f32_rows(y.detach()), 0)
+        _hip.merge(out, proj, 3)
+        ctx.save_for_backward(tc, dc, proj)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t, down, proj = ctx.saved_tensors
+        g = _hip.f32_rows(g)
+        gy = gt = gd = None
+        if ctx.needs_input_grad[0]:
+            gy = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+            _hip.merge(gy, g, 8)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gp = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+            _hip.merge(gp, g, 10, proj)                            # g / 2 where the projection was positive
+            if ctx.needs_input_grad[1]:
+                gt = torch.empty(t.shape, dtype=torch.float32, device=g.device)
+                _hip.gemm(gp, down, gt, b_transposed=True)
+            if ctx.needs_input_grad[2]:
+                gd = _hip.xtg(t, gp)
+        return gy, gt, gd

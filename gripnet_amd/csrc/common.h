@@ -158,6 +158,7 @@ struct gn_rgcn_plan {
     gn::DevBuf<int32_t> rowptr;    // [N + 1]
     gn::DevBuf<uint32_t> key;      // [shard_edges]
     gn::DevBuf<int32_t> row_order; // [N] destination rows by the shard's in-degree, largest first (rgcn_basis.hip deals rows in this order)
+    int64_t heavy_rows = 0;        // rows of more than gn_layout::kBasisHeavyEdges edges (the first entries of row_order)
     // LDS-resident path (rgcn_fast.hip): work items = (relation, source tile, <= chunk edges)
     gn::DevBuf<int32_t> seg_rel;    // [n_items] relation of each work item
     gn::DevBuf<int32_t> item_tile;  // [n_items] source tile of each work item

@@ -538,10 +538,17 @@ __global__ void k_merge(float* __restrict__ dst, int64_t ld_dst, const float* __
             case 3: *d = (*d + fmaxf(s, 0.f)) / 2.0f; break;
             case 4: *d = (*d + s + src2[i * ld_src2 + c]) / 3.0f; break;
             case 5: *d = src2[i * ld_src2 + c] > 0.f ? s : 0.f; break;
-            default: {
+            case 6: {
                 const float r = src2[i * ld_src2 + c];
                 *d = r > 0.f ? s : (r < 0.f ? -s : 0.f);
             } break;
+            case 7: *d = s / 3.0f; break;
+            case 8: *d = s / 2.0f; break;
+            case 9: {
+                const float r = src2[i * ld_src2 + c];
+                *d = r > 0.f ? s / 2.0f : (r < 0.f ? -s / 2.0f : 0.f);
+            } break;
+            default: *d = src2[i * ld_src2 + c] > 0.f ? s / 2.0f : 0.f; break;
         }
     }
 }
@@ -1054,9 +1061,9 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
 gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, const float* src2,
                        int64_t ld_src2, int64_t rows, int64_t cols, int mode, void* stream) {
     GN_REQUIRE(rows >= 0 && cols >= 0 && cols < (1ll << 31), "bad merge size");
-    GN_REQUIRE(mode >= 0 && mode <= 6, "unknown merge mode %d", mode);
+    GN_REQUIRE(mode >= 0 && mode <= 10, "unknown merge mode %d", mode);
     if (rows == 0 || cols == 0) return GN_OK;
-    GN_REQUIRE(dst && src && (mode < 4 || src2), "merge operand pointer is null");
+    GN_REQUIRE(dst && src && (mode < 4 || mode == 7 || mode == 8 || src2), "merge operand pointer is null");
     k_merge<<<gn::stream_grid(rows * cols, 256), 256, 0, gn::as_stream(stream)>>>(dst, ld_dst, src, ld_src, src2,
                                                                                 ld_src2, rows, (int)cols, mode);
     GN_LAUNCH_CHECK();

@@ -599,7 +599,10 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
         for (int64_t i = 0; i < N; ++i) ++first[p->max_row_nnz - (rp[i + 1] - rp[i]) + 1];
         for (size_t d = 1; d < first.size(); ++d) first[d] += first[d - 1];
         std::vector<int32_t> order(N);
-        for (int64_t i = 0; i < N; ++i) order[first[p->max_row_nnz - (rp[i + 1] - rp[i])]++] = (int32_t)i;
+        for (int64_t i = 0; i < N; ++i) {
+            order[first[p->max_row_nnz - (rp[i + 1] - rp[i])]++] = (int32_t)i;
+            p->heavy_rows += (rp[i + 1] - rp[i]) > gn_layout::kBasisHeavyEdges ? 1 : 0;
+        }
         GN_TRY(p->row_order.alloc(N));
         GN_TRY(hipMemcpyAsync(p->row_order.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st));
         GN_TRY(hipStreamSynchronize(st));

@@ -18,8 +18,13 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// loads of a lane's NT consecutive columns: dword-aligned only when NT is odd (global loads need no more)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
-constexpr int kBasisThreads = 256;                 // four waves, a destination row per wave at a time
+constexpr int kBasisThreads = 512, kBasisWaves = kBasisThreads / 64;   // eight waves: a destination row per wave at a time, or a heavy row per workgroup
+constexpr int kHeavyEdges = gn_layout::kBasisHeavyEdges;               // rows with more incoming edges are walked by a whole workgroup
 constexpr int64_t kSlabBytes = 64ll << 20;         // rows of U in flight between the gather and the dense product
 
 struct BasisArgs {
@@ -31,11 +36,128 @@ struct BasisArgs {
     float* u; int64_t ld_u;                        // [row_hi - row_lo][ld_u]: U_i (bases outermost) | x_i | zeros up to kp
     int kp;
     int scale, with_x, vec;
+    int fast_addr;                                 // vec, and every byte offset into x and att fits 32 bits
+    int n_heavy;                                   // rows of more than kHeavyEdges edges: the first entries of `order`
+    unsigned int* next_item;                       // this launch's work counter (zeroed by k_basis_weights)
     gn_side_copy side;
 };
 
+// One chunk of up to 64 edges, any shape: lane L holds edge L's (source, relation); step j contracts edges 4 j + kg.
+template <int BT, int NT>
+__device__ __forceinline__ void chunk_any(const BasisArgs& a, f32x4 (&acc)[BT][NT], uint32_t src, uint32_t rel, int cnt, int c, int kg) {
+    const int steps = (cnt + 3) >> 2;
+    for (int j0 = 0; j0 < steps; j0 += 4) {
+        float av[4][BT], xv[4][NT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sel = 4 * (j0 + q) + kg;                                  // edge of lane group kg in step j0 + q
+            const uint32_t s = (uint32_t)__shfl((int)src, sel & 63), r = (uint32_t)__shfl((int)rel, sel & 63);
+            const bool live = sel < cnt;
+            const float* __restrict__ xr = a.x + (size_t)s * a.ld_x + NT * c;
+            const float* __restrict__ ar = a.att + (size_t)r * a.bases + c;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xv[q][t] = (live && NT * c + t < a.fin) ? xr[t] : 0.f;
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm) av[q][jm] = (live && 16 * jm + c < a.bases) ? ar[16 * jm] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[jm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jm], xv[q][t], acc[jm][t], 0, 0, 0);
+    }
+}
+
+// A FULL chunk of 64 edges on the fast addressing (input width a multiple of 16, rows 16-byte aligned, tables below 4 GB):
+// lane L turns its edge into two 32-bit byte offsets once; a step is two ds_bpermute (the offsets of lane group kg's edge,
+// lane and step folded into the instruction's immediate), two adds of this lane's column offset, the loads in the
+// scalar-base form and the matrix instructions - sixteen steps unrolled, four steps' loads requested together.
+template <int BT, int NT>
+__device__ __forceinline__ void chunk_full(const BasisArgs& a, f32x4 (&acc)[BT][NT], uint32_t xo, uint32_t ao, uint32_t sel0,
+                                           uint32_t lane_x, const uint32_t (&lane_a)[BT], const bool (&base_ok)[BT]) {
+    const char* __restrict__ xb = reinterpret_cast<const char*>(a.x);
+    const char* __restrict__ ab = reinterpret_cast<const char*>(a.att);
+    // steps whose operands are requested together: eight while they fit the registers next to the accumulators (a row's
+    // time is a chain of memory round trips - few rows are in flight per compute unit - so fewer, fatter requests win)
+    constexpr int G = (BT + NT) * 8 + BT * NT * 4 <= 72 ? 8 : 4;
+#pragma unroll
+    for (int g = 0; g < 16 / G; ++g) {
+        float av[G][BT], xv[G][NT];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const uint32_t addr = sel0 + 16u * (uint32_t)(G * g + q);           // byte address of lane 4 j + kg
+            const uint32_t xs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)xo) + lane_x;
+            const uint32_t as = (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)ao);
+#pragma unroll
+            for (int t4 = 0; t4 < NT / 4; ++t4) {
+                const f32x4 v = *reinterpret_cast<const f32x4u*>(xb + (xs + 16u * t4));
+                xv[q][4 * t4] = v[0]; xv[q][4 * t4 + 1] = v[1]; xv[q][4 * t4 + 2] = v[2]; xv[q][4 * t4 + 3] = v[3];
+            }
+            if constexpr (NT % 4 == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2u*>(xb + (xs + 4u * (NT - 2)));
+                xv[q][NT - 2] = v[0]; xv[q][NT - 1] = v[1];
+            } else if constexpr (NT % 4 == 1) {
+                xv[q][NT - 1] = *reinterpret_cast<const float*>(xb + (xs + 4u * (NT - 1)));
+            } else if constexpr (NT % 4 == 3) {
+                const f32x2 v = *reinterpret_cast<const f32x2u*>(xb + (xs + 4u * (NT - 3)));
+                xv[q][NT - 3] = v[0]; xv[q][NT - 2] = v[1];
+                xv[q][NT - 1] = *reinterpret_cast<const float*>(xb + (xs + 4u * (NT - 1)));
+            }
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm) {
+                const float v = *reinterpret_cast<const float*>(ab + (as + lane_a[jm]));
+                av[q][jm] = base_ok[jm] ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[jm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jm], xv[q][t], acc[jm][t], 0, 0, 0);
+    }
+}
+
+// acc += sum over the edges of chunks first, first + step, ... (64 edges each) of [e0, e1): K = four edges per instruction
+template <int BT, int NT>
+__device__ __forceinline__ void accumulate_chunks(const BasisArgs& a, f32x4 (&acc)[BT][NT], int e0, int e1, int first, int step, int lane,
+                                                  int c, int kg) {
+    const uint32_t lane_x = (uint32_t)(NT * c) * 4u, sel0 = (uint32_t)kg * 4u;
+    uint32_t lane_a[BT];
+    bool base_ok[BT];
+#pragma unroll
+    for (int jm = 0; jm < BT; ++jm) {
+        base_ok[jm] = 16 * jm + c < a.bases;
+        lane_a[jm] = base_ok[jm] ? (uint32_t)(16 * jm + c) * 4u : 0u;          // (a lane without a base reads the row's first: in bounds)
+    }
+    const uint32_t ldx4 = (uint32_t)a.ld_x * 4u, b4 = (uint32_t)a.bases * 4u;
+    int eb = e0 + 64 * first;
+    uint32_t k_next = (eb < e1 && eb + lane < e1) ? a.key[eb + lane] : 0u;
+    for (; eb < e1; eb += 64 * step) {
+        const int cnt = min(64, e1 - eb);
+        const uint32_t k = k_next;
+        const int en = eb + 64 * step + lane;                                  // the next chunk's keys travel while this one is contracted
+        k_next = en < e1 ? a.key[en] : 0u;
+        const uint32_t rel = k / a.n, src = k - rel * a.n;                     // (one division per lane and 64 edges)
+        if (cnt == 64 && a.fast_addr) chunk_full<BT, NT>(a, acc, src * ldx4, rel * b4, sel0, lane_x, lane_a, base_ok);
+        else chunk_any<BT, NT>(a, acc, src, rel, cnt, c, kg);
+    }
+}
+
+// the tail of a row of the slab: x_i (the root term's operand) and the zero padding up to the dense product's K
+__device__ __forceinline__ void write_tail(const BasisArgs& a, float* __restrict__ ur, int row, int lane) {
+    const int tail = a.bases * a.fin;
+    if (a.with_x)
+        for (int col = lane; col < a.fin; col += 64) ur[tail + col] = a.x[(size_t)row * a.ld_x + col];
+    for (int col = tail + (a.with_x ? a.fin : 0) + lane; col < a.kp; col += 64) ur[col] = 0.f;
+}
+
 template <int BT, int NT>
 __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
+    __shared__ f32x4 red[kBasisWaves][64];                                     // one accumulator tile of every wave (heavy rows)
     if (a.side.dst) {                                                          // concat slot 0 (layers.py:264-266), by the whole grid
         const int64_t total = a.side.rows * a.side.cols;
         for (int64_t t = (int64_t)blockIdx.x * kBasisThreads + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBasisThreads) {
@@ -45,12 +167,57 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
         }
     }
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
-    const int wave = blockIdx.x * (kBasisThreads / 64) + (threadIdx.x >> 6), W = gridDim.x * (kBasisThreads / 64);
+    const int wv = threadIdx.x >> 6;
+    // ---- work items, drawn from a counter in the plan's order (rows by in-degree, largest first: the greedy longest-first
+    // deal): item h < n_heavy is a heavy row (more than kHeavyEdges incoming edges) walked by the whole workgroup - its
+    // waves take the row's 64-edge chunks in turn, their accumulators meet in LDS tile by tile and are added in wave order
+    // (a hub of the all-nodes graph has thousands of edges: one wave would walk them for 200 us); the items behind are
+    // groups of kBasisWaves light rows, a row per wave.  Every row is summed by one wave (or one workgroup) in a fixed
+    // order, so the results do not depend on who drew what. ----
+    __shared__ unsigned int item_s;
     const int n_rows = (int)a.n;
-    // rows in the plan's order (by in-degree, largest first), dealt to the waves in a snake: wave w takes entries
-    // w, 2W-1-w, 2W+w, ... - every wave gets one row of every round, the heavy end alternating
-    for (int base = 0, round = 0; base < n_rows; base += W, ++round) {
-        const int idx = base + ((round & 1) ? W - 1 - wave : wave);
+    const unsigned int n_items = (unsigned int)(a.n_heavy + (n_rows - a.n_heavy + kBasisWaves - 1) / kBasisWaves);
+    for (;;) {
+        __syncthreads();                                                       // (item_s and red of the previous item have been read)
+        if (threadIdx.x == 0) item_s = atomicAdd(a.next_item, 1u);
+        __syncthreads();
+        const unsigned int item = item_s;
+        if (item >= n_items) break;
+        if ((int)item < a.n_heavy) {
+            const int row = a.order[item];
+            if (row < a.row_lo || row >= a.row_hi) continue;                   // (uniform over the workgroup)
+            const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+            f32x4 acc[BT][NT];
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[jm][t] = (f32x4)(0.f);
+            accumulate_chunks<BT, NT>(a, acc, e0, e1, wv, kBasisWaves, lane, c, kg);
+            const float inv = a.scale ? 1.0f / fmaxf(a.indeg[row], 1.0f) : 1.0f;
+            float* __restrict__ ur = a.u + (size_t)(row - a.row_lo) * a.ld_u;
+#pragma unroll
+            for (int jm = 0; jm < BT; ++jm)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    __syncthreads();                                           // (the previous tile has been read)
+                    red[wv][lane] = acc[jm][t];
+                    __syncthreads();
+                    if (wv == (jm * NT + t) % kBasisWaves) {                   // the tile's owner adds the waves' shares, in wave order
+                        f32x4 s = red[0][lane];
+#pragma unroll
+                        for (int w = 1; w < kBasisWaves; ++w) s += red[w][lane];
+                        if (NT * c + t < a.fin)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int b = 16 * jm + 4 * kg + i;
+                                if (b < a.bases) ur[(size_t)b * a.fin + NT * c + t] = s[i] * inv;
+                            }
+                    }
+                }
+            if (wv == 0) write_tail(a, ur, row, lane);
+            continue;
+        }
+        const int idx = a.n_heavy + (int)(item - (unsigned int)a.n_heavy) * kBasisWaves + wv;
         if (idx >= n_rows) continue;
         const int row = a.order[idx];
         if (row < a.row_lo || row >= a.row_hi) continue;
@@ -60,43 +227,7 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
         for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[jm][t] = (f32x4)(0.f);
-        for (int eb = e0; eb < e1; eb += 64) {
-            const int cnt = min(64, e1 - eb);
-            const uint32_t k = lane < cnt ? a.key[eb + lane] : 0u;
-            const uint32_t rel = k / a.n, src = k - rel * a.n;                 // (one division per lane and 64 edges)
-            const int steps = (cnt + 3) >> 2;
-            for (int j0 = 0; j0 < steps; j0 += 4) {
-                // four steps' operands are requested together (the other waves of the SIMD cover the round trips)
-                float av[4][BT], xv[4][NT];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sel = 4 * (j0 + q) + kg;                          // edge of lane group kg in step j0 + q
-                    const uint32_t s = (uint32_t)__shfl((int)src, sel & 63), r = (uint32_t)__shfl((int)rel, sel & 63);
-                    const bool live = sel < cnt;
-                    const float* __restrict__ xr = a.x + (size_t)s * a.ld_x + NT * c;
-                    const float* __restrict__ ar = a.att + (size_t)r * a.bases + c;
-                    if (NT % 4 == 0 && a.vec) {
-#pragma unroll
-                        for (int t4 = 0; t4 < NT / 4; ++t4) {
-                            const f32x4 v = live ? *reinterpret_cast<const f32x4*>(xr + 4 * t4) : (f32x4)(0.f);
-                            xv[q][4 * t4] = v[0]; xv[q][4 * t4 + 1] = v[1]; xv[q][4 * t4 + 2] = v[2]; xv[q][4 * t4 + 3] = v[3];
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) xv[q][t] = (live && NT * c + t < a.fin) ? xr[t] : 0.f;
-                    }
-#pragma unroll
-                    for (int jm = 0; jm < BT; ++jm) av[q][jm] = (live && 16 * jm + c < a.bases) ? ar[16 * jm] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int jm = 0; jm < BT; ++jm)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            acc[jm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jm], xv[q][t], acc[jm][t], 0, 0, 0);
-            }
-        }
+        accumulate_chunks<BT, NT>(a, acc, e0, e1, 0, 1, lane, c, kg);
         // acc[jm][t][i] = U_i[base 16 jm + 4 kg + i][feature NT c + t]
         const float inv = a.scale ? 1.0f / fmaxf(a.indeg[row], 1.0f) : 1.0f;
         float* __restrict__ ur = a.u + (size_t)(row - a.row_lo) * a.ld_u;
@@ -118,32 +249,33 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
                         if (NT * c + t < a.fin) q[t] = acc[jm][t][i] * inv;
                 }
             }
-        const int tail = a.bases * a.fin;
-        if (a.with_x)
-            for (int col = lane; col < a.fin; col += 64) ur[tail + col] = a.x[(size_t)row * a.ld_x + col];
-        for (int col = tail + (a.with_x ? a.fin : 0) + lane; col < a.kp; col += 64) ur[col] = 0.f;
+        write_tail(a, ur, row, lane);
     }
 }
 
 // [basis ; root ; 0]: the right-hand side of the slab's dense product
 __global__ void k_basis_weights(const float* __restrict__ basis, const float* __restrict__ root, int64_t nb, int64_t nr, int64_t total,
-                                float* __restrict__ w) {
+                                float* __restrict__ w, unsigned int* __restrict__ counters, int n_counters) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_counters) counters[threadIdx.x] = 0u;       // the slabs' work counters
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
         w[t] = t < nb ? basis[t] : (t < nb + nr ? root[t - nb] : 0.f);
 }
 
 struct BasisLayout {
     int kp;
-    int64_t slab_rows;
-    size_t w_off, u_off, total;
+    int64_t slab_rows, slabs;
+    size_t w_off, q_off, u_off, total;
 };
 
 BasisLayout basis_layout(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     BasisLayout l;
     l.kp = (int)(gn::ceil_div((bases + 1) * fin, 32) * 32);
     l.slab_rows = std::min<int64_t>(std::max<int64_t>(plan->num_nodes, 1), std::max<int64_t>(256, kSlabBytes / ((int64_t)l.kp * 4)));
+    l.slab_rows = std::max<int64_t>(l.slab_rows, gn::ceil_div(std::max<int64_t>(plan->num_nodes, 1), 256));   // at most 256 slabs (one work counter each)
+    l.slabs = gn::ceil_div(std::max<int64_t>(plan->num_nodes, 1), l.slab_rows);
     l.w_off = 0;
-    l.u_off = ((size_t)l.kp * fout * sizeof(float) + 255) & ~size_t(255);
+    l.q_off = ((size_t)l.kp * fout * sizeof(float) + 255) & ~size_t(255);
+    l.u_off = l.q_off + (((size_t)l.slabs * sizeof(unsigned int) + 255) & ~size_t(255));
     l.total = l.u_off + (size_t)l.slab_rows * l.kp * sizeof(float);
     return l;
 }
@@ -184,20 +316,27 @@ gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_
     float* W = reinterpret_cast<float*>(static_cast<char*>(ws) + l.w_off);
     float* U = reinterpret_cast<float*>(static_cast<char*>(ws) + l.u_off);
     const int64_t nb = bases * fin * fout, nr = partial ? 0 : fin * fout, total = (int64_t)l.kp * fout;
-    k_basis_weights<<<gn::stream_grid(total, 256), 256, 0, st>>>(basis, root, nb, nr, total, W);
+    unsigned int* counters = reinterpret_cast<unsigned int*>(static_cast<char*>(ws) + l.q_off);
+    GN_REQUIRE(l.slabs <= 256, "too many slabs of rows (%lld)", (long long)l.slabs);
+    k_basis_weights<<<gn::stream_grid(total, 256), 256, 0, st>>>(basis, root, nb, nr, total, W, counters, (int)l.slabs);
     GN_LAUNCH_CHECK();
     BasisArgs a;
     a.x = x; a.ld_x = ld_x; a.fin = (int)fin; a.att = att; a.bases = (int)bases;
     a.rowptr = plan->rowptr.p; a.key = plan->key.p; a.indeg = plan->indeg.p; a.order = plan->row_order.p;
-    a.n = (uint32_t)N; a.u = U; a.ld_u = l.kp; a.kp = l.kp;
+    a.n = (uint32_t)N; a.u = U; a.ld_u = l.kp; a.kp = l.kp; a.n_heavy = (int)plan->heavy_rows;
     a.scale = partial ? 0 : 1; a.with_x = partial ? 0 : 1;
     a.vec = (fin % 16 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    // (measured and dropped: the att table staged in LDS - a fifth of the gathered bytes - made the layer 8 % SLOWER: the
+    // fill costs more than the L2-resident 64-byte rows; what bounds the kernel is the rate of row gathers from L2 / the
+    // Infinity Cache, 6-7 TB/s of 128- and 256-byte pieces of x)
+    a.fast_addr = a.vec && (uint64_t)N * (uint64_t)ld_x * 4 < (1ull << 32) && (uint64_t)plan->num_relations * (uint64_t)bases * 4 < (1ull << 32);
     const int bt = (int)gn::ceil_div(bases, 16), nt = (int)gn::ceil_div(fin, 16);
-    // four waves per SIMD on every compute unit (<= 128 registers), a row per wave at a time
-    const int grid = (int)std::min<int64_t>((int64_t)gn::compute_units() * 4, gn::ceil_div(N, kBasisThreads / 64));
+    // four waves per SIMD on every compute unit where the registers allow (<= 128): two workgroups of eight waves
+    const int grid = (int)std::min<int64_t>((int64_t)gn::compute_units() * 2, std::max<int64_t>(plan->heavy_rows, gn::ceil_div(N, kBasisWaves)));
     for (int64_t r0 = 0; r0 < N; r0 += l.slab_rows) {
         const int64_t r1 = std::min(N, r0 + l.slab_rows);
         a.row_lo = (int)r0; a.row_hi = (int)r1;
+        a.next_item = counters + r0 / l.slab_rows;
         a.side = r0 == 0 ? side : gn_side_copy{nullptr, 0, nullptr, 0, 0, 0, 0};
         gn_status s;
         switch (bt) {

@@ -21,7 +21,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import _hip
-from .autograd import AbsSlotFn, GcnConvFn, RgcnConvFn, Slot, SlotsCatFn, cat_slots, recording
+from .autograd import AbsSlotFn, GcnConvFn, HalfSumAbsFn, HalfSumDownFn, RgcnConvFn, Slot, SlotsCatFn, cat_slots, recording
 
 
 def _unslot(out, side):
@@ -351,9 +351,9 @@ class interGraph(Module):
             y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
             if not self.if_one_external:
                 return y
-            if y.shape[1] == self.target_feat.shape[1]:
-                return (y + torch.abs(self.target_feat)) / 2
-            return (y + torch.relu(self.target_feat @ self.target_feat_down)) / 2
+            if y.shape[1] == self.target_feat.shape[1]:                          # layers.py:378-379
+                return HalfSumAbsFn.apply(y, self.target_feat)
+            return HalfSumDownFn.apply(y, self.target_feat, self.target_feat_down)   # layers.py:381-384
         if not self.if_one_external:                                             # layers.py:372-373
             return self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
         if mod == "cat":                                                         # layers.py:375-376

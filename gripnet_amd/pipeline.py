@@ -107,7 +107,8 @@ class FreebaseCModel(Module):
         z1 = self.qq(None, data.qq_edge_idx, edge_weight=data.qq_edge_weight, if_catout=True)
         z1 = self.qa(z1, data.qa_edge_idx, mod="add", if_relu=True)
         if torch.is_grad_enabled() and (z.requires_grad or self.aa_embeddings.requires_grad):
-            merged = (z + z1 + self.aa_embeddings) / 3                           # training: autograd-tracked
+            from .autograd import MergeMeanFn
+            merged = MergeMeanFn.apply(z, z1, self.aa_embeddings)                # training: autograd-tracked, the library's launches
         else:
             merged = _hip.merge(z, z1, 4, src2=self.aa_embeddings)               # (z + z1 + aae) / 3
         z = self.aa(merged, data.aa_edge_idx, edge_weight=data.aa_edge_weight)

@@ -245,22 +245,26 @@ class _ShardedRgcnFn(torch.autograd.Function):
     def backward(ctx, g):
         x, root, out = ctx.saved_tensors
         owner = ctx.owner
-        g = (g * (out > 0).to(g.dtype)).contiguous()                      # ReLU mask by the saved output
-        gm = g / owner.kernels.in_degree().view(-1, 1)
+        has_bias = ctx.needs_input_grad[4]
+        dbias = None
+        if g.is_cuda:                                                      # ReLU mask, gm = g / deg and the bias gradient: one launch
+            from . import _hip
+            g, gm, dbias = _hip.grad_prologue(g, out, owner.kernels.in_degree(), True, bool(has_bias))
+        else:                                                              # (host tensors: the gloo rehearsal with injected kernels)
+            g = (g * (out > 0).to(g.dtype)).contiguous()                  # ReLU mask by the saved output
+            gm = g / owner.kernels.in_degree().view(-1, 1)
+            dbias = g.sum(dim=0) if has_bias else None
         dxe, dbasis, datt = owner.kernels.edge_gradients(x, gm)
         flat = torch.cat([dxe.reshape(-1), dbasis.reshape(-1), datt.reshape(-1)])
         owner.all_reduce(flat)                                             # the one exchange step of the backward
         a, b = dxe.numel(), dxe.numel() + dbasis.numel()
         dx = flat[:a].view_as(dxe)
         if g.is_cuda:                                                      # + g root^T and x^T g on the library's own kernels
-            from . import _hip
             dx = _hip.gemm(g, root, dx.contiguous(), b_transposed=True, accumulate=True)
             droot = _hip.xtg(x, g)
         else:                                                              # (host tensors: the gloo rehearsal with injected kernels)
             dx, droot = dx + g @ root.t(), x.t() @ g
-        has_bias = ctx.needs_input_grad[4]
-        return (dx, flat[a:b].view_as(dbasis), flat[b:].view_as(datt), droot,
-                g.sum(dim=0) if has_bias else None, None)
+        return (dx, flat[a:b].view_as(dbasis), flat[b:].view_as(datt), droot, dbias, None)
 
 
 class ShardedPoseTraining(ShardedPoseForward):
@@ -288,7 +292,13 @@ class ShardedPoseTraining(ShardedPoseForward):
         pos = k.score(z)
         neg = k.score_edges(z, neg_index[:, self.edge_lo:self.edge_hi].contiguous())
         E = float(self.total_edges)
-        local = -(torch.log(pos + self.EPS).sum() + torch.log(1 - neg + self.EPS).sum()) / E
+        if pos.is_cuda and pos.numel() == neg.numel() and pos.numel() > 0:
+            # this rank's share of the loss in one launch each way: link_loss is -mean(log pos) - mean(log(1 - neg)) over the
+            # shard's edges; times (shard edges / all edges) it is the shard's share of the means over ALL edges
+            from .utils import link_loss
+            local = link_loss(pos, neg, self.EPS) * (pos.numel() / E)
+        else:
+            local = -(torch.log(pos + self.EPS).sum() + torch.log(1 - neg + self.EPS).sum()) / E
         dw = k.decoder_weight()
         kept, dw.grad = dw.grad, None                                      # only THIS step's share is exchanged: what
         local.backward()                                                   # earlier steps accumulated is already a sum

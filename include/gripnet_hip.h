@@ -209,7 +209,9 @@ GN_API gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_
  * concat outputs:  mode 0: dst = src;  1: dst = |src|;  2: dst = (dst + |src|) / 2;
  * 3: dst = (dst + relu(src)) / 2;  4: dst = (dst + src + src2) / 3 (freebase-c merge,
  * GripNet-freebase-c.py:158-162).  Backward helpers:  5: dst = src2 > 0 ? src : 0 (ReLU mask by the
- * saved output);  6: dst = src * sign(src2) (gradient of |.|). */
+ * saved output);  6: dst = src * sign(src2) (gradient of |.|);  7: dst = src / 3 (every operand's share of mode 4);
+ * 8: dst = src / 2 (the first operand's share of modes 2 and 3);  9: dst = src * sign(src2) / 2 (the |.| operand of
+ * mode 2);  10: dst = src2 > 0 ? src / 2 : 0 (the ReLU operand of mode 3). */
 GN_API gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, const float* src2,
                        int64_t ld_src2, int64_t rows, int64_t cols, int mode, void* stream);
 
