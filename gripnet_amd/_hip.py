@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 139                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 140                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
     "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "gn_softmax_rows_f32": (_int, [_p, _i64, _i64, _i64, _p]),
+    "gn_softmax_rows_backward_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     "gn_class_scores_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "gn_rgcn_plan_create": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_rgcn_plan_destroy": (None, [_p]),
@@ -95,6 +96,8 @@ SIGNATURES = {
     "gn_grad_prologue_workspace_bytes": (_sz, []),
     "gn_grad_prologue_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _sz, _p]),
     "gn_adam_step_f32": (_int, [_p, _int, _p, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
+    "gn_class_loss_forward_f32": (_int, [_p, _i64, _p, _i64, _i64, C.c_float, _p, _p, _p]),
+    "gn_class_loss_backward_f32": (_int, [_p, _i64, _p, _i64, _i64, C.c_float, _p, _p, _i64, _p]),
     "gn_link_loss_workspace_bytes": (_sz, []),
     "gn_link_loss_forward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _sz, _p]),
     "gn_link_loss_backward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),

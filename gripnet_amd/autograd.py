@@ -342,6 +342,32 @@ def node_gather_plan(nodes: torch.Tensor, num_rows: int):
     return plan
 
 
+class ClassLossFn(torch.autograd.Function):
+    """``-log(score[range(n), classes] + eps).mean()`` (the loss of GripNet-aminer.py:133) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, score, classes, eps):
+        sc = _hip.f32_rows(score.detach())
+        cl = _hip.i64_vec(classes)
+        if cl.numel() != sc.shape[0]:
+            raise ValueError("{} class ids for {} scored nodes".format(cl.numel(), sc.shape[0]))
+        loss = torch.empty((), dtype=torch.float32, device=sc.device)
+        _hip._call("gn_class_loss_forward_f32", _hip.ptr(sc), _hip.ld(sc), _hip.ptr(cl), sc.shape[0], sc.shape[1], float(eps), _hip.ptr(loss),
+                   _hip.ptr(_hip.error_flag(sc.device)), _hip.stream_ptr(sc.device))
+        ctx.eps = float(eps)
+        ctx.save_for_backward(sc, cl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        sc, cl = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty(sc.shape, dtype=torch.float32, device=sc.device)
+        _hip._call("gn_class_loss_backward_f32", _hip.ptr(sc), _hip.ld(sc), _hip.ptr(cl), sc.shape[0], sc.shape[1], ctx.eps, _hip.ptr(g),
+                   _hip.ptr(d), _hip.ld(d), _hip.stream_ptr(sc.device))
+        return d, None, None
+
+
 class ClassLogitsFn(torch.autograd.Function):
     """``z[node_list] @ W`` (decoder.py:42); forward on gn_class_scores_f32, backward on the library's own kernels: the
     gathered rows and the scatter-add of their gradients through a one-edge-per-node plan (gn_graph_aggregate_f32 /
@@ -382,6 +408,27 @@ class ClassLogitsFn(torch.autograd.Function):
             dz = torch.empty_like(z)
             plan.aggregate_t(gw, dz)
         return dz, dw, None
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """``torch.softmax(logits, dim=1)`` (decoder.py:43) on gn_softmax_rows_f32 / gn_softmax_rows_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        p = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+        _hip.merge(p, _hip.f32_rows(logits.detach()), 0)
+        _hip.softmax_rows(p)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = _hip.f32_rows(g)
+        dx = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        _hip._call("gn_softmax_rows_backward_f32", _hip.ptr(p), _hip.ld(p), _hip.ptr(g), _hip.ld(g), _hip.ptr(dx), _hip.ld(dx),
+                   p.shape[0], p.shape[1], _hip.stream_ptr(p.device))
+        return dx
 
 
 class MergeMeanFn(torch.autograd.Function):

@@ -570,6 +570,22 @@ __global__ void k_softmax_rows(float* __restrict__ x, int64_t ld, int64_t rows, 
     }
 }
 
+// Gradient of the row softmax (autograd of decoder.py:43): dx = p (g - sum_c g_c p_c), one wave per row.
+__global__ void k_softmax_rows_backward(const float* __restrict__ p, int64_t ld_p, const float* __restrict__ g, int64_t ld_g,
+                                        float* __restrict__ dx, int64_t ld_dx, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < rows; i += n_waves) {
+        const float* pr = p + i * ld_p;
+        const float* gr = g + i * ld_g;
+        float dot = 0.f;
+        for (int c = lane; c < cols; c += 64) dot += pr[c] * gr[c];
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        for (int c = lane; c < cols; c += 64) dx[i * ld_dx + c] = pr[c] * (gr[c] - dot);
+    }
+}
+
 // softmax?( z[node_list] @ W ) for a handful of classes (multiClassInnerProductDecoder, decoder.py:42-43): sixteen lanes
 // per selected row, four rows per wave, one row per lane group and launch-wide no loop on the NC shapes.  W (k x n,
 // n <= 16) sits in LDS as [n / 4][k] 16-byte words (the four lane groups read the same words: broadcasts); a lane sums
@@ -1075,6 +1091,17 @@ gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, 
     if (rows == 0 || cols == 0) return GN_OK;
     GN_REQUIRE(x != nullptr, "softmax operand is null");
     k_softmax_rows<<<gn::stream_grid(rows * 64, 256), 256, 0, gn::as_stream(stream)>>>(x, ld, rows, (int)cols);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+gn_status gn_softmax_rows_backward_f32(const float* probs, int64_t ld_probs, const float* grad, int64_t ld_grad, float* dx,
+                                       int64_t ld_dx, int64_t rows, int64_t cols, void* stream) {
+    GN_REQUIRE(rows >= 0 && cols >= 0 && cols < (1ll << 31), "bad softmax size");
+    if (rows == 0 || cols == 0) return GN_OK;
+    GN_REQUIRE(probs && grad && dx && ld_probs >= cols && ld_grad >= cols && ld_dx >= cols, "softmax operand is null or a leading dimension too small");
+    k_softmax_rows_backward<<<gn::stream_grid(rows * 64, 256), 256, 0, gn::as_stream(stream)>>>(probs, ld_probs, grad, ld_grad, dx, ld_dx,
+                                                                                                rows, (int)cols);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -110,9 +110,65 @@ __global__ __launch_bounds__(256) void k_link_loss_grad(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_neg; i += stride) dneg[i] = cn / (1.0f - neg[i] + eps);
 }
 
+// The node-classification loss of the training loops (GripNet-aminer.py:133, every freebase driver alike):
+// loss = - mean_i log(score[i, class_i] + eps).  A few thousand labelled nodes: one workgroup, a fixed slice per thread summed
+// in double, a fixed tree over the threads.
+__global__ __launch_bounds__(1024) void k_class_loss(const float* __restrict__ score, int64_t ld, const int64_t* __restrict__ cls, int64_t n,
+                                                     int classes, float eps, float* __restrict__ loss, int32_t* __restrict__ err) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t c = cls[i];
+        if ((uint64_t)c < (uint64_t)classes) s += (double)__logf(score[i * ld + c] + eps);
+        else if (err) atomicOr(err, 1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *loss = n > 0 ? (float)(-t / (double)n) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_class_loss_grad(const float* __restrict__ score, int64_t ld, const int64_t* __restrict__ cls, int64_t n,
+                                                         int classes, float eps, const float* __restrict__ upstream,
+                                                         float* __restrict__ dscore, int64_t ld_d) {
+    const float g = (upstream ? *upstream : 1.0f) / (float)n;
+    const int64_t total = n * classes, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / classes;
+        const int c = (int)(t - i * classes);
+        dscore[i * ld_d + c] = (int64_t)c == cls[i] ? -g / (score[i * ld + c] + eps) : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+gn_status gn_class_loss_forward_f32(const float* score, int64_t ld_score, const int64_t* classes, int64_t num_nodes, int64_t num_classes,
+                                    float eps, float* loss, int32_t* error_flag, void* stream) {
+    GN_REQUIRE(num_nodes >= 0 && num_classes >= 1 && num_classes < (1ll << 31) && ld_score >= num_classes, "bad class-loss size");
+    GN_REQUIRE(loss && (num_nodes == 0 || (score && classes)), "score / class / loss pointer is null");
+    k_class_loss<<<1, 1024, 0, gn::as_stream(stream)>>>(score, ld_score, classes, num_nodes, (int)num_classes, eps, loss, error_flag);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+gn_status gn_class_loss_backward_f32(const float* score, int64_t ld_score, const int64_t* classes, int64_t num_nodes, int64_t num_classes,
+                                     float eps, const float* upstream_grad, float* dscore, int64_t ld_dscore, void* stream) {
+    GN_REQUIRE(num_nodes >= 0 && num_classes >= 1 && num_classes < (1ll << 31) && ld_score >= num_classes && ld_dscore >= num_classes,
+               "bad class-loss size");
+    if (num_nodes == 0) return GN_OK;
+    GN_REQUIRE(score && classes && dscore, "score / class / gradient pointer is null");
+    k_class_loss_grad<<<gn::stream_grid(num_nodes * num_classes, 256, 1024), 256, 0, gn::as_stream(stream)>>>(
+        score, ld_score, classes, num_nodes, (int)num_classes, eps, upstream_grad, dscore, ld_dscore);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
 
 size_t gn_link_loss_workspace_bytes(void) { return (size_t)kLossGroups * 2 * sizeof(double) + 64; }
 

@@ -12,7 +12,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import _hip
-from .autograd import ClassLogitsFn, DistMultFn, recording
+from .autograd import ClassLogitsFn, DistMultFn, SoftmaxRowsFn, recording
 
 
 class _EdgeList:
@@ -198,7 +198,7 @@ class multiClassInnerProductDecoder(Module):
         _hip.require_gpu(z, node_list, self.weight)
         if recording(z, self.weight):
             logits = ClassLogitsFn.apply(z, self.weight, node_list)
-            return torch.softmax(logits, dim=1) if softmax else logits
+            return SoftmaxRowsFn.apply(logits) if softmax and logits.shape[0] > 0 else logits
         z = _hip.f32_rows(z)
         nodes = _hip.i64_vec(node_list)
         pred = torch.empty((nodes.shape[0], self.num_class), dtype=torch.float32, device=z.device)

@@ -246,6 +246,15 @@ def link_loss(pos_score: torch.Tensor, neg_score: torch.Tensor, eps: float = EPS
     return LinkLossFn.apply(pos_score, neg_score, float(eps))
 
 
+def class_loss(score: torch.Tensor, classes: torch.Tensor, eps: float = EPS) -> torch.Tensor:
+    """``-log(score[range(n), classes] + EPS).mean()``: the training loss of GripNet-aminer.py:133 (and of every freebase
+    driver) as one launch forward and one backward (gn_class_loss_*), differentiable.  The drivers spell it out with torch
+    advanced indexing; that keeps working - this is the same value without the index / log / mean kernels."""
+    from .autograd import ClassLossFn
+    _hip.require_gpu(score, classes)
+    return ClassLossFn.apply(score, classes, float(eps))
+
+
 def set_table_storage(module, storage: str = "bf16"):
     """Switch every GCN-style layer under `module` to "bf16" (or back to "fp32") storage of its gathered table:
     x W is rounded to bf16 once per forward and read at half the bytes; sums, bias, activation, outputs and every

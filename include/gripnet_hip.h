@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 139 /* 0.1.35 */
+#define GN_VERSION 140 /* 0.1.36 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -217,6 +217,9 @@ GN_API gn_status gn_merge_f32(float* dst, int64_t ld_dst, const float* src, int6
 
 /* Row softmax in place (decoder.py:43). */
 GN_API gn_status gn_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int64_t cols, void* stream);
+/* Its gradient (autograd of decoder.py:43 in the training loops, GripNet-aminer.py:124-147): dx = probs * (grad - sum_c grad_c probs_c) per row. */
+GN_API gn_status gn_softmax_rows_backward_f32(const float* probs, int64_t ld_probs, const float* grad, int64_t ld_grad, float* dx,
+                                       int64_t ld_dx, int64_t rows, int64_t cols, void* stream);
 /* out[i, :] = softmax?( z[node_list[i], :] @ W ), i in [0, m): multiClassInnerProductDecoder.forward in one launch
  * (gripnet/decoder.py:42-43: `pred = torch.matmul(z[node_list], self.weight)`, then `torch.softmax(pred, dim=1)`).
  * node_list may be NULL (rows 0..m-1); an entry outside [0, table_rows) scores a row of zeros, as gn_gemm_f32's a_rows.
@@ -492,6 +495,15 @@ GN_API gn_status gn_adam_step_f32(const gn_adam_tensor* tensors, int num_tensors
  * gn_link_loss_workspace_bytes() bytes, 8-byte aligned, ZEROED ONCE by the caller (the launch leaves it ready for the
  * next one); calls on one workspace must be stream-ordered. */
 GN_API size_t gn_link_loss_workspace_bytes(void);
+/* The node-classification loss of the NC training loops and its gradient (GripNet-aminer.py:133 and every freebase driver):
+ *   loss = - mean_i log(score[i, classes[i]] + eps),   dscore[i, c] = c == classes[i] ? - g / (n (score[i, c] + eps)) : 0.
+ * One launch each (the torch expression is an advanced-indexing gather, a log, a mean and their backward kernels).
+ * A class id outside [0, num_classes) sets bit 0 of *error_flag (nullable) and contributes nothing. */
+GN_API gn_status gn_class_loss_forward_f32(const float* score, int64_t ld_score, const int64_t* classes, int64_t num_nodes,
+                                    int64_t num_classes, float eps, float* loss, int32_t* error_flag, void* stream);
+GN_API gn_status gn_class_loss_backward_f32(const float* score, int64_t ld_score, const int64_t* classes, int64_t num_nodes,
+                                     int64_t num_classes, float eps, const float* upstream_grad, float* dscore, int64_t ld_dscore,
+                                     void* stream);
 GN_API gn_status gn_link_loss_forward_f32(const float* pos_score, int64_t num_pos, const float* neg_score, int64_t num_neg, float eps,
                                    float* loss, void* workspace, size_t workspace_bytes, void* stream);
 GN_API gn_status gn_link_loss_backward_f32(const float* pos_score, int64_t num_pos, const float* neg_score, int64_t num_neg, float eps,

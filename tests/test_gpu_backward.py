@@ -899,3 +899,53 @@ def test_pose0_syn_training_step_gradients(gpu):
         assert scale_k > 0, k
         close(p.grad / scale_k, sd[k].grad / scale_k, 1e-4, what=k)
     _hip.raise_if_index_errors(gpu)
+
+
+def test_class_loss_and_softmax_gradients(gpu):
+    """utils.class_loss (gn_class_loss_*) against the expression the NC drivers spell out (GripNet-aminer.py:133), and the
+    row softmax's gradient (gn_softmax_rows_backward_f32) against torch's, through the class decoder under autograd."""
+    from gripnet_amd.utils import EPS, class_loss
+    gen = torch.Generator().manual_seed(211)
+    n, C = 3001, 8
+    score = torch.softmax(torch.randn(n, C, generator=gen), dim=1).to(gpu).requires_grad_(True)
+    cls = torch.randint(0, C, (n,), generator=gen).to(gpu)
+    ref = -torch.log(score.double()[torch.arange(n, device=gpu), cls] + EPS).mean()
+    (2.0 * ref).backward()
+    want = score.grad.clone()
+    score.grad = None
+    loss = class_loss(score, cls)
+    (2.0 * loss).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert float((score.grad - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    z = torch.randn(500, 40, generator=gen)
+    nodes = torch.randint(0, 500, (300,), generator=gen)
+    nodes[:20] = nodes[20:40]                                          # nodes listed twice: their gradients add up
+    proj = torch.randn(300, C, generator=gen)
+    torch.manual_seed(5)
+    dec = gripnet_amd.multiClassInnerProductDecoder(40, C).to(gpu)
+    zg = leaf(z.to(gpu))
+    p = dec(zg, nodes.to(gpu))
+    (p * proj.to(gpu)).sum().backward()
+    zr, wr = leaf(z), leaf(dec.weight.detach().cpu())
+    pr = torch.softmax(zr[nodes] @ wr, dim=1)
+    (pr * proj).sum().backward()
+    close(p, pr, what="softmax")
+    close(zg.grad, zr.grad, what="dz")
+    close(dec.weight.grad, wr.grad, 1e-4, what="dW")
+    _hip.raise_if_index_errors(gpu)
+
+
+@pytest.mark.parametrize("m,k1,k2", [(5000, 128, 64), (3000, 256, 128), (700, 65, 33), (900, 200, 7)])
+def test_wide_weight_gradient_in_tiles(gpu, m, k1, k2):
+    """x^T g wider than one launch of gn_xtg_f32 covers (the 128 x 64 ... 256 x 128 layers of the NC models): tiles of
+    64 x 32 outputs over column slices, alone and inside a dense batch, against float64; the same bits on every call."""
+    gen = torch.Generator().manual_seed(m + k1)
+    x, g = torch.randn(m, k1, generator=gen).to(gpu), torch.randn(m, k2, generator=gen).to(gpu)
+    want = x.double().t() @ g.double()
+    got = _hip.xtg(x, g)
+    assert float((got.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert torch.equal(_hip.xtg(x, g), got)
+    with _hip.dense_batch(gpu):
+        batched = _hip.xtg(x, g, join_batch=True)
+    assert torch.equal(batched, got)
+    _hip.raise_if_index_errors(gpu)
