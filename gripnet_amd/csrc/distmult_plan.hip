@@ -34,13 +34,13 @@ struct gn_distmult_plan {
     // a scored pair belongs to a class that holds both its endpoints, a workgroup serves one class and keeps that class's
     // rows - whole rows, every column - in LDS for the whole launch: one table fill, no column phases, no partial sums
     // parked between phases.  Steps of 16 pairs share a relation; four steps are a batch (one 32-bit word per lane).
-    int cls_ok = 0, cls_features = 0, cls_groups = 0;
+    int cls_ok = 0, cls_features = 0, cls_groups = 0, cls_walks = 1;
     int64_t cls_batches = 0;
     gn::DevBuf<uint32_t> cls_packed;  // [(batches + slack) * 64] local row of u | local row of v << 16
     gn::DevBuf<uint32_t> cls_own;     // [(batches + slack) * 64] position of the slot's edge, or kNoMirror (padding)
     gn::DevBuf<uint32_t> cls_mirror;  // [(batches + slack) * 64]
     gn::DevBuf<uint32_t> cls_rel;     // [(batches + slack) * 2] relation of each of the batch's four steps, 16 bits each
-    gn::DevBuf<int32_t> cls_wg;       // [groups][8] first rows: start, count; second rows: start, count; batches lo, hi; relations lo, count
+    gn::DevBuf<int32_t> cls_wg;       // [groups][4 + 4 walks] first rows: start, count; second rows: start, count; per walk: batches lo, hi; relations lo, count
 };
 
 namespace {
@@ -216,6 +216,7 @@ struct DmClassArgs {
     const float* d; int64_t ld_d;
     const uint32_t* packed; const uint32_t* own; const uint32_t* mirror; const uint32_t* rel; const int32_t* wg;
     float* out; int c0; int sigmoid, first_launch, last_launch;
+    int walks;                 // batch ranges per workgroup: an XCD's workgroups walk its position sub-ranges one after the other
 };
 
 // One wave step: quad q scores the pair of slot 4 q + S.  J 16-byte chunks per lane (lane l4 of the quad holds chunks
@@ -266,105 +267,113 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
     constexpr int STR4 = (J & 1) ? ROW4 : ROW4 + 4;           // LDS stride: an odd number of 64-byte bank slots
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int32_t* __restrict__ g = a.wg + (size_t)blockIdx.x * 8;
-    const int r0s = g[0], r0c = g[1], r1s = g[2], r1c = g[3], rel_lo = g[6], nrel = g[7];
-    const uint32_t b_lo = (uint32_t)g[4], b_hi = (uint32_t)g[5];
+    const int32_t* __restrict__ g = a.wg + (size_t)blockIdx.x * (4 + 4 * a.walks);
+    const int r0s = g[0], r0c = g[1], r1s = g[2], r1c = g[3];
     const int rows = r0c + r1c;
     GN_DM_STAMP(0);
 #ifdef GN_STAMPS
     if (tid == 0 && blockIdx.x < 256) g_dm_stamps[blockIdx.x][3] = 0;
 #endif
-    // The first batches' words are requested BEFORE the table fill (their HBM round trip hides behind it).  Every array
-    // has kClsSlack readable batches behind the last one: no prefetch needs a clamp.  The relation words travel as
-    // vector loads too (lanes 0 / 1 of `rw`): a scalar load shares its counter with the LDS reads and would be waited
-    // for as soon as it is issued.
     const bool first = a.first_launch, last = a.last_launch;
     constexpr uint32_t kStep = kThreads / 64;
-    uint32_t b = b_lo + (uint32_t)wave;
     const uint32_t* __restrict__ pk = a.packed + lane;
     const uint32_t* __restrict__ own = a.own + lane;
     const uint32_t* __restrict__ mir = a.mirror + lane;
     const uint32_t* __restrict__ rel = a.rel + (lane & 1);
-    uint32_t w0 = pk[b * 64u], w1 = pk[(b + kStep) * 64u], w2 = pk[(b + 2 * kStep) * 64u];
-    uint32_t rw0 = rel[2 * b], rw1 = rel[2 * (b + kStep)];
-    uint32_t o0 = own[b * 64u], o1 = own[(b + kStep) * 64u];
-    uint32_t m0 = last ? mir[b * 64u] : kNoMirror, m1 = last ? mir[(b + kStep) * 64u] : kNoMirror;
-    {
-        // the class's rows, whole: eight 16-byte loads in flight per thread; every workgroup starts at its own offset
-        const int total = rows * ROW4;
-        const int rot = (int)((blockIdx.x * 977u) % (unsigned)total);
-        for (int base = 0; base < total; base += 8 * kThreads) {
-            float4 v[8];
-            int at[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                int i = min(base + k * kThreads + tid, total - 1) + rot;
-                i = i < total ? i : i - total;
-                const int row = i / ROW4, c4 = i - row * ROW4;
-                const int grow = row < r0c ? r0s + row : r1s + (row - r0c);
-                at[k] = row * STR4 + c4;
-                v[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)grow * a.ld_z + a.c0 + 4 * c4);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (base + k * kThreads + tid < total) lds4[at[k]] = v[k];
-        }
-        // the relation rows of D this workgroup's batches name
-        float4* dl = lds4 + (size_t)rows * STR4;
-        for (int i = tid; i < nrel * ROW4; i += kThreads) {
-            const int r = i / ROW4, c4 = i - r * ROW4;
-            dl[i] = *reinterpret_cast<const float4*>(a.d + (int64_t)(rel_lo + r) * a.ld_d + a.c0 + 4 * c4);
-        }
-    }
-    __syncthreads();
-    GN_DM_STAMP(1);
     const int l4 = lane & 3;
     const char* lds = reinterpret_cast<const char*>(lds4);
     const uint32_t lane_off = (uint32_t)l4 * 16u;
-    const f32x4* __restrict__ dl = reinterpret_cast<const f32x4*>(lds4 + (size_t)rows * STR4) + l4;
-    if (b < b_hi) {
-        float cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
-        int cur = -1;
-        f32x4 dreg[J];
+    float4* dfill = lds4 + (size_t)rows * STR4;
+    const f32x4* __restrict__ dl = reinterpret_cast<const f32x4*>(dfill) + l4;
+    // A workgroup walks its batch ranges one after the other (one per position sub-range of its XCD: the half-written
+    // score lines of ONE sub-range are what the L2 has to keep); the table is filled once, the relation rows of D a
+    // range's batches name are refilled per range.
+    for (int walk = 0; walk < a.walks; ++walk) {
+        const uint32_t b_lo = (uint32_t)g[4 + 4 * walk], b_hi = (uint32_t)g[5 + 4 * walk];
+        const int rel_lo = g[6 + 4 * walk], nrel = g[7 + 4 * walk];
+        // The first batches' words are requested BEFORE the fills (their HBM round trip hides behind them).  Every array
+        // has kClsSlack readable batches behind the last one: no prefetch needs a clamp.  The relation words travel as
+        // vector loads too (lanes 0 / 1 of `rw`): a scalar load shares its counter with the LDS reads and would be waited
+        // for as soon as it is issued.
+        uint32_t b = b_lo + (uint32_t)wave;
+        uint32_t w0 = pk[b * 64u], w1 = pk[(b + kStep) * 64u], w2 = pk[(b + 2 * kStep) * 64u];
+        uint32_t rw0 = rel[2 * b], rw1 = rel[2 * (b + kStep)];
+        uint32_t o0 = own[b * 64u], o1 = own[(b + kStep) * 64u];
+        uint32_t m0 = last ? mir[b * 64u] : kNoMirror, m1 = last ? mir[(b + kStep) * 64u] : kNoMirror;
+        if (walk == 0) {
+            // the class's rows, whole: eight 16-byte loads in flight per thread; every workgroup starts at its own offset
+            const int total = rows * ROW4;
+            const int rot = (int)((blockIdx.x * 977u) % (unsigned)total);
+            for (int base = 0; base < total; base += 8 * kThreads) {
+                float4 v[8];
+                int at[8];
 #pragma unroll
-        for (int j = 0; j < J; ++j) dreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define GN_CLS_STEP(S, RELV)                                                                                           \
-        {                                                                                                              \
-            const int rs = (int)(RELV);                                                                                \
-            if (rs != cur) {                                                                                           \
-                cur = rs;                                                                                              \
-                const f32x4* dr = dl + (rs - rel_lo) * ROW4;                                                           \
-                _Pragma("unroll") for (int j = 0; j < J; ++j) dreg[j] = dr[4 * j];                                     \
-            }                                                                                                          \
-            class_step<S, J, J1, STR4 * 16>(lds, lane_off, w, l4, dreg, res1, res2);                                   \
-        }
-#pragma unroll 1
-        for (; b < b_hi; b += kStep) {
-            const uint32_t w = w0, mine = o0, mcur = m0;
-            const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)rw0, 0), rb = (uint32_t)__builtin_amdgcn_readlane((int)rw0, 1);
-            const float carried = cnext;
-            w0 = w1; w1 = w2; rw0 = rw1; o0 = o1; m0 = m1;
-            w2 = pk[(b + 3 * kStep) * 64u];
-            rw1 = rel[2 * (b + 2 * kStep)];
-            o1 = own[(b + 2 * kStep) * 64u];
-            if (last) m1 = mir[(b + 2 * kStep) * 64u];
-            cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
-            float res1 = 0.f, res2 = 0.f;
-            GN_CLS_STEP(0, ra & 0xffffu)
-            GN_CLS_STEP(1, ra >> 16)
-            GN_CLS_STEP(2, rb & 0xffffu)
-            GN_CLS_STEP(3, rb >> 16)
-            float total = carried + res1;                       // the column parts add up in the phases' order
-            if constexpr (J1 < J) total = total + res2;
-            if (last) {
-                if (a.sigmoid) total = sigmoid_f32(total);
-                if (mine != kNoMirror) a.out[mine] = total;
-                if (mcur != kNoMirror) a.out[mcur] = total;
-            } else if (mine != kNoMirror) {
-                a.out[mine] = total;
+                for (int k = 0; k < 8; ++k) {
+                    int i = min(base + k * kThreads + tid, total - 1) + rot;
+                    i = i < total ? i : i - total;
+                    const int row = i / ROW4, c4 = i - row * ROW4;
+                    const int grow = row < r0c ? r0s + row : r1s + (row - r0c);
+                    at[k] = row * STR4 + c4;
+                    v[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)grow * a.ld_z + a.c0 + 4 * c4);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (base + k * kThreads + tid < total) lds4[at[k]] = v[k];
             }
+        } else {
+            __syncthreads();                                  // every wave is done with the previous range's relation rows
         }
+        // the relation rows of D this range's batches name
+        for (int i = tid; i < nrel * ROW4; i += kThreads) {
+            const int r = i / ROW4, c4 = i - r * ROW4;
+            dfill[i] = *reinterpret_cast<const float4*>(a.d + (int64_t)(rel_lo + r) * a.ld_d + a.c0 + 4 * c4);
+        }
+        __syncthreads();
+        if (walk == 0) GN_DM_STAMP(1);
+        if (b < b_hi) {
+            float cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
+            int cur = -1;
+            f32x4 dreg[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) dreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define GN_CLS_STEP(S, RELV)                                                                                           \
+            {                                                                                                          \
+                const int rs = (int)(RELV);                                                                            \
+                if (rs != cur) {                                                                                       \
+                    cur = rs;                                                                                          \
+                    const f32x4* dr = dl + (rs - rel_lo) * ROW4;                                                       \
+                    _Pragma("unroll") for (int j = 0; j < J; ++j) dreg[j] = dr[4 * j];                                 \
+                }                                                                                                      \
+                class_step<S, J, J1, STR4 * 16>(lds, lane_off, w, l4, dreg, res1, res2);                               \
+            }
+#pragma unroll 1
+            for (; b < b_hi; b += kStep) {
+                const uint32_t w = w0, mine = o0, mcur = m0;
+                const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)rw0, 0), rb = (uint32_t)__builtin_amdgcn_readlane((int)rw0, 1);
+                const float carried = cnext;
+                w0 = w1; w1 = w2; rw0 = rw1; o0 = o1; m0 = m1;
+                w2 = pk[(b + 3 * kStep) * 64u];
+                rw1 = rel[2 * (b + 2 * kStep)];
+                o1 = own[(b + 2 * kStep) * 64u];
+                if (last) m1 = mir[(b + 2 * kStep) * 64u];
+                cnext = (!first && o0 != kNoMirror) ? a.out[o0] : 0.f;
+                float res1 = 0.f, res2 = 0.f;
+                GN_CLS_STEP(0, ra & 0xffffu)
+                GN_CLS_STEP(1, ra >> 16)
+                GN_CLS_STEP(2, rb & 0xffffu)
+                GN_CLS_STEP(3, rb >> 16)
+                float total = carried + res1;                   // the column parts add up in the phases' order
+                if constexpr (J1 < J) total = total + res2;
+                if (last) {
+                    if (a.sigmoid) total = sigmoid_f32(total);
+                    if (mine != kNoMirror) a.out[mine] = total;
+                    if (mcur != kNoMirror) a.out[mcur] = total;
+                } else if (mine != kNoMirror) {
+                    a.out[mine] = total;
+                }
+            }
 #undef GN_CLS_STEP
+        }
     }
     GN_DM_STAMP(2);
 #ifdef GN_STAMPS
@@ -482,7 +491,7 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
             if ((he = hipMemcpyAsync(p->cls_rel.p, cl.rel32.data(), cl.rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
             if ((he = hipMemcpyAsync(p->cls_wg.p, cl.wg.data(), cl.wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
             if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);
-            p->cls_features = (int)num_features; p->cls_groups = cl.groups; p->cls_batches = cl.batches;
+            p->cls_features = (int)num_features; p->cls_groups = cl.groups; p->cls_batches = cl.batches; p->cls_walks = cl.walks;
             p->cls_ok = 1;
         }
     }
@@ -530,7 +539,7 @@ static gn_status plan_forward_cols(const gn_distmult_plan* plan, const float* z,
             c.z = z; c.ld_z = ld_z; c.d = d; c.ld_d = ld_d;
             c.packed = plan->cls_packed.p; c.own = plan->cls_own.p; c.mirror = plan->cls_mirror.p; c.rel = plan->cls_rel.p;
             c.wg = plan->cls_wg.p; c.out = out; c.c0 = (int)col_lo; c.sigmoid = apply_sigmoid;
-            c.first_launch = col_lo == 0; c.last_launch = col_hi == num_features;
+            c.first_launch = col_lo == 0; c.last_launch = col_hi == num_features; c.walks = plan->cls_walks;
             hipStream_t st = gn::as_stream(stream);
             switch (J * 8 + J1) {
                 case 5 * 8 + 3: return launch_class<5, 3>(plan, c, n, st);

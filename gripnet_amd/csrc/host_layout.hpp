@@ -42,6 +42,8 @@ namespace gn_layout {
 constexpr uint32_t kNoMirror = 0xffffffffu;
 constexpr int kClsDCache = 64;        // relation rows of D a workgroup of k_distmult_class keeps in LDS
 constexpr int kClsSlack = 64;         // readable batches behind the last one (the kernel's prefetches run ahead unclamped)
+constexpr int kClsMaxWalks = 8;       // position sub-ranges an XCD's workgroups walk one after the other (k_distmult_class)
+constexpr int64_t kClsWindowBytes = 1 << 20;   // scores of one sub-range: what an XCD's 4 MB L2 holds half-written next to the streams
 
 // ---- DistMult decoder on a static list (distmult_plan.hip) -------------------------------------------------------------
 // Triples with the same unordered node pair and relation have the same score (the reference's positive list holds every
@@ -173,6 +175,7 @@ inline void deal_run(const int* lu, const int* lv, int count, std::vector<int>& 
 struct ClassLayout {
     bool ok = false;
     int groups = 0;
+    int walks = 1;                      // batch ranges per workgroup (descriptor: 4 + 4 walks ints)
     int64_t batches = 0;
     std::vector<uint32_t> packed, own, mirror, rel32;
     std::vector<int32_t> wg;
@@ -180,7 +183,7 @@ struct ClassLayout {
 
 inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr,
                                       const std::vector<int64_t>& scored, const std::vector<int64_t>& mirror_of, int64_t n,
-                                      int64_t features, int cus) {
+                                      int64_t features, int cus, int64_t window_bytes = kClsWindowBytes) {
     static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
     ClassLayout L;
     if (features < 16 || features % 16 != 0 || features > 128 || scored.empty() || n < 1) return L;
@@ -211,14 +214,20 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     // three classes - so three workgroups write it, a third each.  The list is cut into eight position ranges, one per
     // XCD (workgroup b runs on XCD b % 8), and inside a range each class gets its share of that XCD's compute units: the
     // three writers of a line share an L2, which holds the range's whole share of the scores.
+    // When an XCD's share of the score vector exceeds what its L2 keeps half-written (pose2-syn: 4.2 MB of 33.5: 97 MB were
+    // written for them, the lines leaving L2 a third at a time), the XCD's range is cut into `walks` sub-ranges that its
+    // workgroups walk one after the other: the live window is one sub-range.
     const int64_t S = (int64_t)scored.size();
     const int parts = (cus % 8 == 0 && cus >= 24 && S >= (int64_t)64 * 4 * cus) ? 8 : 1;
-    const int ngroups = parts * nclasses;
+    const int64_t list_bytes = (int64_t)hu.size() * 4;
+    const int walks = parts == 8 ? (int)std::max<int64_t>(1, std::min<int64_t>(kClsMaxWalks, gn::ceil_div(list_bytes / 8, window_bytes))) : 1;
+    const int nparts = parts * walks;                            // part p = XCD (p / walks), walk (p % walks)
+    const int ngroups = nparts * nclasses;
     // scored pairs by (part, class, relation), list order inside
     std::vector<uint32_t> key((size_t)S);
     std::vector<int64_t> idx((size_t)S);
     for (int64_t i = 0; i < S; ++i) {
-        const int part = (int)std::min<int64_t>(parts - 1, i * parts / S);
+        const int part = (int)std::min<int64_t>(nparts - 1, i * nparts / S);
         key[i] = (uint32_t)(part * nclasses + cls_of(scored[i])) << 16 | (uint32_t)hr[scored[i]];
         idx[i] = i;
     }
@@ -289,59 +298,67 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
         for (int64_t gstep = grp_batch0[g] * 4 + grp_steps[g]; gstep < grp_batch0[g + 1] * 4; ++gstep)
             rel16[(size_t)gstep] = gstep > 0 ? rel16[(size_t)gstep - 1] : 0;
     for (int64_t gstep = NB * 4; gstep < NBA * 4; ++gstep) rel16[(size_t)gstep] = NB > 0 ? rel16[(size_t)NB * 4 - 1] : 0;
-    // workgroups: inside a part, a share of the part's compute units per class in proportion to its batches, contiguous
-    // batch ranges; with eight parts workgroup 8 l + x is the l-th of part x
+    // workgroups: inside an XCD's range, a share of its compute units per class in proportion to the class's batches (over
+    // all the range's walks); a workgroup takes the same slice of its class's batches in every walk, contiguous batch
+    // ranges; with eight ranges workgroup 8 l + x is the l-th of range x
     const int per_part = parts == 8 ? cus / 8 : (int)std::min<int64_t>(cus, std::max<int64_t>(NB, 1));
-    struct Wg { int cls; int64_t lo, hi; };
+    struct Wg { int cls; int share, k; };
     std::vector<std::vector<Wg>> part_wgs(parts);
+    auto group_of = [&](int x, int walk, int c) { return (x * walks + walk) * nclasses + c; };
     for (int x = 0; x < parts; ++x) {
         int64_t nb_part = 0;
         int live = 0;
-        for (int c = 0; c < nclasses; ++c) { const int g = x * nclasses + c; nb_part += grp_batch0[g + 1] - grp_batch0[g]; live += grp_batch0[g + 1] > grp_batch0[g]; }
+        std::vector<int64_t> nb_cls(nclasses, 0);
+        for (int c = 0; c < nclasses; ++c) {
+            for (int wk = 0; wk < walks; ++wk) { const int g = group_of(x, wk, c); nb_cls[c] += grp_batch0[g + 1] - grp_batch0[g]; }
+            nb_part += nb_cls[c];
+            live += nb_cls[c] > 0;
+        }
         const int W = parts == 8 ? per_part : std::max(std::min<int>(per_part, (int)std::max<int64_t>(nb_part, 1)), live);
         if (W < live) return L;
         std::vector<int> share(nclasses, 0);
         std::vector<double> frac(nclasses, 0.0);
         int given = 0;
         for (int c = 0; c < nclasses; ++c) {
-            const int g = x * nclasses + c;
-            const int64_t nb = grp_batch0[g + 1] - grp_batch0[g];
-            if (nb == 0) continue;
-            const double want = (double)W * nb / std::max<int64_t>(nb_part, 1);
+            if (nb_cls[c] == 0) continue;
+            const double want = (double)W * nb_cls[c] / std::max<int64_t>(nb_part, 1);
             share[c] = std::max(1, (int)want);
             frac[c] = want - share[c];
             given += share[c];
         }
         while (given < W && live > 0) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] && (best < 0 || frac[c] > frac[best])) best = c; share[best]++; frac[best] -= 1.0; ++given; }
         while (given > W) { int best = -1; for (int c = 0; c < nclasses; ++c) if (share[c] > 1 && (best < 0 || frac[c] < frac[best])) best = c; if (best < 0) break; share[best]--; frac[best] += 1.0; --given; }
-        for (int c = 0; c < nclasses; ++c) {
-            const int g = x * nclasses + c;
-            const int64_t nb = grp_batch0[g + 1] - grp_batch0[g];
-            for (int k = 0; k < share[c]; ++k) part_wgs[x].push_back({c, grp_batch0[g] + nb * k / share[c], grp_batch0[g] + nb * (k + 1) / share[c]});
-        }
-        while (parts == 8 && (int)part_wgs[x].size() < W) part_wgs[x].push_back({0, 0, 0});      // (a part without work for all its units)
+        for (int c = 0; c < nclasses; ++c)
+            for (int k = 0; k < share[c]; ++k) part_wgs[x].push_back({c, share[c], k});
+        while (parts == 8 && (int)part_wgs[x].size() < W) part_wgs[x].push_back({0, 0, 0});      // (a range without work for all its units)
     }
     int G = 0;
     for (int x = 0; x < parts; ++x) G += (int)part_wgs[x].size();
     if (G < 1) return L;
-    std::vector<int32_t> wg((size_t)G * 8, 0);
+    const int dstride = 4 + 4 * walks;
+    std::vector<int32_t> wg((size_t)G * dstride, 0);
     for (int x = 0; x < parts; ++x)
         for (size_t l = 0; l < part_wgs[x].size(); ++l) {
             const Wg& w = part_wgs[x][l];
             const int c = w.cls;
-            int rlo = 1 << 30, rhi = -1;
-            for (int64_t gstep = w.lo * 4; gstep < w.hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
-            if (w.hi <= w.lo) { rlo = 0; rhi = 0; }
-            if (rhi - rlo + 1 > kClsDCache) return L;                             // (the column-phase kernel serves such a list)
-            int32_t* d = wg.data() + (parts == 8 ? (size_t)(8 * l + x) : l) * 8;
+            int32_t* d = wg.data() + (parts == 8 ? (size_t)(8 * l + x) : l) * dstride;
             if (nblocks == 1) { d[0] = 0; d[1] = (int32_t)n; d[2] = 0; d[3] = 0; }
             else { d[0] = (int32_t)bstart(c); d[1] = (int32_t)bsize(c); d[2] = (int32_t)bstart((c + 1) % 3); d[3] = (int32_t)bsize((c + 1) % 3); }
-            d[4] = (int32_t)w.lo; d[5] = (int32_t)w.hi; d[6] = rlo; d[7] = rhi - rlo + 1;
+            for (int wk = 0; wk < walks; ++wk) {
+                const int g = group_of(x, wk, c);
+                const int64_t nb = grp_batch0[g + 1] - grp_batch0[g];
+                const int64_t lo = w.share ? grp_batch0[g] + nb * w.k / w.share : 0, hi = w.share ? grp_batch0[g] + nb * (w.k + 1) / w.share : 0;
+                int rlo = 1 << 30, rhi = -1;
+                for (int64_t gstep = lo * 4; gstep < hi * 4; ++gstep) { rlo = std::min<int>(rlo, rel16[(size_t)gstep]); rhi = std::max<int>(rhi, rel16[(size_t)gstep]); }
+                if (hi <= lo) { rlo = 0; rhi = 0; }
+                if (rhi - rlo + 1 > kClsDCache) return L;                         // (the column-phase kernel serves such a list)
+                d[4 + 4 * wk] = (int32_t)lo; d[5 + 4 * wk] = (int32_t)hi; d[6 + 4 * wk] = rlo; d[7 + 4 * wk] = rhi - rlo + 1;
+            }
         }
     std::vector<uint32_t> rel32((size_t)NBA * 2);
     for (size_t i = 0; i < rel32.size(); ++i) rel32[i] = (uint32_t)rel16[2 * i] | (uint32_t)rel16[2 * i + 1] << 16;
     L.packed.swap(packed); L.own.swap(own); L.mirror.swap(mirror); L.rel32.swap(rel32); L.wg.swap(wg);
-    L.groups = G; L.batches = NB;
+    L.groups = G; L.batches = NB; L.walks = walks;
     L.ok = true;
     return L;
 }

@@ -24,7 +24,8 @@ void set_threads(int n) {
 }
 
 // ---- decoder: pairing + row classes ------------------------------------------------------------------------------------
-gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t features, unsigned seed, bool check) {
+gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t features, unsigned seed, bool check,
+                                   int64_t window_bytes = gn_layout::kClsWindowBytes) {
     std::mt19937_64 rng(seed);
     std::vector<int64_t> hu, hv, hr;
     for (int r = 0; r < R; ++r) {
@@ -41,7 +42,7 @@ gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t fea
     std::vector<int64_t> scored;
     for (int64_t e = 0; e < E; ++e)
         if (!covered[e]) scored.push_back(e);
-    gn_layout::ClassLayout L = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, n, features, 256);
+    gn_layout::ClassLayout L = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, n, features, 256, window_bytes);
     if (!check) return L;
     CHECK(L.ok);
     // every edge position is written exactly once: as a scored pair's own position or as its mirror
@@ -55,21 +56,25 @@ gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t fea
     // workgroups: contiguous batch ranges that together tile [0, batches) (with eight position parts workgroup 8 l + x is
     // the l-th of part x, so they are not in index order); local rows inside the class's rows; relations inside the D cache
     std::vector<std::pair<int64_t, int64_t>> ranges;
+    CHECK(L.walks >= 1 && L.walks <= gn_layout::kClsMaxWalks);
     for (int g = 0; g < L.groups; ++g) {
-        const int32_t* d = L.wg.data() + (size_t)g * 8;
-        CHECK(d[5] >= d[4] && d[4] >= 0 && d[5] <= L.batches);
-        if (d[5] > d[4]) ranges.push_back({d[4], d[5]});
-        CHECK(d[7] >= 1 && d[7] <= gn_layout::kClsDCache);
-        const int rows = d[1] + d[3];
-        for (int64_t b = d[4]; b < d[5]; ++b) {
-            for (int s = 0; s < 64; ++s) {
-                const uint32_t w = L.packed[(size_t)b * 64 + s];
-                CHECK((int)(w & 0xffffu) < rows && (int)(w >> 16) < rows);
-            }
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t word = L.rel32[(size_t)b * 2 + (k >> 1)];
-                const int rel = (int)((k & 1) ? word >> 16 : word & 0xffffu);
-                CHECK(rel >= d[6] && rel < d[6] + d[7]);
+        const int32_t* h = L.wg.data() + (size_t)g * (4 + 4 * L.walks);
+        const int rows = h[1] + h[3];
+        for (int wk = 0; wk < L.walks; ++wk) {                  // a workgroup's batch range of every walk of its position range
+            const int32_t* d = h + 4 * wk;
+            CHECK(d[5] >= d[4] && d[4] >= 0 && d[5] <= L.batches);
+            if (d[5] > d[4]) ranges.push_back({d[4], d[5]});
+            CHECK(d[7] >= 1 && d[7] <= gn_layout::kClsDCache);
+            for (int64_t b = d[4]; b < d[5]; ++b) {
+                for (int s = 0; s < 64; ++s) {
+                    const uint32_t w = L.packed[(size_t)b * 64 + s];
+                    CHECK((int)(w & 0xffffu) < rows && (int)(w >> 16) < rows);
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t word = L.rel32[(size_t)b * 2 + (k >> 1)];
+                    const int rel = (int)((k & 1) ? word >> 16 : word & 0xffffu);
+                    CHECK(rel >= d[6] && rel < d[6] + d[7]);
+                }
             }
         }
     }
@@ -252,6 +257,11 @@ int main() {
         set_threads(16);
         gn_layout::ClassLayout b = decoder_case(c.n, c.R, c.e, c.f, 7, true);
         CHECK(same(a.packed, b.packed) && same(a.own, b.own) && same(a.mirror, b.mirror) && same(a.rel32, b.rel32) && same(a.wg, b.wg));
+    }
+    for (int64_t window : {(int64_t)8 << 10, (int64_t)40 << 10}) {     // an XCD's position range walked in several sub-ranges
+        set_threads(16);
+        gn_layout::ClassLayout w = decoder_case(645, 40, 20000, 80, 9, true, window);
+        CHECK(w.walks == (window == ((int64_t)8 << 10) ? 8 : 3));
     }
     struct { int64_t N, R, E; } pr[] = {{645, 30, 60000}, {200, 5, 9000}, {1, 1, 300}, {300, 964, 20000}};
     for (auto& c : pr) {
