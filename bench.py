@@ -129,6 +129,16 @@ def train_step_entry(dev, steps=20):
             step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    # the eager step (the Python loop a caller of GripNet-pose.py:112-146 runs), and its entry points between HIP events
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    eager_ms = 1e3 * (time.perf_counter() - t0) / 10
+    with _hip.KernelTimer(pool=400) as timer:
+        for _ in range(3):
+            step()
+    per_entry = {k: 1e3 * tot / 3 for k, (calls, tot) in timer.summary().items()}      # us per step (all calls of the entry point)
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad(set_to_none=True)
     with torch.cuda.graph(graph):
@@ -147,10 +157,41 @@ def train_step_entry(dev, steps=20):
     if steps > 0 and torch.equal(before, neg):
         raise RuntimeError("the replayed training step did not draw new negatives")
     _hip.raise_if_index_errors(dev)
+    # ---- algorithmic bytes of the step (SURVEY.md 8d's model carried to the backward pass: the reference's data types,
+    # every edge list read once per pass that needs it, node / parameter tables and their gradients once) ----
+    E = int(data.train_idx.shape[1])
+    fwd = algorithmic_bytes(data, E, E)
+    n_g, n_d, R = data.n_g_node, data.n_d_node, data.n_dd_edge_type
+    e_gg, e_gd = int(data.gg_edge_index.shape[1]) + n_g, int(data.gd_edge_index.shape[1])
+    dm_bwd = E * 28 + 2 * (n_d + R) * 80 * 4                  # one list: (u, v, r, g) once, z and D read, dz and dD written
+    alg = {
+        "forward (gg, gd, dd, DistMult on the positives)": fwd["gg"] + fwd["gd"] + fwd["dd"] + fwd["dmt"],
+        "negative sampling (E pairs written as int64 + the positives' pair set read)": E * 16 + E * 16,
+        "DistMult on the negatives": fwd["dmt"],
+        "loss forward + backward": 2 * 2 * E * 4 + 2 * E * 4,
+        "DistMult backward, positives + negatives": 2 * dm_bwd,
+        "relational layer backward (dx over the reversed edges, dW_r -> dbasis / datt, droot)": 2 * E * 16 + 2 * n_d * 4 * (48 + 32) + 2 * 4 * (32 * 48 * 32 + R * 32 + 48 * 32),
+        "external layer backward": e_gd * 20 + 2 * (n_g * 64 * 4 + n_d * 48 * 4),
+        "gene layers backward": 2 * e_gg * 20 + 2 * n_g * 4 * (32 + 16 + 16 + 16),
+        "Adam (parameters, gradients, two moments read; parameters and moments written)": 7 * 4 * sum(p.numel() for p in model.parameters()),
+    }
+    alg_total = int(sum(alg.values()))
+    bwd_entries = {k: v for k, v in per_entry.items() if "backward" in k or k in ("gn_rel_weight_grad_f32", "gn_graph_aggregate_t_f32", "gn_grad_prologue_f32",
+                                                                                 "gn_dense_batch_end", "gn_xtg_f32", "gn_gemm_f32")}
+    dom = max(bwd_entries, key=bwd_entries.get) if bwd_entries else None
+    dom_bytes = {"gn_distmult_backward_packed_f32": dm_bwd, "gn_distmult_backward_planned_f32": dm_bwd, "gn_distmult_backward_f32": dm_bwd,
+                 "gn_rel_weight_grad_f32": E * 16 + n_d * 4 * (48 + 32) + R * 48 * 32 * 4}.get(dom)
     return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
+            "ms_per_step_eager": round(eager_ms, 4),
             "what": "negative sampling + forward + DistMult on positives and on the fresh negatives + loss (utils.link_loss) + backward + Adam (gripnet_amd.optim.Adam, one launch): "
-                    "one hipGraph replay per step and nothing else; the draw (typed sampler, 22 us) is the graph's first node, its seed moves with a counter on the device "
-                    "(as a BRANCH beside the encoder the step is 40 us slower: a forked hipGraph pays more in its joins than the overlap returns)",
+                    "ms_per_step = one hipGraph replay per step and nothing else; the draw (typed sampler) is the graph's first node, its seed moves with a counter on the device; "
+                    "ms_per_step_eager = the same step as a Python loop over the modules (host-bound)",
+            "algorithmic_bytes": alg_total, "algorithmic_bytes_by_part": {k: int(v) for k, v in alg.items()},
+            "frac": round(alg_total / (dt * 1e9) / HBM_PEAK_GBS, 4),
+            "entry_point_us_per_step": {k: round(v, 1) for k, v in sorted(per_entry.items(), key=lambda kv: -kv[1])},
+            "dominant_backward_entry_point": None if dom is None else {
+                "name": dom, "us_per_step": round(bwd_entries[dom], 1), "algorithmic_bytes": dom_bytes,
+                "frac": None if dom_bytes is None else round(dom_bytes / (bwd_entries[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
             "loss_after": round(losses[-1], 5)}
 
 
@@ -479,8 +520,13 @@ def main():
             dom = max((k for k in CANDIDATES if k != "gn_graph_aggregate_f32[gcn]"), key=lambda k: per_call0.get(k, 0.0))
             # graphs: every stage but the one that holds the dominant entry point replays as a hipGraph; that entry
             # point is launched from Python in both modes, with HIP events around it on its stream in EVERY timed step.
+            # every fourth launch of the dominant entry point is timed: its kernel carries the HIP events as the start / stop
+            # stamps of its own dispatch (gn_time_next_launch -> hipExtLaunchKernel: the duration is the kernel's own, 28.4 us
+            # where event records around the launch read 30.5) - a stamped dispatch still costs the stream ~5 us (measured:
+            # +5.0 us per step with every launch stamped), event records around a launch ~9 us
+            timed_every = 4
             def quick(fn, n=20):                      # under the same event timing as the timed region
-                with _hip.KernelTimer(only=(dom,), every=4):
+                with _hip.KernelTimer(only=(dom,), every=timed_every, pool=64):
                     for _ in range(5):
                         fn()
                     fence()
@@ -520,6 +566,7 @@ def main():
             dom = max((k for k in CANDIDATES if k != "gn_graph_aggregate_f32[gcn]"), key=lambda k: per_call0.get(k, 0.0))
             launch = "eager" if args.launch == "eager" else "graphs" if args.launch == "graphs" else "recorded"
             launch_ms = None
+            timed_every = 4
             if launch == "graphs":                    # replicated gene layers as one graph; the collective is never captured
                 fwd.kernels.encode_genes = Graphed(fwd.kernels.encode_genes).capture()
             step = fwd
@@ -528,9 +575,9 @@ def main():
 
         # the event pool exists before the warm-up, and the W warm-up steps run under the same timer as the K timed ones
         # (their records are dropped): nothing but the fence sits between the last warm-up step and the first timed one
-        # (every fourth launch of the dominant entry point is bracketed: an event record costs ~4.5 us of stream time, and
-        # two per step would be a tenth of the step; `timed_launches` says how many went into the average)
-        timer = _hip.KernelTimer(only=(dom,), pool=2 * (args.steps + max(args.warmup, 1)) + 8, every=4)
+        # (every fourth launch of the dominant entry point is timed - its kernel carries the events as its dispatch's own stamps
+        # where it can, else event records bracket the launch; `timed_launches` says how many went into the average)
+        timer = _hip.KernelTimer(only=(dom,), pool=2 * (args.steps + max(args.warmup, 1)) + 8, every=timed_every)
         fence()
         with timer:
             for _ in range(max(args.warmup, 1)):
@@ -631,18 +678,20 @@ def main():
                                  "(three products instead of six, <= 2^-16 per product); the eager step with it takes {:.1f} us of entry "
                                  "points against {:.1f}".format(sum(fast_breakdown.values()), sum(breakdown.values())))
 
+    timed_how = ("every fourth launch, the events carried by the kernel's own dispatch (hipExtLaunchKernel: the kernel's own start / stop stamps)"
+                 if dom in _hip._STAMPED else "event records around every fourth launch")
     if sharded is not None:
         launch_note = ("the forward's entry-point calls recorded once and made again from one loop around the all-reduce (which "
-                       "torch.distributed issues in every step); {} HIP-event timed around every fourth launch".format(dom)
+                       "torch.distributed issues in every step); {} HIP-event timed, {}".format(dom, timed_how)
                        if launch == "recorded" else
-                       "replicated gene layers replayed as {}, the rest eager; {} HIP-event timed around every fourth launch".format(
-                           "one hipGraph" if launch == "graphs" else "eager launches", dom))
+                       "replicated gene layers replayed as {}, the rest eager; {} HIP-event timed, {}".format(
+                           "one hipGraph" if launch == "graphs" else "eager launches", dom, timed_how))
     elif launch == "eager":
-        launch_note = "eager; {} HIP-event timed around every fourth launch".format(dom)
+        launch_note = "eager; {} HIP-event timed, {}".format(dom, timed_how)
     elif launch == "recorded":
         launch_note = ("the step's {} entry-point calls recorded once and made again from one Python loop (ordinary launches on the "
                        "recording's buffers; no hipGraph: a graph launch leaves the GPU idle ~9 us in front of its first kernel on this "
-                       "stack); {} HIP-event timed around every fourth launch".format(len(modes["recorded"]._whole.calls), dom))
+                       "stack); {} HIP-event timed, {}".format(len(modes["recorded"]._whole.calls), dom, timed_how))
     elif dom == "gn_rgcn_forward_f32":
         launch_note = ("gene and external layers replayed as one hipGraph; {} launched and HIP-event timed from Python, the decoder "
                        "(one kernel) launched from Python as well".format(dom))

@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 140                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 141                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -33,6 +33,8 @@ _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 SIGNATURES = {
     "gn_version": (_int, []),
     "gn_last_error": (C.c_char_p, []),
+    "gn_time_next_launch": (_int, [_p, _p]),
+    "gn_time_launch_pending": (_int, []),
     "gn_gcn_plan_create": (_int, [_p, _p, _p, _i64, _i64, _int, _p, C.POINTER(_p)]),
     "gn_bipartite_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_sum_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
@@ -224,12 +226,13 @@ class KernelTimer:
     """Optional per-entry-point device timing: while active, every launch made through this
     module is bracketed by HIP events on the launching stream (used by bench.py's roofline)."""
 
-    def __init__(self, only=None, pool=0, every=1):
+    def __init__(self, only=None, pool=0, every=1, records_only=False):
         """`pool`: events created (and recorded once, which is when HIP allocates them) up front, so that a timed
         region pays two event records per bracketed launch and nothing else.  `every`: bracket only every n-th launch
         of an entry point (an event record costs ~4.5 us of stream time on this stack: two per step are 9 % of a 95 us
         step; a sample of the launches gives the same average duration)."""
         self.events = {}
+        self.records_only = bool(records_only)      # never the kernels' own dispatch stamps (gn_time_next_launch)
         self.every, self._seen = max(1, int(every)), {}
         self.only = None if only is None else set(only)
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
@@ -258,6 +261,31 @@ class KernelTimer:
 
 
 _timer = None
+
+# Entry points whose kernel can carry its own start / stop events (gn_time_next_launch): no marker packets in the stream.  An
+# entry point that turns out to launch another kernel (the events stay pending) is timed with event records from then on.
+_STAMPED = {"gn_rgcn_forward_f32", "gn_distmult_plan_forward_f32"}
+
+
+def _timed_call(t, fn, args, name, tag):
+    """One bracketed call under KernelTimer `t`: the kernel's own dispatch stamps where the entry point supports them,
+    else an event record in front of and behind the launch (each ~4.5 us of stream time on this stack)."""
+    start, stop = t.event(), t.event()
+    if name in _STAMPED and not t.records_only and start.cuda_event and stop.cuda_event:      # (a pooled event: its handle exists)
+        lib = load()
+        lib.gn_time_next_launch(start.cuda_event, stop.cuda_event)
+        status = fn(*args)
+        if lib.gn_time_launch_pending():                  # another kernel served the call: untimed this once, records from now on
+            _STAMPED.discard(name)
+            t._pool.extend((start, stop))
+        else:
+            t.add(tag or name, start, stop)
+        return status
+    start.record()
+    status = fn(*args)
+    stop.record()
+    t.add(tag or name, start, stop)
+    return status
 
 
 class Recorder:
@@ -293,11 +321,7 @@ def replay(calls):
             seen = t._seen.get(name, 0)
             t._seen[name] = seen + 1
             if seen % t.every == 0:
-                start, stop = t.event(), t.event()
-                start.record()
-                status = fn(*args)
-                stop.record()
-                t.add(tag or name, start, stop)
+                status = _timed_call(t, fn, args, name, tag)
                 if status:
                     check(status)
                 continue
@@ -400,11 +424,7 @@ def _call(name, *args, tag=None):
         t._seen[name] = seen + 1
         timed = seen % t.every == 0
     if timed:
-        start, stop = t.event(), t.event()
-        start.record()
-        status = fn(*args)
-        stop.record()
-        t.add(tag or name, start, stop)
+        status = _timed_call(t, fn, args, name, tag)
     else:
         status = fn(*args)
     check(status)

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -99,6 +100,12 @@ inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 8) 
 
 // Opt a kernel in to more than 64 KB of dynamic LDS, once per (kernel, device).
 gn_status allow_large_lds(const void* kernel, int bytes);
+
+// HIP events that the calling thread asked the NEXT timed kernel launch to carry (gn_time_next_launch): the launch site
+// that supports it hands them to hipExtLaunchKernelGGL, which stamps the dispatch itself - no marker packets in the stream
+// (an event record in front of and behind a launch costs ~4.5 us of stream time each on this stack).
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+LaunchEvents take_launch_events();          // the pending pair (or nulls), cleared
 
 }  // namespace gn
 

@@ -385,7 +385,9 @@ template <int J, int J1>
 gn_status launch_class(const gn_distmult_plan* plan, const DmClassArgs& a, int64_t n, hipStream_t st) {
     gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_class<J, J1>), 160 * 1024);
     if (s != GN_OK) return s;
-    k_distmult_class<J, J1><<<plan->cls_groups, kThreads, 160 * 1024, st>>>(a);
+    const gn::LaunchEvents ev = gn::take_launch_events();
+    if (ev.start || ev.stop) hipExtLaunchKernelGGL((k_distmult_class<J, J1>), dim3(plan->cls_groups), dim3(kThreads), 160 * 1024, st, ev.start, ev.stop, 0, a);
+    else k_distmult_class<J, J1><<<plan->cls_groups, kThreads, 160 * 1024, st>>>(a);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -28,7 +28,30 @@ gn_status allow_large_lds(const void* kernel, int bytes) {
     done.insert({kernel, dev});
     return GN_OK;
 }
+
+static thread_local LaunchEvents pending_launch_events;
+LaunchEvents take_launch_events() {
+    const LaunchEvents e = pending_launch_events;
+    pending_launch_events = LaunchEvents{};
+    return e;
+}
 }  // namespace gn
+
+extern "C" {
+// The next launch of an entry point that supports it (gn_rgcn_forward_f32 on the destination-major kernel,
+// gn_distmult_plan_forward_f32 on the row-class kernel) carries these two HIP events as its dispatch's own start / stop stamps.
+gn_status gn_time_next_launch(void* start_event, void* stop_event) {
+    gn::pending_launch_events.start = static_cast<hipEvent_t>(start_event);
+    gn::pending_launch_events.stop = static_cast<hipEvent_t>(stop_event);
+    return GN_OK;
+}
+// 1 when the events of gn_time_next_launch are still waiting (the call in between launched a kernel that does not take them);
+// clears them.
+int gn_time_launch_pending(void) {
+    const gn::LaunchEvents e = gn::take_launch_events();
+    return (e.start || e.stop) ? 1 : 0;
+}
+}
 
 namespace {
 

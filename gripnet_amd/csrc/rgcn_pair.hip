@@ -711,11 +711,15 @@ gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t s
     if (a.xp) {
         gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS, true>), kLdsBytes);
         if (s != GN_OK) return s;
-        k_rgcn_pair<NT, BT, TERMS, true><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
+        const gn::LaunchEvents ev = gn::take_launch_events();
+        if (ev.start || ev.stop) hipExtLaunchKernelGGL((k_rgcn_pair<NT, BT, TERMS, true>), dim3(plan->pair_groups), dim3(kThreads), kLdsBytes, st, ev.start, ev.stop, 0, a, stamp++);
+        else k_rgcn_pair<NT, BT, TERMS, true><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
     } else {
         gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS, false>), kLdsBytes);
         if (s != GN_OK) return s;
-        k_rgcn_pair<NT, BT, TERMS, false><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
+        const gn::LaunchEvents ev = gn::take_launch_events();
+        if (ev.start || ev.stop) hipExtLaunchKernelGGL((k_rgcn_pair<NT, BT, TERMS, false>), dim3(plan->pair_groups), dim3(kThreads), kLdsBytes, st, ev.start, ev.stop, 0, a, stamp++);
+        else k_rgcn_pair<NT, BT, TERMS, false><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, stamp++);
     }
     GN_LAUNCH_CHECK();
     return GN_OK;

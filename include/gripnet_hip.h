@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 140 /* 0.1.36 */
+#define GN_VERSION 141 /* 0.1.37 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -244,6 +244,15 @@ GN_API gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, con
                               gn_rgcn_plan** plan);
 GN_API void gn_rgcn_plan_destroy(gn_rgcn_plan* plan);
 GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
+
+/* Timing without marker packets: the NEXT kernel launched by this thread through gn_rgcn_forward_f32 (destination-major
+ * kernel) or gn_distmult_plan_forward_f32 (row-class kernel) carries the two HIP events (hipEvent_t, created by the caller)
+ * as the start / stop stamps of its own dispatch (hipExtLaunchKernel); hipEventElapsedTime(start, stop) is then the
+ * kernel's duration on its stream.  A pair of hipEventRecord calls around a launch costs ~9 us of stream time on this
+ * stack - a tenth of the PoSE forward.  gn_time_launch_pending: 1 when the events are still waiting (the call in
+ * between took a kernel that does not carry them: time it with event records instead); clears them. */
+GN_API gn_status gn_time_next_launch(void* start_event, void* stop_event);
+GN_API int gn_time_launch_pending(void);
 
 /* Bytes of caller-provided scratch a gn_rgcn_forward_f32 call with these shapes and flags needs: none on the
  * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, a slab of rows (<= 64 MB) and the stacked
