@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 141                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 142                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -91,6 +91,9 @@ SIGNATURES = {
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
     "gn_negative_sampler_sample_packed": (_int, [_p, C.c_uint64, _p, _p, _p, _p, _p]),
     "gn_negative_sampler_sample_stepped": (_int, [_p, C.c_uint64, _p, _p, _p, _p, _p, _p]),
+    "gn_rgcn_weight_grad_workspace_bytes": (_sz, [_p, _i64, _i64]),
+    "gn_rgcn_weight_grad_supported": (_int, [_p, _i64, _i64]),
+    "gn_rgcn_weight_grad_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _sz, _p]),
     "gn_rel_grad_plan_create": (_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_rel_grad_plan_destroy": (None, [_p]),
     "gn_rel_weight_grad_supported": (_int, [_p, _i64, _i64]),
@@ -788,6 +791,24 @@ class RgcnPlan:
                     raise
                 self._wgrad = False
         return self._wgrad or None
+
+    def general_weight_grad(self, x, gm):
+        """dw [R, fin * fout] = sum over each relation's edges of x[src]^T gm[dst] on gn_rgcn_weight_grad_f32 (any number of
+        nodes), or None where it does not cover the shapes."""
+        fin, fout = x.shape[1], gm.shape[1]
+        lib = load()
+        if not lib.gn_rgcn_weight_grad_supported(self._h, fin, fout):
+            return None
+        ei = self._edge_index
+        dw = torch.empty((self.num_relations, fin * fout), dtype=torch.float32, device=x.device)
+        need = int(lib.gn_rgcn_weight_grad_workspace_bytes(self._h, fin, fout))
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+        base = ei.data_ptr()
+        _call("gn_rgcn_weight_grad_f32", self._h, base, base + 8 * self.num_edges, ptr(x), ld(x), fin, ptr(gm), ld(gm), fout, ptr(dw),
+              ptr(ws), need, stream_ptr(x.device))
+        if _recorder is not None:
+            _recorder.keep.append(ei)
+        return dw
 
     def _workspace(self, fin, fout, bases, flags=0):
         need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases, flags))

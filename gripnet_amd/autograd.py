@@ -7,10 +7,10 @@ parts of every gradient run in HIP kernels behind the C ABI (transposed normalis
 DistMult scatter), and so do the dense contractions: the tall-skinny weight gradients dW = x^T g (gn_xtg_f32), the relational
 dW_r = X^T Q_r (gn_rel_weight_grad_f32), dx = g W^T and the basis / attention gradients (gn_gemm_f32 with operands given
 transposed; x^T g wider than 64 x 32 outputs in tiles), the class decoder's row gather / scatter-add through a one-edge-per-node
-plan, the merges of the external layer's mod="add" branches and of freebase-c.  torch arithmetic is left in ONE place: the
-relational weight gradient of graphs too large for the fused kernel (rgcn_edge_gradients: more than 65,534 nodes or a
-gradient table beyond the LDS - the all-nodes baseline of rgcn_pose.py), where the (relation, source) sums are scattered with
-index_add_ and contracted with a batched matmul per slab of relations.
+plan, the merges of the external layer's mod="add" branches and of freebase-c, the relational weight gradient of graphs beyond
+the fused kernel per relation on gn_rgcn_weight_grad_f32 (the all-nodes baseline of rgcn_pose.py).  torch arithmetic is left
+for shapes outside every kernel only (a relational layer with more than 128 input or 64 output features: rgcn_edge_gradients'
+index_add_ + batched matmul per slab of relations; more than 64 bases: att^T dW).
 """
 from __future__ import annotations
 
@@ -195,6 +195,8 @@ def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, n
         wg = plan.weight_grad_plan()
         if wg is not None and x.stride(1) == 1 and gm.stride(1) == 1 and wg.supported(fin, fout):
             dw = wg.weight_grad(x, gm)                                       # X^T Q_r in one launch, Q never in memory
+        elif x.stride(1) == 1 and gm.stride(1) == 1 and (dw_general := plan.general_weight_grad(x, gm)) is not None:
+            dw = dw_general                                                  # per relation x[src]^T gm[dst], O(E) memory, any size
         elif R * n * fout <= Q_BUDGET_FLOATS:
             q = torch.empty((R * n, fout), dtype=torch.float32, device=x.device)
             pairs.aggregate(gm, None, False, q)

@@ -166,6 +166,12 @@ struct gn_rgcn_plan {
     gn::DevBuf<uint32_t> key;      // [shard_edges]
     gn::DevBuf<int32_t> row_order; // [N] destination rows by the shard's in-degree, largest first (rgcn_basis.hip deals rows in this order)
     int64_t heavy_rows = 0;        // rows of more than gn_layout::kBasisHeavyEdges edges (the first entries of row_order)
+    // relation-major work items of the general weight gradient (rgcn_basis.hip): (relation, first edge, end edge, part | parts << 16)
+    // over the shard's edges in the caller's (type-sorted) order, <= gn_layout::kRelDwItemEdges edges each
+    gn::DevBuf<int32_t> dw_items;  // [n_dw_items][4]
+    int64_t n_dw_items = 0, n_dw_parts = 0;   // parts: items of relations cut into more than one (their sums meet in a workspace)
+    gn::DevBuf<int32_t> dw_multi;  // [n_dw_multi][4] relations of several parts: (relation, first slot, parts, 0)
+    int64_t n_dw_multi = 0;
     // LDS-resident path (rgcn_fast.hip): work items = (relation, source tile, <= chunk edges)
     gn::DevBuf<int32_t> seg_rel;    // [n_items] relation of each work item
     gn::DevBuf<int32_t> item_tile;  // [n_items] source tile of each work item

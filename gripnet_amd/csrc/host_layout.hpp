@@ -369,6 +369,7 @@ constexpr int kPairWaves = 16;             // waves of a workgroup
 constexpr int kPairRowBytes = 128;         // LDS stride of an att row
 constexpr int kPairMaxD = 3;               // destination rows per workgroup
 constexpr int kPairSectionCap = 64;        // blocks of a section inside one unit
+constexpr int kRelDwItemEdges = 512;       // rgcn_basis.hip: edges of one work item of the general relational weight gradient
 constexpr int kBasisHeavyEdges = 512;      // rgcn_basis.hip: destination rows with more incoming edges are walked by a whole workgroup
 constexpr int kPairSlackBlocks = 192;      // readable blocks behind the last wave's stream (the window reads ahead)
 

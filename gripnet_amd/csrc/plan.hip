@@ -630,6 +630,38 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
         GN_TRY(hipMemcpyAsync(p->row_order.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st));
         GN_TRY(hipStreamSynchronize(st));
     }
+    {
+        // the general weight gradient's work items: every relation's share of the shard's edges, cut into items of at most
+        // kRelDwItemEdges edges; a relation of several items gets slots in a workspace (its parts are added in order)
+        std::vector<int32_t> items, multi;
+        int64_t parts_total = 0;
+        for (int64_t r = 0; r < R; ++r) {
+            const int64_t a = std::max<int64_t>(ranges[2 * r], lo), b = std::min<int64_t>(ranges[2 * r + 1], hi);
+            if (b <= a) continue;
+            const int64_t parts = gn::ceil_div(b - a, gn_layout::kRelDwItemEdges);
+            if (parts > 65535) { items.clear(); multi.clear(); parts_total = 0; break; }   // (a relation of > 33 M edges: the caller's fallback)
+            if (parts > 1) { multi.push_back((int32_t)r); multi.push_back((int32_t)parts_total); multi.push_back((int32_t)parts); multi.push_back(0); }
+            for (int64_t k = 0; k < parts; ++k) {
+                items.push_back((int32_t)r);
+                items.push_back((int32_t)(a + k * gn_layout::kRelDwItemEdges));
+                items.push_back((int32_t)std::min<int64_t>(b, a + (k + 1) * gn_layout::kRelDwItemEdges));
+                items.push_back((int32_t)(parts > 1 ? (parts_total + k) : -1));   // workspace slot of a part, -1: the relation's only item
+            }
+            if (parts > 1) parts_total += parts;
+        }
+        p->n_dw_items = (int64_t)items.size() / 4;
+        p->n_dw_parts = parts_total;
+        p->n_dw_multi = (int64_t)multi.size() / 4;
+        if (p->n_dw_items > 0) {
+            GN_TRY(p->dw_items.alloc(items.size()));
+            GN_TRY(hipMemcpyAsync(p->dw_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            if (p->n_dw_multi > 0) {
+                GN_TRY(p->dw_multi.alloc(multi.size()));
+                GN_TRY(hipMemcpyAsync(p->dw_multi.p, multi.data(), multi.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            }
+            GN_TRY(hipStreamSynchronize(st));
+        }
+    }
     gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
     if (fs != GN_OK) return bail(fs);
     fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
@@ -645,6 +677,8 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->rowptr.release();
     p->key.release();
     p->row_order.release();
+    p->dw_items.release();
+    p->dw_multi.release();
     p->seg_rel.release();
     p->item_tile.release();
     p->seg_begin.release();

@@ -295,6 +295,121 @@ gn_status launch_bt(int nt, const BasisArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
+// ---- the layer's weight gradient for large supervertices -----------------------------------------------------------------
+//   dw[r] = sum_{e in r} x[src_e]^T gm[dst_e]        ([R][in][out]; then dbasis = att^T dw, datt = dw basis^T: layers.py:172-173)
+// Where the fused kernel of rel_grad.hip does not apply (its gradient table lives in LDS: a few thousand nodes) the reference's
+// own formulation is the only O(E) one: per relation, the outer products of the edges' endpoint rows.  A wave owns an item
+// (<= kRelDwItemEdges edges of one relation, contiguous in the caller's type-sorted list); per FOUR edges it issues
+// v_mfma_f32_16x16x4_f32 with A = x[src_e, features] (M = in), B = gm[dst_e, outputs] (N = out), K = the four edges: dw[r]
+// accumulates in registers.  A relation that is one item is stored as it is; the parts of a larger one go to slots of the
+// workspace and k_rel_dw_combine adds them in part order - no atomics, the same bits every run.
+struct RelDwArgs {
+    const int64_t* src; const int64_t* dst;
+    const float* x; int64_t ld_x; int fin;
+    const float* gm; int64_t ld_g; int fout;
+    const int32_t* items; int n_items;
+    float* dw;                                     // [R][fin * fout]
+    float* parts;                                  // [n_parts][fin * fout]
+    int vec;
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_rel_dw(RelDwArgs a) {
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), W = gridDim.x * 4;
+    const int64_t ff = (int64_t)a.fin * a.fout;
+    for (int it = wave; it < a.n_items; it += W) {
+        const int32_t* __restrict__ d = a.items + 4 * (size_t)it;
+        const int rel = d[0], e0 = d[1], e1 = d[2], slot = d[3];
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = (f32x4)(0.f);
+        int64_t s_next = e0 + lane < e1 ? a.src[e0 + lane] : 0, d_next = e0 + lane < e1 ? a.dst[e0 + lane] : 0;
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int cnt = min(64, e1 - eb);
+            const int64_t s_mine = s_next, d_mine = d_next;
+            const int en = eb + 64 + lane;                                     // the next chunk's ids travel while this one is contracted
+            s_next = en < e1 ? a.src[en] : 0; d_next = en < e1 ? a.dst[en] : 0;
+            const int steps = (cnt + 3) >> 2;
+            for (int j0 = 0; j0 < steps; j0 += 4) {
+                float xv[4][MT], gv[4][NT];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sel = 4 * (j0 + q) + kg;                          // edge of lane group kg in step j0 + q
+                    const int64_t s = __shfl(s_mine, sel & 63), t = __shfl(d_mine, sel & 63);
+                    const bool live = sel < cnt;
+                    const float* __restrict__ xr = a.x + s * a.ld_x + MT * c;   // features MT c .. of the edge's source
+                    const float* __restrict__ gr = a.gm + t * a.ld_g + NT * c;  // outputs NT c .. of its destination
+                    if (a.vec && MT % 4 == 0) {
+#pragma unroll
+                        for (int t4 = 0; t4 < MT / 4; ++t4) {
+                            const f32x4 v = live ? *reinterpret_cast<const f32x4u*>(xr + 4 * t4) : (f32x4)(0.f);
+                            xv[q][4 * t4] = v[0]; xv[q][4 * t4 + 1] = v[1]; xv[q][4 * t4 + 2] = v[2]; xv[q][4 * t4 + 3] = v[3];
+                        }
+                    } else {
+#pragma unroll
+                        for (int tm = 0; tm < MT; ++tm) xv[q][tm] = (live && MT * c + tm < a.fin) ? xr[tm] : 0.f;
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < NT; ++tn) gv[q][tn] = (live && NT * c + tn < a.fout) ? gr[tn] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < NT; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q][tm], gv[q][tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        // acc[tm][tn][i] = dw[feature MT (4 kg + i) + tm][output NT c + tn]
+        float* __restrict__ out = slot >= 0 ? a.parts + (size_t)slot * ff : a.dw + (size_t)rel * ff;
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = MT * (4 * kg + i) + tm;
+                if (f >= a.fin) continue;
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn)
+                    if (NT * c + tn < a.fout) out[(size_t)f * a.fout + NT * c + tn] = acc[tm][tn][i];
+            }
+    }
+}
+
+// dw[r] of a relation cut into parts = its parts' sums, in part order; relations without edges in the shard are zero
+__global__ __launch_bounds__(256) void k_rel_dw_combine(const int32_t* __restrict__ multi, int n_multi, const float* __restrict__ parts,
+                                                        float* __restrict__ dw, int64_t ff) {
+    for (int m = blockIdx.x; m < n_multi; m += gridDim.x) {
+        const int rel = multi[4 * m], slot0 = multi[4 * m + 1], np = multi[4 * m + 2];
+        for (int64_t o = threadIdx.x; o < ff; o += 256) {
+            float s = 0.f;
+            int p = 0;
+            for (; p + 4 <= np; p += 4) {                                       // four parts requested together, added in order
+                const float v0 = parts[(size_t)(slot0 + p) * ff + o], v1 = parts[(size_t)(slot0 + p + 1) * ff + o];
+                const float v2 = parts[(size_t)(slot0 + p + 2) * ff + o], v3 = parts[(size_t)(slot0 + p + 3) * ff + o];
+                s += v0; s += v1; s += v2; s += v3;
+            }
+            for (; p < np; ++p) s += parts[(size_t)(slot0 + p) * ff + o];
+            dw[(size_t)rel * ff + o] = s;
+        }
+    }
+}
+
+template <int MT>
+gn_status launch_dw(int nt, const RelDwArgs& a, int grid, hipStream_t st) {
+#define GN_DW_CASE(N) case N: if constexpr (MT * N <= 16) { k_rel_dw<MT, N><<<grid, 256, 0, st>>>(a); break; } else return gn::fail(GN_ERR_UNSUPPORTED, "unsupported shape")
+    switch (nt) {
+        GN_DW_CASE(1); GN_DW_CASE(2); GN_DW_CASE(3); GN_DW_CASE(4);
+        default: return gn::fail(GN_ERR_UNSUPPORTED, "unsupported shape");
+    }
+#undef GN_DW_CASE
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 // ---- called from rgcn.hip ----
 bool gn_rgcn_basis_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     if (!plan || !plan->row_order.p || fin < 1 || fin > 128 || bases < 1 || bases > 64 || fout < 1) return false;
@@ -305,6 +420,61 @@ bool gn_rgcn_basis_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fou
 size_t gn_rgcn_basis_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     return basis_layout(plan, fin, fout, bases).total;
 }
+
+extern "C" {
+
+size_t gn_rgcn_weight_grad_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout) {
+    if (!plan || fin < 1 || fout < 1) return 0;
+    return (size_t)std::max<int64_t>(plan->n_dw_parts, 1) * fin * fout * sizeof(float);
+}
+
+int gn_rgcn_weight_grad_supported(const gn_rgcn_plan* plan, int64_t fin, int64_t fout) {
+    if (!plan || fin < 1 || fout < 1 || fin > 128 || fout > 64) return 0;
+    if (plan->shard_edges > 0 && plan->n_dw_items == 0) return 0;                 // (a relation too long for the item list)
+    return gn::ceil_div(fin, 16) * gn::ceil_div(fout, 16) <= 16;
+}
+
+gn_status gn_rgcn_weight_grad_f32(const gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst, const float* x, int64_t ld_x,
+                                  int64_t fin, const float* gm, int64_t ld_g, int64_t fout, float* dw, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(plan != nullptr, "plan is null");
+    if (!gn_rgcn_weight_grad_supported(plan, fin, fout))
+        return gn::fail(GN_ERR_UNSUPPORTED, "the general relational weight gradient covers up to 128 input and 64 output features");
+    const int64_t R = plan->num_relations, ff = fin * fout;
+    if (R == 0) return GN_OK;
+    GN_REQUIRE(dw && (plan->shard_edges == 0 || (src && dst && x && gm)) && ld_x >= fin && ld_g >= fout, "operand pointer is null or a leading dimension too small");
+    GN_REQUIRE(plan->n_dw_parts == 0 || (workspace && workspace_bytes >= gn_rgcn_weight_grad_workspace_bytes(plan, fin, fout)),
+               "workspace too small: need %zu bytes", gn_rgcn_weight_grad_workspace_bytes(plan, fin, fout));
+    hipStream_t st = gn::as_stream(stream);
+    GN_HIP(hipMemsetAsync(dw, 0, (size_t)R * ff * sizeof(float), st));         // relations without edges in the shard
+    if (plan->n_dw_items == 0) return GN_OK;
+    RelDwArgs a;
+    a.src = src; a.dst = dst; a.x = x; a.ld_x = ld_x; a.fin = (int)fin; a.gm = gm; a.ld_g = ld_g; a.fout = (int)fout;
+    a.items = plan->dw_items.p; a.n_items = (int)plan->n_dw_items; a.dw = dw; a.parts = static_cast<float*>(workspace);
+    a.vec = (fin % 16 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const int mt = (int)gn::ceil_div(fin, 16), nt = (int)gn::ceil_div(fout, 16);
+    const int grid = (int)std::min<int64_t>((int64_t)gn::compute_units() * 4, gn::ceil_div(plan->n_dw_items, 4));
+    gn_status s;
+    switch (mt) {
+        case 1: s = launch_dw<1>(nt, a, grid, st); break;
+        case 2: s = launch_dw<2>(nt, a, grid, st); break;
+        case 3: s = launch_dw<3>(nt, a, grid, st); break;
+        case 4: s = launch_dw<4>(nt, a, grid, st); break;
+        case 5: s = launch_dw<5>(nt, a, grid, st); break;
+        case 6: s = launch_dw<6>(nt, a, grid, st); break;
+        case 7: s = launch_dw<7>(nt, a, grid, st); break;
+        default: s = launch_dw<8>(nt, a, grid, st); break;
+    }
+    if (s != GN_OK) return s;
+    if (plan->n_dw_multi > 0) {
+        k_rel_dw_combine<<<(int)std::min<int64_t>(plan->n_dw_multi, 1024), 256, 0, st>>>(plan->dw_multi.p, (int)plan->n_dw_multi,
+                                                                                         static_cast<const float*>(workspace), dw, ff);
+        GN_LAUNCH_CHECK();
+    }
+    return GN_OK;
+}
+
+}  // extern "C"
 
 gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                 const float* att, int64_t bases, const float* root, const float* bias, int64_t fout, int relu,

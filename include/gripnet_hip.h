@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 141 /* 0.1.37 */
+#define GN_VERSION 142 /* 0.1.38 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -301,6 +301,17 @@ GN_API gn_status gn_rgcn_finalize_f32(const gn_rgcn_plan* plan, const float* sum
  * atomics: the same bits every run.  GN_ERR_UNSUPPORTED (see gn_rel_weight_grad_supported) for in_features other than
  * 16 / 32 / 48 / 64, out_features other than 16 / 32, or a gm table that does not fit the LDS: sum the rows with
  * gn_graph_aggregate_f32 on the plain-sum plan and contract them with x per relation instead. */
+/* The same gradient for supervertices beyond the fused kernel (any number of nodes; up to 128 input and 64 output features):
+ * per relation the outer products of its edges' endpoint rows on the fp32 matrix instruction, O(E) memory - the reference's
+ * own per-relation formulation (layers.py:178-186 under autograd; the all-nodes baseline rgcn_pose.py:53-106).  src / dst:
+ * the rows of the caller's [2, E] int64 edge_index the plan was built from (type-sorted; a shard's plan covers its edge
+ * range).  workspace: gn_rgcn_weight_grad_workspace_bytes (the parts of relations of more than 512 edges, added in part
+ * order: the same bits every run). */
+GN_API size_t gn_rgcn_weight_grad_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features);
+GN_API int gn_rgcn_weight_grad_supported(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features);
+GN_API gn_status gn_rgcn_weight_grad_f32(const gn_rgcn_plan* plan, const int64_t* src, const int64_t* dst, const float* x, int64_t ld_x,
+                                  int64_t in_features, const float* gm, int64_t ld_g, int64_t out_features, float* dw, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 typedef struct gn_rel_grad_plan gn_rel_grad_plan;
 GN_API gn_status gn_rel_grad_plan_create(const gn_graph_plan* relation_source_sums, int64_t num_nodes, int64_t num_relations,
                                   void* stream, gn_rel_grad_plan** plan);

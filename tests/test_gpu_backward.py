@@ -949,3 +949,55 @@ def test_wide_weight_gradient_in_tiles(gpu, m, k1, k2):
         batched = _hip.xtg(x, g, join_batch=True)
     assert torch.equal(batched, got)
     _hip.raise_if_index_errors(gpu)
+
+
+@pytest.mark.parametrize("n,fin,fout,bases,R", [(8000, 64, 32, 16, 520), (70000, 16, 32, 4, 7), (3000, 40, 24, 5, 12), (2500, 128, 16, 8, 5)])
+def test_relational_layer_gradients_beyond_the_lds_kernels(gpu, n, fin, fout, bases, R):
+    """myRGCN under autograd on graphs the LDS-resident kernels do not cover (the all-nodes baseline, rgcn_pose.py:53-106):
+    forward on the O(E) basis-space path, dx through the same path on the reversed edges, the weight gradient per relation
+    on gn_rgcn_weight_grad_f32 (relations of one item, hub relations cut into parts, empty relations; widths that are no
+    multiple of 16) - every gradient against torch autograd through the oracle; the kernel alone against float64, over two
+    shards' edge ranges, and the same bits on every call."""
+    gen = torch.Generator().manual_seed(n + R)
+    torch.manual_seed(n + fin)
+    sizes = [20000, 0, 1, 700] + [int(s) for s in torch.randint(0, 300, (R - 4,), generator=gen)]
+    blocks = [torch.randint(0, n - n // 11, (2, s), generator=gen) for s in sizes]
+    ei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    proj = torch.randn(n, fout, generator=gen)
+    rg = gripnet_amd.myRGCN(fin, fout, R, bases, False, bias=True).to(gpu)
+    rg.bias.data.normal_()
+    xg, eig = leaf(x.to(gpu)), ei.to(gpu)
+    y = rg(xg, eig, None, rl, _relu=True)
+    wg = rg._plan.weight_grad_plan()
+    assert rg._plan.path(fin, fout, bases) == "general" and (wg is None or not wg.supported(fin, fout))
+    (y * proj.to(gpu)).sum().backward()
+    sd = {k: leaf(v.cpu()) for k, v in rg.state_dict().items()}
+    xr = leaf(x)
+    yr = torch.relu(orc.rgcn_forward(xr, ei, rl, sd["basis"], sd["att"], sd["root"], sd["bias"]))
+    (yr * proj).sum().backward()
+    close(y, yr, 2e-5 * max(1.0, float(yr.abs().max())), what="forward")
+    close(xg.grad / max(1.0, float(xr.grad.abs().max())), xr.grad / max(1.0, float(xr.grad.abs().max())), 1e-4, what="dx")
+    for k, p in rg.named_parameters():
+        scale_k = max(1.0, float(sd[k].grad.abs().max()))
+        close(p.grad / scale_k, sd[k].grad / scale_k, 1e-4, what=k)
+    # the kernel on its own
+    gm = torch.randn(n, fout, generator=gen).to(gpu)
+    xd = x.to(gpu)
+    plan = rg._plan
+    dw = plan.general_weight_grad(xd, gm)
+    rel = torch.repeat_interleave(torch.arange(R), torch.tensor(sizes)).to(gpu)
+    ref = torch.zeros(R, fin * fout, dtype=torch.float64, device=gpu)
+    step = 1 << 16
+    for a0 in range(0, ei.shape[1], step):
+        s = slice(a0, a0 + step)
+        outer = (xd.double()[eig[0, s]].unsqueeze(2) * gm.double()[eig[1, s]].unsqueeze(1)).reshape(-1, fin * fout)
+        ref.index_add_(0, rel[s], outer)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((dw.double() - ref).abs().max()) / scale <= 2e-6
+    assert torch.equal(plan.general_weight_grad(xd, gm), dw)
+    E = ei.shape[1]
+    parts = [_hip.RgcnPlan(eig, rl, n, lo, hi).general_weight_grad(xd, gm) for lo, hi in ((0, E // 3), (E // 3, E))]
+    assert float(((parts[0] + parts[1]).double() - ref).abs().max()) / scale <= 2e-6
+    _hip.raise_if_index_errors(gpu)
