@@ -269,6 +269,9 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int32_t* __restrict__ g = a.wg + (size_t)blockIdx.x * (4 + 4 * a.walks);
     const int r0s = g[0], r0c = g[1], r1s = g[2], r1c = g[3];
+    // (the first walk's range is read with the rows - one scalar load of the descriptor's first 32 bytes - and every further
+    // walk's range one walk ahead: read where it is used, it put a memory round trip in front of the first batches' requests)
+    int nb_lo = g[4], nb_hi = g[5], nrel_lo = g[6], nnrel = g[7];
     const int rows = r0c + r1c;
     GN_DM_STAMP(0);
 #ifdef GN_STAMPS
@@ -289,8 +292,9 @@ __global__ __launch_bounds__(kThreads) void k_distmult_class(DmClassArgs a) {
     // score lines of ONE sub-range are what the L2 has to keep); the table is filled once, the relation rows of D a
     // range's batches name are refilled per range.
     for (int walk = 0; walk < a.walks; ++walk) {
-        const uint32_t b_lo = (uint32_t)g[4 + 4 * walk], b_hi = (uint32_t)g[5 + 4 * walk];
-        const int rel_lo = g[6 + 4 * walk], nrel = g[7 + 4 * walk];
+        const uint32_t b_lo = (uint32_t)nb_lo, b_hi = (uint32_t)nb_hi;
+        const int rel_lo = nrel_lo, nrel = nnrel;
+        if (walk + 1 < a.walks) { nb_lo = g[8 + 4 * walk]; nb_hi = g[9 + 4 * walk]; nrel_lo = g[10 + 4 * walk]; nnrel = g[11 + 4 * walk]; }
         // The first batches' words are requested BEFORE the fills (their HBM round trip hides behind them).  Every array
         // has kClsSlack readable batches behind the last one: no prefetch needs a clamp.  The relation words travel as
         // vector loads too (lanes 0 / 1 of `rw`): a scalar load shares its counter with the LDS reads and would be waited

@@ -9,6 +9,7 @@
 #                                                         FETCH_SIZE, WRITE_SIZE, TCC_EA0_RDREQ and MFMA passes of the SAME command.
 #                                                         -> gpurun_out/step_<tag>.md (per-step kernel durations, their sum against
 #                                                         the step's wall time), traffic_<tag>.json, mfma_<tag>.json
+#   tools/prof.sh quick <tag> [K]                         only the kernel trace + per-step table of the same command (A / B of a kernel in its step)
 #   tools/prof.sh train <tag> [K]                         the same for the replayed training step (tools/train_step.py)
 #   tools/prof.sh counters <tag> <python args...>         the SQ / LDS passes used for DESIGN.md's limiter statements
 set -u
@@ -44,6 +45,11 @@ counters)
     python3 tools/summarize_pmc.py gpurun_out/pmc_${tag}_sq
     pmc gpurun_out/pmc_${tag}_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE" "$@"
     python3 tools/summarize_pmc.py gpurun_out/pmc_${tag}_lds
+    ;;
+quick)      # tools/prof.sh quick <tag> [K]: the kernel trace of the timed region only (no counter passes): an A / B of kernel variants in their step
+    K=${1:-40}
+    trace gpurun_out/step_$tag tools/step_only.py --steps $K
+    python3 tools/summarize_step.py gpurun_out/step_$tag --steps $K --log gpurun_out/step_$tag.log
     ;;
 step|train)
     K=${1:-40}
