@@ -489,14 +489,16 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     const int rows = a.B * FIN;                                                // rows of basis
     const int o4 = tid % og, sl = tid / og;
     const int per = (rows + slices - 1) / slices;                              // <= kRowsMax (checked on the host)
+    // (twelve rows are requested here, while this wave's accumulators are still alive; rows 12.. of the narrow layers - kRowsMax 16 -
+    // behind the shares' store, where the accumulators are dead: with all sixteen alive next to them the NT <= 2 kernels spilled
+    // 14-24 registers, 19 MB of scratch traffic per launch of the reversed layer of a training step)
+    constexpr int kRowsPre = 12;
     f32x4 bv[kRowsMax];
-    {
-        const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis);
+    const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis);
 #pragma unroll
-        for (int j = 0; j < kRowsMax; ++j) {
-            const int nr = j * slices + sl;                                    // row base * FIN + feature of basis
-            bv[j] = (sl < slices && j < per && nr < rows) ? bp[(uint32_t)(min(nr, rows - 1) * og + o4)] : (f32x4)(0.f);
-        }
+    for (int j = 0; j < kRowsPre; ++j) {
+        const int nr = j * slices + sl;                                        // row base * FIN + feature of basis
+        bv[j] = (sl < slices && j < per && nr < rows) ? bp[(uint32_t)(min(nr, rows - 1) * og + o4)] : (f32x4)(0.f);
     }
     // the output element this thread writes at the very end: its divisor, bias and share of the root term x_i . root
     // (eight adjacent lanes per element), requested before the barrier too
@@ -533,6 +535,14 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
             // the feature's pad floats are zero: they are summed like the rest, and a thread without a row of basis in
             // a pass (bv = 0) multiplies the LAST entry of U - a pad - by that zero
             if (kg == 3) *reinterpret_cast<f32x4*>(q + 4 * BT) = (f32x4)(0.f);
+        }
+    }
+    if constexpr (kRowsMax > kRowsPre) {
+        asm volatile("" ::: "memory");                                         // (behind the stores above: the accumulators are dead)
+#pragma unroll
+        for (int j = kRowsPre; j < kRowsMax; ++j) {
+            const int nr = j * slices + sl;
+            bv[j] = (sl < slices && j < per && nr < rows) ? bp[(uint32_t)(min(nr, rows - 1) * og + o4)] : (f32x4)(0.f);
         }
     }
     __syncthreads();
@@ -575,6 +585,9 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
             for (int d = 0; d < kMaxD; ++d) sum[d] += usum[(size_t)d * KP + k] * bv[j];
             base += dbase; feat += dfeat;
             if (feat >= FIN) { feat -= FIN; ++base; }
+            // (sixteen rows: the LDS reads stay four rows at a time - hoisted in front of the products, their 48 values lived
+            // next to all sixteen rows of basis and the narrow kernels spilled 14-24 registers)
+            if constexpr (kRowsMax > 12) { if ((j & 3) == 3) asm volatile("" ::: "memory"); }
         }
     }
 #ifdef GN_STAMPS

@@ -255,6 +255,17 @@ def class_loss(score: torch.Tensor, classes: torch.Tensor, eps: float = EPS) -> 
     return ClassLossFn.apply(score, classes, float(eps))
 
 
+def forget_call_memos(module) -> int:
+    """Drop the recorded call sequences (``_hip.CallMemo``) of every layer / decoder under `module`: the steady-state shortcut
+    of the inference forwards keeps the plans and graph tensors its recordings name alive (at most eight entries per module) -
+    call this after switching to another dataset to release them at once.  Returns the number of memos dropped."""
+    dropped = 0
+    for m in module.modules():
+        if m.__dict__.pop("_memo", None) is not None:
+            dropped += 1
+    return dropped
+
+
 def set_table_storage(module, storage: str = "bf16"):
     """Switch every GCN-style layer under `module` to "bf16" (or back to "fp32") storage of its gathered table:
     x W is rounded to bf16 once per forward and read at half the bytes; sums, bias, activation, outputs and every

@@ -92,8 +92,9 @@ def test_kernel_register_budgets():
         assert r[".private_segment_fixed_size"] == 0, (name, r)
         assert r[".vgpr_spill_count"] == 0 and r[".sgpr_spill_count"] == 0, (name, r)
     # every instantiation of the destination-major kernel keeps four waves per SIMD (the narrow ones park up to sixteen
-    # rows of basis per thread in their epilogue and spill a few of them THERE, behind the unit loop)
+    # rows of basis per thread in their epilogue and spill at most eight registers THERE, behind the unit loop: round 5 - they
+    # spilled 14-24, 19 MB of scratch traffic per launch of the reversed layer of a training step)
     for name, r in res.items():
         if name.startswith("k_rgcn_pair<"):
             assert r[".vgpr_count"] + r.get(".agpr_count", 0) <= 128, (name, r)
-            assert r[".private_segment_fixed_size"] <= 160, (name, r)
+            assert r[".private_segment_fixed_size"] <= 64 and r[".vgpr_spill_count"] <= 12, (name, r)
