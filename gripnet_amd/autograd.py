@@ -84,9 +84,10 @@ class GcnConvFn(torch.autograd.Function):
     external layer's closed form."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None):
+    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None, planes=None):
         # slot: a Slot of a concat buffer the output is written into (the concat of layers.py:309,376 without a copy, SlotsCatFn);
-        # side: (tensor, Slot, mode) copied by the same launch, as on the inference path
+        # side: (tensor, Slot, mode) copied by the same launch, as on the inference path; planes: (SplitPlanes, col_main, col_side) -
+        # the launch leaves its output and side copy as bf16 split planes too (the external layer in front of a relational layer)
         x = _hip.f32_rows(x.detach())
         w = weight.detach()
         out = slot.view() if slot is not None else torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=x.device)
@@ -94,11 +95,11 @@ class GcnConvFn(torch.autograd.Function):
             side = (side[0].detach(), side[1].view(), side[2])
         b = None if bias is None else bias.detach()
         if _hip.transform_fusable(w.shape[0], w.shape[1], x) and w.is_contiguous():
-            plan.aggregate(x, b, relu, out, side, weight=w)    # (A_norm x) W in one launch, as the inference path
+            plan.aggregate(x, b, relu, out, side, weight=w, planes=planes)    # (A_norm x) W in one launch, as the inference path
         else:
             xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
             _hip.gemm(x, w, xw)
-            plan.aggregate(xw, b, relu, out, side)
+            plan.aggregate(xw, b, relu, out, side, planes=planes)
         ctx.plan, ctx.relu, ctx.has_bias = plan, bool(relu), bias is not None
         ctx.save_for_backward(x, w, out if relu else None)
         return out
@@ -120,19 +121,20 @@ class GcnConvFn(torch.autograd.Function):
                 dx = torch.empty((gxw.shape[0], w.shape[0]), dtype=torch.float32, device=gxw.device)
                 _hip.gemm(gxw, w, dx, b_transposed=True, join_batch=True)
             dw = _hip.xtg(x, gxw, join_batch=True) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class RgcnConvFn(torch.autograd.Function):
     """``act(mean_{e: dst=i} x[src_e] W_{r(e)} + x[i] root + b)`` (myRGCN.forward, layers.py:165-197)."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, bias, plan, relu, slot=None, side=None):
+    def forward(ctx, x, basis, att, root, bias, plan, relu, slot=None, side=None, x_planes=None):
         xc = _hip.f32_rows(x.detach())
         out = slot.view() if slot is not None else torch.empty((xc.shape[0], basis.shape[2]), dtype=torch.float32, device=xc.device)
         if side is not None:
             side = (side[0].detach(), side[1].view(), side[2])
-        plan.forward(xc, basis.detach(), att.detach(), root.detach(), None if bias is None else bias.detach(), relu, out, side=side)
+        plan.forward(xc, basis.detach(), att.detach(), root.detach(), None if bias is None else bias.detach(), relu, out, side=side,
+                     x_planes=x_planes)
         ctx.plan, ctx.relu = plan, bool(relu)
         ctx.save_for_backward(xc, basis, att, root, out if relu else None)
         return out
@@ -152,7 +154,7 @@ class RgcnConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:                        # dx = dxe + g root^T: the product is added onto the edge sums
                 dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True, join_batch=True)
             droot = _hip.xtg(x, g, join_batch=True) if ctx.needs_input_grad[3] else None
-        return dx, dbasis, datt, droot, dbias, None, None, None, None
+        return dx, dbasis, datt, droot, dbias, None, None, None, None, None
 
 
 # (relation, source) sums Q of more than this many floats are reduced per slab of relations (the dense Q of a graph

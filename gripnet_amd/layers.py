@@ -92,7 +92,9 @@ class myGCN(Module):
     def _run(self, plan, x, n_out, out, relu, side, planes=None):
         self._planes_written = False                 # did this call's launch leave the split planes it was offered?
         if recording(x, self.weight, self.bias):                                 # training: autograd path (out / side: Slots)
-            return GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side)
+            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side, planes)
+            self._planes_written = planes is not None
+            return y
         out, side = _unslot(out, side)
         x = _hip.f32_rows(x.detach())
         if out is None:
@@ -196,7 +198,8 @@ class myRGCN(Module):
             raise ValueError("range_list has {} rows for {} relations".format(range_list.shape[0], self.num_relations))
         plan = self.plan_for(edge_index, range_list, x.shape[0])
         if recording(x, self.basis, self.att, self.root, self.bias):             # training: autograd path
-            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu, _out, _side)   # (Slots)
+            planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None
+            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu, _out, _side, planes)   # (Slots)
         _out, _side = _unslot(_out, _side)
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
@@ -345,9 +348,20 @@ class interGraph(Module):
             if self.if_one_external and mod == "cat":
                 # [y | |target_feat|] (layers.py:376) in one launch: both written into their columns, no concat, no abs
                 _, (ys, ts) = cat_slots([self.target_dim, self.target_feat_dim], self.n_target, dev)
+                # the same launch leaves the row as bf16 split planes (as on the inference path): a relational layer that takes
+                # this output contracts with them instead of splitting x in every unit
+                width, planes = self.target_dim + self.target_feat_dim, None
+                if width % 16 == 0 and width <= 64 and self.conv.table_storage == "fp32":
+                    planes = getattr(self, "_planes", None)
+                    if planes is None or planes.device != dev:
+                        planes = self._planes = _hip.SplitPlanes(self.n_target, width // 16, dev)
                 y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu, _out=ys,
-                                                _side=(self.target_feat, ts, 1))
-                return SlotsCatFn.apply([ys, ts], y, AbsSlotFn.apply(self.target_feat, ts))
+                                                _side=(self.target_feat, ts, 1),
+                                                _planes=None if planes is None else (planes, 0, self.target_dim))
+                out = SlotsCatFn.apply([ys, ts], y, AbsSlotFn.apply(self.target_feat, ts))
+                if planes is not None and getattr(self.conv, "_planes_written", False):
+                    planes.tag(out)
+                return out
             y = self.conv.forward_bipartite(x, inter_edge_index, self.n_target, edge_weight, _relu=if_relu)
             if not self.if_one_external:
                 return y
