@@ -40,6 +40,8 @@ inline void parallel_for(int64_t n, int64_t grain, F fn) {
 namespace gn_layout {
 
 constexpr uint32_t kNoMirror = 0xffffffffu;
+constexpr int kRelDwItemEdges = 512;  // rgcn_basis.hip: edges of one work item of the general relational weight gradient
+constexpr int kBasisHeavyEdges = 512; // rgcn_basis.hip: destination rows with more incoming edges are walked by a whole workgroup
 constexpr int kClsDCache = 64;        // relation rows of D a workgroup of k_distmult_class keeps in LDS
 constexpr int kClsSlack = 64;         // readable batches behind the last one (the kernel's prefetches run ahead unclamped)
 constexpr int kClsMaxWalks = 8;       // position sub-ranges an XCD's workgroups walk one after the other (k_distmult_class)
@@ -364,13 +366,59 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
 }
 
 
+// ---- relational layer of any size (rgcn_basis.hip): the rows' degree order and the weight gradient's work items ---------------------
+// Rows by in-degree, largest first (a counting sort; ties by row id), and the number of rows a whole workgroup walks.
+inline void degree_order(const std::vector<int32_t>& rp, std::vector<int32_t>& order, int64_t& heavy_rows) {
+    const int64_t N = (int64_t)rp.size() - 1;
+    order.assign((size_t)std::max<int64_t>(N, 0), 0);
+    heavy_rows = 0;
+    if (N <= 0) return;
+    int64_t max_deg = 0;
+    for (int64_t i = 0; i < N; ++i) max_deg = std::max<int64_t>(max_deg, rp[i + 1] - rp[i]);
+    std::vector<int64_t> first((size_t)max_deg + 2, 0);
+    for (int64_t i = 0; i < N; ++i) ++first[(size_t)(max_deg - (rp[i + 1] - rp[i]) + 1)];
+    for (size_t d = 1; d < first.size(); ++d) first[d] += first[d - 1];
+    for (int64_t i = 0; i < N; ++i) {
+        order[(size_t)first[(size_t)(max_deg - (rp[i + 1] - rp[i]))]++] = (int32_t)i;
+        heavy_rows += (rp[i + 1] - rp[i]) > kBasisHeavyEdges ? 1 : 0;
+    }
+}
+
+// The general weight gradient's work items: every relation's share [max(start, lo), min(end, hi)) of the shard's edges, cut
+// into items of at most kRelDwItemEdges edges - (relation, first edge, end edge, slot): slot = -1 for a relation's only item,
+// else the item's slot among the parts that meet in a workspace; `multi`: (relation, first slot, parts, 0) of every relation of
+// several items.  ok = false when a relation would need more than 65,535 parts.
+struct RelDwItems {
+    bool ok = true;
+    std::vector<int32_t> items, multi;
+    int64_t parts = 0;
+};
+
+inline RelDwItems build_rel_dw_items(const std::vector<int64_t>& ranges, int64_t lo, int64_t hi) {
+    RelDwItems L;
+    const int64_t R = (int64_t)ranges.size() / 2;
+    for (int64_t r = 0; r < R; ++r) {
+        const int64_t a = std::max<int64_t>(ranges[2 * r], lo), b = std::min<int64_t>(ranges[2 * r + 1], hi);
+        if (b <= a) continue;
+        const int64_t parts = gn::ceil_div(b - a, kRelDwItemEdges);
+        if (parts > 65535) { L.ok = false; L.items.clear(); L.multi.clear(); L.parts = 0; return L; }
+        if (parts > 1) { L.multi.push_back((int32_t)r); L.multi.push_back((int32_t)L.parts); L.multi.push_back((int32_t)parts); L.multi.push_back(0); }
+        for (int64_t k = 0; k < parts; ++k) {
+            L.items.push_back((int32_t)r);
+            L.items.push_back((int32_t)(a + k * kRelDwItemEdges));
+            L.items.push_back((int32_t)std::min<int64_t>(b, a + (k + 1) * kRelDwItemEdges));
+            L.items.push_back((int32_t)(parts > 1 ? (L.parts + k) : -1));
+        }
+        if (parts > 1) L.parts += parts;
+    }
+    return L;
+}
+
 // ---- relational layer, destination-major kernel (rgcn_pair.hip) -----------------------------------------------------------
 constexpr int kPairWaves = 16;             // waves of a workgroup
 constexpr int kPairRowBytes = 128;         // LDS stride of an att row
 constexpr int kPairMaxD = 3;               // destination rows per workgroup
 constexpr int kPairSectionCap = 64;        // blocks of a section inside one unit
-constexpr int kRelDwItemEdges = 512;       // rgcn_basis.hip: edges of one work item of the general relational weight gradient
-constexpr int kBasisHeavyEdges = 512;      // rgcn_basis.hip: destination rows with more incoming edges are walked by a whole workgroup
 constexpr int kPairSlackBlocks = 192;      // readable blocks behind the last wave's stream (the window reads ahead)
 
 // The blocks of one section: four lists of relation ids (one per lane group), `nb` blocks of four positions each.

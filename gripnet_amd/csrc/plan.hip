@@ -617,47 +617,25 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
     if (bad) return bail(gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld)", (long long)N));
     for (int64_t i = 0; i < N; ++i) p->max_row_nnz = std::max<int64_t>(p->max_row_nnz, rp[i + 1] - rp[i]);
     if (N > 0) {
-        // rows by in-degree, largest first (a counting sort on the host: the row pointers are here anyway), ties by row id
-        std::vector<int64_t> first(p->max_row_nnz + 2, 0);
-        for (int64_t i = 0; i < N; ++i) ++first[p->max_row_nnz - (rp[i + 1] - rp[i]) + 1];
-        for (size_t d = 1; d < first.size(); ++d) first[d] += first[d - 1];
-        std::vector<int32_t> order(N);
-        for (int64_t i = 0; i < N; ++i) {
-            order[first[p->max_row_nnz - (rp[i + 1] - rp[i])]++] = (int32_t)i;
-            p->heavy_rows += (rp[i + 1] - rp[i]) > gn_layout::kBasisHeavyEdges ? 1 : 0;
-        }
+        // rows by in-degree, largest first (host_layout.hpp: the row pointers are on the host anyway)
+        std::vector<int32_t> order;
+        gn_layout::degree_order(rp, order, p->heavy_rows);
         GN_TRY(p->row_order.alloc(N));
         GN_TRY(hipMemcpyAsync(p->row_order.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st));
         GN_TRY(hipStreamSynchronize(st));
     }
     {
-        // the general weight gradient's work items: every relation's share of the shard's edges, cut into items of at most
-        // kRelDwItemEdges edges; a relation of several items gets slots in a workspace (its parts are added in order)
-        std::vector<int32_t> items, multi;
-        int64_t parts_total = 0;
-        for (int64_t r = 0; r < R; ++r) {
-            const int64_t a = std::max<int64_t>(ranges[2 * r], lo), b = std::min<int64_t>(ranges[2 * r + 1], hi);
-            if (b <= a) continue;
-            const int64_t parts = gn::ceil_div(b - a, gn_layout::kRelDwItemEdges);
-            if (parts > 65535) { items.clear(); multi.clear(); parts_total = 0; break; }   // (a relation of > 33 M edges: the caller's fallback)
-            if (parts > 1) { multi.push_back((int32_t)r); multi.push_back((int32_t)parts_total); multi.push_back((int32_t)parts); multi.push_back(0); }
-            for (int64_t k = 0; k < parts; ++k) {
-                items.push_back((int32_t)r);
-                items.push_back((int32_t)(a + k * gn_layout::kRelDwItemEdges));
-                items.push_back((int32_t)std::min<int64_t>(b, a + (k + 1) * gn_layout::kRelDwItemEdges));
-                items.push_back((int32_t)(parts > 1 ? (parts_total + k) : -1));   // workspace slot of a part, -1: the relation's only item
-            }
-            if (parts > 1) parts_total += parts;
-        }
-        p->n_dw_items = (int64_t)items.size() / 4;
-        p->n_dw_parts = parts_total;
-        p->n_dw_multi = (int64_t)multi.size() / 4;
+        // the general weight gradient's work items (host_layout.hpp)
+        const gn_layout::RelDwItems dwl = gn_layout::build_rel_dw_items(ranges, lo, hi);
+        p->n_dw_items = (int64_t)dwl.items.size() / 4;
+        p->n_dw_parts = dwl.parts;
+        p->n_dw_multi = (int64_t)dwl.multi.size() / 4;
         if (p->n_dw_items > 0) {
-            GN_TRY(p->dw_items.alloc(items.size()));
-            GN_TRY(hipMemcpyAsync(p->dw_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            GN_TRY(p->dw_items.alloc(dwl.items.size()));
+            GN_TRY(hipMemcpyAsync(p->dw_items.p, dwl.items.data(), dwl.items.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
             if (p->n_dw_multi > 0) {
-                GN_TRY(p->dw_multi.alloc(multi.size()));
-                GN_TRY(hipMemcpyAsync(p->dw_multi.p, multi.data(), multi.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                GN_TRY(p->dw_multi.alloc(dwl.multi.size()));
+                GN_TRY(hipMemcpyAsync(p->dw_multi.p, dwl.multi.data(), dwl.multi.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
             }
             GN_TRY(hipStreamSynchronize(st));
         }
