@@ -40,8 +40,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s 
 # "bound": "hbm" names the roofline the path is priced against, this names what actually limits it.
 LIMITERS = {
     "gn_rgcn_forward_f32": "instruction issue (7.6 M vector + 2.7 M scalar + 1.3 M LDS instructions per launch; waves wait to be picked 34 % and at "
-                           "s_waitcnt 41 % of their resident cycles); 63 units in the three-row workgroups against 52.9 on average (3.5 us of "
-                           "the loop); 6.3 us epilogue; MFMA pipe 9 % busy; HBM moves 18 MB, less than the algorithmic bytes (DESIGN.md 4.1)",
+                           "s_waitcnt 41 % of their resident cycles) next to the 121 MB of x-plane pieces a launch pulls through the L2s; evening out "
+                           "the waves or the workgroups (63 / 42 units) was built twice and bought nothing (profiles/r05_experiments.md 11-12); "
+                           "6.3 us epilogue; MFMA pipe 9 % busy; HBM moves 18 MB, less than the algorithmic bytes (DESIGN.md 4.1)",
     "gn_distmult_plan_forward_f32": "VALU issue (4.1 M instructions = ~6.6 us of the ~10 us loop) next to the LDS array (busy 5.9 us, 21 % of it "
                                     "bank conflicts); 4.4 us table fill from the Infinity Cache; scores written through one L2 per list range "
                                     "(8.3 MB = the scores themselves) (DESIGN.md 4.2, profiles/r04_decoder_pmc.md)",
