@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 142                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 143                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "gn_graph_plan_build_transpose": (_int, [_p, _p]),
     "gn_graph_aggregate_t_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
+    "gn_gemm_addend_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _i64, _int, _p]),
     "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "gn_softmax_rows_f32": (_int, [_p, _i64, _i64, _i64, _p]),
     "gn_softmax_rows_backward_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
@@ -525,11 +526,12 @@ def ptr(t):
 # ---- thin typed wrappers ---------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=False, a_rows=None,
          batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None, fast=False,
-         b_transposed=False, accumulate=False, a_transposed=False, join_batch=False):
+         b_transposed=False, accumulate=False, a_transposed=False, join_batch=False, addend=None):
     """`join_batch`: inside ``with dense_batch(...)`` the product may be queued and leave with the batch (it must not depend
     on another queued product).  `fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic.
     `b_transposed`: b is [n, k] (out = a b^T); `a_transposed`: a is [k, m] (out = a^T b; m <= 64 or n <= 32 only);
-    `accumulate`: out += a b."""
+    `accumulate`: out += a b; `addend`: an [m, n] fp32 matrix (rows contiguous, any row stride) added to what is stored
+    (gn_gemm_addend_f32) - the other gradient of a tensor with two consumers, see `addend_ok`."""
     if a_transposed:
         m = a.shape[1] if m is None else m
         k = a.shape[0] if k is None else k
@@ -538,14 +540,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
     n = (b.shape[0] if b_transposed else b.shape[-1]) if n is None else n
     join_batch = join_batch and getattr(_batch_tls, 'open', None) is not None
     if join_batch:                                           # a queued product reads its operands when the batch leaves
-        _batch_tls.open.keep.extend((a, b, out, bias, a_rows))
-    _call("gn_gemm_f32", ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
-                          ptr(b), ld(b) if ldb is None else ldb, stride_b,
-                          ptr(out), ld(out) if ldc is None else ldc, stride_c,
-          m, n, k, batch, ptr(bias), (GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0) |
-          (GN_GEMM_B_TRANSPOSED if b_transposed else 0) | (GN_GEMM_ACCUMULATE if accumulate else 0) |
-          (GN_GEMM_A_TRANSPOSED if a_transposed else 0) | (GN_GEMM_JOIN_BATCH if join_batch else 0), stream_ptr(a.device))
+        _batch_tls.open.keep.extend((a, b, out, bias, a_rows, addend))
+    flags = ((GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0) | (GN_GEMM_B_TRANSPOSED if b_transposed else 0) |
+             (GN_GEMM_ACCUMULATE if accumulate else 0) | (GN_GEMM_A_TRANSPOSED if a_transposed else 0) | (GN_GEMM_JOIN_BATCH if join_batch else 0))
+    head = (ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
+            ptr(b), ld(b) if ldb is None else ldb, stride_b,
+            ptr(out), ld(out) if ldc is None else ldc, stride_c, m, n, k, batch, ptr(bias))
+    if addend is None:
+        _call("gn_gemm_f32", *head, flags, stream_ptr(a.device))
+    else:
+        if not addend_ok(addend, m, n) or batch != 1:
+            raise ValueError("addend: an fp32 [m, n] matrix with contiguous rows, single product")
+        _call("gn_gemm_addend_f32", *head, ptr(addend), ld(addend), flags, stream_ptr(a.device))
     return out
+
+
+def addend_ok(t, m, n) -> bool:
+    """Can `t` ride on a product's store as its addend?  (fp32, [m, n], unit column stride - a column slice of a concat's gradient is)"""
+    return (t is not None and t.dtype == torch.float32 and t.dim() == 2 and tuple(t.shape) == (m, n) and t.is_cuda and
+            (n == 1 or t.stride(1) == 1) and (m == 1 or t.stride(0) >= n))
 
 
 _xtg_ws = {}

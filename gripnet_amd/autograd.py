@@ -84,10 +84,15 @@ class GcnConvFn(torch.autograd.Function):
     external layer's closed form."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None, planes=None):
+    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None, planes=None, passthrough=False):
         # slot: a Slot of a concat buffer the output is written into (the concat of layers.py:309,376 without a copy, SlotsCatFn);
         # side: (tensor, Slot, mode) copied by the same launch, as on the inference path; planes: (SplitPlanes, col_main, col_side) -
-        # the launch leaves its output and side copy as bf16 split planes too (the external layer in front of a relational layer)
+        # the launch leaves its output and side copy as bf16 split planes too (the external layer in front of a relational layer);
+        # passthrough: x is ALSO returned, for the concat that holds it next to this layer's output (layers.py:280-281,307-309):
+        # x then has this Function as its only consumer, and backward adds the concat's gradient columns of x where it stores
+        # dx (the addend of gn_gemm_addend_f32) - the autograd engine's own sum of two gradients was one launch more per layer
+        x_in = x
+        ctx.set_materialize_grads(False)                       # (an output nobody differentiates arrives as None, not as a fresh matrix of zeros)
         x = _hip.f32_rows(x.detach())
         w = weight.detach()
         out = slot.view() if slot is not None else torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=x.device)
@@ -102,11 +107,13 @@ class GcnConvFn(torch.autograd.Function):
             plan.aggregate(xw, b, relu, out, side, planes=planes)
         ctx.plan, ctx.relu, ctx.has_bias = plan, bool(relu), bias is not None
         ctx.save_for_backward(x, w, out if relu else None)
-        return out
+        return (out, x_in) if passthrough else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pass=None):
         x, w, out = ctx.saved_tensors
+        if g is None:                                              # only the passed-through input is used downstream
+            return (g_pass if ctx.needs_input_grad[0] else None,) + (None,) * 9
         # one launch: the ReLU mask by the saved output (gradient passes where the output is positive), the bias gradient
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.relu or need_db or g.stride(1) != 1:
@@ -117,18 +124,25 @@ class GcnConvFn(torch.autograd.Function):
         ctx.plan.aggregate_t(gm, gxw)                          # A_norm^T g  (HIP, source-major CSR)
         dx = None
         with _hip.dense_batch(gxw.device):                     # dx and dW do not depend on each other: one launch
-            if ctx.needs_input_grad[0]:                        # gxw W^T (gn_gemm_f32, W given as it is stored)
+            late = None
+            if ctx.needs_input_grad[0]:                        # gxw W^T (gn_gemm_f32, W given as it is stored) + the concat's columns of x
                 dx = torch.empty((gxw.shape[0], w.shape[0]), dtype=torch.float32, device=gxw.device)
-                _hip.gemm(gxw, w, dx, b_transposed=True, join_batch=True)
+                rides = _hip.addend_ok(g_pass, dx.shape[0], dx.shape[1])
+                _hip.gemm(gxw, w, dx, b_transposed=True, join_batch=True, addend=g_pass if rides else None)
+                late = None if rides else g_pass
             dw = _hip.xtg(x, gxw, join_batch=True) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None, None, None, None, None, None
+        if late is not None:
+            dx = dx + late
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class RgcnConvFn(torch.autograd.Function):
     """``act(mean_{e: dst=i} x[src_e] W_{r(e)} + x[i] root + b)`` (myRGCN.forward, layers.py:165-197)."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, bias, plan, relu, slot=None, side=None, x_planes=None):
+    def forward(ctx, x, basis, att, root, bias, plan, relu, slot=None, side=None, x_planes=None, passthrough=False):
+        # (slot, side, passthrough: as GcnConvFn's)
+        ctx.set_materialize_grads(False)
         xc = _hip.f32_rows(x.detach())
         out = slot.view() if slot is not None else torch.empty((xc.shape[0], basis.shape[2]), dtype=torch.float32, device=xc.device)
         if side is not None:
@@ -137,12 +151,14 @@ class RgcnConvFn(torch.autograd.Function):
                      x_planes=x_planes)
         ctx.plan, ctx.relu = plan, bool(relu)
         ctx.save_for_backward(xc, basis, att, root, out if relu else None)
-        return out
+        return (out, x) if passthrough else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pass=None):
         # out[i] = (sum_{e: dst=i} x[src_e] W_{r(e)}) / deg_i + x[i] root + b,   W_r = sum_b att[r,b] basis[b]
         x, basis, att, root, out = ctx.saved_tensors
+        if g is None:
+            return (g_pass if ctx.needs_input_grad[0] else None,) + (None,) * 10
         deg = ctx.plan.grad_plans()[2]
         # one launch: ReLU mask, gm = g / deg (the gradient of the un-normalised sum), the bias gradient
         g, gm, dbias = _hip.grad_prologue(g, out if ctx.relu else None, deg, True, bool(ctx.needs_input_grad[4]))
@@ -150,11 +166,15 @@ class RgcnConvFn(torch.autograd.Function):
         with _hip.dense_batch(x.device):
             dxe, dbasis, datt = rgcn_edge_gradients(ctx.plan, x, basis.detach(), att.detach(), gm,
                                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-            dx = None
-            if ctx.needs_input_grad[0]:                        # dx = dxe + g root^T: the product is added onto the edge sums
-                dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True, join_batch=True)
+            dx, late = None, None
+            if ctx.needs_input_grad[0]:                        # dx = dxe + g root^T (+ the concat's columns of x): added onto the edge sums
+                rides = _hip.addend_ok(g_pass, dxe.shape[0], dxe.shape[1])
+                dx = _hip.gemm(g, root.detach(), dxe, b_transposed=True, accumulate=True, join_batch=True, addend=g_pass if rides else None)
+                late = None if rides else g_pass
             droot = _hip.xtg(x, g, join_batch=True) if ctx.needs_input_grad[3] else None
-        return dx, dbasis, datt, droot, dbias, None, None, None, None, None
+        if late is not None:
+            dx = dx + late
+        return dx, dbasis, datt, droot, dbias, None, None, None, None, None, None
 
 
 # (relation, source) sums Q of more than this many floats are reduced per slab of relations (the dense Q of a graph

@@ -23,6 +23,7 @@ struct GemmArgs {
     int64_t sbk, sbn;                     // element (k, col) of B sits at b[k * sbk + col * sbn]: (ldb, 1), or (1, ldb) for B given transposed
     int64_t sam, sak;                     // element (row, k) of A at a[row * sam + k * sak]: (lda, 1), or (1, lda) for A given transposed
     int accumulate;                       // c += a b instead of c = a b
+    const float* addend; int64_t ld_add;  // (may be null) c = a b + addend: a second gradient of the same tensor, added where the product is stored
 };
 
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
             if (row < g.m) {
                 float v = acc[t][i] + bias;
                 if (g.accumulate) v += C[(int64_t)row * g.ldc + col];
+                if (g.addend) v += g.addend[(int64_t)row * g.ld_add + col];
                 if (g.relu) v = fmaxf(v, 0.f);
                 C[(int64_t)row * g.ldc + col] = v;
             }
@@ -208,6 +210,7 @@ __device__ __forceinline__ void gemm_deep_body(const GemmArgs& g, int bx, int by
             if (g.bias) v += g.bias[col];
             float* c = g.c + (int64_t)row * g.ldc + col;
             if (g.accumulate) v += *c;
+            if (g.addend) v += g.addend[(int64_t)row * g.ld_add + col];
             if (g.relu) v = fmaxf(v, 0.f);
             *c = v;
         }
@@ -293,6 +296,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmArgs& g, int row_tiles, 
                 if (row < g.m) {
                     float v = acc[t][i] + bias;
                     if (g.accumulate) v += g.c[(int64_t)row * g.ldc + col];
+                    if (g.addend) v += g.addend[(int64_t)row * g.ld_add + col];
                     if (g.relu) v = fmaxf(v, 0.f);
                     g.c[(int64_t)row * g.ldc + col] = v;
                 }
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
                 if (row < g.m) {
                     float v = acc[t][i] + bias;
                     if (g.accumulate) v += g.c[(int64_t)row * g.ldc + col];
+                    if (g.addend) v += g.addend[(int64_t)row * g.ld_add + col];
                     if (g.relu) v = fmaxf(v, 0.f);
                     g.c[(int64_t)row * g.ldc + col] = v;
                 }
@@ -1012,6 +1017,14 @@ extern "C" {
 gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
                       int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream) {
+    return gn_gemm_addend_f32(a, lda, stride_a, a_rows, a_table_rows, b, ldb, stride_b, c, ldc, stride_c, m, n, k, batch, bias, nullptr, 0, flags, stream);
+}
+
+gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
+                             const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
+                             int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, const float* addend, int64_t ld_addend,
+                             int flags, void* stream) {
+    GN_REQUIRE(!addend || (batch == 1 && ld_addend >= n), "an addend goes with a single product and has rows of at least n floats");
     const int relu = flags & GN_GEMM_RELU, fast = flags & GN_GEMM_ARITH_FAST;
     const bool bt = (flags & GN_GEMM_B_TRANSPOSED) != 0, accumulate = (flags & GN_GEMM_ACCUMULATE) != 0, at = (flags & GN_GEMM_A_TRANSPOSED) != 0;
     GN_REQUIRE(!at || !a_rows, "a row gather of a transposed A is not supported");
@@ -1027,6 +1040,7 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     g.m = (int)m; g.n = (int)n; g.k = (int)k; g.bias = bias; g.relu = relu;
     g.a_vec_ok = ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
     g.sbk = bt ? 1 : ldb; g.sbn = bt ? ldb : 1; g.accumulate = accumulate ? 1 : 0;
+    g.addend = addend; g.ld_add = ld_addend;
     g.sam = at ? 1 : lda; g.sak = at ? lda : 1;
     if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
@@ -1043,7 +1057,7 @@ gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64
     GN_REQUIRE(!at, "A given transposed: at most 64 rows or 32 columns of output (the deep and narrow kernel)");
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
     const int row_tiles = (int)gn::ceil_div(m, 16);
-    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !bt && !accumulate && !gn::fast_paths_disabled()) {
+    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !bt && !accumulate && !addend && !gn::fast_paths_disabled()) {
         // tall-skinny, one shared B: the bf16 matrix instruction on split operands
         const int terms = fast ? 2 : 3;
         // a wave keeps 64 columns of a row tile, or 128 when the product is wider than 64 (A is then read once per 128)

@@ -89,12 +89,14 @@ class myGCN(Module):
             self.cached_result = build()
         return self.cached_result
 
-    def _run(self, plan, x, n_out, out, relu, side, planes=None):
+    def _run(self, plan, x, n_out, out, relu, side, planes=None, passthrough=False):
         self._planes_written = False                 # did this call's launch leave the split planes it was offered?
         if recording(x, self.weight, self.bias):                                 # training: autograd path (out / side: Slots)
-            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side, planes)
+            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side, planes, passthrough)
             self._planes_written = planes is not None
             return y
+        if passthrough:                                                          # (a frozen layer: x goes to the concat as it is)
+            return self._run(plan, x, n_out, out, relu, side, planes), x
         out, side = _unslot(out, side)
         x = _hip.f32_rows(x.detach())
         if out is None:
@@ -114,7 +116,8 @@ class myGCN(Module):
         self._planes_written = planes is not None
         return plan.aggregate(xw, self.bias, relu, out, side, planes=planes)     # layers.py:92-100
 
-    def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None):
+    def forward(self, x, edge_index, edge_weight=None, *, _out=None, _relu=False, _side=None, _pass=False):
+        # (_pass: also return x, for the concat that holds it - homoGraph's training path; GcnConvFn)
         _hip.require_gpu(x, edge_index, edge_weight, self.weight)
         n = x.size(0)
         def build():
@@ -123,7 +126,7 @@ class myGCN(Module):
                 plan.build_blocked(self.out_channels)    # schedule of the CSR, worth it only for a graph that is kept
             return plan
         plan = self._plan(edge_index, build)
-        return self._run(plan, x, n, _out, _relu, _side)
+        return self._run(plan, x, n, _out, _relu, _side, passthrough=_pass)
 
     def forward_bipartite(self, x, inter_edge_index, n_target, edge_weight=None, *, _out=None, _relu=False, _side=None,
                           _planes=None):
@@ -187,7 +190,7 @@ class myRGCN(Module):
             self._plan_key = (edge_index, range_list, key)
         return self._plan
 
-    def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False, _side=None):
+    def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False, _side=None, _pass=False):
         # edge_type is accepted and unused, as in the reference (the relation of an edge is the
         # range_list row that contains it, layers.py:171-186)
         _hip.require_gpu(x, edge_index, self.basis)
@@ -199,7 +202,9 @@ class myRGCN(Module):
         plan = self.plan_for(edge_index, range_list, x.shape[0])
         if recording(x, self.basis, self.att, self.root, self.bias):             # training: autograd path
             planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None
-            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu, _out, _side, planes)   # (Slots)
+            return RgcnConvFn.apply(x, self.basis, self.att, self.root, self.bias, plan, _relu, _out, _side, planes, _pass)   # (Slots)
+        if _pass:                                                                # (a frozen layer: x goes to the concat as it is)
+            return self.forward(x, edge_index, edge_type, range_list, _out=_out, _relu=_relu, _side=_side), x
         _out, _side = _unslot(_out, _side)
         out = _out if _out is not None else torch.empty((x.shape[0], self.out_channels), dtype=torch.float32,
                                                         device=x.device)
@@ -253,15 +258,19 @@ class homoGraph(Module):
             slots = [None] * (len(self.conv_list) + 1)
             if if_catout:
                 _, slots = cat_slots([x.shape[1]] + [c.out_channels for c in self.conv_list], x.shape[0], x.device)
-            outs, h = [x], x
+            # (with the concat a layer hands its input on to it - `_pass` - so that the input's gradient is ONE sum, made where
+            # the layer's backward stores dx, not a launch of the autograd engine's)
+            outs, h = [], x
             for i, net in enumerate(self.conv_list):
                 side = (x, slots[0], 0) if if_catout and i == 0 else None
                 if self.multi_relational:
-                    h = net(h, homo_edge_index, edge_type, range_list, _relu=True, _out=slots[i + 1], _side=side)
+                    h = net(h, homo_edge_index, edge_type, range_list, _relu=True, _out=slots[i + 1], _side=side, _pass=if_catout)
                 else:
-                    h = net(h, homo_edge_index, edge_weight, _relu=True, _out=slots[i + 1], _side=side)
-                outs.append(h)
-            return SlotsCatFn.apply(slots, *outs) if if_catout else h
+                    h = net(h, homo_edge_index, edge_weight, _relu=True, _out=slots[i + 1], _side=side, _pass=if_catout)
+                if if_catout:
+                    h, seen = h
+                    outs.append(seen)
+            return SlotsCatFn.apply(slots, *outs, h) if if_catout else h
         x = _hip.f32_rows(x)
         n = x.shape[0]
         widths = [x.shape[1]] + [c.out_channels for c in self.conv_list]

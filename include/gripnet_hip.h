@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 142 /* 0.1.38 */
+#define GN_VERSION 143 /* 0.1.39 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -192,6 +192,14 @@ GN_API gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float
 GN_API gn_status gn_gemm_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
                       const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
                       int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, int flags, void* stream);
+/* The same product with an ADDEND: c = a b (+ bias) (+ c with GN_GEMM_ACCUMULATE) + addend, addend [m, n] with rows ld_addend
+ * floats apart (may be NULL: gn_gemm_f32), batch == 1.  For the backward pass of a layer whose input also sits in a concat
+ * (layers.py:280-281,307-309): dx = g W^T + (the concat's gradient columns of that input) leaves one launch instead of the
+ * product and an element-wise sum.  The addend is only read; it may be a column slice of a wider matrix. */
+GN_API gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, const int64_t* a_rows, int64_t a_table_rows,
+                      const float* b, int64_t ldb, int64_t stride_b, float* c, int64_t ldc, int64_t stride_c,
+                      int64_t m, int64_t n, int64_t k, int64_t batch, const float* bias, const float* addend, int64_t ld_addend,
+                      int flags, void* stream);
 
 /* out[k1, k2] = x^T g over m rows (x [m, k1], g [m, k2]; k1 * k2 <= 4096): the weight gradients dW = x^T (A_norm^T g)
  * of the GCN-style layers and d root = x^T g of the relational one (autograd of layers.py:73,193).  Row slices are

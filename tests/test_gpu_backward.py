@@ -951,6 +951,79 @@ def test_wide_weight_gradient_in_tiles(gpu, m, k1, k2):
     _hip.raise_if_index_errors(gpu)
 
 
+@pytest.mark.parametrize("m,n,k", [(19081, 32, 16), (645, 48, 32), (50, 7, 1000), (3000, 96, 40), (9, 5, 3)])
+def test_product_with_an_addend(gpu, m, n, k):
+    """c = a b^T + addend (gn_gemm_addend_f32): the dx of a layer whose input also sits in a concat - the addend is a column
+    slice of the concat's gradient; every kernel the product can take (deep and narrow, tall-skinny fp32, generic), alone,
+    on top of GN_GEMM_ACCUMULATE, and queued in a dense batch, against float64; the addend is left as it was."""
+    gen = torch.Generator().manual_seed(m + n + k)
+    a, b = torch.randn(m, k, generator=gen).to(gpu), torch.randn(n, k, generator=gen).to(gpu)
+    wide = torch.randn(m, n + 24, generator=gen).to(gpu)
+    addend = wide[:, 8:8 + n]
+    kept = wide.clone()
+    want = a.double() @ b.double().t() + addend.double()
+    tol = 2e-5 * float(want.abs().max())
+    got = _hip.gemm(a, b, torch.empty(m, n, device=gpu), b_transposed=True, addend=addend)
+    assert float((got.double() - want).abs().max()) <= tol
+    base = torch.randn(m, n, generator=gen).to(gpu)
+    acc = _hip.gemm(a, b, base.clone(), b_transposed=True, accumulate=True, addend=addend)
+    assert float((acc.double() - want - base.double()).abs().max()) <= tol
+    with _hip.dense_batch(gpu):
+        queued = _hip.gemm(a, b, torch.empty(m, n, device=gpu), b_transposed=True, join_batch=True, addend=addend)
+        other = _hip.xtg(a, base, join_batch=True)
+    assert torch.equal(queued, got)
+    assert float((other.double() - a.double().t() @ base.double()).abs().max()) <= 1e-4 * float(other.abs().max())
+    assert torch.equal(wide, kept)
+    assert _hip.addend_ok(addend, m, n) and not _hip.addend_ok(addend.t(), n, m) and not _hip.addend_ok(addend.double(), m, n)
+    with pytest.raises(ValueError):
+        _hip.gemm(a, b, torch.empty(m, n, device=gpu), b_transposed=True, addend=wide)
+    _hip.raise_if_index_errors(gpu)
+
+
+def test_an_input_that_also_sits_in_the_concat_gets_one_gradient(gpu):
+    """homoGraph with if_catout (layers.py:280-281,307-309): a layer's input is used by the layer AND by the concat.  The
+    training path hands the input through the layer's Function, whose backward adds the concat's gradient columns where it
+    stores dx (no element-wise launch of the autograd engine in between: torch's profiler sees no aten::add in the backward);
+    gradients against torch autograd through the oracle for a GCN stack whose first input is the embedding, at a size where
+    the products take the tall-skinny kernel, with every layer trainable and with a frozen first layer; an input that is a
+    plain tensor needing a gradient gets the sum as well."""
+    gen = torch.Generator().manual_seed(77)
+    n, e = 3000, 40000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    torch.manual_seed(5)
+    hg = gripnet_amd.homoGraph([24, 16, 16], start_graph=True, in_dim=n).to(gpu)
+    proj = torch.randn(n, 24 + 16 + 16, generator=gen)
+    for frozen in (False, True):
+        hg.zero_grad()
+        for p in hg.conv_list[0].parameters():
+            p.requires_grad_(not frozen)
+        out = hg(None, ei.to(gpu), if_catout=True)
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            (out * proj.to(gpu)).sum().backward()
+        adds = [ev.name for ev in prof.events() if ev.name in ("aten::add", "aten::add_")]
+        assert not adds, adds
+        sd = {"h." + k: leaf(v.cpu()) for k, v in hg.state_dict().items()}
+        ref = orc.homo_forward(sd, "h.", None, ei, None, if_catout=True)
+        (ref * proj).sum().backward()
+        close(out, ref, what="forward")
+        for k, p in hg.named_parameters():
+            if not p.requires_grad:
+                assert p.grad is None
+                continue
+            close(p.grad, sd["h." + k].grad, 1e-4, what=k)
+    x = torch.randn(n, 24, generator=gen)
+    xg = x.to(gpu).requires_grad_(True)
+    plain = gripnet_amd.homoGraph([24, 16]).to(gpu)
+    out = plain(xg, ei.to(gpu), if_catout=True)
+    (out * proj[:, :40].to(gpu)).sum().backward()
+    sd = {"h." + k: leaf(v.cpu()) for k, v in plain.state_dict().items()}
+    xr = leaf(x)
+    ref = orc.homo_forward(sd, "h.", xr, ei, None, if_catout=True)
+    (ref * proj[:, :40]).sum().backward()
+    close(xg.grad, xr.grad, 1e-4, what="dx of an input that sits in the concat")
+    _hip.raise_if_index_errors(gpu)
+
+
 @pytest.mark.parametrize("n,fin,fout,bases,R", [(8000, 64, 32, 16, 520), (70000, 16, 32, 4, 7), (3000, 40, 24, 5, 12), (2500, 128, 16, 8, 5)])
 def test_relational_layer_gradients_beyond_the_lds_kernels(gpu, n, fin, fout, bases, R):
     """myRGCN under autograd on graphs the LDS-resident kernels do not cover (the all-nodes baseline, rgcn_pose.py:53-106):
