@@ -734,7 +734,9 @@ __global__ __launch_bounds__(256) void k_xtg_partial(const float* __restrict__ x
 // them round-robin (A operand = x read down its columns, B = g; loads of the next chunk in flight), the waves' accumulators
 // meet in LDS and are added in wave order, the slice's sums are stored write-through, and the last slice to arrive adds all
 // slices in slice order (no fence: MI355X_MICROARCH.md's form for a few KB).  Deterministic; fp32 MFMA = fp32 FMA chains.
-constexpr int kXtgMfmaSlices = 32;
+constexpr int kXtgMfmaSlices = 32;       // slices the last one to arrive adds alone
+constexpr int kXtgMfmaMax = 128;         // slices of a long product (two levels: sets of kXtgSet), <= kXtgSlices - kXtgMfmaMax / kXtgSet
+constexpr int kXtgSet = 16;
 
 struct XtgArgs {
     const float* x; int64_t ld_x; const float* g; int64_t ld_g; int64_t m; int k1, k2;
@@ -815,6 +817,48 @@ __device__ __forceinline__ void xtg_mfma_body(const XtgArgs& a, int bx, int nblo
     if (single) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's write-through stores have reached L2 ...
     __syncthreads();                                                       // ... and so have every other wave's when the ticket is drawn
+    const unsigned int* __restrict__ parts = reinterpret_cast<const unsigned int*>(partial);
+    if (nblocks > kXtgMfmaSlices) {
+        // More than 32 slices (the 50,000-row layers of the node-classification models: 32 workgroups were an eighth of the
+        // chip): two levels of the same hand-over - the slices in sets of kXtgSet, the last of a set adds its set in slice
+        // order and leaves the sum behind the slices (rows kXtgMfmaMax.. of `partial`), the last set to finish adds the sets.
+        const int set = bx / kXtgSet, n_sets = (nblocks + kXtgSet - 1) / kXtgSet, set_n = min(kXtgSet, nblocks - set * kXtgSet);
+        if (tid == 0) *last_flag = __hip_atomic_fetch_add(ticket + 1 + set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(set_n - 1);
+        __syncthreads();
+        if (!*last_flag) return;
+        for (int o = tid; o < outs; o += 1024) {
+            float p[kXtgSet];
+#pragma unroll
+            for (int sl = 0; sl < kXtgSet; ++sl)
+                p[sl] = __uint_as_float(__hip_atomic_load(parts + (size_t)(set * kXtgSet + min(sl, set_n - 1)) * outs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < kXtgSet; ++sl) v += sl < set_n ? p[sl] : 0.f;
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)(kXtgMfmaMax + set) * outs + o, __float_as_uint(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(ticket + 1 + set, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_sets - 1);
+        }
+        __syncthreads();
+        if (!*last_flag) return;
+        constexpr int kSetsMax = kXtgMfmaMax / kXtgSet;
+        for (int o = tid; o < outs; o += 1024) {
+            float p[kSetsMax];
+#pragma unroll
+            for (int sl = 0; sl < kSetsMax; ++sl)
+                p[sl] = __uint_as_float(__hip_atomic_load(parts + (size_t)(kXtgMfmaMax + min(sl, n_sets - 1)) * outs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < kSetsMax; ++sl) v += sl < n_sets ? p[sl] : 0.f;
+            out[(int64_t)(o / k2) * ld_out + o % k2] = v;
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (tid == 0) *last_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
     __syncthreads();
     if (!*last_flag) return;
@@ -823,8 +867,7 @@ __device__ __forceinline__ void xtg_mfma_body(const XtgArgs& a, int bx, int nblo
         float p[kXtgMfmaSlices];
 #pragma unroll
         for (int sl = 0; sl < kXtgMfmaSlices; ++sl)
-            p[sl] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(partial) + (size_t)min(sl, nblocks - 1) * outs + o,
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            p[sl] = __uint_as_float(__hip_atomic_load(parts + (size_t)min(sl, nblocks - 1) * outs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         float v = 0.f;
 #pragma unroll
         for (int sl = 0; sl < kXtgMfmaSlices; ++sl) v += sl < nblocks ? p[sl] : 0.f;
@@ -840,6 +883,9 @@ __global__ __launch_bounds__(1024) void k_xtg_mfma(XtgArgs a) {
     xtg_mfma_body<MT, NT>(a, blockIdx.x, gridDim.x, xtg_part, &last);
 }
 
+int xtg_slices(int64_t m);
+static_assert(kXtgMfmaMax + kXtgMfmaMax / kXtgSet <= kXtgSlices && (1 + kXtgMfmaMax / kXtgSet) * 4 <= 64, "the sets' sums and tickets live in the workspace of gn_xtg_workspace_bytes");
+
 template <int MT, int NT>
 gn_status launch_xtg_mfma(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int k1, int k2, float* out, int64_t ld_out,
                           void* workspace, hipStream_t st) {
@@ -849,7 +895,7 @@ gn_status launch_xtg_mfma(const float* x, int64_t ld_x, const float* g, int64_t 
         if (ls != GN_OK) return ls;
     }
     // about two chunks per wave; the ticket sits behind the slices' sums
-    const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kXtgMfmaSlices, gn::ceil_div(m, 16 * 16 * 2)));
+    const int slices = xtg_slices(m);
     float* partial = static_cast<float*>(workspace);
     unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (size_t)kXtgSlices * k1 * k2 * sizeof(float));
     const XtgArgs a = {x, ld_x, g, ld_g, m, k1, k2, partial, ticket, out, ld_out};
@@ -941,7 +987,10 @@ XtgArgs xtg_args(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int
     unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (size_t)kXtgSlices * k1 * k2 * sizeof(float));
     return XtgArgs{x, ld_x, g, ld_g, m, k1, k2, partial, ticket, out, ld_out};
 }
-int xtg_slices(int64_t m) { return (int)std::max<int64_t>(1, std::min<int64_t>(kXtgMfmaSlices, gn::ceil_div(m, 16 * 16 * 2))); }
+int xtg_slices(int64_t m) {      // about two chunks of sixteen rows per wave; up to 40 of them are 32 (one level), more are up to 128 (two)
+    const int64_t want = gn::ceil_div(m, 16 * 16 * 2);
+    return (int)std::max<int64_t>(1, want <= 40 ? std::min<int64_t>(kXtgMfmaSlices, want) : std::min<int64_t>(kXtgMfmaMax, want));
+}
 
 gn_status launch_xtg_op(const BatchOp& op, hipStream_t st) {
     const XtgArgs& a = op.x;

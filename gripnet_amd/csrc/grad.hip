@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int kGradThreads = 256, kGradGroups = 1024;
+constexpr int kGradSet = 32;                                 // workgroups whose column sums the last of them adds (then the sets' sums: two levels)
 
 template <int CP>     // columns padded to a power of two: thread (tid / CP, tid % CP) keeps its column
 __global__ __launch_bounds__(kGradThreads) void k_grad_prologue(const float* __restrict__ g, int64_t ld_g, const float* __restrict__ saved,
@@ -52,53 +53,70 @@ __global__ __launch_bounds__(kGradThreads) void k_grad_prologue(const float* __r
     if (!colsum) return;
     red[tid] = sum;
     __syncthreads();
+    // Two levels, both "the last to arrive adds in index order" (write-through stores, drained, ticket; agent-scope loads): the
+    // workgroups in sets of kGradSet consecutive ones, then the sets.  (One level - the last of up to 1,024 workgroups adding
+    // all their sums, RP row lanes per column - was a chain of 64-512 memory round trips in ONE workgroup: 128 of the 145 us of a
+    // 50,000 x 128 layer's launch.)
+    unsigned int* mine = reinterpret_cast<unsigned int*>(partial) + (size_t)blockIdx.x * CP;
     if (tid < CP) {                                                        // the workgroup's row lanes, in order
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < RP; ++k) s += red[k * CP + tid];
-        __hip_atomic_store(reinterpret_cast<unsigned int*>(partial) + (size_t)blockIdx.x * CP + tid, __float_as_uint(s), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + tid, __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's write-through stores have reached L2 ...
     __syncthreads();                                                       // ... and so have every other wave's when the ticket is drawn
-    if (tid == 0) last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    const unsigned set = blockIdx.x / kGradSet, n_sets = (gridDim.x + kGradSet - 1) / kGradSet;
+    const unsigned set_lo = set * kGradSet, set_n = min((unsigned)kGradSet, gridDim.x - set_lo);
+    if (tid == 0) last = __hip_atomic_fetch_add(arrived + 1 + set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == set_n - 1;
     __syncthreads();
     if (!last) return;
-    {
-        // row lane k takes workgroups k, k + RP, ... in that order, then the row lanes are added in order: the same association
-        // whatever the arrival order was
-        // (eight workgroups' sums requested before any is added: a load - add chain over 512 write-through loads paid a
-        // memory round trip each, 145 us for a 128-column layer; the order of the additions is unchanged)
+    // the sums of this set: row lane k takes its workgroups k, k + RP, ... in that order (eight requested before any is added),
+    // then the row lanes are added in order - the same association whatever the arrival order was
+    auto fold = [&](const unsigned int* base, unsigned count) {
         float s = 0.f;
-        for (unsigned b0 = rl; b0 < gridDim.x; b0 += 8 * RP) {
+        for (unsigned b0 = rl; b0 < count; b0 += 8 * RP) {
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned b = min(b0 + k * RP, gridDim.x - 1);
-                v[k] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(partial) + (size_t)b * CP + c, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT));
+                const unsigned b = min(b0 + k * RP, count - 1);
+                v[k] = __uint_as_float(__hip_atomic_load(base + (size_t)b * CP + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += (b0 + k * RP < gridDim.x) ? v[k] : 0.f;
+            for (int k = 0; k < 8; ++k) s += (b0 + k * RP < count) ? v[k] : 0.f;
         }
         __syncthreads();                                                   // (red was read above)
         red[tid] = s;
         __syncthreads();
-        if (tid < cols) {
-            float t = 0.f;
+        float t = 0.f;
+        if (tid < CP)
 #pragma unroll
             for (int k = 0; k < RP; ++k) t += red[k * CP + tid];
-            colsum[tid] = t;
-        }
+        return t;
+    };
+    const float set_sum = fold(reinterpret_cast<const unsigned int*>(partial) + (size_t)set_lo * CP, set_n);
+    unsigned int* sets = reinterpret_cast<unsigned int*>(partial) + (size_t)kGradGroups * 256;      // [kGradGroups / kGradSet][256]
+    if (tid < CP) __hip_atomic_store(sets + (size_t)set * CP + tid, __float_as_uint(set_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(arrived + 1 + set, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sets - 1;
     }
-    if (tid == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    __syncthreads();
+    if (!last) return;
+    const float total = fold(sets, n_sets);
+    if (tid < cols) colsum[tid] = total;
+    if (tid == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t gn_grad_prologue_workspace_bytes(void) { return (size_t)kGradGroups * 256 * sizeof(float) + 64; }
+size_t gn_grad_prologue_workspace_bytes(void) {      // the workgroups' sums, the sets' sums, the tickets (one + one per set)
+    return ((size_t)kGradGroups * 256 + (size_t)(kGradGroups / kGradSet) * 256) * sizeof(float) + (size_t)(1 + kGradGroups / kGradSet) * sizeof(unsigned int) + 60;
+}
 
 gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_out, int64_t ld_saved, const float* rowdiv, int64_t rows,
                                int64_t cols, float* gm, int64_t ld_gm, float* gd, int64_t ld_gd, float* colsum, void* workspace,
@@ -113,7 +131,7 @@ gn_status gn_grad_prologue_f32(const float* g, int64_t ld_g, const float* saved_
     GN_REQUIRE(!colsum || (workspace && workspace_bytes >= gn_grad_prologue_workspace_bytes() && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0),
                "column sums need a workspace of %zu bytes, zeroed once", gn_grad_prologue_workspace_bytes());
     float* partial = static_cast<float*>(workspace);
-    unsigned int* arrived = workspace ? reinterpret_cast<unsigned int*>(partial + (size_t)kGradGroups * 256) : nullptr;
+    unsigned int* arrived = workspace ? reinterpret_cast<unsigned int*>(partial + (size_t)kGradGroups * 256 + (size_t)(kGradGroups / kGradSet) * 256) : nullptr;
     hipStream_t st = gn::as_stream(stream);
     // a launch covers up to 256 columns (a thread keeps its column); wider layers take one launch per block of 256 columns, the
     // operands being row-strided already.  The launches share the workspace: they are ordered by the stream, and the last

@@ -600,11 +600,12 @@ def test_short_row_sums_over_a_small_table(gpu, monkeypatch, features, table_row
     assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("rows,cols", [(19081, 16), (645, 32), (645, 48), (7, 80), (1, 1), (3000, 200)])
+@pytest.mark.parametrize("rows,cols", [(19081, 16), (645, 32), (645, 48), (7, 80), (1, 1), (3000, 200), (50000, 128), (50000, 64), (70000, 256)])
 def test_backward_prologue_in_one_launch(gpu, rows, cols):
     """gn_grad_prologue_f32: ReLU mask by the saved output, division by the rows' divisor and the column sums of the masked
     gradient against the torch expressions, on a row-strided gradient (a slot of a concatenated output's gradient); the
-    same bits on every launch; every output optional."""
+    same bits on every launch; every output optional.  (50,000 x 128 and 70,000 x 256: the node-classification models'
+    layers - 1,024 workgroups whose sums meet in 32 sets of 32, then once more.)"""
     gen = torch.Generator().manual_seed(rows + cols)
     wide = torch.randn(rows, cols + 24, generator=gen).to(gpu)
     g = wide[:, 8:8 + cols]
@@ -800,6 +801,14 @@ def test_last_arriver_hand_overs_replayed(gpu):
         outs.append((it % 4, (it // 4) % 4, _hip.xtg(xs[it % 4], gs[(it // 4) % 4])))
     for i, j, got in outs:
         assert float((got.double() - want[i][j]).abs().max()) <= 1e-4 * float(want[i][j].abs().max())
+    # a long product: more than 32 slices, handed over in two levels (sets of sixteen slices, then the sets)
+    xl = [torch.randn(45000, 64, generator=gen).to(gpu) for _ in range(2)]
+    gl = [torch.randn(45000, 32, generator=gen).to(gpu) for _ in range(2)]
+    wantl = [[(x.double().t() @ g.double()) for g in gl] for x in xl]
+    outs = [(it % 2, (it // 2) % 2, _hip.xtg(xl[it % 2], gl[(it // 2) % 2])) for it in range(600)]
+    for i, j, got in outs:
+        assert float((got.double() - wantl[i][j]).abs().max()) <= 1e-4 * float(wantl[i][j].abs().max())
+    del xl, gl, outs
     outs = []
     sav = torch.relu(torch.randn(m, k2, generator=gen)).to(gpu)
     wantc = [(g * (sav > 0)).double().sum(0) for g in gs]
@@ -935,7 +944,7 @@ def test_class_loss_and_softmax_gradients(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
-@pytest.mark.parametrize("m,k1,k2", [(5000, 128, 64), (3000, 256, 128), (700, 65, 33), (900, 200, 7)])
+@pytest.mark.parametrize("m,k1,k2", [(5000, 128, 64), (3000, 256, 128), (700, 65, 33), (900, 200, 7), (50000, 128, 64), (70001, 64, 32), (21000, 48, 32)])
 def test_wide_weight_gradient_in_tiles(gpu, m, k1, k2):
     """x^T g wider than one launch of gn_xtg_f32 covers (the 128 x 64 ... 256 x 128 layers of the NC models): tiles of
     64 x 32 outputs over column slices, alone and inside a dense batch, against float64; the same bits on every call."""
