@@ -66,8 +66,11 @@ __global__ __launch_bounds__(kGradThreads) void k_grad_prologue(const float* __r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's write-through stores have reached L2 ...
     __syncthreads();                                                       // ... and so have every other wave's when the ticket is drawn
-    const unsigned set = blockIdx.x / kGradSet, n_sets = (gridDim.x + kGradSet - 1) / kGradSet;
-    const unsigned set_lo = set * kGradSet, set_n = min((unsigned)kGradSet, gridDim.x - set_lo);
+    // (a launch whose workgroups' sums are two requests deep for the last one - 16 x RP of them - keeps ONE level: the sets
+    // would cost it a hand-over more, ~1 us on the PoSE layers)
+    const bool one_level = gridDim.x <= 16u * RP;
+    const unsigned set = one_level ? 0u : blockIdx.x / kGradSet, n_sets = one_level ? 1u : (gridDim.x + kGradSet - 1) / kGradSet;
+    const unsigned set_lo = set * kGradSet, set_n = one_level ? gridDim.x : min((unsigned)kGradSet, gridDim.x - set_lo);
     if (tid == 0) last = __hip_atomic_fetch_add(arrived + 1 + set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == set_n - 1;
     __syncthreads();
     if (!last) return;
@@ -95,6 +98,11 @@ __global__ __launch_bounds__(kGradThreads) void k_grad_prologue(const float* __r
         return t;
     };
     const float set_sum = fold(reinterpret_cast<const unsigned int*>(partial) + (size_t)set_lo * CP, set_n);
+    if (one_level) {
+        if (tid < cols) colsum[tid] = set_sum;
+        if (tid == 0) __hip_atomic_store(arrived + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     unsigned int* sets = reinterpret_cast<unsigned int*>(partial) + (size_t)kGradGroups * 256;      // [kGradGroups / kGradSet][256]
     if (tid < CP) __hip_atomic_store(sets + (size_t)set * CP + tid, __float_as_uint(set_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
