@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
         const int l = idx & 63, t = (idx >> 6) % CT, ch = idx / (64 * CT);
         const int col = col0 + 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = g.b[(int64_t)(kb + j) * g.ldb + min(col, g.n - 1)];
+        for (int j = 0; j < 8; ++j) v[j] = g.b[(int64_t)(kb + j) * g.sbk + (int64_t)min(col, g.n - 1) * g.sbn];      // (B as stored or given transposed)
         if (col >= g.n) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -1106,8 +1106,9 @@ gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, cons
     GN_REQUIRE(!at, "A given transposed: at most 64 rows or 32 columns of output (the deep and narrow kernel)");
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
     const int row_tiles = (int)gn::ceil_div(m, 16);
-    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !bt && !accumulate && !addend && !gn::fast_paths_disabled()) {
-        // tall-skinny, one shared B: the bf16 matrix instruction on split operands
+    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled()) {
+        // tall-skinny, one shared B (as stored, or given transposed: the dx = g W^T of the wide layers' backward): the bf16 matrix
+        // instruction on split operands.  (Not queued in a dense batch: on 50,000 x 128 x 128 it takes a third of the fp32 instruction's time.)
         const int terms = fast ? 2 : 3;
         // a wave keeps 64 columns of a row tile, or 128 when the product is wider than 64 (A is then read once per 128)
         const int ct = n > 64 ? 8 : 4;

@@ -960,10 +960,10 @@ def test_wide_weight_gradient_in_tiles(gpu, m, k1, k2):
     _hip.raise_if_index_errors(gpu)
 
 
-@pytest.mark.parametrize("m,n,k", [(19081, 32, 16), (645, 48, 32), (50, 7, 1000), (3000, 96, 40), (9, 5, 3)])
+@pytest.mark.parametrize("m,n,k", [(19081, 32, 16), (645, 48, 32), (50, 7, 1000), (3000, 96, 40), (9, 5, 3), (5000, 64, 64), (50000, 256, 128)])
 def test_product_with_an_addend(gpu, m, n, k):
     """c = a b^T + addend (gn_gemm_addend_f32): the dx of a layer whose input also sits in a concat - the addend is a column
-    slice of the concat's gradient; every kernel the product can take (deep and narrow, tall-skinny fp32, generic), alone,
+    slice of the concat's gradient; every kernel the product can take (deep and narrow, tall-skinny fp32 and split bf16, generic), alone,
     on top of GN_GEMM_ACCUMULATE, and queued in a dense batch, against float64; the addend is left as it was."""
     gen = torch.Generator().manual_seed(m + n + k)
     a, b = torch.randn(m, k, generator=gen).to(gpu), torch.randn(n, k, generator=gen).to(gpu)
