@@ -1,3 +1,7 @@
+"""Development probe: time of the tall-skinny products of the node-classification layers' backward (dx = g W^T of a 50,000-row
+layer) on gn_gemm_f32 - B as stored / given transposed / with an addend / accumulating - next to torch.matmul.
+    python tools/probes/gemm_time_probe.py
+"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from gripnet_amd import _hip

@@ -1,3 +1,7 @@
+"""Development probe: which aten ops torch itself still launches inside an eager PoSE training step (torch profiler, one step):
+the autograd engine's sums of two gradients of one tensor, copies made contiguous.
+    python tools/probes/torch_ops_probe.py
+"""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 import bench
