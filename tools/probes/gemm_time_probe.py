@@ -14,7 +14,8 @@ def t(fn, n=50):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / n
-for (m, n, k) in [(50000, 256, 128), (50000, 128, 128), (50000, 128, 64), (50000, 64, 128), (20000, 128, 128)]:
+for (m, n, k) in [(50000, 256, 128), (50000, 128, 128), (50000, 128, 64), (50000, 64, 128), (20000, 128, 128), (50000, 64, 256), (50000, 128, 256),
+                  (50000, 128, 512), (50000, 32, 64)]:
     A = torch.randn(m, k, device=dev); Bt = torch.randn(n, k, device=dev); B = Bt.t().contiguous()
     out = torch.empty(m, n, device=dev)
     wide = torch.randn(m, n + 128, device=dev); add = wide[:, :n]
