@@ -206,7 +206,8 @@ GN_API gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_
  * reduced in a fixed order: bitwise reproducible.  Scratch is caller-provided (gn_xtg_workspace_bytes).
  * flags: GN_XTG_TICKET_ZEROED promises that the 64 bytes at offset gn_xtg_workspace_bytes(k1, k2) - 64 of the workspace
  * were zeroed once by the caller and are touched by nobody else (calls on one workspace stream-ordered): up to 64 x 32 outputs then take ONE launch on the matrix
- * cores (slices added in slice order by the last slice to arrive) instead of a partial-sum launch and a fold. */
+ * cores (slices added in slice order by the last slice to arrive - beyond 32 slices, the products over tens of thousands of
+ * rows, in two levels: sets of sixteen slices, then the sets) instead of a partial-sum launch and a fold. */
 #define GN_XTG_TICKET_ZEROED 1
 #define GN_XTG_JOIN_BATCH 2      /* the product may leave with the open batch (gn_dense_batch_begin / _end) */
 GN_API size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2);
@@ -476,7 +477,7 @@ GN_API gn_status gn_negative_sampler_sample_stepped(const gn_negative_sampler* s
 /* Independent small products in ONE launch.  Between gn_dense_batch_begin() and gn_dense_batch_end(stream) (per host thread,
  * not nested) the calls that carry GN_GEMM_JOIN_BATCH / GN_XTG_JOIN_BATCH - those of gn_gemm_f32 that take the deep-and-narrow kernel (a single product with at most 64 rows or 32 columns
  * of output and A given transposed or K >= 256) or the tall-skinny fp32 kernel (a single product of >= 256 rows whose B fits 64 KB
- * of LDS, no row gather) and of gn_xtg_f32 that take the one-launch kernel are queued instead of launched,
+ * of LDS, no row gather; a product of >= 2048 rows with K a multiple of 32 takes the split-bf16 kernel instead and launches at once) and of gn_xtg_f32 that take the one-launch kernel are queued instead of launched,
  * and leave together at _end as one grid (up to four per launch; a product alone in its batch launches as usual); every other
  * call inside the bracket (without the flag, of another shape, or made by the library inside another entry point) launches at once.  The caller promises that the queued products neither depend on each other nor
  * share a workspace (a second gn_xtg_f32 on a queued workspace launches at once), and that their operands stay valid until
