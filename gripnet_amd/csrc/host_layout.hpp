@@ -225,12 +225,87 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     const int walks = parts == 8 ? (int)std::max<int64_t>(1, std::min<int64_t>(kClsMaxWalks, gn::ceil_div(list_bytes / 8, window_bytes))) : 1;
     const int nparts = parts * walks;                            // part p = XCD (p / walks), walk (p % walks)
     const int ngroups = nparts * nclasses;
+    // The class of a pair INSIDE one block is free between the two classes that hold the block.  With eight position ranges an
+    // XCD's 32 compute units go to the three classes as 11 + 11 + 10, and a class that gets ten for a third of the batches
+    // has 65 per workgroup where the others have 59: five batches for some of its waves, four for everyone else's (pose0-syn:
+    // 77 of the 256 workgroups, and the launch ends with them - `tools/dm_stamps.py`: last waves done 11.9-16.0 us; with the
+    // parts and classes evened out no workgroup has more than 63, and the step is 1.2 us shorter, same box).  So the
+    // free pairs are dealt per (part, relation, block) - a relation's pairs of a block stay one run - to whichever of the two
+    // classes is further below its share of the part: class loads in the ratio of the units they will get.
+    // The position parts themselves are cut by BATCHES, not by pairs: a relation's pairs of a (part, class) are a run padded to
+    // steps of sixteen slots - about eight slots per run and class - so a range of many small relations (the tail of the
+    // type-sorted list) has more batches per pair than the head's few large ones (pose0-syn: 2,083 against 1,954 with
+    // equal pair counts, 65 batches per workgroup against 61).  Every pair weighs 1 + 24 / (its relation's pairs).
+    std::vector<int32_t> part_of((size_t)S);
+    int64_t n_rel = 0;
+    {
+        for (int64_t i = 0; i < S; ++i) n_rel = std::max<int64_t>(n_rel, hr[scored[i]] + 1);
+        std::vector<int64_t> rel_cnt((size_t)n_rel, 0);
+        for (int64_t i = 0; i < S; ++i) rel_cnt[(size_t)hr[scored[i]]]++;
+        double total_w = 0.0;
+        for (int64_t r = 0; r < n_rel; ++r) total_w += rel_cnt[(size_t)r] > 0 ? (double)rel_cnt[(size_t)r] + 24.0 : 0.0;
+        double cum = 0.0;
+        for (int64_t i = 0; i < S; ++i) {
+            const double w = 1.0 + 24.0 / (double)rel_cnt[(size_t)hr[scored[i]]];
+            part_of[(size_t)i] = (int32_t)std::min<int64_t>(nparts - 1, (int64_t)((cum + 0.5 * w) * nparts / total_w));
+            cum += w;
+        }
+        for (int64_t i = 1; i < S; ++i) part_of[(size_t)i] = std::max(part_of[(size_t)i], part_of[(size_t)i - 1]);   // (list order: monotone)
+    }
+    // (A group of a few hundred pairs or more - the head of the list is one or two relations - is CUT between its two classes
+    // where that evens them out: the first free_cut pairs of the group, in list order, go to the block's own class.)
+    std::vector<int32_t> free_cut;                               // [part][relation][block]: pairs of the group that go to class `block`
+    if (nblocks == 3 && parts == 8) {
+        free_cut.assign((size_t)nparts * n_rel * 3, 0);
+        const int W = cus / 8;
+        std::vector<int64_t> fixed((size_t)nparts * 3, 0), flex((size_t)nparts * n_rel * 3, 0);
+        for (int64_t i = 0; i < S; ++i) {
+            const int64_t e = scored[i];
+            const int part = part_of[(size_t)i];
+            const int bu = (int)(hu[e] / blk), bv = (int)(hv[e] / blk);
+            if (bu != bv) fixed[(size_t)part * 3 + ((bu + 1) % 3 == bv ? bu : bv)]++;
+            else flex[((size_t)part * n_rel + hr[e]) * 3 + bu]++;
+        }
+        for (int part = 0; part < nparts; ++part) {
+            // the units of the classes: as even as W allows, the smaller shares to the classes with the least fixed load
+            int order3[3] = {0, 1, 2};
+            std::sort(order3, order3 + 3, [&](int x, int y) { return fixed[(size_t)part * 3 + x] != fixed[(size_t)part * 3 + y] ? fixed[(size_t)part * 3 + x] > fixed[(size_t)part * 3 + y] : x < y; });
+            double share[3];
+            for (int k = 0; k < 3; ++k) share[order3[k]] = (double)(W / 3 + (k < W % 3 ? 1 : 0));
+            double load[3] = {(double)fixed[(size_t)part * 3], (double)fixed[(size_t)part * 3 + 1], (double)fixed[(size_t)part * 3 + 2]};
+            // largest groups first (ties in (relation, block) order)
+            std::vector<std::pair<int64_t, int32_t>> groups;
+            for (int64_t r = 0; r < n_rel; ++r)
+                for (int b = 0; b < 3; ++b)
+                    if (flex[((size_t)part * n_rel + r) * 3 + b] > 0) groups.push_back({-flex[((size_t)part * n_rel + r) * 3 + b], (int32_t)(r * 3 + b)});
+            std::sort(groups.begin(), groups.end());
+            for (const auto& gq : groups) {
+                const int b = gq.second % 3, c0 = b, c1 = (b + 2) % 3;            // the two classes that hold block b
+                const double m = (double)-gq.first;
+                // x pairs to c0 so that both end at the same load per unit: (load0 + x) / share0 = (load1 + m - x) / share1
+                double x = (share[c0] * (load[c1] + m) - share[c1] * load[c0]) / (share[c0] + share[c1]);
+                x = std::min(m, std::max(0.0, x));
+                if (m < 512.0) x = x >= 0.5 * m ? m : 0.0;                       // a small group stays one run
+                else x = std::min(m, std::floor(x / 64.0 + 0.5) * 64.0);
+                load[c0] += x; load[c1] += m - x;
+                free_cut[(size_t)part * n_rel * 3 + gq.second] = (int32_t)x;
+            }
+        }
+    }
     // scored pairs by (part, class, relation), list order inside
     std::vector<uint32_t> key((size_t)S);
     std::vector<int64_t> idx((size_t)S);
+    std::vector<int32_t> free_seen(free_cut.size(), 0);
     for (int64_t i = 0; i < S; ++i) {
-        const int part = (int)std::min<int64_t>(nparts - 1, i * nparts / S);
-        key[i] = (uint32_t)(part * nclasses + cls_of(scored[i])) << 16 | (uint32_t)hr[scored[i]];
+        const int part = part_of[(size_t)i];
+        const int64_t e = scored[i];
+        int c = cls_of(e);
+        if (!free_cut.empty() && hu[e] / blk == hv[e] / blk) {
+            const int b = (int)(hu[e] / blk);
+            const size_t cell = ((size_t)part * n_rel + hr[e]) * 3 + (size_t)b;
+            c = free_seen[cell]++ < free_cut[cell] ? b : (b + 2) % 3;
+        }
+        key[i] = (uint32_t)(part * nclasses + c) << 16 | (uint32_t)hr[e];
         idx[i] = i;
     }
     std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });

@@ -82,6 +82,18 @@ gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t fea
     int64_t at = 0;
     for (auto& r : ranges) { CHECK(r.first == at); at = r.second; }
     CHECK(at == L.batches);
+    // eight position ranges, three classes: the parts are cut by batches and the free pairs dealt so that no workgroup is far
+    // above the mean (a wave takes whole batches: one batch too many in a workgroup is one more trip for the whole launch)
+    if (L.groups == 256 && n > 512 && L.batches >= 256 * 32) {
+        int64_t most = 0;
+        for (int g = 0; g < L.groups; ++g) {
+            const int32_t* h = L.wg.data() + (size_t)g * (4 + 4 * L.walks);
+            int64_t nb = 0;
+            for (int wk = 0; wk < L.walks; ++wk) nb += h[5 + 4 * wk] - h[4 + 4 * wk];
+            most = std::max(most, nb);
+        }
+        CHECK(most * L.groups <= L.batches + 3 * L.groups + L.batches / 50);
+    }
     return L;
 }
 
@@ -307,7 +319,7 @@ int main() {
     general_case(20000, 600, 300000, 21);
     general_case(50, 3, 40, 22);
     general_case(1, 1, 1500, 23);
-    struct { int64_t n; int R; int64_t e; int64_t f; } dec[] = {{645, 40, 20000, 80}, {200, 7, 3000, 80}, {645, 3, 50000, 48}, {30, 2, 5, 16}};
+    struct { int64_t n; int R; int64_t e; int64_t f; } dec[] = {{645, 40, 20000, 80}, {200, 7, 3000, 80}, {645, 3, 50000, 48}, {30, 2, 5, 16}, {645, 200, 150000, 80}};
     for (auto& c : dec) {
         set_threads(1);
         gn_layout::ClassLayout a = decoder_case(c.n, c.R, c.e, c.f, 7, true);
