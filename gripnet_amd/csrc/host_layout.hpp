@@ -227,31 +227,11 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     const int ngroups = nparts * nclasses;
     // The class of a pair INSIDE one block is free between the two classes that hold the block.  With eight position ranges an
     // XCD's 32 compute units go to the three classes as 11 + 11 + 10, and a class that gets ten for a third of the batches
-    // has 65 per workgroup where the others have 59: five batches for some of its waves, four for everyone else's (pose0-syn:
-    // 77 of the 256 workgroups, and the launch ends with them - `tools/dm_stamps.py`: last waves done 11.9-16.0 us; with the
-    // parts and classes evened out no workgroup has more than 63, and the step is 1.2 us shorter, same box).  So the
-    // free pairs are dealt per (part, relation, block) - a relation's pairs of a block stay one run - to whichever of the two
-    // classes is further below its share of the part: class loads in the ratio of the units they will get.
-    // The position parts themselves are cut by BATCHES, not by pairs: a relation's pairs of a (part, class) are a run padded to
-    // steps of sixteen slots - about eight slots per run and class - so a range of many small relations (the tail of the
-    // type-sorted list) has more batches per pair than the head's few large ones (pose0-syn: 2,083 against 1,954 with
-    // equal pair counts, 65 batches per workgroup against 61).  Every pair weighs 1 + 24 / (its relation's pairs).
-    std::vector<int32_t> part_of((size_t)S);
-    int64_t n_rel = 0;
-    {
-        for (int64_t i = 0; i < S; ++i) n_rel = std::max<int64_t>(n_rel, hr[scored[i]] + 1);
-        std::vector<int64_t> rel_cnt((size_t)n_rel, 0);
-        for (int64_t i = 0; i < S; ++i) rel_cnt[(size_t)hr[scored[i]]]++;
-        double total_w = 0.0;
-        for (int64_t r = 0; r < n_rel; ++r) total_w += rel_cnt[(size_t)r] > 0 ? (double)rel_cnt[(size_t)r] + 24.0 : 0.0;
-        double cum = 0.0;
-        for (int64_t i = 0; i < S; ++i) {
-            const double w = 1.0 + 24.0 / (double)rel_cnt[(size_t)hr[scored[i]]];
-            part_of[(size_t)i] = (int32_t)std::min<int64_t>(nparts - 1, (int64_t)((cum + 0.5 * w) * nparts / total_w));
-            cum += w;
-        }
-        for (int64_t i = 1; i < S; ++i) part_of[(size_t)i] = std::max(part_of[(size_t)i], part_of[(size_t)i - 1]);   // (list order: monotone)
-    }
+    // has 65 per workgroup where the others have 59 (pose0-syn: 59-70 over the 256 workgroups, and the launch ends with the
+    // fullest - `tools/dm_stamps.py`: last waves done 11.9-16.0 us; evened out, 61-63 and 12.8-15.2 us, the step 1.2 us
+    // shorter on the same box).  So the free pairs are dealt per (part, relation, block) - a relation's pairs of a block stay
+    // one run - to whichever of the two classes is further below its share of the part: class loads in the ratio of the units
+    // they will get.  (What counts is a compute unit's batches, not its waves' trips: see the walks below.)
     // (A group of a few hundred pairs or more - the head of the list is one or two relations - is CUT between its two classes
     // where that evens them out: the first free_cut pairs of the group, in list order, go to the block's own class.)
     std::vector<int32_t> free_cut;                               // [part][relation][block]: pairs of the group that go to class `block`
@@ -267,9 +247,14 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
             else flex[((size_t)part * n_rel + hr[e]) * 3 + bu]++;
         }
         for (int part = 0; part < nparts; ++part) {
-            // the units of the classes: as even as W allows, the smaller shares to the classes with the least fixed load
+            // the units of the classes: as even as W allows, the smaller shares to the classes with the least fixed load - of the
+            // whole RANGE (its workgroups keep their class through all its walks)
+            const int x0 = part / walks * walks;
+            int64_t fixed_x[3] = {0, 0, 0};
+            for (int wk = 0; wk < walks; ++wk)
+                for (int c = 0; c < 3; ++c) fixed_x[c] += fixed[(size_t)(x0 + wk) * 3 + c];
             int order3[3] = {0, 1, 2};
-            std::sort(order3, order3 + 3, [&](int x, int y) { return fixed[(size_t)part * 3 + x] != fixed[(size_t)part * 3 + y] ? fixed[(size_t)part * 3 + x] > fixed[(size_t)part * 3 + y] : x < y; });
+            std::sort(order3, order3 + 3, [&](int a, int b) { return fixed_x[a] != fixed_x[b] ? fixed_x[a] > fixed_x[b] : a < b; });
             double share[3];
             for (int k = 0; k < 3; ++k) share[order3[k]] = (double)(W / 3 + (k < W % 3 ? 1 : 0));
             double load[3] = {(double)fixed[(size_t)part * 3], (double)fixed[(size_t)part * 3 + 1], (double)fixed[(size_t)part * 3 + 2]};
