@@ -232,6 +232,28 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     // shorter on the same box).  So the free pairs are dealt per (part, relation, block) - a relation's pairs of a block stay
     // one run - to whichever of the two classes is further below its share of the part: class loads in the ratio of the units
     // they will get.  (What counts is a compute unit's batches, not its waves' trips: see the walks below.)
+    // The position parts themselves are cut by BATCHES, not by pairs: a relation's pairs of a (part, class) are a run padded to
+    // steps of sixteen slots - about eight slots per run and class - so a range of many small relations (the tail of the
+    // type-sorted list) has more batches per pair than the head's few large ones (pose0-syn: 2,083 against 1,954 with
+    // equal pair counts, 65 batches per workgroup against 61).  Every pair weighs 1 + 24 / (its relation's pairs).
+    // (Walks of equal weight: cutting them in whole wave trips - 17 trips of sixteen batches per workgroup at pose2-syn instead
+    // of 5 x 4 - changed nothing, 47.4 us either way: the loop follows a compute unit's batches, not its waves' trips.)
+    std::vector<int32_t> part_of((size_t)S);
+    int64_t n_rel = 0;
+    {
+        for (int64_t i = 0; i < S; ++i) n_rel = std::max<int64_t>(n_rel, hr[scored[i]] + 1);
+        std::vector<int64_t> rel_cnt((size_t)n_rel, 0);
+        for (int64_t i = 0; i < S; ++i) rel_cnt[(size_t)hr[scored[i]]]++;
+        double total_w = 0.0;
+        for (int64_t r = 0; r < n_rel; ++r) total_w += rel_cnt[(size_t)r] > 0 ? (double)rel_cnt[(size_t)r] + 24.0 : 0.0;
+        double cum = 0.0;
+        for (int64_t i = 0; i < S; ++i) {
+            const double w = 1.0 + 24.0 / (double)rel_cnt[(size_t)hr[scored[i]]];
+            part_of[(size_t)i] = (int32_t)std::min<int64_t>(nparts - 1, (int64_t)((cum + 0.5 * w) * nparts / total_w));
+            cum += w;
+        }
+        for (int64_t i = 1; i < S; ++i) part_of[(size_t)i] = std::max(part_of[(size_t)i], part_of[(size_t)i - 1]);   // (list order: monotone)
+    }
     // (A group of a few hundred pairs or more - the head of the list is one or two relations - is CUT between its two classes
     // where that evens them out: the first free_cut pairs of the group, in list order, go to the block's own class.)
     std::vector<int32_t> free_cut;                               // [part][relation][block]: pairs of the group that go to class `block`
