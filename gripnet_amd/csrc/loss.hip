@@ -79,12 +79,19 @@ __global__ __launch_bounds__(kLossThreads) void k_link_loss(const float* __restr
     if (!last) return;
     // the last workgroup to arrive adds the partial sums: thread t takes workgroups t, t + 256, ... in that order, then a fixed
     // tree over the threads - the same association whatever the arrival order was
+    // (two workgroups' pairs of sums requested before any is added: as a load - add chain the 512 workgroups' sums were four
+    // memory round trips in this one workgroup)
     double a = 0.0, b = 0.0;
-    for (unsigned g = tid; g < gridDim.x; g += kLossThreads) {
-        a += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(partial) + 2 * g, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT));
-        b += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(partial) + 2 * g + 1, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned long long* __restrict__ ps = reinterpret_cast<const unsigned long long*>(partial);
+    for (unsigned g0 = tid; g0 < gridDim.x; g0 += 2 * kLossThreads) {
+        const unsigned g1 = min(g0 + kLossThreads, gridDim.x - 1);
+        const unsigned long long a0 = __hip_atomic_load(ps + 2 * g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b0 = __hip_atomic_load(ps + 2 * g0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long a1 = __hip_atomic_load(ps + 2 * g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b1 = __hip_atomic_load(ps + 2 * g1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a += __longlong_as_double((long long)a0);
+        b += __longlong_as_double((long long)b0);
+        if (g0 + kLossThreads < gridDim.x) { a += __longlong_as_double((long long)a1); b += __longlong_as_double((long long)b1); }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }

@@ -288,9 +288,17 @@ __global__ __launch_bounds__(kRelThreads) void k_rel_weight_grad(RelArgs a) {
             if (*last_part) {
                 const uint32_t* __restrict__ all = reinterpret_cast<const uint32_t*>(a.scratch + (size_t)slot0 * kRelMaxOutputs);
                 for (int o = tid; o < FF; o += kRelThreads) {
+                    // (eight parts requested before any is added - a load - add chain paid a memory round trip per part, and a
+                    // hub relation has dozens; the order of the additions is unchanged)
                     float v = 0.f;
-                    for (int p = 0; p < parts; ++p)
-                        v += __uint_as_float(__hip_atomic_load(all + (size_t)p * kRelMaxOutputs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    for (int p0 = 0; p0 < parts; p0 += 8) {
+                        float q[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            q[k] = __uint_as_float(__hip_atomic_load(all + (size_t)min(p0 + k, parts - 1) * kRelMaxOutputs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v += (p0 + k < parts) ? q[k] : 0.f;
+                    }
                     a.dw[(size_t)rel * FF + o] = v;
                 }
                 if (tid == 0) __hip_atomic_store(a.ticket + rel, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
