@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 143                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 144                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "gn_graph_plan_blocked_cols": (_i64, [_p]),
     "gn_graph_plan_build_transpose": (_int, [_p, _p]),
     "gn_graph_aggregate_t_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
+    "gn_xtg_wide_supported": (_int, [_i64, _i64, _i64]),
     "gn_gemm_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _int, _p]),
     "gn_gemm_addend_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _i64, _int, _p]),
     "gn_merge_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p]),
@@ -567,16 +568,28 @@ GN_XTG_TICKET_ZEROED, GN_XTG_JOIN_BATCH = 1, 2
 
 def xtg(x: torch.Tensor, g: torch.Tensor, join_batch=False):
     """x^T g for a tall x [m, k1] and g [m, k2] (weight gradients) on gn_xtg_f32: up to 64 x 32 outputs in one launch; wider
-    products (the 128 x 64 ... 256 x 128 layers of the node-classification models) in tiles of 64 x 32 outputs over column
-    slices of x and g, every tile with a workspace of its own.  `join_batch`: as in `gemm`."""
+    products (the 128 x 64 ... 256 x 128 layers of the node-classification models) as wide products of up to 256 x 128 outputs
+    (a launch + a fold) where the sizes allow, else in tiles of 64 x 32 outputs over column slices of x and g; every block
+    with a workspace of its own.  `join_batch`: as in `gemm`."""
     k1, k2 = x.shape[1], g.shape[1]
     out = torch.empty((k1, k2), dtype=torch.float32, device=x.device)
     if k1 * k2 == 0:
         return out
     if x.shape[0] == 0:
         return out.zero_()
-    tiles = [(c0, min(64, k1 - c0), d0, min(32, k2 - d0)) for c0 in range(0, k1, 64) for d0 in range(0, k2, 32)] \
-        if (k1 > 64 or k2 > 32) else [(0, k1, 0, k2)]
+    if k1 <= 64 and k2 <= 32:
+        tiles = [(0, k1, 0, k2)]
+    else:
+        # blocks of up to 256 x 128 outputs that gn_xtg_f32 takes as ONE wide product (x and g read once); what is left, in
+        # tiles of 64 x 32
+        tiles, lib, m = [], load(), x.shape[0]
+        for c0 in range(0, k1, 256):
+            for d0 in range(0, k2, 128):
+                w1, w2 = min(256, k1 - c0), min(128, k2 - d0)
+                if lib.gn_xtg_wide_supported(m, w1, w2):
+                    tiles.append((c0, w1, d0, w2))
+                else:
+                    tiles.extend((c0 + a, min(64, w1 - a), d0 + b, min(32, w2 - b)) for a in range(0, w1, 64) for b in range(0, w2, 32))
     batched = join_batch and getattr(_batch_tls, 'open', None) is not None
     for t, (c0, w1, d0, w2) in enumerate(tiles):
         need = int(load().gn_xtg_workspace_bytes(w1, w2))

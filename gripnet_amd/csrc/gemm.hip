@@ -876,6 +876,92 @@ __device__ __forceinline__ void xtg_mfma_body(const XtgArgs& a, int bx, int nblo
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
 }
 
+// The same product for WIDE outputs (the 128 x 64 ... 256 x 128 weight gradients of the node-classification layers, over
+// 20,000-50,000 rows).  In tiles of 64 x 32 outputs, one launch each, x and g were read once per tile (307 MB for the 77 MB
+// of a 256 x 128 product) and every tile paid its own fill, LDS reduction and hand-over.  Here a workgroup takes a slice of
+// the rows and ALL TI x TJ tiles: a wave per tile (or 16 / tiles waves per tile, which then split the slice's chunks and add
+// up through LDS in wave order) walks the slice's 16-row chunks with the A operand x[:, 64 ti ..] and the B operand g[:, 32 tj ..]
+// - the waves of a workgroup read the same rows, the L1 serves the repeats - and leaves the slice's sums in `partial`;
+// k_xtg_fold adds the slices in slice order behind it.  fp32 matrix instruction: the sums are fp32 FMA chains; bitwise reproducible.
+template <int TI, int TJ>
+__global__ __launch_bounds__(1024) void k_xtg_wide(XtgArgs a) {
+    extern __shared__ f32x4 wide_part[];                                 // [16 waves][8][64] (when several waves share a tile)
+    constexpr int TILES = TI * TJ, WPT = 16 / TILES;
+    static_assert(TILES >= 2 && 16 % TILES == 0, "2, 4, 8 or 16 tiles");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int tile = wave / WPT, sub = wave % WPT, ti = tile / TJ, tj = tile % TJ;
+    const float* __restrict__ x = a.x + 64 * ti;
+    const float* __restrict__ g = a.g + 32 * tj;
+    const int64_t ld_x = a.ld_x, ld_g = a.ld_g, m = a.m;
+    const int k2 = a.k2;
+    const int chunks = (int)((m + 15) / 16), per = (chunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c0 = (int)blockIdx.x * per, c1 = min(chunks, c0 + per);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&](int ch, float (&av)[4][4], float (&bv)[2][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = min<int64_t>(16 * (int64_t)ch + 4 * q + j, m - 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[t][j] = x[row * ld_x + 16 * t + r];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bv[u][j] = g[row * ld_g + 16 * u + r];
+        }
+    };
+    float av[4][4], bv[2][4];
+    if (c0 + sub < c1) load_chunk(c0 + sub, av, bv);
+    for (int ch = c0 + sub; ch < c1; ch += WPT) {
+        float an[4][4], bn[2][4];
+        load_chunk(ch + WPT < c1 ? ch + WPT : ch, an, bn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool row_ok = 16 * (int64_t)ch + 4 * q + j < m;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float xa = row_ok ? av[t][j] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv[u][j], acc[t][u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[t][j] = an[t][j];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bv[u][j] = bn[u][j];
+        }
+    }
+    // element i of lane l of tile (t, u): row 16 t + 4 (l >> 4) + i, column 16 u + (l & 15) of the wave's 64 x 32 outputs
+    float* __restrict__ mine = a.partial + (size_t)blockIdx.x * a.k1 * k2;
+    if constexpr (WPT == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    mine[(size_t)(64 * ti + 16 * t + 4 * q + i) * k2 + 32 * tj + 16 * u + r] = acc[t][u][i];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) wide_part[(wave * 8 + t * 2 + u) * 64 + lane] = acc[t][u];
+        __syncthreads();
+        for (int o = tid; o < TILES * 8 * 256; o += 1024) {
+            const int tl = o / (8 * 256), rem = o - tl * (8 * 256), tu = rem >> 8, l = (rem & 255) >> 2, i = rem & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPT; ++w) v += wide_part[((tl * WPT + w) * 8 + tu) * 64 + l][i];
+            const int row = 64 * (tl / TJ) + 16 * (tu >> 1) + 4 * (l >> 4) + i, col = 32 * (tl % TJ) + 16 * (tu & 1) + (l & 15);
+            mine[(size_t)row * k2 + col] = v;
+        }
+    }
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(1024) void k_xtg_mfma(XtgArgs a) {
     extern __shared__ f32x4 xtg_part[];                                  // [16 waves][MT * NT][64]
@@ -1193,6 +1279,12 @@ gn_status gn_class_scores_f32(const float* z, int64_t ld_z, int64_t table_rows, 
 }
 
 
+int gn_xtg_wide_supported(int64_t m, int64_t k1, int64_t k2) {
+    if (gn::fast_paths_disabled() || m < 4096 || k1 < 64 || k2 < 32 || k1 % 64 != 0 || k2 % 32 != 0 || k1 > 256 || k2 > 128) return 0;
+    const int64_t tiles = (k1 / 64) * (k2 / 32);
+    return tiles >= 2 && tiles <= 16 && 16 % tiles == 0 ? 1 : 0;
+}
+
 size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2) {
     if (k1 <= 0 || k2 <= 0) return 0;
     return (size_t)kXtgSlices * k1 * k2 * sizeof(float) + 64;           // (+ the ticket of the one-launch kernel)
@@ -1202,12 +1294,33 @@ gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g,
                      int64_t ld_out, void* workspace, size_t workspace_bytes, int flags, void* stream) {
     GN_REQUIRE(m >= 0 && k1 >= 0 && k2 >= 0, "negative size");
     if (k1 == 0 || k2 == 0) return GN_OK;
-    if (k1 * k2 > 4096) return gn::fail(GN_ERR_UNSUPPORTED, "x^T g: %lld x %lld outputs (at most 4096)", (long long)k1, (long long)k2);
+    const bool wide = gn_xtg_wide_supported(m, k1, k2) != 0;
+    if (k1 * k2 > 4096 && !wide)
+        return gn::fail(GN_ERR_UNSUPPORTED, "x^T g: %lld x %lld outputs (at most 4096, or a wide product: gn_xtg_wide_supported)", (long long)k1, (long long)k2);
     GN_REQUIRE(out && ld_out >= k2, "output pointer is null or its leading dimension too small");
     GN_REQUIRE(m == 0 || (x && g && ld_x >= k1 && ld_g >= k2), "operand pointer is null or a leading dimension too small");
     GN_REQUIRE(workspace && workspace_bytes >= gn_xtg_workspace_bytes(k1, k2), "workspace too small: need %zu bytes",
                gn_xtg_workspace_bytes(k1, k2));
     hipStream_t st = gn::as_stream(stream);
+    if (wide) {
+        // all tiles of a row slice in one workgroup, then the fold (two launches whatever the width; never queued in a batch)
+        const int ti = (int)(k1 / 64), tj = (int)(k2 / 32), wpt = 16 / (ti * tj);
+        const int64_t chunks = gn::ceil_div(m, 16);
+        const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kXtgSlices, gn::compute_units()), chunks / (2 * wpt)));
+        const XtgArgs a = {x, ld_x, g, ld_g, m, (int)k1, (int)k2, static_cast<float*>(workspace), nullptr, out, ld_out};
+        const size_t lds = wpt > 1 ? (size_t)16 * 8 * 64 * sizeof(f32x4) : 0;
+#define GN_WIDE_CASE(TI, TJ)                                                                                              \
+        if (ti == TI && tj == TJ) {                                                                                       \
+            if (lds > 64 * 1024) { const gn_status ls = gn::allow_large_lds(reinterpret_cast<const void*>(k_xtg_wide<TI, TJ>), 136 * 1024); if (ls != GN_OK) return ls; } \
+            k_xtg_wide<TI, TJ><<<slices, 1024, lds, st>>>(a);                                                             \
+        }
+        GN_WIDE_CASE(1, 2) GN_WIDE_CASE(2, 1) GN_WIDE_CASE(2, 2) GN_WIDE_CASE(1, 4) GN_WIDE_CASE(4, 1) GN_WIDE_CASE(2, 4) GN_WIDE_CASE(4, 2) GN_WIDE_CASE(4, 4)
+#undef GN_WIDE_CASE
+        GN_LAUNCH_CHECK();
+        k_xtg_fold<<<(unsigned)gn::ceil_div(k1 * k2, 16), 256, 0, st>>>(static_cast<const float*>(workspace), slices, (int)(k1 * k2), (int)k2, out, ld_out);
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     if (m > 0 && k1 <= 64 && k2 <= 32 && (flags & GN_XTG_TICKET_ZEROED) && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0 &&
         !gn::fast_paths_disabled()) {
         const int mt = (int)gn::ceil_div(k1, 16), nt = (int)gn::ceil_div(k2, 16);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 143 /* 0.1.39 */
+#define GN_VERSION 144 /* 0.1.40 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -211,6 +211,11 @@ GN_API gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_
 #define GN_XTG_TICKET_ZEROED 1
 #define GN_XTG_JOIN_BATCH 2      /* the product may leave with the open batch (gn_dense_batch_begin / _end) */
 GN_API size_t gn_xtg_workspace_bytes(int64_t k1, int64_t k2);
+/* 1 when gn_xtg_f32 takes a product of these sizes as ONE wide product (k1 in {64, 128, 256}, k2 in {32, 64, 128}, 2-16 tiles of
+ * 64 x 32, at least 4096 rows: a workgroup per row slice computes every tile, a fold launch adds the slices in slice order; x and g
+ * are read once) - the weight gradients of the 128 x 64 ... 256 x 128 layers of the node-classification models.  Such a product may
+ * have more than 4096 outputs; it is never queued in a dense batch. */
+GN_API int gn_xtg_wide_supported(int64_t m, int64_t k1, int64_t k2);
 GN_API gn_status gn_xtg_f32(const float* x, int64_t ld_x, const float* g, int64_t ld_g, int64_t m, int64_t k1, int64_t k2,
                      float* out, int64_t ld_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
 

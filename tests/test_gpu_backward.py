@@ -944,10 +944,13 @@ def test_class_loss_and_softmax_gradients(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
-@pytest.mark.parametrize("m,k1,k2", [(5000, 128, 64), (3000, 256, 128), (700, 65, 33), (900, 200, 7), (50000, 128, 64), (70001, 64, 32), (21000, 48, 32)])
+@pytest.mark.parametrize("m,k1,k2", [(5000, 128, 64), (3000, 256, 128), (700, 65, 33), (900, 200, 7), (50000, 128, 64), (70001, 64, 32), (21000, 48, 32),
+                                     (50000, 256, 128), (20003, 512, 128), (9000, 64, 64), (9000, 192, 64), (4097, 128, 32), (30000, 256, 32), (8000, 64, 128)])
 def test_wide_weight_gradient_in_tiles(gpu, m, k1, k2):
-    """x^T g wider than one launch of gn_xtg_f32 covers (the 128 x 64 ... 256 x 128 layers of the NC models): tiles of
-    64 x 32 outputs over column slices, alone and inside a dense batch, against float64; the same bits on every call."""
+    """x^T g wider than one launch of gn_xtg_f32 covers (the 128 x 64 ... 256 x 128 layers of the NC models): as WIDE products
+    (a workgroup per row slice computes all 2-16 tiles of 64 x 32 outputs, a fold adds the slices; every tile shape the kernel
+    has, 512 columns as two blocks) where rows and widths allow, else tiles of 64 x 32 outputs over column slices; alone and
+    inside a dense batch, against float64; the same bits on every call."""
     gen = torch.Generator().manual_seed(m + k1)
     x, g = torch.randn(m, k1, generator=gen).to(gpu), torch.randn(m, k2, generator=gen).to(gpu)
     want = x.double().t() @ g.double()
