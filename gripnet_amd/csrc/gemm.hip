@@ -24,6 +24,7 @@ struct GemmArgs {
     int64_t sam, sak;                     // element (row, k) of A at a[row * sam + k * sak]: (lda, 1), or (1, lda) for A given transposed
     int accumulate;                       // c += a b instead of c = a b
     const float* addend; int64_t ld_add;  // (may be null) c = a b + addend: a second gradient of the same tensor, added where the product is stored
+    int c_vec_ok;                         // c (and bias, addend) take 16-byte accesses at column multiples of four
 };
 
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
@@ -323,6 +324,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // TERMS = 3 (default): v = hi + mid + lo, six products (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi): what is dropped is
 //             below 2^-23 of a product, fp32's own rounding - the fp32-faithful mode.
 // TERMS = 2 (GN_GEMM_ARITH_FAST): v = hi + lo, three products, <= 2^-16 per product.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {            // quad_perm exchange inside every quad of lanes
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 template <int TERMS>
 __device__ __forceinline__ void split_terms(float a, float b, uint32_t (&t)[3]) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -376,8 +382,16 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
     auto get_b = [&](int idx, float (&v)[8]) {
         const int l = idx & 63, t = (idx >> 6) % CT, ch = idx / (64 * CT);
         const int col = col0 + 16 * t + (l & 15), kb = 32 * ch + 8 * (l >> 4);
+        if (g.sbk == 1 && (g.sbn & 3) == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0) {
+            // B given transposed: the lane's eight k are 32 contiguous bytes (two 16-byte loads, not eight 4-byte ones at the
+            // lanes' row stride)
+            const f32x4* __restrict__ pb = reinterpret_cast<const f32x4*>(g.b + (int64_t)min(col, g.n - 1) * g.sbn + kb);
+            const f32x4 lo = pb[0], hi = pb[1];
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = g.b[(int64_t)(kb + j) * g.sbk + (int64_t)min(col, g.n - 1) * g.sbn];      // (B as stored or given transposed)
+            for (int j = 0; j < 8; ++j) v[j] = g.b[(int64_t)(kb + j) * g.sbk + (int64_t)min(col, g.n - 1) * g.sbn];      // (B as stored or given transposed)
+        }
         if (col >= g.n) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -413,6 +427,31 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
     };
     auto store_tile = [&](int t0) {
         const int row0 = t0 * 16;
+        if (g.c_vec_ok) {
+            // A lane holds four ROWS of one column; transposed inside its quad of lanes (two DPP exchanges) it holds four
+            // COLUMNS of one row - one 16-byte store (and one 16-byte load of what is accumulated / added) per lane and tile
+            // instead of four 4-byte ones: a 50,000 x 256 output is 51 MB, and as 4-byte pieces its stores were the longest part
+            // of the launch.
+            const int s4 = r & 3, row = row0 + 4 * q + s4;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int col = col0 + 16 * t + (r & ~3);
+                const bool odd = (s4 & 1) != 0, hi = (s4 & 2) != 0;
+                const float v0 = acc[t][0], v1 = acc[t][1], v2 = acc[t][2], v3 = acc[t][3];
+                const float a0 = dpp_f<0xB1>(v1), a1 = dpp_f<0xB1>(v0), a2 = dpp_f<0xB1>(v3), a3 = dpp_f<0xB1>(v2);
+                const float w0 = odd ? a0 : v0, w1 = odd ? v1 : a1, w2 = odd ? a2 : v2, w3 = odd ? v3 : a3;
+                const float b0 = dpp_f<0x4E>(w2), b1 = dpp_f<0x4E>(w3), b2 = dpp_f<0x4E>(w0), b3 = dpp_f<0x4E>(w1);
+                f32x4 v = {hi ? b0 : w0, hi ? b1 : w1, hi ? w2 : b2, hi ? w3 : b3};
+                if (col >= g.n || row >= g.m) continue;
+                if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+                float* cp = g.c + (int64_t)row * g.ldc + col;
+                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
+                if (g.addend) v += *reinterpret_cast<const f32x4*>(g.addend + (int64_t)row * g.ld_add + col);
+                if (g.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<f32x4*>(cp) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const int col = col0 + 16 * t + r;
@@ -1176,6 +1215,8 @@ gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, cons
     g.a_vec_ok = ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
     g.sbk = bt ? 1 : ldb; g.sbn = bt ? ldb : 1; g.accumulate = accumulate ? 1 : 0;
     g.addend = addend; g.ld_add = ld_addend;
+    g.c_vec_ok = (n % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
+                 (!addend || ((ld_addend % 4 == 0) && (reinterpret_cast<uintptr_t>(addend) & 15) == 0)) ? 1 : 0;
     g.sam = at ? 1 : lda; g.sak = at ? lda : 1;
     if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
