@@ -196,6 +196,55 @@ def train_step_entry(dev, steps=20):
             "loss_after": round(losses[-1], 5)}
 
 
+def nc_train_entry(model, data, nodes, labels, steps=10):
+    """us per training step of a node-classification model: a Python loop over the modules (host-bound), and one hipGraph replay."""
+    from gripnet_amd.optim import Adam
+    from gripnet_amd.utils import class_loss
+    opt = Adam(model.parameters(), lr=0.01)
+
+    def step():
+        opt.zero_grad()
+        _, score = model(data, nodes)
+        loss = class_loss(score, labels)
+        loss.backward(one)
+        opt.step()
+        return loss
+
+    one = torch.ones((), dtype=torch.float32, device=nodes.device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):                                     # plans, optimizer state
+            first = float(step().detach())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    eager_us = 1e6 * (time.perf_counter() - t0) / steps
+    out = {"us_per_step_eager": round(eager_us, 1)}
+    try:
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss = step()
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        out["us_per_step"] = round(1e6 * (time.perf_counter() - t0) / steps, 1)
+        out["loss_first_last"] = [round(first, 4), round(float(loss.detach()), 4)]
+        del graph
+    except Exception as exc:                                   # (the eager figure stands; say why the replay does not)
+        out["us_per_step"] = None
+        out["graph_error"] = str(exc)[:200]
+    return out
+
+
 def extra_workloads(dev, budget_s, with_cpu):
     """The other BASELINE.json configs on one GPU, each with the same event timing as the headline and a CPU-oracle time:
     pose2-syn (config 4's graph, unsharded), aminer-syn (config 3), freebase-c-syn (config 5, fp32 storage)."""
@@ -357,6 +406,11 @@ def extra_workloads(dev, budget_s, with_cpu):
                      "dominant_entry_point": {"name": dom, "us_per_call": round(calls[dom], 1),
                                               "algorithmic_bytes_per_call": None if dom_bytes is None else dom_bytes // max(dom_calls, 1),
                                               "frac": None if dom_bytes is None else round(dom_bytes / max(dom_calls, 1) / (calls[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+            if storage == "fp32" and left() > 12:
+                # the model's training step (the loop body of GripNet-aminer.py:120-147 / GripNet-freebase-c.py:146-176: forward, class
+                # loss, backward, Adam - every launch the library's own): eager, and as one hipGraph replay per step
+                with torch.enable_grad():
+                    entry["training_step"] = nc_train_entry(model, data, nodes_dev, data.a_label[nodes_dev].contiguous())
             if with_cpu and storage == "fp32" and left() > 10:
                 d = data_cpu
                 t1 = time.perf_counter()
