@@ -338,6 +338,10 @@ def replay(calls):
 # Test hooks the library reads from the environment at call time (common.h, aggregate.cuh, gcn_blocked.hip): part of every
 # memo key, so that a shortcut recorded under one setting is not replayed under another.
 _ENV_HOOKS = ("GN_DISABLE_FAST", "GN_DISABLE_QUAD", "GN_DISABLE_BLOCKED", "GN_BLOCKED_ANY", "GN_DISABLE_LDS_TABLE")
+# hooks the C side reads that can NOT change what a memoised inference forward launches: the host threads of the plan builders
+# (plans do not depend on them) and the sampler's kernel choice (same draws; no module forward calls the sampler).
+# tests/test_abi.py::test_env_hooks_cover_the_library holds the two lists to the getenv calls of csrc/.
+_ENV_NEUTRAL = ("GN_PLAN_THREADS", "GN_SAMPLER_TASKS")
 _ENV_DATA = getattr(os.environ, "_data", None)
 _ENV_KEYS = tuple(k.encode() for k in _ENV_HOOKS) if isinstance(_ENV_DATA, dict) and all(isinstance(k, bytes) for k in list(_ENV_DATA)[:1]) else None
 

@@ -107,6 +107,24 @@ class HipShardKernels:
         """Scores of my edge range's relations on another edge list of the same length (negative samples)."""
         return self.model.dmt(z, edge_index, self.et, sigmoid=sigmoid)
 
+    def layer_gradient(self, g, out, want_bias):
+        """ReLU mask by the saved output, gm = g / in-degree and the bias gradient: one launch (gn_grad_prologue_f32)."""
+        return self._hip.grad_prologue(g, out, self.in_degree(), True, bool(want_bias))
+
+    def root_gradients(self, g, root, x, dx):
+        """dx += g root^T and droot = x^T g on the library's own products."""
+        dx = self._hip.gemm(g, root, dx.contiguous(), b_transposed=True, accumulate=True)
+        return dx, self._hip.xtg(x, g)
+
+    def shard_loss(self, pos, neg, total_edges, eps):
+        """This rank's share of the loss of GripNet-pose.py:140-142 in one launch each way: link_loss is -mean(log pos) -
+        mean(log(1 - neg)) over the shard's edges; times (shard edges / all edges) it is the shard's share of the means
+        over ALL edges."""
+        from .utils import link_loss
+        if pos.numel() != neg.numel() or pos.numel() == 0:
+            raise ValueError("a shard scores as many negatives as positives, and at least one ({} / {})".format(pos.numel(), neg.numel()))
+        return link_loss(pos, neg, eps) * (pos.numel() / float(total_edges))
+
 
 class ShardedPoseForward:
     """``z, score_of_my_edge_range = fwd()`` on every rank; ``z`` is identical on all ranks."""
@@ -246,24 +264,12 @@ class _ShardedRgcnFn(torch.autograd.Function):
         x, root, out = ctx.saved_tensors
         owner = ctx.owner
         has_bias = ctx.needs_input_grad[4]
-        dbias = None
-        if g.is_cuda:                                                      # ReLU mask, gm = g / deg and the bias gradient: one launch
-            from . import _hip
-            g, gm, dbias = _hip.grad_prologue(g, out, owner.kernels.in_degree(), True, bool(has_bias))
-        else:                                                              # (host tensors: the gloo rehearsal with injected kernels)
-            g = (g * (out > 0).to(g.dtype)).contiguous()                  # ReLU mask by the saved output
-            gm = g / owner.kernels.in_degree().view(-1, 1)
-            dbias = g.sum(dim=0) if has_bias else None
+        g, gm, dbias = owner.kernels.layer_gradient(g, out, has_bias)      # ReLU mask, gm = g / deg, bias gradient
         dxe, dbasis, datt = owner.kernels.edge_gradients(x, gm)
         flat = torch.cat([dxe.reshape(-1), dbasis.reshape(-1), datt.reshape(-1)])
         owner.all_reduce(flat)                                             # the one exchange step of the backward
         a, b = dxe.numel(), dxe.numel() + dbasis.numel()
-        dx = flat[:a].view_as(dxe)
-        if g.is_cuda:                                                      # + g root^T and x^T g on the library's own kernels
-            dx = _hip.gemm(g, root, dx.contiguous(), b_transposed=True, accumulate=True)
-            droot = _hip.xtg(x, g)
-        else:                                                              # (host tensors: the gloo rehearsal with injected kernels)
-            dx, droot = dx + g @ root.t(), x.t() @ g
+        dx, droot = owner.kernels.root_gradients(g, root, x, flat[:a].view_as(dxe))   # + g root^T, x^T g
         return (dx, flat[a:b].view_as(dbasis), flat[b:].view_as(datt), droot, dbias, None)
 
 
@@ -291,14 +297,7 @@ class ShardedPoseTraining(ShardedPoseForward):
         z = _SumGradAcrossRanks.apply(torch.cat([x, out], dim=1), self)
         pos = k.score(z)
         neg = k.score_edges(z, neg_index[:, self.edge_lo:self.edge_hi].contiguous())
-        E = float(self.total_edges)
-        if pos.is_cuda and pos.numel() == neg.numel() and pos.numel() > 0:
-            # this rank's share of the loss in one launch each way: link_loss is -mean(log pos) - mean(log(1 - neg)) over the
-            # shard's edges; times (shard edges / all edges) it is the shard's share of the means over ALL edges
-            from .utils import link_loss
-            local = link_loss(pos, neg, self.EPS) * (pos.numel() / E)
-        else:
-            local = -(torch.log(pos + self.EPS).sum() + torch.log(1 - neg + self.EPS).sum()) / E
+        local = k.shard_loss(pos, neg, self.total_edges, self.EPS)
         dw = k.decoder_weight()
         kept, dw.grad = dw.grad, None                                      # only THIS step's share is exchanged: what
         local.backward()                                                   # earlier steps accumulated is already a sum

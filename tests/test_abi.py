@@ -99,3 +99,29 @@ def test_kernel_register_budgets():
             assert r[".vgpr_count"] + r.get(".agpr_count", 0) <= 128, (name, r)
             narrow = name.startswith(("k_rgcn_pair<1,", "k_rgcn_pair<2,"))
             assert r[".private_segment_fixed_size"] <= (64 if narrow else 160), (name, r)
+
+
+def test_env_hooks_cover_the_library():
+    """A memoised forward (_hip.CallMemo) replays recorded kernel choices; its key carries the library's environment hooks.
+    Every getenv("GN_...") of the C sources must be in _hip._ENV_HOOKS (part of the key) or in _hip._ENV_NEUTRAL (declared
+    unable to change a forward's launches) - a new hook that is in neither fails here instead of replaying stale choices."""
+    found = set()
+    csrc = os.path.join(REPO, "gripnet_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".hpp", ".cuh", ".inc")):
+            found |= set(re.findall(r'getenv\(\s*"(GN_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+    assert found, "no getenv calls found: the pattern is stale"
+    assert found == set(_hip._ENV_HOOKS) | set(_hip._ENV_NEUTRAL), (sorted(found), _hip._ENV_HOOKS, _hip._ENV_NEUTRAL)
+    assert len(_hip.env_stamp()) == len(_hip._ENV_HOOKS)
+
+
+def test_generated_gather_is_current_and_the_generator_does_not_write_by_default():
+    """tools/gen_pair_asm.py without --write only compares (its --help once rewrote the tracked .inc and made every object stale)."""
+    import subprocess
+    import sys
+    inc = os.path.join(REPO, "gripnet_amd", "csrc", "rgcn_pair_asm.inc")
+    before = os.stat(inc).st_mtime_ns
+    for extra in ([], ["--help"]):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_pair_asm.py")] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert os.stat(inc).st_mtime_ns == before

@@ -67,6 +67,17 @@ class OracleShardKernels:
     def score_edges(self, z, edge_index, sigmoid=True):
         return self.orc.distmult(z, edge_index, self.data.train_et[self.lo:self.hi], self.sd["dmt.weight"], sigmoid=sigmoid)
 
+    # the element-wise glue of the sharded training step (the product's kernels do these on the library's launches)
+    def layer_gradient(self, g, out, want_bias):
+        g = (g * (out > 0).to(g.dtype)).contiguous()                   # ReLU mask by the saved output
+        return g, g / self.in_degree().view(-1, 1), (g.sum(dim=0) if want_bias else None)
+
+    def root_gradients(self, g, root, x, dx):
+        return dx + g @ root.t(), x.t() @ g
+
+    def shard_loss(self, pos, neg, total_edges, eps):
+        return -(torch.log(pos + eps).sum() + torch.log(1 - neg + eps).sum()) / float(total_edges)
+
     def parameters(self):
         return list(self.sd.values())
 

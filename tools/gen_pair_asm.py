@@ -20,6 +20,7 @@ without a gap: the tail of a unit requests rows(N), rows(N+1) - the first two bl
 the next unit re-reads its first four words from the window (soff stays on its word 4).
 """
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "gripnet_amd", "csrc", "rgcn_pair_asm.inc")
@@ -120,19 +121,42 @@ def unit(bt):
     return L
 
 
+def render():
+    out = ["// Generated by tools/gen_pair_asm.py - do not edit.  The gather of one unit (see rgcn_pair.hip).\n",
+           "#define GN_PAIR_ASM_CLOBBERS {}\n\n".format(", ".join('"v{}"'.format(RB + i) for i in range(NREGS)))]
+    for bt, name in ((2, "GN_PAIR_UNIT_ASM_B64"), (1, "GN_PAIR_UNIT_ASM_B32")):
+        out.append("#define {} \\\n".format(name))
+        lines = unit(bt)
+        for i, ln in enumerate(lines):
+            sep = "\\n" if ln.endswith(":") else "\\n\\t"
+            out.append('    "{}{}"{}\n'.format(ln, sep, " \\" if i + 1 < len(lines) else ""))
+        out.append("\n")
+    return "".join(out)
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser(description="Generates gripnet_amd/csrc/rgcn_pair_asm.inc.  Without --write nothing is written: "
+                                             "the generated text is compared with the tracked file (exit code 1 if they differ).")
+    ap.add_argument("--write", action="store_true", help="overwrite the tracked .inc (only if the text changed)")
+    ap.add_argument("--stdout", action="store_true", help="print the generated text instead")
+    args = ap.parse_args()
+    text = render()
+    if args.stdout:
+        sys.stdout.write(text)
+        return 0
+    have = open(OUT).read() if os.path.exists(OUT) else None
+    if have == text:
+        print("up to date:", OUT)
+        return 0
+    if not args.write:
+        print("differs from the generated text (run with --write):", OUT)
+        return 1
     with open(OUT, "w") as f:
-        f.write("// Generated by tools/gen_pair_asm.py - do not edit.  The gather of one unit (see rgcn_pair.hip).\n")
-        f.write("#define GN_PAIR_ASM_CLOBBERS {}\n\n".format(", ".join('"v{}"'.format(RB + i) for i in range(NREGS))))
-        for bt, name in ((2, "GN_PAIR_UNIT_ASM_B64"), (1, "GN_PAIR_UNIT_ASM_B32")):
-            f.write("#define {} \\\n".format(name))
-            lines = unit(bt)
-            for i, ln in enumerate(lines):
-                sep = "\\n" if ln.endswith(":") else "\\n\\t"
-                f.write('    "{}{}"{}\n'.format(ln, sep, " \\" if i + 1 < len(lines) else ""))
-            f.write("\n")
+        f.write(text)
     print("wrote", OUT)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
