@@ -22,10 +22,10 @@ GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, G
 GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST = 1, 4                                  # flags of gn_rgcn_forward_f32
 GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}                  # kernel choice (tests, measurements)
-GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH = 1, 2, 4, 8, 16, 32                                     # flags of gn_gemm_f32
+GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 144                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 145                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -531,12 +531,14 @@ def ptr(t):
 # ---- thin typed wrappers ---------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=False, a_rows=None,
          batch=1, stride_a=0, stride_b=0, stride_c=0, m=None, n=None, k=None, lda=None, ldb=None, ldc=None, fast=False,
-         b_transposed=False, accumulate=False, a_transposed=False, join_batch=False, addend=None):
+         b_transposed=False, accumulate=False, a_transposed=False, join_batch=False, addend=None, out_bf16=False):
     """`join_batch`: inside ``with dense_batch(...)`` the product may be queued and leave with the batch (it must not depend
     on another queued product).  `fast`: two-term bf16 splits (<= 2^-16 per product) instead of the default fp32-faithful arithmetic.
     `b_transposed`: b is [n, k] (out = a b^T); `a_transposed`: a is [k, m] (out = a^T b; m <= 64 or n <= 32 only);
     `accumulate`: out += a b; `addend`: an [m, n] fp32 matrix (rows contiguous, any row stride) added to what is stored
-    (gn_gemm_addend_f32) - the other gradient of a tensor with two consumers, see `addend_ok`."""
+    (gn_gemm_addend_f32) - the other gradient of a tensor with two consumers, see `addend_ok`.  `out_bf16`: `out` is a bf16
+    table, every value rounded once where it is stored (GN_GEMM_OUT_BF16; raises GripNetHipError with GN_ERR_UNSUPPORTED for
+    shapes outside the tall-skinny kernel)."""
     if a_transposed:
         m = a.shape[1] if m is None else m
         k = a.shape[0] if k is None else k
@@ -547,7 +549,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias=None, relu=Fa
     if join_batch:                                           # a queued product reads its operands when the batch leaves
         _batch_tls.open.keep.extend((a, b, out, bias, a_rows, addend))
     flags = ((GN_GEMM_RELU if relu else 0) | (GN_GEMM_ARITH_FAST if fast else 0) | (GN_GEMM_B_TRANSPOSED if b_transposed else 0) |
-             (GN_GEMM_ACCUMULATE if accumulate else 0) | (GN_GEMM_A_TRANSPOSED if a_transposed else 0) | (GN_GEMM_JOIN_BATCH if join_batch else 0))
+             (GN_GEMM_ACCUMULATE if accumulate else 0) | (GN_GEMM_A_TRANSPOSED if a_transposed else 0) | (GN_GEMM_JOIN_BATCH if join_batch else 0) |
+             (GN_GEMM_OUT_BF16 if out_bf16 else 0))
     head = (ptr(a), ld(a) if lda is None else lda, stride_a, ptr(a_rows), a.shape[0],
             ptr(b), ld(b) if ldb is None else ldb, stride_b,
             ptr(out), ld(out) if ldc is None else ldc, stride_c, m, n, k, batch, ptr(bias))
@@ -750,9 +753,13 @@ class GraphPlan:
 
     def aggregate_bf16(self, xw: torch.Tensor, bias, relu: bool, out: torch.Tensor, side=None):
         """out = act(A_norm bf16(xw) + b): the gathered table is rounded to bf16 once and read at half the bytes;
-        sums, bias, activation and `out` are fp32 (gn_cast_bf16 + gn_graph_aggregate_bf16)."""
-        table = torch.empty(xw.shape, dtype=torch.bfloat16, device=xw.device)
-        _call("gn_cast_bf16", ptr(xw), ld(xw), ptr(table), ld(table), xw.shape[0], xw.shape[1], stream_ptr(xw.device))
+        sums, bias, activation and `out` are fp32.  `xw` is the fp32 product (rounded here by gn_cast_bf16) or already the
+        bf16 table (written by the product's own store, GN_GEMM_OUT_BF16: no extra pass)."""
+        if xw.dtype == torch.bfloat16:
+            table = xw
+        else:
+            table = torch.empty(xw.shape, dtype=torch.bfloat16, device=xw.device)
+            _call("gn_cast_bf16", ptr(xw), ld(xw), ptr(table), ld(table), xw.shape[0], xw.shape[1], stream_ptr(xw.device))
         sc = side_copy(side)
         _call("gn_graph_aggregate_bf16", self._h, ptr(table), ld(table), xw.shape[1], ptr(bias), int(bool(relu)),
               ptr(out), ld(out), _ref(sc), stream_ptr(xw.device), tag="gn_graph_aggregate_bf16[{}]".format(self.kind))

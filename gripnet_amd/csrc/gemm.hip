@@ -25,6 +25,7 @@ struct GemmArgs {
     int accumulate;                       // c += a b instead of c = a b
     const float* addend; int64_t ld_add;  // (may be null) c = a b + addend: a second gradient of the same tensor, added where the product is stored
     int c_vec_ok;                         // c (and bias, addend) take 16-byte accesses at column multiples of four
+    int out_bf16 = 0;                     // GN_GEMM_OUT_BF16: c is a bf16 table (ldc in bf16 elements), each value rounded to nearest even once
 };
 
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
@@ -444,6 +445,17 @@ __global__ __launch_bounds__(kSplitThreads) void k_gemm_split_lds(GemmArgs g, in
                 f32x4 v = {hi ? b0 : w0, hi ? b1 : w1, hi ? w2 : b2, hi ? w3 : b3};
                 if (col >= g.n || row >= g.m) continue;
                 if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+                if (g.out_bf16) {                                           // the table a bf16-storage layer gathers from, written here
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));   // (gn_cast_bf16's rounding: nearest even, once)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    if (g.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                    const f32x2 lo2 = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                    const u32x2 pk = {__builtin_bit_cast(uint32_t, __builtin_convertvector(lo2, bf16x2)),
+                                      __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2))};
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(g.c) + (int64_t)row * g.ldc + col) = pk;
+                    continue;
+                }
                 float* cp = g.c + (int64_t)row * g.ldc + col;
                 if (g.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
                 if (g.addend) v += *reinterpret_cast<const f32x4*>(g.addend + (int64_t)row * g.ld_add + col);
@@ -1218,6 +1230,15 @@ gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, cons
     g.c_vec_ok = (n % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                  (!addend || ((ld_addend % 4 == 0) && (reinterpret_cast<uintptr_t>(addend) & 15) == 0)) ? 1 : 0;
     g.sam = at ? 1 : lda; g.sak = at ? lda : 1;
+    if (flags & GN_GEMM_OUT_BF16) {
+        // c is a bf16 table: only the tall-skinny split kernel stores it (what a bf16-storage layer of the node-classification
+        // models needs); anything else is GN_ERR_UNSUPPORTED and the caller rounds a fp32 product with gn_cast_bf16
+        const bool split_path = batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled();
+        const bool vec = (n % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 7) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+        if (!split_path || !vec || accumulate || addend || at)
+            return gn::fail(GN_ERR_UNSUPPORTED, "GN_GEMM_OUT_BF16: a tall-skinny product (m >= 2048, k %% 32 == 0) with n %% 4 == 0, 8-byte aligned rows, no accumulate / addend");
+        g.out_bf16 = 1; g.c_vec_ok = 1;
+    }
     if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
         if (batch_open && (flags & GN_GEMM_JOIN_BATCH)) {         // between gn_dense_batch_begin / _end: leaves with the others

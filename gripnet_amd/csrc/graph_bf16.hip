@@ -110,6 +110,71 @@ __global__ __launch_bounds__(256) void k_aggregate_bf16(AggBf16Args a) {
     }
 }
 
+// The many-short-rows form (k_aggregate_group of aggregate.cuh on a bf16 table): LPE lanes own a row - 64 / LPE rows per wave side
+// by side, one row per group, no grid-stride loop - with 16 bytes = 8 bf16 features per lane; the group reads its (col, coef)
+// pairs LPE at a time with one coalesced load and requests U neighbour rows before it consumes the first.  fp32 sums in
+// neighbour order (bitwise reproducible).  Round 6: the wave-per-row kernel above paid the row's latency chain per wave and made
+// bf16 storage SLOWER than fp32 (freebase-c-syn 414.7 against 381.7 us per forward).
+template <int LPE, int U>
+__global__ __launch_bounds__(256) void k_aggregate_group_bf16(AggBf16Args a) {
+    constexpr int S = gn::kWave / LPE;
+    const int lane = threadIdx.x & 63, slot = lane / LPE, j = lane % LPE;
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int fcol = 8 * j;
+    const bool active = fcol < a.features;
+    if (a.side.dst) {
+        const int64_t total = a.side.rows * a.side.cols;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / a.side.cols, c = t - i * a.side.cols;
+            const float v = a.side.src[i * a.side.ld_src + c];
+            a.side.dst[i * a.side.ld_dst + c] = a.side.mode ? fabsf(v) : v;
+        }
+    }
+    const int row = wave * S + slot;
+    const bool live = row < a.rows;
+    const int begin = live ? a.rowptr[row] : 0, end = live ? a.rowptr[row + 1] : 0;
+    const uint16_t* __restrict__ tab = a.table + fcol;
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int base = begin; __any(base < end); base += LPE) {
+        const int mine = base + j;
+        const uint32_t c = mine < end ? a.col[mine] : 0u;
+        const float v = mine < end ? (a.coef ? a.coef[mine] : 1.0f) : 0.f;
+        const int cnt = min(LPE, end - base);                  // of this group (<= 0 once its row is done)
+        for (int t0 = 0; __any(t0 < cnt); t0 += U) {
+            u32x4 r[U];
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t cc = (uint32_t)__shfl((int)c, t0 + u, LPE);
+                vv[u] = __shfl(v, t0 + u, LPE);
+                r[u] = (u32x4){0u, 0u, 0u, 0u};
+                if (t0 + u < cnt && active) r[u] = *reinterpret_cast<const u32x4*>(tab + (int64_t)cc * a.ld_table);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[2 * k] += vv[u] * __uint_as_float(r[u][k] << 16);
+                    acc[2 * k + 1] += vv[u] * __uint_as_float(r[u][k] & 0xffff0000u);
+                }
+        }
+    }
+    if (live && active) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float val = acc[t];
+            if (a.bias) val += a.bias[fcol + t];
+            if (a.relu) val = fmaxf(val, 0.f);
+            acc[t] = val;
+        }
+        float* dst = a.out + (int64_t)row * a.ld_out + fcol;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -143,6 +208,20 @@ gn_status gn_graph_aggregate_bf16(const gn_graph_plan* plan, const uint16_t* tab
     while (lpe < num_features / 8 && lpe < gn::kWave) lpe <<= 1;
     const int grid = (int)std::min<int64_t>(gn::ceil_div(a.rows, 4), GN_AGG_GRID);
     hipStream_t st = gn::as_stream(stream);
+    if (lpe <= 32 && plan->nnz < GN_AGG_GROUP_MAX_DEG * plan->rows && plan->rows >= 4096 && !gn::fast_paths_disabled()) {
+        // many short rows (the node-classification graphs): lane groups own rows, eight row gathers in flight per lane
+        const int ggrid = (int)gn::ceil_div((int64_t)a.rows * lpe, 256);
+        switch (lpe) {
+            case 1: k_aggregate_group_bf16<1, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 2: k_aggregate_group_bf16<2, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 4: k_aggregate_group_bf16<4, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 8: k_aggregate_group_bf16<8, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            case 16: k_aggregate_group_bf16<16, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+            default: k_aggregate_group_bf16<32, GN_AGG_GROUP_U><<<ggrid, 256, 0, st>>>(a); break;
+        }
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     switch (lpe) {
         case 1: k_aggregate_bf16<1><<<grid, 256, 0, st>>>(a); break;
         case 2: k_aggregate_bf16<2><<<grid, 256, 0, st>>>(a); break;

@@ -102,8 +102,16 @@ class myGCN(Module):
         if out is None:
             out = torch.empty((n_out, self.out_channels), dtype=torch.float32, device=x.device)
         if self.table_storage == "bf16" and self.out_channels % 8 == 0 and _hip.ld(out) % 4 == 0 and out.data_ptr() % 16 == 0:
-            xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
-            _hip.gemm(x, self.weight, xw)                                        # layers.py:73, fp32
+            # layers.py:73 in fp32 arithmetic; the product's own store rounds the table to bf16 (round 6: no gn_cast_bf16 pass),
+            # shapes outside the tall-skinny kernel leave a fp32 product that aggregate_bf16 rounds
+            xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.bfloat16, device=x.device)
+            try:
+                _hip.gemm(x, self.weight, xw, out_bf16=True, fast=self.arithmetic == "fast")
+            except _hip.GripNetHipError as err:
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+                xw = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
+                _hip.gemm(x, self.weight, xw, fast=self.arithmetic == "fast")
             return plan.aggregate_bf16(xw, self.bias, relu, out, side)
         if self.weight.is_contiguous() and (plan.blocked_ok(self.in_channels, self.out_channels, x) or
                                             plan.transform_ok(self.in_channels, self.out_channels, x)):

@@ -107,6 +107,28 @@ def make_pose(name: str = "tiny", seed: int = 7, dd_scale: int = 1, **override) 
     )
 
 
+def add_pose_test_split(data: Data, seed: int = 13, ratio: int = 9) -> Data:
+    """Adds ``test_idx / test_et / test_range`` to a synthetic PoSE graph: per relation one held-out pair for every `ratio`
+    training pairs (the reference splits every relation's pairs 90 / 10, gripnet/utils.py:168-198 with p = 0.9), in the same
+    layout as the training list (both directions, type-sorted, cumulative ranges).  What test() of GripNet-pose.py:180-201 scores."""
+    g = torch.Generator().manual_seed(seed)
+    n_d = int(data.n_d_node)
+    sizes = ((data.train_range[:, 1] - data.train_range[:, 0]) // 2).tolist()
+    blocks = []
+    for s_r in sizes:
+        k = max(1, int(s_r) // ratio)
+        e = torch.randint(0, n_d, (2, k), generator=g)
+        e = e[:, e[0] != e[1]]
+        if e.shape[1] == 0:                           # (a relation keeps at least one test pair)
+            e = torch.tensor([[0], [1 % n_d]])
+        blocks.append(to_bidirection(e))
+    data.test_idx = torch.cat(blocks, dim=1).long()
+    data.test_range = get_range_list(blocks)
+    data.test_et = torch.repeat_interleave(torch.arange(len(blocks), dtype=torch.long),
+                                           data.test_range[:, 1] - data.test_range[:, 0])
+    return data
+
+
 def pose_edges_aggregated(data: Data) -> int:
     """Numerator of the headline metric: A = 2(E_gg + n_g) + E_gd + E_dd."""
     return (2 * (int(data.gg_edge_index.shape[1]) + int(data.n_g_node))

@@ -695,9 +695,12 @@ def test_aminer_syn_vs_oracle(gpu, arithmetic):
     close(pred, ref["score"], TOL)
 
 
-def test_freebase_c_syn_vs_oracle(gpu):
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_freebase_c_syn_vs_oracle(gpu, storage):
     """freebase-c/d-style model (three supervertices, two external layers in `add` mode merged with the
-    target embeddings, GripNet-freebase-c.py:102-105,150-165) at the same scale."""
+    target embeddings, GripNet-freebase-c.py:102-105,150-165) at the same scale; fp32, and with bf16 storage of the gathered
+    tables (BASELINE.json config 5 as written; the reference has no reduced precision: tolerance as for freebase-a/b - one bf16
+    rounding of every gathered element, 2^-7 of the largest activation on z, 5e-3 on the class probabilities)."""
     from gripnet_amd.synth import make_nc
     data = make_nc("aminer-syn")
     torch.manual_seed(1111)
@@ -708,10 +711,16 @@ def test_freebase_c_syn_vs_oracle(gpu):
                                  data.qq_edge_weight, data.qa_edge_idx, sd["aa_embeddings"], data.aa_edge_idx,
                                  data.aa_edge_weight, nodes, data.n_a_node)
     model = model.to(gpu)
+    if storage == "bf16":
+        assert len(gripnet_amd.utils.set_table_storage(model, "bf16")) == 7
     with torch.no_grad():
         z, pred = model(make_nc("aminer-syn").to(gpu), nodes.to(gpu))
-    close(z, ref["z"], TOL)
-    close(pred, ref["score"], TOL)
+    if storage == "fp32":
+        close(z, ref["z"], TOL)
+        close(pred, ref["score"], TOL)
+    else:
+        close(z, ref["z"], 2.0 ** -7 * float(ref["z"].abs().max()))
+        close(pred, ref["score"], 5e-3)
 
 
 @pytest.mark.parametrize("storage", ["fp32", "bf16"])
@@ -1071,6 +1080,63 @@ def test_gcn_bf16_table_is_exact_against_the_rounded_table(gpu, fout):
     close(y16, ref16)
     scale = float(y32.abs().max())
     assert float((y16 - y32).abs().max()) <= 2.0 ** -8 * max(scale, 1.0)          # stated tolerance of the bf16 variant
+
+
+@needs_fast_paths
+@pytest.mark.parametrize("n,fin,fout", [(4096, 64, 32), (9000, 128, 128), (5003, 256, 128), (20000, 32, 24)])
+def test_product_stores_the_bf16_table_itself(gpu, n, fin, fout):
+    """GN_GEMM_OUT_BF16 (round 6): the tall-skinny product rounds its output to bf16 where it stores it - bit for bit the
+    table gn_cast_bf16 makes of the fp32 product (same arithmetic, nearest-even, once), without the extra pass; with bias and
+    ReLU; shapes outside the tall-skinny kernel are refused with GN_ERR_UNSUPPORTED (the caller then casts)."""
+    gen = torch.Generator().manual_seed(n + fout)
+    x = torch.randn(n, fin, generator=gen).to(gpu)
+    w = (torch.randn(fin, fout, generator=gen) / fin ** 0.5).to(gpu)
+    b = torch.randn(fout, generator=gen).to(gpu)
+    for bias, relu in ((None, False), (b, True)):
+        c32 = torch.empty(n, fout, device=gpu)
+        _hip.gemm(x, w, c32, bias=bias, relu=relu)
+        want = c32.to(torch.bfloat16)                                  # nearest even, as gn_cast_bf16 (whose pass needs fout % 8 == 0)
+        if fout % 8 == 0:
+            cast = torch.empty(n, fout, dtype=torch.bfloat16, device=gpu)
+            _hip._call("gn_cast_bf16", c32.data_ptr(), _hip.ld(c32), cast.data_ptr(), _hip.ld(cast), n, fout, _hip.stream_ptr(gpu))
+            assert torch.equal(cast.view(torch.int16), want.view(torch.int16))
+        got = torch.full((n, fout), float("nan"), dtype=torch.bfloat16, device=gpu)
+        _hip.gemm(x, w, got, bias=bias, relu=relu, out_bf16=True)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    small = torch.empty(100, fout, dtype=torch.bfloat16, device=gpu)
+    with pytest.raises(_hip.GripNetHipError) as err:
+        _hip.gemm(x[:100], w, small, out_bf16=True)
+    assert err.value.status == _hip.GN_ERR_UNSUPPORTED
+
+
+@needs_fast_paths
+@pytest.mark.parametrize("fout", [8, 32, 128, 256])
+def test_bf16_group_gather_on_many_short_rows(gpu, fout):
+    """k_aggregate_group_bf16 (round 6: lane groups own rows, as the fp32 layers of the node-classification graphs): the layer
+    with bf16 storage on a graph of many short rows equals the fp32 oracle run on the rounded table; hubs, isolated rows
+    and weights included; and it agrees with the wave-per-row kernel (GN_DISABLE_FAST=1) to fp32 summation order."""
+    gen = torch.Generator().manual_seed(fout)
+    n, fin, e = 6000, 64, 40000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[1, :300] = 17                                                  # one hub row
+    ei = ei[:, ei[1] % 11 != 3]                                       # isolated destination rows
+    w = torch.rand(ei.shape[1], generator=gen) + 0.5
+    x = torch.randn(n, fin, generator=gen)
+    torch.manual_seed(2000 + fout)
+    conv = gripnet_amd.myGCN(fin, fout, cached=True).to(gpu)
+    conv.bias.data.normal_()
+    gripnet_amd.utils.set_table_storage(conv, "bf16")
+    with torch.no_grad():
+        y16 = conv(x.to(gpu), ei.to(gpu), w.to(gpu), _relu=True)
+        table = torch.empty(n, fout, dtype=torch.bfloat16, device=gpu)
+        _hip.gemm(x.to(gpu), conv.weight.detach(), table, out_bf16=True)
+    wt, b = conv.weight.detach().cpu(), conv.bias.detach().cpu()
+    ei2, norm = orc.gcn_norm(ei, n, w)
+    xw16 = table.float().cpu()
+    ref16 = torch.relu(torch.zeros(n, fout).index_add_(0, ei2[1], norm.view(-1, 1) * xw16.index_select(0, ei2[0])) + b)
+    close(y16, ref16)
+    ref32 = torch.relu(torch.zeros(n, fout).index_add_(0, ei2[1], norm.view(-1, 1) * (x @ wt).index_select(0, ei2[0])) + b)
+    assert float((y16.cpu() - ref32).abs().max()) <= 2.0 ** -7 * max(float(ref32.abs().max()), 1.0)
 
 
 def test_nc_pipeline_with_bf16_tables(gpu, golden):
