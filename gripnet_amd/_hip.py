@@ -19,13 +19,13 @@ _lib = None
 _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
-GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST = 1, 4                                  # flags of gn_rgcn_forward_f32
+GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST, GN_RGCN_PAIR_SUMS_ONLY, GN_RGCN_PAIR_SUMS_READY = 1, 4, 16, 32                                  # flags of gn_rgcn_forward_f32
 GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 145                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 146                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -34,6 +34,7 @@ SIGNATURES = {
     "gn_version": (_int, []),
     "gn_last_error": (C.c_char_p, []),
     "gn_time_next_launch": (_int, [_p, _p]),
+    "gn_stream_order": (_int, [_p, _p]),
     "gn_time_launch_pending": (_int, []),
     "gn_gcn_plan_create": (_int, [_p, _p, _p, _i64, _i64, _int, _p, C.POINTER(_p)]),
     "gn_bipartite_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
@@ -799,6 +800,7 @@ class RgcnPlan:
         self.num_nodes, self.num_relations, self.num_edges = int(num_nodes), int(rl.shape[0]), e
         self.edge_lo, self.edge_hi = lo, hi
         self._ws = None
+        self._sums, self._sums_stream = None, None            # the pair sums of the split launches (start_pair_sums)
         self._edge_index, self._range_list, self._grad, self._wgrad = ei, rl, None, None
 
     def grad_plans(self):
@@ -863,10 +865,21 @@ class RgcnPlan:
         code = int(load().gn_rgcn_forward_path(self._h, fin, fout, bases, self.mode_flags(fast, path)))
         return {v: k for k, v in RGCN_PATHS.items()}.get(code, "?")
 
-    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, fast=False, path="auto", x_planes=None):
+    def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, fast=False, path="auto", x_planes=None,
+                pair_sums=False):
         """`x_planes`: SplitPlanes of x left by its producer (the destination-major kernel then skips its own split of x;
-        the other kernels ignore them)."""
+        the other kernels ignore them).  `pair_sums`: the sums of this step are on their way (start_pair_sums): the launch is
+        ordered behind them and contracts them (GN_RGCN_PAIR_SUMS_READY)."""
         mode = self.mode_flags(fast, path)
+        if pair_sums:
+            sc = side_copy(side)
+            flags = (GN_RGCN_PARTIAL if partial else 0) | mode | GN_RGCN_PAIR_SUMS_READY
+            _call("gn_stream_order", self._sums_stream, stream_ptr(x.device))
+            _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
+                  ptr(root), ptr(bias), basis.shape[2], int(bool(relu)), flags,
+                  ptr(out), ld(out), _ref(sc), x_planes.buf.data_ptr(), ptr(self._sums), self._sums.numel(),
+                  stream_ptr(x.device))
+            return out
         ws, need = self._workspace(x.shape[1], basis.shape[2], basis.shape[0], mode)
         sc = side_copy(side)
         flags = (GN_RGCN_PARTIAL if partial else 0) | mode
@@ -875,6 +888,28 @@ class RgcnPlan:
               ptr(out), ld(out), _ref(sc), None if x_planes is None else x_planes.buf.data_ptr(), ptr(ws), need,
               stream_ptr(x.device))
         return out
+
+    def pair_sums_supported(self, x, basis, x_planes, fast=False, path="auto"):
+        """Can this layer run as two launches (the x-independent pair sums, then the contraction)?"""
+        if x_planes is None or fast or path not in ("auto", "pair"):
+            return False
+        return self.path(x.shape[1], basis.shape[2], basis.shape[0], False, path) == "pair"
+
+    def start_pair_sums(self, att, fin, fout, bases, stream):
+        """The x-INDEPENDENT half of the layer on `stream` (a torch.cuda.Stream; GN_RGCN_PAIR_SUMS_ONLY): reads `att` and the
+        plan only.  Ordered behind what the current stream has been given so far (att may just have been written there);
+        `forward(..., pair_sums=True)` orders itself behind it.  Every step: the sums are never kept across steps."""
+        flags = GN_RGCN_PAIR_SUMS_ONLY
+        need = int(load().gn_rgcn_workspace_bytes(self._h, fin, fout, bases, flags))
+        if self._sums is None or self._sums.numel() < need:
+            self._sums = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
+        main = stream_ptr(att.device)
+        side = stream.cuda_stream
+        _call("gn_stream_order", main, side)
+        _call("gn_rgcn_forward_f32", self._h, None, fin, fin, None, ptr(att), bases, None, None, fout, 0, flags,
+              None, fout, None, None, ptr(self._sums), need, side, tag="gn_rgcn_forward_f32[pair sums]")
+        self._sums_stream = side
+        return self._sums
 
     def finalize(self, summed, x, root, bias, relu, out, side=None):
         sc = side_copy(side)

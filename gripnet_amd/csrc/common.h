@@ -193,6 +193,7 @@ struct gn_rgcn_plan {
     gn::DevBuf<uint32_t> pair_wave_desc;  // [groups * 16] first descriptor of every wave
     gn::DevBuf<int32_t> pair_wg_dst;      // [groups][4] destination rows of a workgroup (-1: none)
     int pair_groups = 0, pair_d = 0, pair_chunks = 0;
+    int64_t pair_unit_slots = 0;          // unit descriptors (the pair-sum buffer of the split launches has one 4 KB slot each at 32 bases)
     int64_t pair_blocks = 0;
     int pair_ok = 0;
 };

@@ -51,6 +51,24 @@ int gn_time_launch_pending(void) {
     const gn::LaunchEvents e = gn::take_launch_events();
     return (e.start || e.stop) ? 1 : 0;
 }
+
+// `later` waits for what `earlier` has been given so far.  A wait takes the event's state at the time of the call, so the events
+// are reused round-robin (a ring per device and thread; 64 orderings can be in flight before an event is recorded again - and
+// re-recording an event a stream still waits on is harmless: the wait was bound to the earlier record).
+gn_status gn_stream_order(void* earlier_stream, void* later_stream) {
+    if (earlier_stream == later_stream) return GN_OK;
+    constexpr int kRing = 64, kDevices = 16;
+    static thread_local hipEvent_t ring[kDevices][kRing] = {};
+    static thread_local unsigned next[kDevices] = {};
+    int dev = 0;
+    GN_HIP(hipGetDevice(&dev));
+    GN_REQUIRE(dev >= 0 && dev < kDevices, "device index %d out of range", dev);
+    hipEvent_t& ev = ring[dev][next[dev]++ % kRing];
+    if (!ev) GN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GN_HIP(hipEventRecord(ev, gn::as_stream(earlier_stream)));
+    GN_HIP(hipStreamWaitEvent(gn::as_stream(later_stream), ev, 0));
+    return GN_OK;
+}
 }
 
 namespace {

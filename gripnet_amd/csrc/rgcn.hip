@@ -23,7 +23,8 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
-                               const void* x_planes, hipStream_t st);
+                               const void* x_planes, hipStream_t st, int mode, void* pair_sums);
+size_t gn_rgcn_pair_sums_bytes(const gn_rgcn_plan* plan, int64_t bases);
 
 bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed);
 gn_status gn_rgcn_fast_finalize(const gn_rgcn_plan* plan, const float* summed, const float* x, int64_t ld_x, int64_t fin,
@@ -98,8 +99,8 @@ __global__ void k_rgcn_finalize(const float* __restrict__ summed, int64_t ld_s, 
 extern "C" {
 
 // Scratch of ONE kernel for these shapes: what a call that takes `path` writes.
-static size_t path_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int path) {
-    if (path == GN_RGCN_PATH_PAIR) return 0;
+static size_t path_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int path, int flags = 0) {
+    if (path == GN_RGCN_PATH_PAIR) return (flags & (GN_RGCN_PAIR_SUMS_ONLY | GN_RGCN_PAIR_SUMS_READY)) ? gn_rgcn_pair_sums_bytes(plan, bases) : 0;
     if (path == GN_RGCN_PATH_LDS) return gn_rgcn_fast_workspace_bytes(plan, fin, fout, bases);
     if (path == GN_RGCN_PATH_GENERAL) return gn_rgcn_basis_workspace_bytes(plan, fin, fout, bases);
     return general_layout(plan, fin, fout).total;
@@ -109,7 +110,7 @@ size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t fin, int64_t fo
     if (!plan || fin <= 0 || fout <= 0 || bases <= 0) return 0;
     // of the kernel a forward with these flags takes when its `basis` is 16-byte aligned (torch allocations are); a
     // call that ends up on another kernel - an unaligned basis - is refused with the size it needs, never under-served
-    return path_workspace_bytes(plan, fin, fout, bases, select_path(plan, fin, fout, bases, flags, nullptr));
+    return path_workspace_bytes(plan, fin, fout, bases, select_path(plan, fin, fout, bases, flags, nullptr), flags);
 }
 
 int gn_rgcn_forward_path(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases, int flags) {
@@ -127,13 +128,28 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     GN_REQUIRE(fin > 0 && fout > 0 && bases > 0, "feature / basis counts must be positive");
     const int64_t N = plan->num_nodes, R = plan->num_relations;
     if (N == 0) return GN_OK;
+    const int split = flags & (GN_RGCN_PAIR_SUMS_ONLY | GN_RGCN_PAIR_SUMS_READY);
+    GN_REQUIRE(split != (GN_RGCN_PAIR_SUMS_ONLY | GN_RGCN_PAIR_SUMS_READY), "GN_RGCN_PAIR_SUMS_ONLY and _READY exclude each other");
+    if (split == GN_RGCN_PAIR_SUMS_ONLY) {
+        // the x-independent half on its own: att and the plan are all it reads (x, basis, root, out may be NULL)
+        GN_REQUIRE(att != nullptr, "att is null");
+        if (select_path(plan, fin, fout, bases, flags, nullptr) != GN_RGCN_PATH_PAIR)
+            return gn::fail(GN_ERR_UNSUPPORTED, "pair sums: these shapes do not take the destination-major kernel");
+        const size_t need = gn_rgcn_pair_sums_bytes(plan, bases);
+        GN_REQUIRE(workspace && workspace_bytes >= need, "workspace too small: the pair sums need %zu bytes, got %zu", need, workspace_bytes);
+        gn_side_copy none = {nullptr, 0, nullptr, 0, 0, 0, 0};
+        return gn_rgcn_pair_forward(plan, nullptr, fin, fin, nullptr, att, bases, nullptr, nullptr, fout, 0, 0, 0, nullptr, fout, none,
+                                    nullptr, gn::as_stream(stream), 1, workspace);
+    }
     GN_REQUIRE(x && basis && att && out && (partial || root), "operand pointer is null");
     GN_REQUIRE(ld_x >= fin && ld_out >= fout, "leading dimension smaller than the row length");
     // the workspace is checked against the kernel THIS call takes (a forced general or table path, or a basis pointer the
     // destination-major kernel cannot use, needs its own scratch whatever gn_rgcn_workspace_bytes said for the
     // default choice)
     const int path = select_path(plan, fin, fout, bases, flags, basis);
-    const size_t need = path_workspace_bytes(plan, fin, fout, bases, path);
+    if (split && (path != GN_RGCN_PATH_PAIR || !x_planes || (flags & GN_RGCN_ARITH_FAST)))
+        return gn::fail(GN_ERR_UNSUPPORTED, "GN_RGCN_PAIR_SUMS_READY: the destination-major kernel with x as split planes, default arithmetic");
+    const size_t need = path_workspace_bytes(plan, fin, fout, bases, path, flags);
     GN_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "workspace too small: this call needs %zu bytes, got %zu",
                need, workspace_bytes);
     hipStream_t st = gn::as_stream(stream);
@@ -143,7 +159,7 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
 
     if (path == GN_RGCN_PATH_PAIR)
         return gn_rgcn_pair_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
-                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, x_planes, st);
+                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, x_planes, st, split ? 2 : 0, split ? workspace : nullptr);
     if (path == GN_RGCN_PATH_LDS)
         return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
                                     out, ld_out, sc, workspace, workspace_bytes, st);

@@ -64,7 +64,14 @@ struct PairArgs {
     const int32_t* wg_dst;
     int n, R, B, fout, chunks, relu, partial, att_dma;
     gn_side_copy side;
+    float* psum = nullptr;               // MODE 1 writes, MODE 2 reads: the pair sums of every unit, [unit slot][4][64 lanes] 16-byte words
 };
+
+// MODE of k_rgcn_pair (round 6): 0 = the whole layer in one launch; 1 = only the x-INDEPENDENT half - the gather of the att rows
+// into the (destination, source) pair sums P, stored per unit exactly as the lanes hold them; 2 = only the x-dependent half - P
+// read back by the same lanes of the same unit, contracted with x, epilogue.  1 then 2 give the bits of 0 (same sums, same
+// products, same order): the split exists so that 1 can run on a side stream beside the layers that produce x.
+constexpr int kModeFused = 0, kModeSums = 1, kModeContract = 2;
 
 #ifdef GN_STAMPS
 __device__ unsigned long long g_pair_stamps[2][256 * kWaves][12];
@@ -327,7 +334,7 @@ __device__ __forceinline__ void contract_planes(const typename Acc<BT>::type (&p
     }
 }
 
-template <int NT, int BT, int TERMS, bool XP>
+template <int NT, int BT, int TERMS, bool XP, int MODE = kModeFused>
 __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_set) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     typedef typename Acc<BT>::type acc_t;
@@ -370,14 +377,16 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     w.lane4 = (uint32_t)lane * 4u;
     w.soff = 256u;                                                             // a unit reads its first four words itself (behind soff)
     w.sdma = 3u * 512u;                                                        // the window starts with blocks 0..23
-    if (lane < 32) {
+    if (MODE != kModeContract && lane < 32) {
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(w.sbase) + lane;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)q * 32),
                                              (__attribute__((address_space(3))) void*)(uintptr_t)(w.ring_base + q * 512u), 16, 0, 0);
     }
-    if (a.att_dma) {
+    if constexpr (MODE == kModeContract) {
+        // (no att table, no stream window: this launch reads the pair sums)
+    } else if (a.att_dma) {
         // rows of 32 bases are the LDS rows: 1 KB per wave instruction straight into LDS
         const int pieces = a.R / 8;
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(a.att);
@@ -403,8 +412,8 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #pragma unroll
     for (int d = 0; d < kMaxD; ++d) nd += my_dst[d] >= 0 ? 1 : 0;
     const uint32_t ranges = (uint32_t)my_dst[3];                               // first wave of rows 1 and 2 (eight bits each)
-    if (tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
-    if (a.side.dst) {                                                          // concat slot 0, by the whole grid: its round
+    if (MODE != kModeContract && tid < 64) reinterpret_cast<float*>(lds)[a.R * 32 + tid] = 0.f;        // the two zero rows padded slots name
+    if (MODE != kModeSums && a.side.dst) {                                                          // concat slot 0, by the whole grid: its round
         const int64_t total = a.side.rows * a.side.cols;                       // trip hides behind the table fill (it was the kernel's last act)
         for (int64_t t = (int64_t)g * kThreads + tid; t < total; t += (int64_t)gridDim.x * kThreads) {
             const int64_t i = t / a.side.cols, cc = t - i * a.side.cols;
@@ -429,6 +438,14 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) acc[jm][jn] = (f32x4)(0.f);
 
+    f32x4 pnext[2 * BT];                                                       // MODE 2: the pair sums of the next unit, in flight
+    if constexpr (MODE == kModeContract) {
+        if (n_units) {
+            const f32x4* __restrict__ p0 = reinterpret_cast<const f32x4*>(a.psum) + (size_t)(desc_b >> 7) * (2 * BT * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < 2 * BT; ++q) pnext[q] = p0[q * 64];
+        }
+    }
 #pragma unroll 1
     for (uint32_t u = 0; u < n_units; ++u) {
         if (u && (u & 1u) == 0u) {                                             // next page: requested a page (two units) ago
@@ -447,12 +464,41 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         // (lane constants of the planes path, recomputed from lane * 4 where they are used: registers are what is short)
         const uint32_t idsel = ((lane4 >> 2) & 0x30u) + 32u + (uint32_t)o * 4u;      // dword 8 + 4 kg (+ the unit's half of the page)
         const uint32_t lane_b = (lane4 & 0x3cu) * (uint32_t)((3 * NT + 1) / 2);      // c * bytes of a cell
-        if constexpr (XP) load_planes_hm<NT>(xp, descv, idsel, lane_b, hm); else load_chunk<NT>(a, descv, o, kg, c, raw);
         acc_t p[8];
+        // the unit's slot in the pair-sum buffer: its descriptor's index (unique per unit); a lane's 8 BT floats as 16-byte words
+        // [word][lane]: a wave instruction moves 1 KB of consecutive bytes
+        constexpr int PW = 2 * BT;                                                   // 16-byte words per lane and unit
+        f32x4* __restrict__ pslot = reinterpret_cast<f32x4*>(a.psum) + ((size_t)(desc_b >> 7) + u) * (PW * 64) + lane;
+        if constexpr (MODE == kModeSums) {
+            gather_unit<BT>(w, c03, c47, p);
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                if constexpr (BT == 2) pslot[q * 64] = (f32x4){p[2 * q][0], p[2 * q][1], p[2 * q + 1][0], p[2 * q + 1][1]};
+                else pslot[q * 64] = (f32x4){p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]};
+            }
+            continue;
+        }
+        if constexpr (MODE == kModeContract) {
+            // this unit's sums were requested a unit ago; the next unit's are requested behind this unit's x cells (requests return
+            // in order: the cells must not wait behind sums that are not needed yet)
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                const f32x4 v = pnext[q];
+                if constexpr (BT == 2) { p[2 * q] = (f32x2){v[0], v[1]}; p[2 * q + 1] = (f32x2){v[2], v[3]}; }
+                else { p[4 * q] = v[0]; p[4 * q + 1] = v[1]; p[4 * q + 2] = v[2]; p[4 * q + 3] = v[3]; }
+            }
+        }
+        if constexpr (XP) load_planes_hm<NT>(xp, descv, idsel, lane_b, hm); else load_chunk<NT>(a, descv, o, kg, c, raw);
 #ifdef GN_STAMPS
         const unsigned long long cg0 = __builtin_amdgcn_s_memtime();
         cyc_x += cg0 - cx0;
 #endif
+        if constexpr (MODE == kModeContract) {
+            if (u + 1 < n_units) {
+#pragma unroll
+                for (int q = 0; q < PW; ++q) pnext[q] = pslot[PW * 64 + q * 64];
+            }
+        } else
         gather_unit<BT>(w, c03, c47, p);
 #ifdef GN_STAMPS
         const unsigned long long cg1 = __builtin_amdgcn_s_memtime();
@@ -473,6 +519,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                // window refills retire
+    if constexpr (MODE == kModeSums) return;                                   // (no epilogue: the sums are in memory)
 #ifdef GN_STAMPS
     const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -718,9 +765,26 @@ int bits_for(int64_t n) {
 
 bool pair_disabled() { return gn::fast_paths_disabled(); }     // (a kernel is chosen by flag, GN_RGCN_PATH_*; GN_DISABLE_FAST=1 turns every fast path off)
 
+template <int NT, int BT, int TERMS, int MODE>
+gn_status launch_pair_mode(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st) {
+    constexpr bool XP = MODE == kModeContract;                  // (the sums' own launch reads no x at all; one instantiation per BT)
+    gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS, XP, MODE>), kLdsBytes);
+    if (s != GN_OK) return s;
+    const gn::LaunchEvents ev = gn::take_launch_events();
+    if (ev.start || ev.stop) hipExtLaunchKernelGGL((k_rgcn_pair<NT, BT, TERMS, XP, MODE>), dim3(plan->pair_groups), dim3(kThreads), kLdsBytes, st, ev.start, ev.stop, 0, a, 0);
+    else k_rgcn_pair<NT, BT, TERMS, XP, MODE><<<plan->pair_groups, kThreads, kLdsBytes, st>>>(a, 0);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 template <int NT, int BT, int TERMS>
-gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st) {
+gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t st, int mode = kModeFused) {
     static int stamp = 0;
+    if (mode == kModeSums) return launch_pair_mode<1, BT, 3, kModeSums>(plan, a, st);
+    if (mode == kModeContract) {
+        if constexpr (TERMS == 3) { if (a.xp) return launch_pair_mode<NT, BT, 3, kModeContract>(plan, a, st); }
+        return gn::fail(GN_ERR_UNSUPPORTED, "the pair sums are contracted with x given as split planes, on three-term splits");
+    }
     if (a.xp) {
         gn_status s = gn::allow_large_lds(reinterpret_cast<const void*>(k_rgcn_pair<NT, BT, TERMS, true>), kLdsBytes);
         if (s != GN_OK) return s;
@@ -739,16 +803,16 @@ gn_status launch_pair(const gn_rgcn_plan* plan, const PairArgs& a, hipStream_t s
 }
 
 template <int TERMS>
-gn_status dispatch_pair(const gn_rgcn_plan* plan, const PairArgs& a, int nt, int bt, hipStream_t st) {
+gn_status dispatch_pair(const gn_rgcn_plan* plan, const PairArgs& a, int nt, int bt, hipStream_t st, int mode = kModeFused) {
     switch (nt * 2 + (bt - 1)) {
-        case 2: return launch_pair<1, 1, TERMS>(plan, a, st);
-        case 3: return launch_pair<1, 2, TERMS>(plan, a, st);
-        case 4: return launch_pair<2, 1, TERMS>(plan, a, st);
-        case 5: return launch_pair<2, 2, TERMS>(plan, a, st);
-        case 6: return launch_pair<3, 1, TERMS>(plan, a, st);
-        case 7: return launch_pair<3, 2, TERMS>(plan, a, st);
-        case 8: return launch_pair<4, 1, TERMS>(plan, a, st);
-        case 9: return launch_pair<4, 2, TERMS>(plan, a, st);
+        case 2: return launch_pair<1, 1, TERMS>(plan, a, st, mode);
+        case 3: return launch_pair<1, 2, TERMS>(plan, a, st, mode);
+        case 4: return launch_pair<2, 1, TERMS>(plan, a, st, mode);
+        case 5: return launch_pair<2, 2, TERMS>(plan, a, st, mode);
+        case 6: return launch_pair<3, 1, TERMS>(plan, a, st, mode);
+        case 7: return launch_pair<3, 2, TERMS>(plan, a, st, mode);
+        case 8: return launch_pair<4, 1, TERMS>(plan, a, st, mode);
+        case 9: return launch_pair<4, 2, TERMS>(plan, a, st, mode);
     }
     return gn::fail(GN_ERR_UNSUPPORTED, "no destination-major relational kernel for these widths");
 }
@@ -846,6 +910,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     GN_HIP(hipMemcpyAsync(plan->pair_wg_dst.p, wg_dst.data(), wg_dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipStreamSynchronize(st));
     plan->pair_groups = G;
+    plan->pair_unit_slots = (int64_t)desc.size() / 32 + 2;      // descriptors (one per unit; a wave's last page may be half empty)
     plan->pair_d = D;
     plan->pair_chunks = chunks;
     plan->pair_blocks = (int64_t)(total / 16);
@@ -880,11 +945,18 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
     return need <= kLdsBytes && nt * bt <= 6 && per <= (nt <= 2 ? 16 : 12);   // (rows of basis a thread holds in registers)
 }
 
+size_t gn_rgcn_pair_sums_bytes(const gn_rgcn_plan* plan, int64_t bases) {
+    if (!plan || !plan->pair_ok) return 0;
+    return (size_t)plan->pair_unit_slots * 64 * 16 * (size_t)(2 * ((bases + 15) / 16));
+}
+
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
-                               const void* x_planes, hipStream_t st) {
+                               const void* x_planes, hipStream_t st, int mode, void* pair_sums) {
     PairArgs a;
+    a.psum = static_cast<float*>(pair_sums);
+    GN_REQUIRE(mode == kModeFused || (pair_sums && (reinterpret_cast<uintptr_t>(pair_sums) & 15) == 0), "the pair sums need a 16-byte aligned buffer");
     a.xp = static_cast<const unsigned char*>(x_planes);
     GN_REQUIRE(ld_x < (1ll << 21), "x rows more than 2^21 floats apart are not supported by the destination-major kernel");
     a.x = x; a.ld_x = ld_x; a.att = att; a.basis = basis; a.root = root; a.bias = bias;
@@ -898,5 +970,6 @@ gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t
     a.att_dma = bases == 32 && (reinterpret_cast<uintptr_t>(att) & 15) == 0;
     a.side = side;
     const int nt = (int)(fin / 16), bt = (int)((bases + 15) / 16);
-    return fast_arith ? dispatch_pair<2>(plan, a, nt, bt, st) : dispatch_pair<3>(plan, a, nt, bt, st);
+    if (mode != kModeFused && fast_arith) return gn::fail(GN_ERR_UNSUPPORTED, "the split launches run the default arithmetic");
+    return fast_arith ? dispatch_pair<2>(plan, a, nt, bt, st) : dispatch_pair<3>(plan, a, nt, bt, st, mode);
 }

@@ -198,6 +198,32 @@ class myRGCN(Module):
             self._plan_key = (edge_index, range_list, key)
         return self._plan
 
+    def start_pair_sums(self, edge_index, range_list, num_nodes):
+        """OPTIONAL, once per step and before the layers that produce this layer's input: starts the x-INDEPENDENT half of
+        the layer - the att rows of the edges of every (destination, source) pair, summed (rgcn_pair.hip; W_r is never
+        formed, layers.py:172-173 becomes these sums) - on the device's side stream, so that it runs beside the gene and
+        external layers instead of in front of this layer's contraction.  The next inference `forward` on the same graph
+        then only contracts the sums with x (same bits as the one-launch form).  The sums are recomputed by every call -
+        nothing is kept across steps.  Returns False (and does nothing) where the split does not apply: another kernel
+        than the destination-major one, widths whose x does not travel as split planes, arithmetic "fast", training."""
+        _hip.require_gpu(edge_index, self.att)
+        self._sums_pending = None
+        if torch.is_grad_enabled() and recording(self.basis, self.att, self.root, self.bias):
+            return False
+        if self.in_channels % 16 != 0 or self._fast() or self.kernel not in ("auto", "pair"):
+            return False
+        plan = self.plan_for(edge_index, range_list, num_nodes)
+        if plan.path(self.in_channels, self.out_channels, self.num_bases, False, self.kernel) != "pair":
+            return False
+        plan.start_pair_sums(self.att.detach(), self.in_channels, self.out_channels, self.num_bases, _hip.side_stream(edge_index.device))
+        self._sums_pending = plan
+        return True
+
+    def _take_pair_sums(self, plan, planes):
+        """Are this step's pair sums on their way for `plan`?  (Consumes the note start_pair_sums left.)"""
+        pend, self._sums_pending = self.__dict__.get("_sums_pending"), None
+        return pend is not None and pend is plan and planes is not None and not self._fast()
+
     def forward(self, x, edge_index, edge_type, range_list, *, _out=None, _relu=False, _side=None, _pass=False):
         # edge_type is accepted and unused, as in the reference (the relation of an edge is the
         # range_list row that contains it, layers.py:171-186)
@@ -218,7 +244,7 @@ class myRGCN(Module):
                                                         device=x.device)
         planes = _hip.SplitPlanes.of(x, self.in_channels // 16) if self.in_channels % 16 == 0 else None
         return plan.forward(x, self.basis, self.att, self.root, self.bias, _relu, out, side=_side, fast=self._fast(),
-                            path=self.kernel, x_planes=planes)
+                            path=self.kernel, x_planes=planes, pair_sums=self._take_pair_sums(plan, planes))
 
     def __repr__(self):
         return "{}({}, {}, num_relations={})".format(self.__class__.__name__, self.in_channels,
@@ -293,7 +319,7 @@ class homoGraph(Module):
                  id(edge_weight), 0 if edge_weight is None else edge_weight._version,
                  id(range_list), getattr(range_list, "_version", 0), if_catout, id(planes),
                  tuple([(id(c._plan) if self.multi_relational else id(c.cached_result), c.arithmetic,
-                         c.kernel if self.multi_relational else c.table_storage) +
+                         c.kernel if self.multi_relational else c.table_storage, c.__dict__.get("_sums_pending") is not None) +
                         tuple([0 if p is None else p.data_ptr() for p in c._parameters.values()]) for c in convs]),
                  _hip.launch_context(x.device), _hip.env_stamp())
         memo = self.__dict__.get("_memo")
@@ -303,6 +329,9 @@ class homoGraph(Module):
         hit = memo.get(key)
         if hit is not None:
             _hip.replay(hit[0])
+            if self.multi_relational:
+                for c in convs:                                  # (the replayed calls consumed this step's pair sums)
+                    c._sums_pending = None
             return out
         run = lambda: self._infer(x, homo_edge_index, edge_weight, edge_type, range_list, if_catout, widths, out)
         if not memo.second_sighting(guard):

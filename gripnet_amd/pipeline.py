@@ -32,7 +32,14 @@ class PoseModel(Module):
         self.dd = homoGraph(dd_nhids, multi_relational=True, n_rela=n_dd_edge_type, n_base=n_base)  # pose.py:97
         self.dmt = multiRelaInnerProductDecoder(sum(dd_nhids), n_dd_edge_type)                 # pose.py:98
 
+    # True: every inference step starts the relational layer's x-independent half (the pair sums of its att rows) on the side
+    # stream before the gene layers (myRGCN.start_pair_sums) and the layer itself only contracts them.  Measured in round 6
+    # (profiles/r06_pair_sums.md); the default is what measured faster.
+    split_relational = False
+
     def encode(self, data):
+        if self.split_relational and not torch.is_grad_enabled():
+            self.dd.conv_list[0].start_pair_sums(data.train_idx, data.train_range, int(data.n_d_node))
         z = self.gg(None, data.gg_edge_index, edge_weight=data.edge_weight, if_catout=True)    # pose.py:117-119
         z = self.gd(z, data.gd_edge_index, mod="cat", if_relu=True)                            # pose.py:120
         return self.dd(z, data.train_idx, edge_type=data.train_et, range_list=data.train_range,
@@ -271,6 +278,8 @@ class PoseStages:
         return self._decode()
 
     def _step_eager(self):
+        if self.model.split_relational and not torch.is_grad_enabled():
+            self.conv.start_pair_sums(self.data.train_idx, self.data.train_range, int(self.data.n_d_node))
         self.x = self._genes_eager()
         self._drugs_eager()
         return self.z, self._decode_eager()

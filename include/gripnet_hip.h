@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 145 /* 0.1.41 */
+#define GN_VERSION 146 /* 0.1.42 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -270,6 +270,11 @@ GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
  * stack - a tenth of the PoSE forward.  gn_time_launch_pending: 1 when the events are still waiting (the call in
  * between took a kernel that does not carry them: time it with event records instead); clears them. */
 GN_API gn_status gn_time_next_launch(void* start_event, void* stop_event);
+
+/* Stream ordering as an entry point (so that a recorded call sequence can carry it): what is given to `later_stream` after
+ * this call starts only when everything given to `earlier_stream` before this call has finished (one hipEventRecord +
+ * hipStreamWaitEvent on an event the library owns; no host synchronisation). */
+GN_API gn_status gn_stream_order(void* earlier_stream, void* later_stream);
 GN_API int gn_time_launch_pending(void);
 
 /* Bytes of caller-provided scratch a gn_rgcn_forward_f32 call with these shapes and flags needs: none on the
@@ -281,6 +286,16 @@ GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_featu
 #define GN_RGCN_PARTIAL 1        /* flags of gn_rgcn_forward_f32 */
 #define GN_RGCN_ARITH_FAST 4     /* dense products on two-term bf16 splits (<= 2^-16 relative per product) instead of the
                                   * default fp32-faithful arithmetic (three-term splits / the fp32 matrix instruction) */
+/* The layer as TWO launches (destination-major kernel, default arithmetic, x given as split planes; round 6).  The per-edge work
+ * of the layer - the att rows of the edges of every (destination, source) pair summed: P_i[s,:] = sum_{e: s -> i} att[r(e),:] -
+ * does not depend on x.  GN_RGCN_PAIR_SUMS_ONLY: only that half, written to `workspace` (gn_rgcn_workspace_bytes with this
+ * flag; ~55 MB on PoSE-0); reads `att` and the plan only (x, basis, root, out may be NULL): it can run on another stream
+ * while the layers that produce x still run.  GN_RGCN_PAIR_SUMS_READY: `workspace` holds the sums of THIS step (the caller
+ * orders the two calls, e.g. gn_stream_order); the launch reads them back, contracts with x and finishes the layer - the
+ * bits of the one-launch form.  The reference recomputes W_r from att every forward (layers.py:172-173): so must the sums
+ * be - every step, never kept across steps.  GN_ERR_UNSUPPORTED where the destination-major kernel does not apply. */
+#define GN_RGCN_PAIR_SUMS_ONLY 16
+#define GN_RGCN_PAIR_SUMS_READY 32
 /* Kernel choice, for tests and measurements (0 = the library decides; a kernel that does not cover the shapes is not
  * forced): (GN_RGCN_PATH_x << GN_RGCN_PATH_SHIFT) in flags.  gn_rgcn_forward_path tells which one a call would take. */
 #define GN_RGCN_PATH_SHIFT 8

@@ -82,7 +82,9 @@ def test_kernel_register_budgets():
     res = kernel_resources(_hip.library_path())
     assert len(res) > 50, "no kernels found in the gfx950 code objects"
     # the kernels of the headline step: no scratch at all
-    strict = ["k_rgcn_pair<3, 2, 3, true>", "k_rgcn_pair<3, 2, 3, false>", "k_rgcn_pair<3, 2, 2, false>", "k_distmult_class<5, 3>",
+    # (k_rgcn_pair's last argument: 0 = the whole layer, 1 = the pair sums only, 2 = their contraction - round 6's two-launch form)
+    strict = ["k_rgcn_pair<3, 2, 3, true, 0>", "k_rgcn_pair<3, 2, 3, false, 0>", "k_rgcn_pair<3, 2, 2, false, 0>",
+              "k_rgcn_pair<1, 2, 3, false, 1>", "k_rgcn_pair<3, 2, 3, true, 2>", "k_distmult_class<5, 3>",
               "k_distmult_class<3, 3>", "k_distmult_class<2, 2>", "k_col_gather<2>", "k_col_gather<1>", "k_col_transform<32, 1, 2>",
               "k_col_transform<16, 1, 2>"]
     for name in strict:

@@ -409,6 +409,86 @@ def test_rgcn_lds_resident_shapes(gpu, n, fin, bases, path):
 
 
 @needs_fast_paths
+@pytest.mark.parametrize("n,fin,bases", [(645, 48, 32), (300, 16, 5), (520, 32, 16), (700, 64, 8), (90, 48, 20)])
+def test_relational_layer_as_two_launches_gives_the_same_bits(gpu, n, fin, bases):
+    """Round 6: GN_RGCN_PAIR_SUMS_ONLY (the x-independent half - the att rows of every (destination, source) pair's edges summed -
+    on the side stream) + GN_RGCN_PAIR_SUMS_READY (the contraction with x, ordered behind it by gn_stream_order) = the bits of
+    the one-launch layer; the sums follow att (recomputed by every start_pair_sums, never kept); a note that was not consumed
+    by the next forward is dropped by the next start; arithmetic "fast", another kernel and training refuse the split."""
+    gen = torch.Generator().manual_seed(n * 5 + fin)
+    torch.manual_seed(n + fin + bases)
+    sizes = [3000, 0, 40, 900, 1, 600]
+    blocks = [torch.randint(0, max(1, n - n // 9), (2, s), generator=gen) for s in sizes]
+    rei = torch.cat(blocks, dim=1).to(gpu)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen).to(gpu)
+    rg = gripnet_amd.myRGCN(fin, 32, len(sizes), bases, False, bias=True).to(gpu)
+    rg.bias.data.normal_()
+    for prm in rg.parameters():
+        prm.requires_grad_(False)
+    planes = _hip.SplitPlanes(n, fin // 16, gpu).fill_from(x)
+    planes.tag(x)
+    with torch.no_grad():
+        y_one = rg(x, rei, None, rl, _relu=True)
+        assert rg.start_pair_sums(rei, rl, n) is True
+        y_two = rg(x, rei, None, rl, _relu=True)
+        assert torch.equal(y_one, y_two)
+        assert rg.__dict__.get("_sums_pending") is None                  # consumed
+        # the sums are this step's: att changed in place -> both forms follow, and still agree bit for bit
+        rg.att.data.mul_(1.5)
+        y_one2 = rg(x, rei, None, rl, _relu=True)
+        assert not torch.equal(y_one2, y_one)
+        assert rg.start_pair_sums(rei, rl, n)
+        assert torch.equal(rg(x, rei, None, rl, _relu=True), y_one2)
+        # garbage in the buffer must show (the second launch really reads it) ...
+        assert rg.start_pair_sums(rei, rl, n)
+        torch.cuda.synchronize()
+        rg._plan._sums.zero_()
+        assert not torch.equal(rg(x, rei, None, rl, _relu=True), y_one2)
+        # ... a forward without a start in front of it is the one-launch layer again
+        assert torch.equal(rg(x, rei, None, rl, _relu=True), y_one2)
+        # what the split does not cover refuses it (and the layer stays one launch)
+        rg.arithmetic = "fast"
+        assert rg.start_pair_sums(rei, rl, n) is False
+        rg.arithmetic = "fp32"
+        rg.kernel = "general"
+        assert rg.start_pair_sums(rei, rl, n) is False
+        rg.kernel = "auto"
+    sd = {k: v.detach().cpu().double() for k, v in rg.state_dict().items()}
+    ref = torch.relu(orc.rgcn_forward(x.cpu().double(), rei.cpu(), rl, sd["basis"], sd["att"], sd["root"], sd.get("bias")))
+    close(y_one2, ref.float(), TIGHT)
+    for prm in rg.parameters():
+        prm.requires_grad_(True)
+    assert rg.start_pair_sums(rei, rl, n) is False                       # training: the autograd path keeps the one-launch layer
+
+
+@needs_fast_paths
+def test_pose_forward_with_the_split_relational_layer(gpu):
+    """PoseModel.split_relational: the whole forward with the pair sums started in front of the gene layers - eager modules,
+    their memoised replays and the recorded step - gives the bits of the default forward, step after step."""
+    from gripnet_amd.pipeline import PoseStages
+    data = make_pose("small", n_d=300, e_dd_dir=60000).to(gpu)
+    torch.manual_seed(1111)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    with torch.no_grad():
+        z0, s0 = model(data)
+        z0, s0 = z0.clone(), s0.clone()
+        model.split_relational = True
+        for _ in range(4):                                               # first sighting, recording, replays
+            z, s = model(data)
+            assert torch.equal(z, z0) and torch.equal(s, s0)
+        rec = PoseStages(model, data, recorded=True)
+        names = [c[3] or c[2] for c in rec._whole.calls]
+        assert "gn_rgcn_forward_f32[pair sums]" in names and names.count("gn_stream_order") == 2
+        for _ in range(3):
+            z, s = rec.step()
+            assert torch.equal(z, z0) and torch.equal(s, s0)
+        model.split_relational = False
+        z, s = model(data)
+        assert torch.equal(z, z0) and torch.equal(s, s0)
+
+
+@needs_fast_paths
 @pytest.mark.parametrize("n,fin,bases,arith", [(645, 48, 32, "fp32"), (300, 16, 5, "fp32"), (520, 32, 16, "fp32"),
                                                (700, 64, 8, "fp32"), (645, 48, 32, "fast"), (90, 48, 20, "fp32")])
 def test_rgcn_takes_x_as_split_planes(gpu, n, fin, bases, arith):
