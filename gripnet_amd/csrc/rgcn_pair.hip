@@ -493,13 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         const unsigned long long cg0 = __builtin_amdgcn_s_memtime();
         cyc_x += cg0 - cx0;
 #endif
-        if constexpr (MODE == kModeContract) {
-            if (u + 1 < n_units) {
-#pragma unroll
-                for (int q = 0; q < PW; ++q) pnext[q] = pslot[PW * 64 + q * 64];
-            }
-        } else
-        gather_unit<BT>(w, c03, c47, p);
+        if constexpr (MODE != kModeContract) gather_unit<BT>(w, c03, c47, p);
 #ifdef GN_STAMPS
         const unsigned long long cg1 = __builtin_amdgcn_s_memtime();
         cyc_gather += cg1 - cg0;
@@ -507,6 +501,16 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
         if constexpr (XP) {
             XLo<NT> lo;
             if constexpr (TERMS == 3) load_planes_lo<NT>(xp, descv, idsel, lane_b, lo);
+            if constexpr (MODE == kModeContract) {
+                // the next unit's sums: requested BEHIND this unit's last x cells - requests return in order, and the products that
+                // consume the cells must not wait for sums that are needed a unit later
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < n_units) {
+#pragma unroll
+                    for (int q = 0; q < PW; ++q) pnext[q] = pslot[PW * 64 + q * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             contract_planes<NT, BT, TERMS>(p, hm, lo, acc);
         } else {
             XFrag<NT> xf;

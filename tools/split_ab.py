@@ -51,4 +51,55 @@ with torch.no_grad():
             for _ in range(10):
                 st.step()
         out["us_per_call_" + name] = {k: round(1e3 * tot / calls, 2) for k, (calls, tot) in kt.summary().items()}
+    # ---- the three launches on their own: back-to-back on ONE stream, events around 20 of them ----
+    conv = model.dd.conv_list[0]
+    plan = conv._plan
+    x = fused.x
+    x = x.clone()
+    planes = _hip.SplitPlanes(x.shape[0], conv.in_channels // 16, dev).fill_from(x)
+    planes.tag(x)
+    zbuf = torch.empty((data.n_d_node, 80), device=dev)
+    cur = torch.cuda.current_stream()
+
+    def evtime(fn, n=20):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return round(1e3 * a.elapsed_time(b) / n, 2)
+
+    args = (x, conv.basis, conv.att, conv.root, conv.bias, True, zbuf[:, 48:])
+    out["us_alone"] = {
+        "one launch": evtime(lambda: plan.forward(*args, x_planes=planes)),
+        "pair sums": evtime(lambda: plan.start_pair_sums(conv.att.detach(), 48, 32, 32, cur)),
+        "contraction": evtime(lambda: plan.forward(*args, x_planes=planes, pair_sums=True)),
+    }
+    out["pair_sums_bytes"] = int(plan._sums.numel())
+    # ---- the gene + external chain alone, and with the pair sums running beside it on the side stream ----
+    side = _hip.side_stream(dev)
+
+    def genes():
+        fused._genes_eager()
+
+    def genes_with_sums():
+        plan.start_pair_sums(conv.att.detach(), 48, 32, 32, side)
+        fused._genes_eager()
+        _hip._call("gn_stream_order", side.cuda_stream, _hip.stream_ptr(dev))
+
+    def wall(fn, n=200):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round(1e6 * (time.perf_counter() - t) / n, 2)
+
+    out["us_gene_chain"] = {"alone": wall(genes), "with the pair sums beside it (joined at its end)": wall(genes_with_sums), "alone again": wall(genes)}
 print(json.dumps(out, indent=1))
