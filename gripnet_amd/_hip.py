@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 146                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 147                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -109,6 +109,10 @@ SIGNATURES = {
     "gn_link_loss_workspace_bytes": (_sz, []),
     "gn_link_loss_forward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _sz, _p]),
     "gn_link_loss_backward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),
+    "gn_link_metrics_plan_create": (_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_link_metrics_plan_destroy": (None, [_p]),
+    "gn_link_metrics_plan_workspace_bytes": (_sz, [_p]),
+    "gn_link_metrics_planned_f32": (_int, [_p, _p, _p, _p, _p, _sz, _p]),
     "gn_link_metrics_workspace_bytes": (_sz, [_i64, _i64]),
     "gn_link_metrics_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
 }
@@ -1250,20 +1254,63 @@ class NegativeSampler:
             _lib.gn_negative_sampler_destroy(h)
 
 
+class MetricsPlan:
+    """Owner of a gn_link_metrics_plan handle: the segments of one range list (what relation_metrics needs besides the scores)."""
+
+    def __init__(self, range_list, device):
+        rl = torch.as_tensor(range_list).to("cpu", torch.int64).contiguous().view(-1, 2)
+        self.R = int(rl.shape[0])
+        self.E = int(rl[-1, 1]) if self.R else 0
+        self.device = torch.device(device)
+        h = _p()
+        with torch.cuda.device(self.device):
+            check(load().gn_link_metrics_plan_create(rl.data_ptr(), self.R, self.E, stream_ptr(self.device), C.byref(h)))
+        self._h = h
+        self.workspace_bytes = int(load().gn_link_metrics_plan_workspace_bytes(h))
+        self._ws = None
+
+    def workspace(self):
+        if self._ws is None:
+            self._ws = torch.empty((max(self.workspace_bytes, 1),), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gn_link_metrics_plan_destroy(h)
+
+
+_metric_plans = []          # (range_list object, _version, device, MetricsPlan) of the last few range lists
+
+
+def metrics_plan(range_list, device):
+    """The MetricsPlan of a range list, kept while the same tensor (unmodified) keeps coming: an epoch loop's train / test ranges."""
+    ver = getattr(range_list, "_version", None)
+    dev = torch.device(device)
+    for rl, v, d, plan in _metric_plans:
+        if rl is range_list and v == ver and d == dev:
+            return plan
+    plan = MetricsPlan(range_list, dev)
+    if ver is not None:                                  # (a list / array has no version to watch: not kept)
+        _metric_plans.insert(0, (range_list, ver, dev, plan))
+        del _metric_plans[4:]
+    return plan
+
+
 def link_metrics(pos_score, neg_score, range_list):
     """(auprc, auroc, ap), each a float64 [R] tensor on the GPU: scikit-learn's three link-prediction
-    metrics for every relation block at once (reference: one sklearn call per relation and epoch)."""
+    metrics for every relation block at once (reference: one sklearn call per relation and epoch).  Asynchronous."""
     require_gpu(pos_score, neg_score)
     pos = pos_score.detach().to(torch.float32).contiguous()
     neg = neg_score.detach().to(torch.float32).contiguous()
     if pos.numel() != neg.numel():
         raise ValueError("positive and negative score lists differ in length")
-    rl = torch.as_tensor(range_list).to("cpu", torch.int64).contiguous().view(-1, 2)
-    R, E = int(rl.shape[0]), int(pos.numel())
-    out = torch.empty((3, R), dtype=torch.float64, device=pos.device)
-    need = int(load().gn_link_metrics_workspace_bytes(R, E))
-    ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=pos.device)
-    _call("gn_link_metrics_f32", ptr(pos), ptr(neg), rl.data_ptr(), R, E, ptr(out), ptr(ws), need, stream_ptr(pos.device))
+    plan = metrics_plan(range_list, pos.device)
+    if plan.E != int(pos.numel()):
+        raise ValueError("range_list covers {} edges, {} scores given".format(plan.E, int(pos.numel())))
+    out = torch.empty((3, plan.R), dtype=torch.float64, device=pos.device)
+    ws = plan.workspace()
+    _call("gn_link_metrics_planned_f32", plan._h, ptr(pos), ptr(neg), ptr(out), ptr(ws), ws.numel(), stream_ptr(pos.device))
     return out[0], out[1], out[2]
 
 

@@ -1,33 +1,40 @@
 // Per-relation link-prediction metrics on the device.
 //
-// After every epoch the reference computes, for each of the R relations, AUPRC / AUROC / AP of that
-// relation's positive and negative scores with scikit-learn on the host: R device -> host copies and R
-// sklearn calls per epoch (GripNet-pose.py:148-160,188-199; gripnet/utils.py:28-35).  Here one pass does
-// all relations:
-//   keys (relation << 32 | descending-order bits of the score) of the 2E scores, labels as values,
-//   one radix sort; a global inclusive scan of the labels gives the true-positive count at every rank
-//   (false positives = rank - TP); an exclusive max-scan gives, at every rank, the end of the previous
-//   group of tied scores; every group end then contributes the trapezoid / step terms of the three
-//   curves (the definitions scikit-learn uses: roc_auc_score, average_precision_score,
-//   auc(precision_recall_curve) with the extra point (recall 0, precision 1)); a segmented reduction per
-//   relation sums them in double precision.
+// After every epoch the reference computes, for each of the R relations, AUPRC / AUROC / AP of that relation's positive
+// and negative scores with scikit-learn on the host: R device -> host copies and R sklearn calls per epoch
+// (GripNet-pose.py:148-160,188-199; gripnet/utils.py:28-35).
+//
+// Round 6: own kernels that use the layout of the score vectors instead of a global 64-bit radix sort (rocPRIM: ~40
+// launches and 715 us for the 2 x 2 M scores of pose0-syn's training list - more than the training step itself).  The scores of
+// a relation are CONTIGUOUS in both vectors (type-sorted edge list, range_list), so every (relation, class) pair is a
+// SEGMENT that is sorted on its own:
+//   1. k_metric_sort_chunks: a segment is cut into chunks of <= 4,096 scores; a workgroup turns a chunk's scores into
+//      32-bit keys (ascending key = descending score), sorts them in LDS (bitonic) and writes them back in place;
+//   2. k_metric_merge (only when a segment has more than one chunk; log2(chunks) rounds, ping-pong): pairs of adjacent
+//      sorted runs of one segment are merged by merge path, a workgroup per 1,024 outputs;
+//   3. k_metric_terms: with both classes of a relation sorted, the four counts every curve point needs - positives and
+//      negatives above / at-or-above a threshold - are an element's own index and two binary searches in the other class.
+//      The LAST element of every group of tied scores of a class stands for the group: a positive one adds the terms of the
+//      precision-recall trapezoid and of the average-precision step, a negative one the ROC trapezoid (the definitions
+//      scikit-learn uses: roc_auc_score, average_precision_score, auc(precision_recall_curve) with the extra point
+//      (recall 0, precision 1); thresholds where only the other class changes contribute zero to a curve's sum).  Terms are
+//      summed in double precision, in a fixed order, per tile of 1,024 elements;
+//   4. k_metric_fold: a wave per relation adds its tiles' sums in tile order.  Bitwise reproducible, no atomics.
+// What depends on the range list only (segments, chunk / tile maps) is a PLAN (gn_link_metrics_plan_*): built once per
+// list, a planned call is asynchronous and makes 4 + rounds launches.
 #include "common.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_segmented_reduce.hpp>
-
+#include <algorithm>
 #include <vector>
 
 namespace {
 
-size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+constexpr int kChunk = 4096;               // keys a workgroup sorts in LDS (16 KB)
+constexpr int kSortThreads = 256;
+constexpr int kTile = 1024;                // outputs of a merge workgroup, elements of a terms workgroup
+constexpr int kTileThreads = 256;
 
-int bits_for(int64_t n) {
-    int b = 1;
-    while (((int64_t)1 << b) < n) ++b;
-    return b;
-}
+size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 
 __device__ __forceinline__ uint32_t descending_bits(float x) {
     const uint32_t u = __float_as_uint(x);
@@ -35,157 +42,335 @@ __device__ __forceinline__ uint32_t descending_bits(float x) {
     return ~asc;
 }
 
-__global__ void k_metric_keys(const float* __restrict__ pos, const float* __restrict__ neg,
-                              const int64_t* __restrict__ starts, int R, int64_t E, uint64_t* __restrict__ keys,
-                              int32_t* __restrict__ labels) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 2 * E; i += (int64_t)gridDim.x * blockDim.x) {
-        const bool is_pos = i < E;
-        const int64_t e = is_pos ? i : i - E;
-        int a = 0, b = R;                                    // last r with starts[r] <= e
-        while (b - a > 1) {
-            int mid = (a + b) >> 1;
-            if (starts[mid] <= e) a = mid; else b = mid;
-        }
-        keys[i] = ((uint64_t)a << 32) | descending_bits(is_pos ? pos[e] : neg[e]);
-        labels[i] = is_pos ? 1 : 0;
+// first index in [0, n) with a[idx] >= v (n if none)
+__device__ __forceinline__ int lower_bound_u32(const uint32_t* __restrict__ a, int n, uint32_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
     }
+    return lo;
+}
+// first index in [0, n) with a[idx] > v (n if none)
+__device__ __forceinline__ int upper_bound_u32(const uint32_t* __restrict__ a, int n, uint32_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// last s with prefix[s] <= v, prefix ascending with prefix[0] = 0
+__device__ __forceinline__ int owner_of(const int32_t* __restrict__ prefix, int n, int v) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
-__global__ void k_group_end_index(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ ge) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        ge[i] = (i == n - 1 || keys[i + 1] != keys[i]) ? (int32_t)i : -1;
-}
-
-struct MaxOp {
-    __device__ __host__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; }
+// Segment s = (relation s >> 1, class s & 1): class 0 = positives, 1 = negatives.  Keys of class c live at key[c * E + position].
+struct Segs {
+    const int64_t* start;      // [R + 1] positions of the relations' ranges (the range list's starts, then E)
+    int64_t E;
+    int S;                     // 2 R
+    __device__ __forceinline__ int64_t base(int s) const { return (int64_t)(s & 1) * E + start[s >> 1]; }
+    __device__ __forceinline__ int len(int s) const { return (int)(start[(s >> 1) + 1] - start[s >> 1]); }
 };
 
-// terms of the three curves at every group end (0 elsewhere)
-__global__ void k_metric_terms(const uint64_t* __restrict__ keys, const int32_t* __restrict__ tp_scan,
-                               const int32_t* __restrict__ ge, const int32_t* __restrict__ prev_end,
-                               const int64_t* __restrict__ starts, int64_t n, double* __restrict__ t_auprc,
-                               double* __restrict__ t_auroc, double* __restrict__ t_ap) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double a = 0.0, b = 0.0, c = 0.0;
-        if (ge[i] >= 0) {
-            const int r = (int)(keys[i] >> 32);
-            const int64_t s = 2 * starts[r], e = 2 * starts[r + 1];      // this relation's slice of the sorted array
-            const double P = (double)(e - s) / 2, N = P;                  // E_r positives, E_r negatives
-            const int64_t base = s > 0 ? tp_scan[s - 1] : 0;
-            const double tp = (double)(tp_scan[i] - base), fp = (double)(i - s + 1) - tp;
-            double tp0 = 0.0, fp0 = 0.0, prec0 = 1.0;                     // the curve's start point
-            const int64_t j = prev_end[i];
-            if (j >= s) {
-                tp0 = (double)(tp_scan[j] - base);
-                fp0 = (double)(j - s + 1) - tp0;
-                prec0 = tp0 / (tp0 + fp0);
+__global__ __launch_bounds__(kSortThreads) void k_metric_sort_chunks(const float* __restrict__ pos, const float* __restrict__ neg, Segs sg,
+                                                                      const int32_t* __restrict__ chunk_prefix, uint32_t* __restrict__ key) {
+    __shared__ uint32_t buf[kChunk];
+    const int s = owner_of(chunk_prefix, sg.S + 1, (int)blockIdx.x);
+    const int c = (int)blockIdx.x - chunk_prefix[s];
+    const int n_seg = sg.len(s);
+    const int off = c * kChunk, n = min(kChunk, n_seg - off);
+    const float* __restrict__ src = ((s & 1) ? neg : pos) + sg.start[s >> 1] + off;
+    int N = 64;
+    while (N < n) N <<= 1;
+    for (int i = threadIdx.x; i < N; i += kSortThreads) buf[i] = i < n ? descending_bits(src[i]) : 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (N >> 1); t += kSortThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));          // the lower index of pair t at distance j
+                const int p = i | j;
+                const uint32_t a = buf[i], b = buf[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { buf[i] = b; buf[p] = a; }
             }
-            const double prec = tp / (tp + fp);
-            a = (tp - tp0) / P * (prec + prec0) * 0.5;                     // trapezoid of the PR curve
-            b = (fp - fp0) * (tp + tp0) * 0.5 / (P * N);                   // trapezoid of the ROC curve
-            c = (tp - tp0) / P * prec;                                     // average precision step
+            __syncthreads();
         }
-        t_auprc[i] = a; t_auroc[i] = b; t_ap[i] = c;
+    uint32_t* __restrict__ dst = key + sg.base(s) + off;
+    for (int i = threadIdx.x; i < n; i += kSortThreads) dst[i] = buf[i];
+}
+
+// merge path: how many of the first `d` outputs of merge(A, B) come from A (ties: A first)
+__device__ __forceinline__ int merge_path(const uint32_t* __restrict__ A, int na, const uint32_t* __restrict__ B, int nb, int d) {
+    int lo = max(0, d - nb), hi = min(d, na);
+    while (lo < hi) {
+        const int i = (lo + hi) >> 1;          // take i from A, d - i from B: valid if A[i] > B[d - i - 1] is false ...
+        if (A[i] <= B[d - 1 - i]) lo = i + 1; else hi = i;
+    }
+    return lo;
+}
+
+// One round: inside every segment with more than one chunk, runs of length L (the last may be shorter) are merged in pairs.
+// Workgroup -> (big segment, tile of kTile outputs); 2 L is a multiple of kTile, so a tile never straddles two pairs.
+__global__ __launch_bounds__(kTileThreads) void k_metric_merge(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, Segs sg,
+                                                                const int32_t* __restrict__ big_seg, const int32_t* __restrict__ big_tile_prefix,
+                                                                int n_big, int L) {
+    __shared__ uint32_t la[kTile + 1], lb[kTile + 1];
+    __shared__ int split[2];
+    const int bs = owner_of(big_tile_prefix, n_big + 1, (int)blockIdx.x);
+    const int s = big_seg[bs];
+    const int t = (int)blockIdx.x - big_tile_prefix[bs];
+    const int n = sg.len(s);
+    const int64_t base = sg.base(s);
+    const int out0 = t * kTile;                                // first output of the tile inside the segment
+    const int pair0 = (out0 / (2 * L)) * (2 * L);              // start of the pair of runs inside the segment
+    const int na = min(L, n - pair0), nb = max(0, min(L, n - pair0 - L));
+    const uint32_t* __restrict__ A = src + base + pair0;
+    const uint32_t* __restrict__ B = A + na;
+    const int d0 = out0 - pair0, d1 = min(d0 + kTile, na + nb);
+    if (threadIdx.x < 2) split[threadIdx.x] = merge_path(A, na, B, nb, threadIdx.x ? d1 : d0);
+    __syncthreads();
+    const int ia0 = split[0], ia1 = split[1], ib0 = d0 - ia0, ib1 = d1 - ia1;
+    const int ca = ia1 - ia0, cb = ib1 - ib0;
+    for (int i = threadIdx.x; i < ca; i += kTileThreads) la[i] = A[ia0 + i];
+    for (int i = threadIdx.x; i < cb; i += kTileThreads) lb[i] = B[ib0 + i];
+    __syncthreads();
+    constexpr int PER = kTile / kTileThreads;
+    const int q0 = min((int)threadIdx.x * PER, ca + cb);
+    int i = merge_path(la, ca, lb, cb, q0), j = q0 - i;
+    uint32_t* __restrict__ o = dst + base + out0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (q0 + q >= ca + cb) break;
+        const bool from_a = j >= cb || (i < ca && la[i] <= lb[j]);
+        o[q0 + q] = from_a ? la[i] : lb[j];
+        if (from_a) ++i; else ++j;
     }
 }
 
-__global__ void k_seg_offsets(const int64_t* __restrict__ starts, int R, int64_t* __restrict__ off) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= R) off[i] = 2 * starts[i];
+// Terms of the three curves, per tile of kTile elements of a segment; sums[tile] = (a, b): positives (PR trapezoid, AP step),
+// negatives (ROC trapezoid, 0).
+__global__ __launch_bounds__(kTileThreads) void k_metric_terms(const uint32_t* __restrict__ key_small, const uint32_t* __restrict__ key_big, Segs sg,
+                                                                const int32_t* __restrict__ tile_prefix, const uint8_t* __restrict__ is_big,
+                                                                double* __restrict__ sums) {
+    __shared__ double red[2][kTileThreads];
+    const int s = owner_of(tile_prefix, sg.S + 1, (int)blockIdx.x);
+    const int t = (int)blockIdx.x - tile_prefix[s];
+    const int n = sg.len(s);
+    const uint32_t* __restrict__ own = (is_big[s] ? key_big : key_small) + sg.base(s);
+    const uint32_t* __restrict__ oth = (is_big[s ^ 1] ? key_big : key_small) + sg.base(s ^ 1);     // the other class: same length
+    const double P = (double)n;
+    double a = 0.0, b = 0.0;
+    constexpr int PER = kTile / kTileThreads;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {                            // (consecutive threads take consecutive elements: their searches walk the same path)
+        const int i = t * kTile + q * kTileThreads + (int)threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t k = own[i];
+        if (i + 1 < n && own[i + 1] == k) continue;            // not the last of its group of ties
+        const int own_le = i + 1;
+        const int own_lt = (i == 0 || own[i - 1] != k) ? i : lower_bound_u32(own, i, k);
+        const int oth_lt = lower_bound_u32(oth, n, k);
+        const int oth_le = (oth_lt < n && oth[oth_lt] == k) ? oth_lt + upper_bound_u32(oth + oth_lt, n - oth_lt, k) : oth_lt;
+        if ((s & 1) == 0) {                                    // positives: tp0 = own_lt, tp = own_le, fp0 = oth_lt, fp = oth_le
+            const double tp0 = own_lt, tp = own_le, fp0 = oth_lt, fp = oth_le;
+            const double prec = tp / (tp + fp), prec0 = (tp0 + fp0) > 0.0 ? tp0 / (tp0 + fp0) : 1.0;
+            a += (tp - tp0) / P * (prec + prec0) * 0.5;        // trapezoid of the PR curve
+            b += (tp - tp0) / P * prec;                        // average precision step
+        } else {                                               // negatives: fp0 = own_lt, fp = own_le, tp0 = oth_lt, tp = oth_le
+            const double fp0 = own_lt, fp = own_le, tp0 = oth_lt, tp = oth_le;
+            a += (fp - fp0) * (tp + tp0) * 0.5 / (P * P);      // trapezoid of the ROC curve (as many negatives as positives)
+        }
+    }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int w = kTileThreads / 2; w > 0; w >>= 1) {           // fixed tree: the same bits every run
+        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[2 * (size_t)blockIdx.x] = red[0][0]; sums[2 * (size_t)blockIdx.x + 1] = red[1][0]; }
 }
 
-__global__ void k_nan_empty(const int64_t* __restrict__ starts, int R, double* __restrict__ out) {   // [3][R]
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * R && starts[i % R + 1] == starts[i % R]) out[i] = __builtin_nan("");
+// out [3][R]: a wave per relation adds its tiles' sums in tile order (lanes stride over the tiles, then a fixed butterfly).
+__global__ __launch_bounds__(256) void k_metric_fold(const double* __restrict__ sums, const int32_t* __restrict__ tile_prefix, Segs sg, int R,
+                                                     double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    if (r >= R) return;
+    double acc[3] = {0.0, 0.0, 0.0};                           // auprc, auroc, ap
+    for (int c = 0; c < 2; ++c) {
+        const int s = 2 * r + c;
+        for (int t = tile_prefix[s] + lane; t < tile_prefix[s + 1]; t += 64) {
+            if (c == 0) { acc[0] += sums[2 * (size_t)t]; acc[2] += sums[2 * (size_t)t + 1]; }
+            else acc[1] += sums[2 * (size_t)t];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += __shfl_xor(acc[k], off);
+    if (lane == 0) {
+        const bool empty = sg.len(2 * r) == 0;
+        const double nan = __builtin_nan("");
+        out[r] = empty ? nan : acc[0];
+        out[R + r] = empty ? nan : acc[1];
+        out[2 * (size_t)R + r] = empty ? nan : acc[2];
+    }
 }
 
-struct Layout {
-    size_t keys, keys_sorted, labels, labels_sorted, tp, ge, prev, t0, t1, t2, starts, offs, tmp, total;
+}  // namespace
+
+struct gn_link_metrics_plan {
+    int64_t R = 0, E = 0;
+    int chunks = 0, tiles = 0, big_tiles = 0, n_big = 0, rounds = 0;
+    gn::DevBuf<int64_t> start;            // [R + 1]
+    gn::DevBuf<int32_t> chunk_prefix;     // [2 R + 1]
+    gn::DevBuf<int32_t> tile_prefix;      // [2 R + 1]
+    gn::DevBuf<int32_t> big_seg;          // [n_big] segments with more than one chunk
+    gn::DevBuf<int32_t> big_tile_prefix;  // [n_big + 1]
+    gn::DevBuf<uint8_t> is_big;           // [2 R]: the segment's sorted keys end in the buffer the last merge round wrote
+    ~gn_link_metrics_plan() {
+        start.release(); chunk_prefix.release(); tile_prefix.release(); big_seg.release(); big_tile_prefix.release(); is_big.release();
+    }
 };
 
-Layout layout(int64_t E, int64_t R) {
-    const size_t n = 2 * (size_t)E;
-    size_t b_sort = 0, b_scan = 0, b_scan2 = 0, b_red = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, b_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                                    (int32_t*)nullptr, n, 0, 64, (hipStream_t)0);
-    (void)rocprim::inclusive_scan(nullptr, b_scan, (const int32_t*)nullptr, (int32_t*)nullptr, n, rocprim::plus<int32_t>(),
-                                  (hipStream_t)0);
-    (void)rocprim::exclusive_scan(nullptr, b_scan2, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)-1, n, MaxOp(),
-                                  (hipStream_t)0);
-    (void)rocprim::segmented_reduce(nullptr, b_red, (const double*)nullptr, (double*)nullptr, (unsigned)R,
-                                    (const int64_t*)nullptr, (const int64_t*)nullptr, rocprim::plus<double>(), 0.0,
-                                    (hipStream_t)0);
+namespace {
+
+struct Layout { size_t key_a, key_b, sums, total; };
+
+Layout layout(int64_t E, int64_t tiles) {
     Layout l;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return at; };
-    l.keys = take(n * 8); l.keys_sorted = take(n * 8); l.labels = take(n * 4); l.labels_sorted = take(n * 4);
-    l.tp = take(n * 4); l.ge = take(n * 4); l.prev = take(n * 4);
-    l.t0 = take(n * 8); l.t1 = take(n * 8); l.t2 = take(n * 8);
-    l.starts = take((R + 1) * 8); l.offs = take((R + 1) * 8);
-    l.tmp = take(std::max(std::max(b_sort, b_scan), std::max(b_scan2, b_red)));
+    l.key_a = take(2 * (size_t)E * 4); l.key_b = take(2 * (size_t)E * 4); l.sums = take(2 * (size_t)std::max<int64_t>(tiles, 1) * 8);
     l.total = o;
     return l;
 }
 
 }  // namespace
 
-extern "C" size_t gn_link_metrics_workspace_bytes(int64_t R, int64_t E) {
-    if (R <= 0 || E <= 0) return 0;
-    return layout(E, R).total;
-}
+extern "C" {
 
-// out: [3, R] float64 (device): AUPRC, AUROC, AP of every relation (NaN for a relation without edges).
-extern "C" gn_status gn_link_metrics_f32(const float* pos_score, const float* neg_score, const int64_t* range_list_host,
-                                         int64_t R, int64_t E, double* out, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
-    GN_REQUIRE(R >= 1 && E >= 0 && 2 * E < (1ll << 31), "bad size (R=%lld, E=%lld)", (long long)R, (long long)E);
-    GN_REQUIRE(out != nullptr && range_list_host != nullptr, "null pointer");
-    hipStream_t st = gn::as_stream(stream);
-    std::vector<int64_t> starts(R + 1);
+gn_status gn_link_metrics_plan_create(const int64_t* range_list_host, int64_t R, int64_t E, void* stream, gn_link_metrics_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(R >= 1 && E >= 0 && 2 * E < (1ll << 31) && 2 * R < (1ll << 30), "bad size (R=%lld, E=%lld)", (long long)R, (long long)E);
+    GN_REQUIRE(range_list_host != nullptr, "range_list is null");
+    std::vector<int64_t> start(R + 1);
     int64_t cursor = 0;
     for (int64_t r = 0; r < R; ++r) {
         GN_REQUIRE(range_list_host[2 * r] == cursor && range_list_host[2 * r + 1] >= cursor,
                    "range_list must tile [0,E) in relation order (row %lld)", (long long)r);
-        starts[r] = cursor;
+        start[r] = cursor;
         cursor = range_list_host[2 * r + 1];
     }
     GN_REQUIRE(cursor == E, "range_list covers %lld edges, %lld scores given", (long long)cursor, (long long)E);
-    starts[R] = E;
-    if (E == 0) {
-        std::vector<double> nan(3 * R, __builtin_nan(""));
-        GN_HIP(hipMemcpyAsync(out, nan.data(), nan.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        GN_HIP(hipStreamSynchronize(st));
+    start[R] = E;
+    const int S = (int)(2 * R);
+    std::vector<int32_t> chunk_prefix(S + 1, 0), tile_prefix(S + 1, 0), big_seg, big_tile_prefix(1, 0);
+    std::vector<uint8_t> is_big(S, 0);
+    int64_t max_chunks = 1;
+    for (int s = 0; s < S; ++s) {
+        const int64_t n = start[(s >> 1) + 1] - start[s >> 1];
+        const int64_t ch = (n + kChunk - 1) / kChunk, ti = (n + kTile - 1) / kTile;
+        chunk_prefix[s + 1] = chunk_prefix[s] + (int32_t)ch;
+        tile_prefix[s + 1] = tile_prefix[s] + (int32_t)ti;
+        if (ch > 1) {
+            big_seg.push_back(s);
+            big_tile_prefix.push_back(big_tile_prefix.back() + (int32_t)ti);
+            max_chunks = std::max(max_chunks, ch);
+        }
+    }
+    gn_link_metrics_plan* p = new gn_link_metrics_plan();
+    p->R = R; p->E = E; p->chunks = chunk_prefix[S]; p->tiles = tile_prefix[S];
+    p->n_big = (int)big_seg.size(); p->big_tiles = big_tile_prefix.back();
+    while ((1ll << p->rounds) < max_chunks) ++p->rounds;
+    if (p->rounds & 1) for (int32_t s : big_seg) is_big[s] = 1;   // an odd number of ping-pong rounds ends in the second buffer
+    hipStream_t st = gn::as_stream(stream);
+    auto bail = [&](hipError_t e, const char* what) { delete p; return gn::fail(GN_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e)); };
+#define GN_UP(buf, vec)                                                                                                  \
+    do {                                                                                                                 \
+        hipError_t e_ = p->buf.alloc(std::max<size_t>((vec).size(), 1));                                                 \
+        if (e_ != hipSuccess) return bail(e_, "hipMalloc");                                                              \
+        if (!(vec).empty()) {                                                                                            \
+            e_ = hipMemcpyAsync(p->buf.p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, st);      \
+            if (e_ != hipSuccess) return bail(e_, "hipMemcpyAsync");                                                     \
+        }                                                                                                                \
+    } while (0)
+    GN_UP(start, start); GN_UP(chunk_prefix, chunk_prefix); GN_UP(tile_prefix, tile_prefix);
+    GN_UP(big_seg, big_seg); GN_UP(big_tile_prefix, big_tile_prefix); GN_UP(is_big, is_big);
+#undef GN_UP
+    hipError_t e = hipStreamSynchronize(st);                  // the vectors above are the sources of asynchronous copies
+    if (e != hipSuccess) return bail(e, "hipStreamSynchronize");
+    *out = p;
+    return GN_OK;
+}
+
+void gn_link_metrics_plan_destroy(gn_link_metrics_plan* plan) { delete plan; }
+
+size_t gn_link_metrics_plan_workspace_bytes(const gn_link_metrics_plan* plan) {
+    if (!plan || plan->E == 0) return 0;
+    return layout(plan->E, plan->tiles).total;
+}
+
+// out: [3, R] float64 (device): AUPRC, AUROC, AP of every relation (NaN for a relation without edges).  Asynchronous.
+gn_status gn_link_metrics_planned_f32(const gn_link_metrics_plan* plan, const float* pos_score, const float* neg_score, double* out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(plan != nullptr && out != nullptr, "null pointer");
+    hipStream_t st = gn::as_stream(stream);
+    const int R = (int)plan->R;
+    Segs sg{plan->start.p, plan->E, 2 * R};
+    if (plan->E == 0) {
+        k_metric_fold<<<(int)gn::ceil_div((int64_t)R * 64, 256), 256, 0, st>>>(nullptr, plan->tile_prefix.p, sg, R, out);
+        GN_LAUNCH_CHECK();
         return GN_OK;
     }
     GN_REQUIRE(pos_score && neg_score, "score pointers are null");
-    const Layout l = layout(E, R);
+    const Layout l = layout(plan->E, plan->tiles);
     GN_REQUIRE(workspace && workspace_bytes >= l.total, "workspace too small: need %zu bytes", l.total);
     char* ws = static_cast<char*>(workspace);
-    uint64_t *keys = (uint64_t*)(ws + l.keys), *keys_s = (uint64_t*)(ws + l.keys_sorted);
-    int32_t *lab = (int32_t*)(ws + l.labels), *lab_s = (int32_t*)(ws + l.labels_sorted);
-    int32_t *tp = (int32_t*)(ws + l.tp), *ge = (int32_t*)(ws + l.ge), *prev = (int32_t*)(ws + l.prev);
-    double *t0 = (double*)(ws + l.t0), *t1 = (double*)(ws + l.t1), *t2 = (double*)(ws + l.t2);
-    int64_t *starts_d = (int64_t*)(ws + l.starts), *offs = (int64_t*)(ws + l.offs);
-    size_t tmp_bytes = l.total - l.tmp;
-    const size_t n = 2 * (size_t)E;
-    GN_HIP(hipMemcpyAsync(starts_d, starts.data(), (R + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    k_metric_keys<<<gn::stream_grid(n, 256), 256, 0, st>>>(pos_score, neg_score, starts_d, (int)R, E, keys, lab);
+    uint32_t* ka = reinterpret_cast<uint32_t*>(ws + l.key_a);
+    uint32_t* kb = reinterpret_cast<uint32_t*>(ws + l.key_b);
+    double* sums = reinterpret_cast<double*>(ws + l.sums);
+    k_metric_sort_chunks<<<plan->chunks, kSortThreads, 0, st>>>(pos_score, neg_score, sg, plan->chunk_prefix.p, ka);
     GN_LAUNCH_CHECK();
-    GN_HIP(rocprim::radix_sort_pairs(ws + l.tmp, tmp_bytes, keys, keys_s, lab, lab_s, n, 0, 32 + bits_for(R), st));
-    GN_HIP(rocprim::inclusive_scan(ws + l.tmp, tmp_bytes, lab_s, tp, n, rocprim::plus<int32_t>(), st));
-    k_group_end_index<<<gn::stream_grid(n, 256), 256, 0, st>>>(keys_s, (int64_t)n, ge);
+    uint32_t *src = ka, *dst = kb;
+    for (int round = 0; round < plan->rounds; ++round) {
+        k_metric_merge<<<plan->big_tiles, kTileThreads, 0, st>>>(src, dst, sg, plan->big_seg.p, plan->big_tile_prefix.p, plan->n_big,
+                                                                  kChunk << round);
+        GN_LAUNCH_CHECK();
+        std::swap(src, dst);
+    }
+    // (single-chunk segments never left `ka`; the others are where the last round put them: `kb` after an odd number of rounds)
+    k_metric_terms<<<plan->tiles, kTileThreads, 0, st>>>(ka, (plan->rounds & 1) ? kb : ka, sg, plan->tile_prefix.p, plan->is_big.p, sums);
     GN_LAUNCH_CHECK();
-    GN_HIP(rocprim::exclusive_scan(ws + l.tmp, tmp_bytes, ge, prev, (int32_t)-1, n, MaxOp(), st));
-    k_metric_terms<<<gn::stream_grid(n, 256), 256, 0, st>>>(keys_s, tp, ge, prev, starts_d, (int64_t)n, t0, t1, t2);
+    k_metric_fold<<<(int)gn::ceil_div((int64_t)R * 64, 256), 256, 0, st>>>(sums, plan->tile_prefix.p, sg, R, out);
     GN_LAUNCH_CHECK();
-    k_seg_offsets<<<(int)gn::ceil_div(R + 1, 256), 256, 0, st>>>(starts_d, (int)R, offs);
-    GN_LAUNCH_CHECK();
-    double* terms[3] = {t0, t1, t2};
-    for (int k = 0; k < 3; ++k)
-        GN_HIP(rocprim::segmented_reduce(ws + l.tmp, tmp_bytes, terms[k], out + k * R, (unsigned)R, offs, offs + 1,
-                                         rocprim::plus<double>(), 0.0, st));
-    k_nan_empty<<<(int)gn::ceil_div(3 * R, 256), 256, 0, st>>>(starts_d, (int)R, out);
-    GN_LAUNCH_CHECK();
-    GN_HIP(hipStreamSynchronize(st));        // `starts` (host) was the source of an async copy
     return GN_OK;
 }
+
+size_t gn_link_metrics_workspace_bytes(int64_t R, int64_t E) {
+    if (R <= 0 || E <= 0) return 0;
+    return layout(E, (E + kTile - 1) / kTile * 2 + 2 * R).total;      // (an upper bound of the tiles: every segment rounds up once)
+}
+
+// The same without a kept plan (one is built, used and dropped: synchronises `stream`).
+gn_status gn_link_metrics_f32(const float* pos_score, const float* neg_score, const int64_t* range_list_host,
+                              int64_t R, int64_t E, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+    gn_link_metrics_plan* plan = nullptr;
+    gn_status s = gn_link_metrics_plan_create(range_list_host, R, E, stream, &plan);
+    if (s != GN_OK) return s;
+    s = gn_link_metrics_planned_f32(plan, pos_score, neg_score, out, workspace, workspace_bytes, stream);
+    hipError_t e = hipStreamSynchronize(gn::as_stream(stream));
+    gn_link_metrics_plan_destroy(plan);
+    if (s == GN_OK && e != hipSuccess) return gn::fail(GN_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    return s;
+}
+
+}  // extern "C"

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 146 /* 0.1.42 */
+#define GN_VERSION 147 /* 0.1.43 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -568,7 +568,19 @@ GN_API gn_status gn_link_loss_backward_f32(const float* pos_score, int64_t num_p
  * each, segmented by the same range_list ([R,2] on the host).  out is [3, R] float64 on the device:
  * row 0 area under the precision-recall curve (trapezoid, with the point recall 0 / precision 1),
  * row 1 ROC AUC, row 2 average precision, per relation, with scikit-learn's treatment of tied scores;
- * NaN for a relation without edges.  Synchronises `stream` once. */
+ * NaN for a relation without edges. */
+typedef struct gn_link_metrics_plan gn_link_metrics_plan;
+/* What depends on the range list only (the (relation, class) segments of the two score vectors, their chunk and tile maps):
+ * built once per list (synchronises `stream` once); a planned call is asynchronous - chunk sort in LDS, merge rounds for the
+ * relations longer than 4,096 edges, the curves' terms from binary searches between a relation's two sorted classes, a fold in
+ * fixed order (bitwise reproducible).  workspace: gn_link_metrics_plan_workspace_bytes. */
+GN_API gn_status gn_link_metrics_plan_create(const int64_t* range_list_host, int64_t num_relations, int64_t num_edges, void* stream,
+                                      gn_link_metrics_plan** plan);
+GN_API void gn_link_metrics_plan_destroy(gn_link_metrics_plan* plan);
+GN_API size_t gn_link_metrics_plan_workspace_bytes(const gn_link_metrics_plan* plan);
+GN_API gn_status gn_link_metrics_planned_f32(const gn_link_metrics_plan* plan, const float* pos_score, const float* neg_score,
+                                      double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same without a kept plan (builds one, uses it, drops it: synchronises `stream`). */
 GN_API size_t gn_link_metrics_workspace_bytes(int64_t num_relations, int64_t num_edges);
 GN_API gn_status gn_link_metrics_f32(const float* pos_score, const float* neg_score, const int64_t* range_list_host,
                               int64_t num_relations, int64_t num_edges, double* out, void* workspace,

@@ -752,6 +752,43 @@ def test_relation_metrics_match_sklearn(gpu):
             assert abs(a - b) <= 1e-9, "relation {} {}: {} vs sklearn {}".format(r, name, a, b)
 
 
+@pytest.mark.parametrize("sizes", [[5000, 7, 4096, 4097, 0, 9000], [70000, 300, 8192, 20000], [33000, 1, 1024], [150000, 12]])
+def test_relation_metrics_with_relations_beyond_one_chunk(gpu, sizes):
+    """Round 6 (own segment sort): relations longer than the 4,096 scores a workgroup sorts in LDS go through merge rounds (1, 2, 4
+    and 6 here: even and odd numbers of ping-pong rounds; lengths on and next to chunk and tile boundaries); all scores of a
+    relation tied, ties that straddle chunk boundaries, ties BETWEEN the classes; against scikit-learn per block (<= 1e-9), the
+    same bits twice in a row, and the plan-less entry point agrees bit for bit."""
+    from gripnet_amd.utils import auprc_auroc_ap, relation_metrics
+    gen = torch.Generator().manual_seed(sum(sizes))
+    rl = gripnet_amd.utils.get_range_list([torch.zeros(2, s) for s in sizes])
+    E = sum(sizes)
+    pos = torch.sigmoid(torch.randn(E, generator=gen) + 0.4)
+    neg = torch.sigmoid(torch.randn(E, generator=gen) - 0.1)
+    a, b = int(rl[0, 0]), int(rl[0, 1])
+    pos[a:b] = torch.round(pos[a:b] * 64) / 64                       # 65 distinct values over many chunks, shared with the negatives
+    neg[a:b] = torch.round(neg[a:b] * 64) / 64
+    a, b = int(rl[1, 0]), int(rl[1, 1])
+    pos[a:b] = 0.5                                                    # a relation whose scores are all the same
+    neg[a:b] = 0.5
+    got = torch.stack(relation_metrics(pos.to(gpu), neg.to(gpu), rl)).cpu()
+    again = torch.stack(relation_metrics(pos.to(gpu), neg.to(gpu), rl)).cpu()
+    assert torch.equal(got.nan_to_num(-1.0), again.nan_to_num(-1.0))
+    out = torch.empty((3, len(sizes)), dtype=torch.float64, device=gpu)
+    need = int(_hip.load().gn_link_metrics_workspace_bytes(len(sizes), E))
+    ws = torch.empty((need,), dtype=torch.uint8, device=gpu)
+    pg, ng = pos.to(gpu), neg.to(gpu)
+    _hip._call("gn_link_metrics_f32", pg.data_ptr(), ng.data_ptr(), rl.contiguous().data_ptr(), len(sizes), E, out.data_ptr(), ws.data_ptr(), need,
+               _hip.stream_ptr(gpu))
+    assert torch.equal(out.cpu().nan_to_num(-1.0), got.nan_to_num(-1.0))
+    for r, (s, e) in enumerate(rl.tolist()):
+        if e == s:
+            assert torch.isnan(got[:, r]).all()
+            continue
+        ref = auprc_auroc_ap(torch.cat([torch.ones(e - s), torch.zeros(e - s)]), torch.cat([pos[s:e], neg[s:e]]))
+        for k, name in enumerate(("auprc", "auroc", "ap")):
+            assert abs(float(got[k, r]) - ref[k]) <= 1e-9, "relation {} ({} edges) {}: {} vs sklearn {}".format(r, e - s, name, float(got[k, r]), ref[k])
+
+
 # ---- BASELINE.json configs 2 and 4 at scale: the NC suite, large supervertices, wide features --------------
 @pytest.mark.parametrize("arithmetic", ["fp32", "fast"])
 def test_aminer_syn_vs_oracle(gpu, arithmetic):
