@@ -79,29 +79,76 @@ struct Segs {
     __device__ __forceinline__ int len(int s) const { return (int)(start[(s >> 1) + 1] - start[s >> 1]); }
 };
 
+// Bitonic sort of 256 x EPT keys held EPT per thread (thread t: elements EPT t .. EPT t + EPT - 1).  A compare-exchange at
+// distance j < EPT stays inside a thread's registers; up to 32 threads apart it is a shuffle inside the wave; only the last
+// stages of the largest size (64 and 128 threads apart) go through LDS: 3 exchanges with barriers instead of the 78 of a sort
+// that keeps the keys in LDS (measured: 91 us per launch for that one, the launch ending with its slowest workgroup).
+template <int EPT>
+__device__ __forceinline__ void sort_in_registers(uint32_t* __restrict__ buf, int tid) {
+    constexpr int LOGN = EPT == 16 ? 12 : (EPT == 4 ? 10 : 8);
+    uint32_t v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) v[e] = buf[EPT * tid + e];
+#pragma unroll
+    for (int lk = 1; lk <= LOGN; ++lk) {
+        const int k = 1 << lk;
+#pragma unroll
+        for (int lj = lk - 1; lj >= 0; --lj) {
+            const int j = 1 << lj;
+            if (j < EPT) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    if (e & j) continue;
+                    const bool up = ((EPT * tid + e) & k) == 0;
+                    const uint32_t a = v[e], b = v[e | j];
+                    const uint32_t lo = min(a, b), hi = max(a, b);
+                    v[e] = up ? lo : hi;
+                    v[e | j] = up ? hi : lo;
+                }
+            } else {
+                const int td = j / EPT;                        // the partner is `td` threads away
+                const bool lower = (tid & td) == 0;
+                uint32_t other[EPT];
+                if (td < 64) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) other[e] = (uint32_t)__shfl_xor((int)v[e], td);
+                } else {
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) buf[EPT * tid + e] = v[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) other[e] = buf[EPT * (tid ^ td) + e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const bool up = ((EPT * tid + e) & k) == 0;
+                    v[e] = (lower == up) ? min(v[e], other[e]) : max(v[e], other[e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) buf[EPT * tid + e] = v[e];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kSortThreads) void k_metric_sort_chunks(const float* __restrict__ pos, const float* __restrict__ neg, Segs sg,
-                                                                      const int32_t* __restrict__ chunk_prefix, uint32_t* __restrict__ key) {
+                                                                      const int32_t* __restrict__ chunk_prefix, const int32_t* __restrict__ chunk_seg,
+                                                                      uint32_t* __restrict__ key) {
     __shared__ uint32_t buf[kChunk];
-    const int s = owner_of(chunk_prefix, sg.S + 1, (int)blockIdx.x);
+    const int s = chunk_seg[blockIdx.x];                      // (a table: the binary search over the prefix was eleven dependent loads in front of everything)
     const int c = (int)blockIdx.x - chunk_prefix[s];
     const int n_seg = sg.len(s);
     const int off = c * kChunk, n = min(kChunk, n_seg - off);
     const float* __restrict__ src = ((s & 1) ? neg : pos) + sg.start[s >> 1] + off;
-    int N = 64;
-    while (N < n) N <<= 1;
+    const int N = n <= kSortThreads ? kSortThreads : (n <= 4 * kSortThreads ? 4 * kSortThreads : 16 * kSortThreads);   // uniform
     for (int i = threadIdx.x; i < N; i += kSortThreads) buf[i] = i < n ? descending_bits(src[i]) : 0xffffffffu;
     __syncthreads();
-    for (int k = 2; k <= N; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (N >> 1); t += kSortThreads) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));          // the lower index of pair t at distance j
-                const int p = i | j;
-                const uint32_t a = buf[i], b = buf[p];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { buf[i] = b; buf[p] = a; }
-            }
-            __syncthreads();
-        }
+    if (N == kSortThreads) sort_in_registers<1>(buf, threadIdx.x);
+    else if (N == 4 * kSortThreads) sort_in_registers<4>(buf, threadIdx.x);
+    else sort_in_registers<16>(buf, threadIdx.x);
     uint32_t* __restrict__ dst = key + sg.base(s) + off;
     for (int i = threadIdx.x; i < n; i += kSortThreads) dst[i] = buf[i];
 }
@@ -120,10 +167,10 @@ __device__ __forceinline__ int merge_path(const uint32_t* __restrict__ A, int na
 // Workgroup -> (big segment, tile of kTile outputs); 2 L is a multiple of kTile, so a tile never straddles two pairs.
 __global__ __launch_bounds__(kTileThreads) void k_metric_merge(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, Segs sg,
                                                                 const int32_t* __restrict__ big_seg, const int32_t* __restrict__ big_tile_prefix,
-                                                                int n_big, int L) {
+                                                                const int32_t* __restrict__ big_tile_owner, int L) {
     __shared__ uint32_t la[kTile + 1], lb[kTile + 1];
-    __shared__ int split[2];
-    const int bs = owner_of(big_tile_prefix, n_big + 1, (int)blockIdx.x);
+    __shared__ int split[2], cnt[4], open[2];
+    const int bs = big_tile_owner[blockIdx.x];
     const int s = big_seg[bs];
     const int t = (int)blockIdx.x - big_tile_prefix[bs];
     const int n = sg.len(s);
@@ -134,8 +181,30 @@ __global__ __launch_bounds__(kTileThreads) void k_metric_merge(const uint32_t* _
     const uint32_t* __restrict__ A = src + base + pair0;
     const uint32_t* __restrict__ B = A + na;
     const int d0 = out0 - pair0, d1 = min(d0 + kTile, na + nb);
-    if (threadIdx.x < 2) split[threadIdx.x] = merge_path(A, na, B, nb, threadIdx.x ? d1 : d0);
-    __syncthreads();
+    {
+        // both splits at once, 128 threads each: every round samples 128 candidates of the remaining range (the predicate is
+        // monotone: the number of samples that pass names the sub-range) - three rounds for runs of 65,536 where a binary search
+        // by one thread made 17 dependent round trips (most of the launch's 10 us)
+        const int grp = threadIdx.x >> 7, g = threadIdx.x & 127, d = grp ? d1 : d0;
+        int lo = max(0, d - nb), hi = min(d, na);
+        while (true) {                                         // (uniform across the workgroup: both groups loop until both are done)
+            const int span = hi - lo, step = max(1, (span + 127) >> 7);
+            const int i = lo + g * step;
+            const bool ok = span > 0 && i < hi && A[i] <= B[d - 1 - i];
+            const unsigned long long m = __ballot(ok);
+            if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = __popcll(m);
+            __syncthreads();
+            const int c = cnt[2 * grp] + cnt[2 * grp + 1];
+            const int nlo = c > 0 ? lo + (c - 1) * step + 1 : lo;
+            const int nhi = (lo + c * step < hi) ? lo + c * step : hi;
+            if (span > 0) { lo = nlo; hi = nhi; }
+            if (g == 0) open[grp] = hi > lo ? 1 : 0;
+            __syncthreads();
+            if (!(open[0] | open[1])) break;
+        }
+        if (g == 0) split[grp] = lo;
+        __syncthreads();
+    }
     const int ia0 = split[0], ia1 = split[1], ib0 = d0 - ia0, ib1 = d1 - ia1;
     const int ca = ia1 - ia0, cb = ib1 - ib0;
     for (int i = threadIdx.x; i < ca; i += kTileThreads) la[i] = A[ia0 + i];
@@ -155,29 +224,77 @@ __global__ __launch_bounds__(kTileThreads) void k_metric_merge(const uint32_t* _
 }
 
 // Terms of the three curves, per tile of kTile elements of a segment; sums[tile] = (a, b): positives (PR trapezoid, AP step),
-// negatives (ROC trapezoid, 0).
+// negatives (ROC trapezoid, 0).  The tile's own keys (and one neighbour on each side) and the WINDOW of the other class that its
+// first and last key bracket sit in LDS: the two searches per element run there (a search per element in global memory was ~40
+// dependent L2 round trips per thread: 42 us per launch).  A window beyond kWindow keys is searched in global memory, inside its bounds.
+constexpr int kWindow = 4096;
+
 __global__ __launch_bounds__(kTileThreads) void k_metric_terms(const uint32_t* __restrict__ key_small, const uint32_t* __restrict__ key_big, Segs sg,
-                                                                const int32_t* __restrict__ tile_prefix, const uint8_t* __restrict__ is_big,
-                                                                double* __restrict__ sums) {
+                                                                const int32_t* __restrict__ tile_prefix, const int32_t* __restrict__ tile_seg,
+                                                                const uint8_t* __restrict__ is_big, double* __restrict__ sums) {
     __shared__ double red[2][kTileThreads];
-    const int s = owner_of(tile_prefix, sg.S + 1, (int)blockIdx.x);
+    __shared__ uint32_t mine[kTile + 2], win[kWindow];
+    __shared__ int bounds[2], scnt[4], sopen[2];
+    const int s = tile_seg[blockIdx.x];
     const int t = (int)blockIdx.x - tile_prefix[s];
     const int n = sg.len(s);
     const uint32_t* __restrict__ own = (is_big[s] ? key_big : key_small) + sg.base(s);
     const uint32_t* __restrict__ oth = (is_big[s ^ 1] ? key_big : key_small) + sg.base(s ^ 1);     // the other class: same length
+    const int t0 = t * kTile, t1 = min(t0 + kTile, n), cnt = t1 - t0;
+    // mine[1 + q] = own[t0 + q]; mine[0] / mine[cnt + 1] = the neighbours outside the tile (or a key no element has: ~own)
+    for (int q = threadIdx.x; q < cnt + 2; q += kTileThreads) {
+        const int i = t0 - 1 + q;
+        mine[q] = (i >= 0 && i < n) ? own[i] : ~own[min(max(i, 0), n - 1)];
+    }
+    {
+        // the window's two bounds at once, 128 threads each, 128 samples of the remaining range per round (as in k_metric_merge):
+        // group 0 the first index with oth >= the tile's first key, group 1 the first index with oth > its last key
+        const int grp = threadIdx.x >> 7, g = threadIdx.x & 127;
+        const uint32_t kk = grp ? own[t1 - 1] : own[t0];
+        int lo = 0, hi = n;
+        while (true) {
+            const int span = hi - lo, step = max(1, (span + 127) >> 7);
+            const int i = lo + g * step;
+            const bool ok = span > 0 && i < hi && (grp ? oth[i] <= kk : oth[i] < kk);
+            const unsigned long long m = __ballot(ok);
+            if ((threadIdx.x & 63) == 0) scnt[threadIdx.x >> 6] = __popcll(m);
+            __syncthreads();
+            const int c = scnt[2 * grp] + scnt[2 * grp + 1];
+            if (span > 0) {
+                const int nlo = c > 0 ? lo + (c - 1) * step + 1 : lo;
+                hi = (lo + c * step < hi) ? lo + c * step : hi;
+                lo = nlo;
+            }
+            if (g == 0) sopen[grp] = hi > lo ? 1 : 0;
+            __syncthreads();
+            if (!(sopen[0] | sopen[1])) break;
+        }
+        if (g == 0) bounds[grp] = lo;
+        __syncthreads();
+    }
+    const int wlo = bounds[0], whi = bounds[1], wn = whi - wlo;
+    const bool in_lds = wn <= kWindow;
+    if (in_lds)
+        for (int q = threadIdx.x; q < wn; q += kTileThreads) win[q] = oth[wlo + q];
+    __syncthreads();
+    const uint32_t* __restrict__ wp = in_lds ? win : oth + wlo;
     const double P = (double)n;
     double a = 0.0, b = 0.0;
     constexpr int PER = kTile / kTileThreads;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {                            // (consecutive threads take consecutive elements: their searches walk the same path)
-        const int i = t * kTile + q * kTileThreads + (int)threadIdx.x;
-        if (i >= n) continue;
-        const uint32_t k = own[i];
-        if (i + 1 < n && own[i + 1] == k) continue;            // not the last of its group of ties
+    for (int q = 0; q < PER; ++q) {
+        const int li = q * kTileThreads + (int)threadIdx.x, i = t0 + li;
+        if (li >= cnt) continue;
+        const uint32_t k = mine[1 + li];
+        if (mine[2 + li] == k && i + 1 < n) continue;          // not the last of its group of ties
         const int own_le = i + 1;
-        const int own_lt = (i == 0 || own[i - 1] != k) ? i : lower_bound_u32(own, i, k);
-        const int oth_lt = lower_bound_u32(oth, n, k);
-        const int oth_le = (oth_lt < n && oth[oth_lt] == k) ? oth_lt + upper_bound_u32(oth + oth_lt, n - oth_lt, k) : oth_lt;
+        int own_lt = i;
+        if (li > 0 ? mine[li] == k : (i > 0 && mine[0] == k)) {
+            // the group began earlier: inside the tile (LDS), or - the tile's first key - in front of it (global, rare)
+            own_lt = (mine[1] == k && t0 > 0 && mine[0] == k) ? lower_bound_u32(own, t0, k) : t0 + lower_bound_u32(mine + 1, li, k);
+        }
+        const int oth_lt = wlo + lower_bound_u32(wp, wn, k);
+        const int oth_le = wlo + upper_bound_u32(wp, wn, k);
         if ((s & 1) == 0) {                                    // positives: tp0 = own_lt, tp = own_le, fp0 = oth_lt, fp = oth_le
             const double tp0 = own_lt, tp = own_le, fp0 = oth_lt, fp = oth_le;
             const double prec = tp / (tp + fp), prec0 = (tp0 + fp0) > 0.0 ? tp0 / (tp0 + fp0) : 1.0;
@@ -235,8 +352,10 @@ struct gn_link_metrics_plan {
     gn::DevBuf<int32_t> big_seg;          // [n_big] segments with more than one chunk
     gn::DevBuf<int32_t> big_tile_prefix;  // [n_big + 1]
     gn::DevBuf<uint8_t> is_big;           // [2 R]: the segment's sorted keys end in the buffer the last merge round wrote
+    gn::DevBuf<int32_t> chunk_seg, tile_seg, big_tile_owner;   // owner of every chunk / tile / merge tile (a load instead of a search per workgroup)
     ~gn_link_metrics_plan() {
         start.release(); chunk_prefix.release(); tile_prefix.release(); big_seg.release(); big_tile_prefix.release(); is_big.release();
+        chunk_seg.release(); tile_seg.release(); big_tile_owner.release();
     }
 };
 
@@ -305,6 +424,14 @@ gn_status gn_link_metrics_plan_create(const int64_t* range_list_host, int64_t R,
     } while (0)
     GN_UP(start, start); GN_UP(chunk_prefix, chunk_prefix); GN_UP(tile_prefix, tile_prefix);
     GN_UP(big_seg, big_seg); GN_UP(big_tile_prefix, big_tile_prefix); GN_UP(is_big, is_big);
+    std::vector<int32_t> chunk_seg, tile_seg, big_tile_owner;
+    for (int s2 = 0; s2 < S; ++s2) {
+        chunk_seg.insert(chunk_seg.end(), chunk_prefix[s2 + 1] - chunk_prefix[s2], s2);
+        tile_seg.insert(tile_seg.end(), tile_prefix[s2 + 1] - tile_prefix[s2], s2);
+    }
+    for (size_t b2 = 0; b2 + 1 < big_tile_prefix.size(); ++b2)
+        big_tile_owner.insert(big_tile_owner.end(), big_tile_prefix[b2 + 1] - big_tile_prefix[b2], (int32_t)b2);
+    GN_UP(chunk_seg, chunk_seg); GN_UP(tile_seg, tile_seg); GN_UP(big_tile_owner, big_tile_owner);
 #undef GN_UP
     hipError_t e = hipStreamSynchronize(st);                  // the vectors above are the sources of asynchronous copies
     if (e != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -338,17 +465,17 @@ gn_status gn_link_metrics_planned_f32(const gn_link_metrics_plan* plan, const fl
     uint32_t* ka = reinterpret_cast<uint32_t*>(ws + l.key_a);
     uint32_t* kb = reinterpret_cast<uint32_t*>(ws + l.key_b);
     double* sums = reinterpret_cast<double*>(ws + l.sums);
-    k_metric_sort_chunks<<<plan->chunks, kSortThreads, 0, st>>>(pos_score, neg_score, sg, plan->chunk_prefix.p, ka);
+    k_metric_sort_chunks<<<plan->chunks, kSortThreads, 0, st>>>(pos_score, neg_score, sg, plan->chunk_prefix.p, plan->chunk_seg.p, ka);
     GN_LAUNCH_CHECK();
     uint32_t *src = ka, *dst = kb;
     for (int round = 0; round < plan->rounds; ++round) {
-        k_metric_merge<<<plan->big_tiles, kTileThreads, 0, st>>>(src, dst, sg, plan->big_seg.p, plan->big_tile_prefix.p, plan->n_big,
+        k_metric_merge<<<plan->big_tiles, kTileThreads, 0, st>>>(src, dst, sg, plan->big_seg.p, plan->big_tile_prefix.p, plan->big_tile_owner.p,
                                                                   kChunk << round);
         GN_LAUNCH_CHECK();
         std::swap(src, dst);
     }
     // (single-chunk segments never left `ka`; the others are where the last round put them: `kb` after an odd number of rounds)
-    k_metric_terms<<<plan->tiles, kTileThreads, 0, st>>>(ka, (plan->rounds & 1) ? kb : ka, sg, plan->tile_prefix.p, plan->is_big.p, sums);
+    k_metric_terms<<<plan->tiles, kTileThreads, 0, st>>>(ka, (plan->rounds & 1) ? kb : ka, sg, plan->tile_prefix.p, plan->tile_seg.p, plan->is_big.p, sums);
     GN_LAUNCH_CHECK();
     k_metric_fold<<<(int)gn::ceil_div((int64_t)R * 64, 256), 256, 0, st>>>(sums, plan->tile_prefix.p, sg, R, out);
     GN_LAUNCH_CHECK();
