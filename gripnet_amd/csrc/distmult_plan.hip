@@ -419,20 +419,61 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         GN_HIP(hipMemcpyAsync(hr.data(), edge_type, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         GN_HIP(hipStreamSynchronize(st));
     }
-    for (int64_t e = 0; e < E; ++e)
-        if ((uint64_t)hu[e] >= (uint64_t)num_nodes || (uint64_t)hv[e] >= (uint64_t)num_nodes ||
-            (uint64_t)hr[e] >= (uint64_t)num_relations)
-            return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
-                            (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
-                            (long long)num_nodes, (long long)num_relations);
+    {
+        // validation on the builder threads: the first offending edge of every slice, the smallest of them reported
+        std::vector<int64_t> bad(64, -1);
+        gn::parallel_for(64, 1, [&](int64_t s0, int64_t s1) {
+            for (int64_t sl = s0; sl < s1; ++sl)
+                for (int64_t e = E * sl / 64; e < E * (sl + 1) / 64; ++e)
+                    if ((uint64_t)hu[e] >= (uint64_t)num_nodes || (uint64_t)hv[e] >= (uint64_t)num_nodes || (uint64_t)hr[e] >= (uint64_t)num_relations) {
+                        bad[(size_t)sl] = e;
+                        break;
+                    }
+        });
+        for (int64_t e : bad)
+            if (e >= 0)
+                return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
+                                (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
+                                (long long)num_nodes, (long long)num_relations);
+    }
     std::vector<int64_t> mirror_of;
     std::vector<char> covered;
     gn_layout::pair_mirrors(hu, hv, hr, kNodeBits, mirror_of, covered);
-    // batches: 64 consecutive scored edges each, in list order; a batch's slots are dealt independently of the others
     std::vector<int64_t> scored;
     scored.reserve((size_t)E);
     for (int64_t e = 0; e < E; ++e)
         if (!covered[e]) scored.push_back(e);
+    gn_distmult_plan* p = new gn_distmult_plan();
+    p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = 0;
+    auto bail = [&](hipError_t e) {
+        gn_distmult_plan_destroy(p);
+        return gn::fail(GN_ERR_HIP, "DistMult plan upload failed: %s", hipGetErrorString(e));
+    };
+    hipError_t he;
+    // The row-class encoding first (round 6): when it exists, the column-phase encoding below is never read by a launch of the
+    // decoder's own width (a call with columns the row-class kernel has no instantiation for is refused with GN_ERR_UNSUPPORTED
+    // and the caller scores the raw list) - and its dealing was a quarter of the plan's build time.
+    if (num_features > 0 && !gn::fast_paths_disabled()) {
+        gn_layout::ClassLayout cl = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, num_nodes, num_features, gn::compute_units());
+        if (cl.ok) {
+            if ((he = p->cls_packed.alloc(cl.packed.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_own.alloc(cl.own.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_mirror.alloc(cl.mirror.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_rel.alloc(cl.rel32.size())) != hipSuccess) return bail(he);
+            if ((he = p->cls_wg.alloc(cl.wg.size())) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_packed.p, cl.packed.data(), cl.packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_own.p, cl.own.data(), cl.own.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_mirror.p, cl.mirror.data(), cl.mirror.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_rel.p, cl.rel32.data(), cl.rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipMemcpyAsync(p->cls_wg.p, cl.wg.data(), cl.wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
+            if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);
+            p->cls_features = (int)num_features; p->cls_groups = cl.groups; p->cls_batches = cl.batches; p->cls_walks = cl.walks;
+            p->cls_ok = 1;
+            *out = p;
+            return GN_OK;
+        }
+    }
+    // batches: 64 consecutive scored edges each, in list order; a batch's slots are dealt independently of the others
     const int64_t NBs = gn::ceil_div((int64_t)scored.size(), 64);
     std::vector<uint32_t> packed((size_t)NBs * 64), own((size_t)NBs * 64), mirror((size_t)NBs * 64);
     std::vector<int32_t> batch_rel((size_t)NBs);
@@ -463,13 +504,7 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         }
     });
     const int64_t NB = (int64_t)batch_rel.size();
-    gn_distmult_plan* p = new gn_distmult_plan();
-    p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = NB;
-    auto bail = [&](hipError_t e) {
-        gn_distmult_plan_destroy(p);
-        return gn::fail(GN_ERR_HIP, "DistMult plan upload failed: %s", hipGetErrorString(e));
-    };
-    hipError_t he;
+    p->batches = NB;
     if ((he = p->packed.alloc((size_t)NB * 64)) != hipSuccess) return bail(he);
     if ((he = p->batch_rel.alloc((size_t)NB)) != hipSuccess) return bail(he);
     if ((he = p->rel16.alloc((size_t)NB * 64)) != hipSuccess) return bail(he);
@@ -482,24 +517,6 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         if ((he = hipMemcpyAsync(p->mirror.p, mirror.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
         if ((he = hipMemcpyAsync(p->own.p, own.data(), (size_t)NB * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
         if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);     // host vectors go out of scope after this
-    }
-    if (num_features > 0 && !gn::fast_paths_disabled()) {
-        gn_layout::ClassLayout cl = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, num_nodes, num_features, gn::compute_units());
-        if (cl.ok) {
-            if ((he = p->cls_packed.alloc(cl.packed.size())) != hipSuccess) return bail(he);
-            if ((he = p->cls_own.alloc(cl.own.size())) != hipSuccess) return bail(he);
-            if ((he = p->cls_mirror.alloc(cl.mirror.size())) != hipSuccess) return bail(he);
-            if ((he = p->cls_rel.alloc(cl.rel32.size())) != hipSuccess) return bail(he);
-            if ((he = p->cls_wg.alloc(cl.wg.size())) != hipSuccess) return bail(he);
-            if ((he = hipMemcpyAsync(p->cls_packed.p, cl.packed.data(), cl.packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-            if ((he = hipMemcpyAsync(p->cls_own.p, cl.own.data(), cl.own.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-            if ((he = hipMemcpyAsync(p->cls_mirror.p, cl.mirror.data(), cl.mirror.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-            if ((he = hipMemcpyAsync(p->cls_rel.p, cl.rel32.data(), cl.rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-            if ((he = hipMemcpyAsync(p->cls_wg.p, cl.wg.data(), cl.wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
-            if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);
-            p->cls_features = (int)num_features; p->cls_groups = cl.groups; p->cls_batches = cl.batches; p->cls_walks = cl.walks;
-            p->cls_ok = 1;
-        }
     }
     *out = p;
     return GN_OK;
@@ -558,6 +575,9 @@ static gn_status plan_forward_cols(const gn_distmult_plan* plan, const float* z,
             }
         }
     }
+    if (plan->cls_ok && plan->batches == 0)
+        return gn::fail(GN_ERR_UNSUPPORTED, "the plan holds the row-class encoding only (built for %d features): no kernel of it covers columns [%lld, %lld): "
+                                            "use gn_distmult_forward_f32", plan->cls_features, (long long)col_lo, (long long)col_hi);
     DmPlanArgs a;
     a.n_phases = (f % 4 == 0 && ld_z % 4 == 0 && ld_d % 4 == 0 &&
                   ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d)) & 15) == 0)

@@ -51,8 +51,72 @@ constexpr int64_t kClsWindowBytes = 1 << 20;   // scores of one sub-range: what 
 // Triples with the same unordered node pair and relation have the same score (the reference's positive list holds every
 // edge in both directions, utils.py:132-138): they are paired up, the first of a pair is scored and writes both positions.
 // mirror_of[e] = the later copy that takes e's score (-1: none); covered[e] = e is such a later copy.
+// (the serial form: any order of relations)
+inline void pair_mirrors_serial(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
+                                std::vector<int64_t>& mirror_of, std::vector<char>& covered);
+
+// Round 6: a type-sorted list (the reference's layout, utils.py:168-198) pairs up inside every relation on its own - the
+// relations are dealt to the builder threads in contiguous runs of about equal edge counts, each thread with one small
+// open-addressing table that it wipes by the slots it touched.  Same pairs as the serial pass (within a relation the
+// edges are visited in list order).  2 M edges: 92 -> 14 ms on eight threads.
 inline void pair_mirrors(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
                          std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
+    const int64_t E = (int64_t)hu.size();
+    bool sorted = true;
+    for (int64_t e = 1; e < E && sorted; ++e) sorted = hr[e - 1] <= hr[e];
+    if (!sorted || E < (1 << 16)) { pair_mirrors_serial(hu, hv, hr, node_bits, mirror_of, covered); return; }
+    mirror_of.assign((size_t)E, -1);
+    covered.assign((size_t)E, 0);
+    std::vector<int64_t> rel_start;                              // first edge of every run of equal relation ids, then E
+    for (int64_t e = 0; e < E; ++e)
+        if (e == 0 || hr[e] != hr[e - 1]) rel_start.push_back(e);
+    rel_start.push_back(E);
+    const int64_t runs = (int64_t)rel_start.size() - 1;
+    // tasks: contiguous runs of relations of ~E / 64 edges each (a relation is never cut)
+    std::vector<int64_t> task_first(1, 0);
+    {
+        const int64_t want = std::max<int64_t>(1, E / 64);
+        int64_t acc = 0;
+        for (int64_t r = 0; r < runs; ++r) {
+            acc += rel_start[r + 1] - rel_start[r];
+            if (acc >= want && r + 1 < runs) { task_first.push_back(r + 1); acc = 0; }
+        }
+        task_first.push_back(runs);
+    }
+    gn::parallel_for((int64_t)task_first.size() - 1, 1, [&](int64_t t0, int64_t t1) {
+        std::vector<uint64_t> keys;
+        std::vector<int64_t> vals;
+        std::vector<uint32_t> touched;
+        for (int64_t t = t0; t < t1; ++t)
+            for (int64_t r = task_first[t]; r < task_first[t + 1]; ++r) {
+                const int64_t lo_e = rel_start[r], hi_e = rel_start[r + 1];
+                size_t cap = 16;
+                while (cap < (size_t)(hi_e - lo_e) * 2 + 16) cap <<= 1;
+                if (keys.size() < cap) { keys.assign(cap, ~(uint64_t)0); vals.assign(cap, -1); }
+                const size_t mask = cap - 1;
+                touched.clear();
+                for (int64_t e = lo_e; e < hi_e; ++e) {
+                    const uint64_t lo = (uint64_t)std::min(hu[e], hv[e]), hi = (uint64_t)std::max(hu[e], hv[e]);
+                    const uint64_t key = (lo << node_bits) | hi;
+                    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & mask;
+                    while (keys[h] != ~(uint64_t)0 && keys[h] != key) h = (h + 1) & mask;
+                    if (keys[h] == key && vals[h] >= 0) {        // the open copy of this triple: pair up
+                        mirror_of[vals[h]] = e;
+                        covered[e] = 1;
+                        vals[h] = -1;
+                    } else {                                    // first (or third, fifth, ...) copy: stays open
+                        if (keys[h] != key) touched.push_back((uint32_t)h);
+                        keys[h] = key;
+                        vals[h] = e;
+                    }
+                }
+                for (uint32_t h : touched) { keys[h] = ~(uint64_t)0; vals[h] = -1; }
+            }
+    });
+}
+
+inline void pair_mirrors_serial(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
+                                std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
     const int64_t E = (int64_t)hu.size();
     mirror_of.assign((size_t)E, -1);
     covered.assign((size_t)E, 0);
@@ -78,6 +142,18 @@ inline void pair_mirrors(const std::vector<int64_t>& hu, const std::vector<int64
     }
 }
 
+// A bucket of the dealers below: at most 64 entries, no allocation (with std::vector buckets a deal of 64 pairs cost ~50 us -
+// sixteen vectors grown by push_back - and the decoder plan of pose0-syn spent 100 ms of eight threads in them).
+struct SmallStack {
+    int v[64];
+    int n = 0;
+    void push_back(int x) { v[n++] = x; }
+    int back() const { return v[n - 1]; }
+    void pop_back() { --n; }
+    size_t size() const { return (size_t)n; }
+    bool empty() const { return n == 0; }
+};
+
 // Deals the (up to) 64 edges of a batch to its slots.  Lane l of the wave holds slot l; wave step S works on the
 // slots 4 q + S of the 16 quads q, and ds_read_b128 serves the quads in four access groups.  A cell = (step,
 // access group) = four slots that hit the LDS together: its edges should have four different u % 4 and four
@@ -88,7 +164,7 @@ inline void deal_batch(const int64_t* u, const int64_t* v, int count, int* slot_
                                       {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
                                       {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
                                       {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
-    std::vector<int> bucket[4][4];                         // edges by (u % 4, v % 4)
+    SmallStack bucket[4][4];                         // edges by (u % 4, v % 4)
     for (int e = 0; e < count; ++e) bucket[u[e] & 3][v[e] & 3].push_back(e);
     int left = count;
     for (int cell = 0; cell < 16; ++cell) {
@@ -138,7 +214,7 @@ inline void deal_run(const int* lu, const int* lv, int count, std::vector<int>& 
                                       {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
     const int steps = (count + 15) / 16;
     order.assign((size_t)steps * 16, -1);
-    std::vector<int> bucket[4][4];
+    SmallStack bucket[4][4];
     for (int e = count - 1; e >= 0; --e) bucket[lu[e] & 3][lv[e] & 3].push_back(e);   // (popped from the back: list order)
     int left = count;
     for (int cell = 0; cell < steps * 4 && left > 0; ++cell) {
@@ -202,14 +278,7 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     const int nclasses = nblocks == 1 ? 1 : 3;
     auto bstart = [&](int b) { return std::min<int64_t>(n, (int64_t)b * blk); };
     auto bsize = [&](int b) { return bstart(b + 1) - bstart(b); };
-    auto cls_of = [&](int64_t e) {
-        if (nblocks == 1) return 0;
-        const int bu = (int)(hu[e] / blk), bv = (int)(hv[e] / blk);
-        if (bu != bv) return (bu + 1) % 3 == bv ? bu : bv;
-        return (hr[e] & 1) ? (bu + 2) % 3 : bu;                  // a pair inside one block: either class that holds the block
-    };
-    auto local = [&](int64_t node, int k) {
-        const int b = (int)(node / blk);
+    auto local_b = [&](int64_t node, int b, int k) {          // local row of `node` (of block b) in class k's table
         return (int)(b == k ? node - bstart(k) : bsize(k) + node - bstart((k + 1) % 3));
     };
     // Position parts.  A 64-byte line of the score vector holds sixteen consecutive edges of one relation - pairs of all
@@ -220,6 +289,20 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     // written for them, the lines leaving L2 a third at a time), the XCD's range is cut into `walks` sub-ranges that its
     // workgroups walk one after the other: the live window is one sub-range.
     const int64_t S = (int64_t)scored.size();
+    // The scored pairs' endpoints, relation and block ids as compact arrays in list order (round 6): every pass below walks
+    // THESE (8 bytes per pair) instead of chasing scored[] into four int64 arrays of the whole list (64 MB at pose0-syn: the
+    // builder was bound by cache misses, 120 ms on eight threads).
+    std::vector<uint16_t> su((size_t)S), sv((size_t)S), sr((size_t)S);
+    std::vector<uint8_t> sbu((size_t)S), sbv((size_t)S);
+    std::vector<uint32_t> sm((size_t)S);                         // the pair's mirror position (kNoMirror: none)
+    gn::parallel_for(S, 1 << 14, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            const int64_t e = scored[(size_t)i];
+            sm[(size_t)i] = mirror_of[(size_t)e] >= 0 ? (uint32_t)mirror_of[(size_t)e] : kNoMirror;
+            su[(size_t)i] = (uint16_t)hu[(size_t)e]; sv[(size_t)i] = (uint16_t)hv[(size_t)e]; sr[(size_t)i] = (uint16_t)hr[(size_t)e];
+            sbu[(size_t)i] = (uint8_t)(hu[(size_t)e] / blk); sbv[(size_t)i] = (uint8_t)(hv[(size_t)e] / blk);
+        }
+    });
     const int parts = (cus % 8 == 0 && cus >= 24 && S >= (int64_t)64 * 4 * cus) ? 8 : 1;
     const int64_t list_bytes = (int64_t)hu.size() * 4;
     const int walks = parts == 8 ? (int)std::max<int64_t>(1, std::min<int64_t>(kClsMaxWalks, gn::ceil_div(list_bytes / 8, window_bytes))) : 1;
@@ -241,14 +324,14 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     std::vector<int32_t> part_of((size_t)S);
     int64_t n_rel = 0;
     {
-        for (int64_t i = 0; i < S; ++i) n_rel = std::max<int64_t>(n_rel, hr[scored[i]] + 1);
+        for (int64_t i = 0; i < S; ++i) n_rel = std::max<int64_t>(n_rel, (int64_t)sr[(size_t)i] + 1);
         std::vector<int64_t> rel_cnt((size_t)n_rel, 0);
-        for (int64_t i = 0; i < S; ++i) rel_cnt[(size_t)hr[scored[i]]]++;
+        for (int64_t i = 0; i < S; ++i) rel_cnt[(size_t)sr[(size_t)i]]++;
         double total_w = 0.0;
         for (int64_t r = 0; r < n_rel; ++r) total_w += rel_cnt[(size_t)r] > 0 ? (double)rel_cnt[(size_t)r] + 24.0 : 0.0;
         double cum = 0.0;
         for (int64_t i = 0; i < S; ++i) {
-            const double w = 1.0 + 24.0 / (double)rel_cnt[(size_t)hr[scored[i]]];
+            const double w = 1.0 + 24.0 / (double)rel_cnt[(size_t)sr[(size_t)i]];
             part_of[(size_t)i] = (int32_t)std::min<int64_t>(nparts - 1, (int64_t)((cum + 0.5 * w) * nparts / total_w));
             cum += w;
         }
@@ -262,11 +345,10 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
         const int W = cus / 8;
         std::vector<int64_t> fixed((size_t)nparts * 3, 0), flex((size_t)nparts * n_rel * 3, 0);
         for (int64_t i = 0; i < S; ++i) {
-            const int64_t e = scored[i];
             const int part = part_of[(size_t)i];
-            const int bu = (int)(hu[e] / blk), bv = (int)(hv[e] / blk);
+            const int bu = sbu[(size_t)i], bv = sbv[(size_t)i];
             if (bu != bv) fixed[(size_t)part * 3 + ((bu + 1) % 3 == bv ? bu : bv)]++;
-            else flex[((size_t)part * n_rel + hr[e]) * 3 + bu]++;
+            else flex[((size_t)part * n_rel + sr[(size_t)i]) * 3 + bu]++;
         }
         for (int part = 0; part < nparts; ++part) {
             // the units of the classes: as even as W allows, the smaller shares to the classes with the least fixed load - of the
@@ -305,17 +387,25 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     std::vector<int32_t> free_seen(free_cut.size(), 0);
     for (int64_t i = 0; i < S; ++i) {
         const int part = part_of[(size_t)i];
-        const int64_t e = scored[i];
-        int c = cls_of(e);
-        if (!free_cut.empty() && hu[e] / blk == hv[e] / blk) {
-            const int b = (int)(hu[e] / blk);
-            const size_t cell = ((size_t)part * n_rel + hr[e]) * 3 + (size_t)b;
-            c = free_seen[cell]++ < free_cut[cell] ? b : (b + 2) % 3;
+        const int bu = sbu[(size_t)i], bv = sbv[(size_t)i], rel = sr[(size_t)i];
+        int c = 0;                                               // (cls_of, on the compact arrays)
+        if (nblocks != 1) c = bu != bv ? ((bu + 1) % 3 == bv ? bu : bv) : ((rel & 1) ? (bu + 2) % 3 : bu);
+        if (!free_cut.empty() && bu == bv) {
+            const size_t cell = ((size_t)part * n_rel + rel) * 3 + (size_t)bu;
+            c = free_seen[cell]++ < free_cut[cell] ? bu : (bu + 2) % 3;
         }
-        key[i] = (uint32_t)(part * nclasses + c) << 16 | (uint32_t)hr[e];
+        key[i] = (uint32_t)(part * nclasses + c) << 16 | (uint32_t)rel;
         idx[i] = i;
     }
-    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });
+    {
+        // stable counting sort by (group, relation): the keys take ngroups x n_rel values (round 6: std::stable_sort with a
+        // comparator over 10^6 indices was the builder's longest serial stretch)
+        std::vector<int64_t> first((size_t)ngroups * (size_t)n_rel + 1, 0);
+        auto bucket = [&](int64_t i) { return (size_t)(key[(size_t)i] >> 16) * (size_t)n_rel + (size_t)(key[(size_t)i] & 0xffffu); };
+        for (int64_t i = 0; i < S; ++i) first[bucket(i) + 1]++;
+        for (size_t b = 1; b < first.size(); ++b) first[b] += first[b - 1];
+        for (int64_t i = 0; i < S; ++i) idx[(size_t)first[bucket(i)]++] = i;
+    }
     // runs -> steps of 16 slots
     struct Run { int64_t lo, hi; int grp, rel; int64_t step0; };
     std::vector<Run> runs;
@@ -333,15 +423,27 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
     const int64_t NB = grp_batch0[ngroups], NBA = NB + kClsSlack;
     std::vector<uint32_t> packed((size_t)NBA * 64, 0u), own((size_t)NBA * 64, kNoMirror), mirror((size_t)NBA * 64, kNoMirror);
     std::vector<uint16_t> rel16((size_t)NBA * 4, 0);
-    gn::parallel_for((int64_t)runs.size(), 16, [&](int64_t r0, int64_t r1) {
+    // tasks of about equal PAIR counts (contiguous runs): the runs of the list's head are two orders of magnitude longer than
+    // those of its tail, and equal numbers of runs per builder thread left one thread with most of the pairs
+    std::vector<int64_t> task_first(1, 0);
+    {
+        const int64_t want = std::max<int64_t>(1, S / 256);
+        int64_t acc = 0;
+        for (size_t ri = 0; ri < runs.size(); ++ri) {
+            acc += runs[ri].hi - runs[ri].lo;
+            if (acc >= want && ri + 1 < runs.size()) { task_first.push_back((int64_t)ri + 1); acc = 0; }
+        }
+        task_first.push_back((int64_t)runs.size());
+    }
+    gn::parallel_for((int64_t)task_first.size() - 1, 1, [&](int64_t t0, int64_t t1) {
         std::vector<int> lu, lv, order;
-        for (int64_t ri = r0; ri < r1; ++ri) {
+        for (int64_t ri = task_first[(size_t)t0]; ri < task_first[(size_t)t1]; ++ri) {
             const Run& run = runs[ri];
             const int count = (int)(run.hi - run.lo), cls = run.grp % nclasses;
             lu.resize(count); lv.resize(count);
             for (int k = 0; k < count; ++k) {
-                const int64_t e = scored[idx[run.lo + k]];
-                lu[k] = local(hu[e], cls); lv[k] = local(hv[e], cls);
+                const size_t i = (size_t)idx[run.lo + k];
+                lu[k] = local_b(su[i], sbu[i], cls); lv[k] = local_b(sv[i], sbv[i], cls);
             }
             // dealt 64 consecutive pairs (one batch, one store instruction per lane) at a time: the 64 scores of a batch then
             // land inside a window of ~200 list positions.  Dealt over the whole run - more freedom for conflict-free
@@ -369,9 +471,9 @@ inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std:
                         const int src = pr >= 0 ? pr : 0;                       // padding repeats the run's first pair, writes nothing
                         packed[slot] = (uint32_t)lu[src] | (uint32_t)lv[src] << 16;
                         if (pr >= 0) {
-                            const int64_t e = scored[idx[run.lo + pr]];
-                            own[slot] = (uint32_t)e;
-                            mirror[slot] = mirror_of[e] >= 0 ? (uint32_t)mirror_of[e] : kNoMirror;
+                            const size_t i = (size_t)idx[run.lo + pr];
+                            own[slot] = (uint32_t)scored[i];
+                            mirror[slot] = sm[i];
                         }
                     }
             }
