@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 147                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 148                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -109,6 +109,9 @@ SIGNATURES = {
     "gn_link_loss_workspace_bytes": (_sz, []),
     "gn_link_loss_forward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _sz, _p]),
     "gn_link_loss_backward_f32": (_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),
+    "gn_exchange_buffer_bytes": (_sz, [_i64, _int]),
+    "gn_exchange_push_f32": (_int, [_p, _i64, _p, _p, _p, _int, _int, _int, _p]),
+    "gn_exchange_wait_sum_f32": (_int, [_p, _p, _i64, _int, _int, _p, _int, _p, _p]),
     "gn_link_metrics_plan_create": (_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_link_metrics_plan_destroy": (None, [_p]),
     "gn_link_metrics_plan_workspace_bytes": (_sz, [_p]),
@@ -947,6 +950,8 @@ def raise_if_index_errors(device=None):
         bits = int(flag.item())
         if bits != 0:
             flag.zero_()
+            if bits & 4:
+                raise RuntimeError("one-shot exchange: a peer's partial sums did not arrive within the timeout")
             if bits & 2:
                 raise RuntimeError("negative sampler: a relation's positive pairs leave no pair to draw")
             raise IndexError("DistMult decoder saw an edge endpoint or relation id outside its table")

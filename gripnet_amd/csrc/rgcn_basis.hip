@@ -23,6 +23,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
+// (make VARIANT=nomfma VFLAGS=-DGN_BASIS_NO_MFMA: the same launches with every matrix instruction replaced by one FMA that keeps
+// its operands' loads alive - wrong results, for timing what the gathers cost on their own: profiles/r06_experiments.md)
+#ifdef GN_BASIS_NO_MFMA
+__device__ __forceinline__ f32x4 basis_mfma(float a, float b, f32x4 c) { c[0] += a * b; return c; }
+#else
+__device__ __forceinline__ f32x4 basis_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
+
 constexpr int kBasisThreads = 512, kBasisWaves = kBasisThreads / 64;   // eight waves: a destination row per wave at a time, or a heavy row per workgroup
 constexpr int kHeavyEdges = gn_layout::kBasisHeavyEdges;               // rows with more incoming edges are walked by a whole workgroup
 constexpr int64_t kSlabBytes = 64ll << 20;         // rows of U in flight between the gather and the dense product
@@ -66,7 +74,7 @@ __device__ __forceinline__ void chunk_any(const BasisArgs& a, f32x4 (&acc)[BT][N
             for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[jm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jm], xv[q][t], acc[jm][t], 0, 0, 0);
+                    acc[jm][t] = basis_mfma(av[q][jm], xv[q][t], acc[jm][t]);
     }
 }
 
@@ -117,7 +125,7 @@ __device__ __forceinline__ void chunk_full(const BasisArgs& a, f32x4 (&acc)[BT][
             for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[jm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jm], xv[q][t], acc[jm][t], 0, 0, 0);
+                    acc[jm][t] = basis_mfma(av[q][jm], xv[q][t], acc[jm][t]);
     }
 }
 

@@ -126,6 +126,63 @@ class HipShardKernels:
         return link_loss(pos, neg, eps) * (pos.numel() / float(total_edges))
 
 
+class OneShotAllReduce:
+    """The exchange step as ONE hop over xGMI's point-to-point links instead of a collective-library call (82 KB
+    are latency-bound; a ring serialises 2 (G - 1) hops): every rank writes its partial into its slot of every peer's
+    buffer, raises a flag, waits for its own G flags ON THE DEVICE and adds the G slots in rank order
+    (csrc/exchange.hip) - all ranks get the same bits, nothing synchronises the host.
+
+    Setup is collective (every rank of `group` constructs it with the same `numel`): the slot buffers and flag arrays are
+    shared as IPC handles (torch's CUDA-IPC storages, i.e. hipIpcGetMemHandle / hipIpcOpenMemHandle) gathered with
+    `all_gather_object`; afterwards the exchange makes no torch.distributed call.  ``all_reduce(t)`` sums in place, on the
+    current stream.  Cannot be timed on a one-GPU box; tested there with two and three PROCESSES sharing the GPU against the
+    rank-order sum (tests/test_gpu_callers.py)."""
+
+    def __init__(self, numel: int, device, rank: int, world_size: int, group=None, timeout_ms: int = 2000):
+        import torch.distributed as dist
+        from . import _hip
+        self._hip, self.rank, self.world, self.numel = _hip, int(rank), int(world_size), int(numel)
+        self.device, self.timeout_ms, self.step = torch.device(device), int(timeout_ms), 0
+        lib = _hip.load()
+        nbytes = int(lib.gn_exchange_buffer_bytes(self.numel, self.world))
+        # (an IPC handle names the allocator's whole block and the tensor's offset inside it: torch's storages carry both)
+        self.slots = torch.zeros((max(nbytes // 4, 1),), dtype=torch.float32, device=self.device)
+        self.flags = torch.zeros((self.world,), dtype=torch.int32, device=self.device)
+        self.ticket = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        mine = (self.slots.untyped_storage()._share_cuda_(), self.flags.untyped_storage()._share_cuda_())
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        self._peers = []                                             # (keeps the opened storages alive)
+        slot_ptrs, flag_ptrs = [], []
+        for r, (hs, hf) in enumerate(handles):
+            if r == self.rank:
+                ts, tf = self.slots, self.flags
+            else:
+                ts = torch.empty(0, dtype=torch.float32, device=self.device).set_(torch.UntypedStorage._new_shared_cuda(*hs))
+                tf = torch.empty(0, dtype=torch.int32, device=self.device).set_(torch.UntypedStorage._new_shared_cuda(*hf))
+            self._peers.append((ts, tf))
+            slot_ptrs.append(ts.data_ptr())
+            flag_ptrs.append(tf.data_ptr())
+        import ctypes
+        self._slot_ptrs = (ctypes.c_void_p * self.world)(*slot_ptrs)
+        self._flag_ptrs = (ctypes.c_void_p * self.world)(*flag_ptrs)
+        dist.barrier(group=group)                                    # every rank has mapped every buffer before the first push
+
+    def all_reduce(self, t: torch.Tensor):
+        h = self._hip
+        if t.numel() != self.numel or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("one-shot exchange: a contiguous fp32 tensor of {} elements, got {} of {}".format(self.numel, t.dtype, tuple(t.shape)))
+        self.step += 1
+        import ctypes
+        st = h.stream_ptr(t.device)
+        h._call("gn_exchange_push_f32", h.ptr(t), self.numel, ctypes.addressof(self._slot_ptrs), ctypes.addressof(self._flag_ptrs),
+                h.ptr(self.ticket), self.world, self.rank, self.step, st)
+        h._call("gn_exchange_wait_sum_f32", h.ptr(self.slots), h.ptr(self.flags), self.numel, self.world, self.step, h.ptr(t),
+                self.timeout_ms, h.ptr(h.error_flag(t.device)), h.stream_ptr(t.device))
+        return t
+
+
 class ShardedPoseForward:
     """``z, score_of_my_edge_range = fwd()`` on every rank; ``z`` is identical on all ranks."""
 
@@ -146,8 +203,17 @@ class ShardedPoseForward:
         # issue the collectives also at world_size 1 (they are the identity there): lets one GPU exercise the RCCL calls,
         # their stream and their event path (tests/test_gpu_callers.py)
         self.always_exchange = False
+        self.one_shot = None                     # use_one_shot_exchange(): the forward's exchange as one direct hop
+
+    def use_one_shot_exchange(self, timeout_ms: int = 2000):
+        """Collective: from now on the forward's all-reduce of the partial [n_d, out] is the one-shot direct exchange
+        (OneShotAllReduce) instead of `dist.all_reduce`.  (The training step's other exchanges stay on the collective library.)"""
+        self.one_shot = OneShotAllReduce(self._partial.numel(), self._partial.device, self.rank, self.world_size, self.group, timeout_ms)
+        return self
 
     def all_reduce(self, t: torch.Tensor):
+        if self.one_shot is not None and t.data_ptr() == self._partial.data_ptr():
+            return self.one_shot.all_reduce(t)
         if self.world_size > 1 or self.always_exchange:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -155,6 +221,11 @@ class ShardedPoseForward:
 
     def all_reduce_begin(self, t: torch.Tensor):
         """The exchange as an asynchronous collective: what is launched before `all_reduce_end` runs beside it."""
+        if self.one_shot is not None and t.data_ptr() == self._partial.data_ptr():
+            # stream-ordered launches on the current stream: the push goes out at once, the decoder's input-column launch that the
+            # caller issues next is queued BEHIND the wait (one stream) - the overlap of the collective path needs a second stream
+            self.one_shot.all_reduce(t)
+            return None
         if self.world_size > 1 or self.always_exchange:
             import torch.distributed as dist
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

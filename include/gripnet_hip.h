@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 147 /* 0.1.43 */
+#define GN_VERSION 148 /* 0.1.44 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -585,6 +585,20 @@ GN_API size_t gn_link_metrics_workspace_bytes(int64_t num_relations, int64_t num
 GN_API gn_status gn_link_metrics_f32(const float* pos_score, const float* neg_score, const int64_t* range_list_host,
                               int64_t num_relations, int64_t num_edges, double* out, void* workspace,
                               size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One-shot direct exchange: the all-reduce of the sharded relational layer's partial sums ([n_d, 32] floats,
+ * 82,560 B on PoSE: latency-bound) as ONE hop over xGMI's point-to-point links instead of a ring's 2 (G - 1): every rank
+ * writes its partial into its slot of every peer's buffer (peer-mapped device memory: hipIpc handles exchanged by the caller),
+ * raises a flag, waits for its own G flags on the device (bounded: timeout_ms, then bit 2 of *error_flag) and adds the G
+ * slots in RANK ORDER - every rank holds the same bits.  Slot buffer per rank: gn_exchange_buffer_bytes(n, world) bytes
+ * ([2][world][n] floats, slots alternate by step parity); flags: [world] int32, zero before step 1; ticket: one zeroed
+ * uint32; step = 1, 2, 3, ... the same on every rank.  No host synchronisation. */
+GN_API size_t gn_exchange_buffer_bytes(int64_t n, int world);
+GN_API gn_status gn_exchange_push_f32(const float* src, int64_t n, void* const* peer_slots /* [world] device pointers, host array */,
+                               void* const* peer_flags /* [world] */, unsigned int* ticket, int world, int rank, int step, void* stream);
+GN_API gn_status gn_exchange_wait_sum_f32(const void* my_slots, const void* my_flags, int64_t n, int world, int step, float* dst,
+                                   int timeout_ms, int32_t* error_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -619,3 +619,91 @@ def test_typed_negative_sampling_draws_on_the_device(gpu):
     for (s, e), m in zip(sub, sizes):
         assert not np.isin((part[0, at:at + m] * n + part[1, at:at + m]).cpu().numpy(), pos[s:e]).any()
         at += m
+
+
+# ---- the one-shot direct exchange, with two and three PROCESSES on the one GPU ----------------------------------
+def _oneshot_worker(rank, world, port, q, skip_rank):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # handles and the reference sums travel over gloo
+    try:
+        from gripnet_amd import _hip
+        from gripnet_amd.sharded import OneShotAllReduce, ShardedPoseForward
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        n = 645 * 32
+        ex = OneShotAllReduce(n, dev, rank, world, timeout_ms=300 if skip_rank is not None else 5000)
+        same, timed_out = [], False
+        for step in range(6):
+            part = torch.randn(n, generator=torch.Generator().manual_seed(100 * step + rank)) * (10.0 ** (rank - 1))
+            parts = [torch.empty(n) for _ in range(world)]
+            dist.all_gather(parts, part)
+            ref = parts[0].clone()
+            for r in range(1, world):
+                ref += parts[r]                                            # rank order, fp32: what every rank must hold, bit for bit
+            if skip_rank == rank and step == 3:
+                break                                                      # this rank dies here: its peers must time out, not hang
+            t = part.to(dev)
+            ex.all_reduce(t)
+            torch.cuda.synchronize()
+            try:
+                _hip.raise_if_index_errors(dev)
+            except RuntimeError as err:
+                timed_out = "did not arrive" in str(err)
+                break
+            same.append(bool(torch.equal(t.cpu(), ref)))
+        out = {"rank": rank, "same": same, "timed_out": timed_out}
+        if skip_rank is None:
+            # the sharded forward with its exchange on the one-shot path: z identical on both ranks, equal to the unsharded forward
+            data = make_pose("small").to(dev)
+            torch.manual_seed(1111)
+            model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
+            with torch.no_grad():
+                z_ref, _ = model(data)
+                fwd = ShardedPoseForward(model, data, rank, world).use_one_shot_exchange()
+                for _ in range(3):
+                    z, s = fwd()
+                torch.cuda.synchronize()
+                _hip.raise_if_index_errors(dev)
+            zs = [torch.empty(z.shape) for _ in range(world)]
+            dist.all_gather(zs, z.cpu())
+            out["z_same_on_all_ranks"] = all(torch.equal(zs[0], other) for other in zs)
+            out["z_err"] = float((z - z_ref).abs().max())
+        torch.cuda.synchronize()
+        dist.barrier()                                                     # nobody unmaps a buffer a peer's launch may still write
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,skip_rank", [(2, None), (3, None), (2, 1)])
+def test_one_shot_exchange_between_processes_on_one_gpu(gpu, world, skip_rank):
+    """csrc/exchange.hip behind sharded.OneShotAllReduce: every rank writes its partial into peer-mapped buffers (hipIpc through
+    torch's CUDA-IPC storages), waits on the device and adds the slots in rank order - bit for bit the rank-order fp32 sum, the
+    same on every rank, step after step (slots alternate by parity); ShardedPoseForward with its exchange on that path; and a
+    peer that never arrives is a RuntimeError after the timeout, not a hang.  One GPU: the ranks are processes sharing it (the
+    protocol and the IPC mapping are what is tested; the xGMI hop itself cannot be on this pool)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, world, port, q, skip_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=400) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if skip_rank is None:
+        for o in outs:
+            assert o["same"] == [True] * 6, o
+            assert o["z_same_on_all_ranks"] and o["z_err"] <= 1e-5, o
+    else:
+        assert outs[0]["same"] == [True] * 3 and outs[0]["timed_out"], outs     # three good steps, then the peer is gone
