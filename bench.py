@@ -777,6 +777,11 @@ def main():
             from gripnet_amd.pipeline import Graphed, Recorded
             from gripnet_amd.sharded import ShardedPoseForward
             fwd = sharded = ShardedPoseForward(model, data, rank, world)
+            if os.environ.get("GN_SHARD_EXCHANGE") == "one_shot" and world > 1:
+                # (opt-in: the forward's all-reduce as the one-shot direct exchange over peer-mapped buffers, csrc/exchange.hip, instead
+                # of RCCL - what SURVEY 8e asks to measure against ncclAllReduce; never the default of a driver run: untested across
+                # real GPUs on this pool)
+                fwd.use_one_shot_exchange()
             fence()
             t_plan = time.perf_counter()
             for _ in range(3):
@@ -966,7 +971,8 @@ def main():
                    "E_gg": int(data.gg_edge_index.shape[1]), "E_gd": int(data.gd_edge_index.shape[1]), "E_dd": E_dd,
                    "decoder": "static positive list: every unordered (node pair, relation) scored once, the score written to both "
                               "directions' positions (same bits as scoring both; parity checked on all E scores)",
-                   "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + RCCL all-reduce".format(world),
+                   "parallelism": "single GPU" if world == 1 else "dd edge-range (relation) shards x{} + {}".format(
+                       world, "one-shot direct exchange (peer-mapped buffers)" if getattr(sharded, "one_shot", None) is not None else "RCCL all-reduce"),
                    "launch": launch_note},
         "ms_per_step_min": spread["ms_per_step_min"],
         "spread": spread,

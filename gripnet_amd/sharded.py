@@ -159,8 +159,11 @@ class OneShotAllReduce:
             if r == self.rank:
                 ts, tf = self.slots, self.flags
             else:
-                ts = torch.empty(0, dtype=torch.float32, device=self.device).set_(torch.UntypedStorage._new_shared_cuda(*hs))
-                tf = torch.empty(0, dtype=torch.int32, device=self.device).set_(torch.UntypedStorage._new_shared_cuda(*hf))
+                # (the opened storage lives on the EXPORTER's device - another GPU of the node; opening it enables peer access, so
+                # this rank's launches may write through the pointer)
+                ss, sf = torch.UntypedStorage._new_shared_cuda(*hs), torch.UntypedStorage._new_shared_cuda(*hf)
+                ts = torch.empty(0, dtype=torch.float32, device=ss.device).set_(ss)
+                tf = torch.empty(0, dtype=torch.int32, device=sf.device).set_(sf)
             self._peers.append((ts, tf))
             slot_ptrs.append(ts.data_ptr())
             flag_ptrs.append(tf.data_ptr())
