@@ -101,7 +101,7 @@ def train_step_entry(dev, steps=20):
     from gripnet_amd import _hip
     from gripnet_amd.pipeline import PoseModel
     from gripnet_amd.synth import make_pose
-    from gripnet_amd.utils import link_loss
+    from gripnet_amd.utils import link_prediction_loss
     from gripnet_amd.synth import add_pose_test_split
     data = add_pose_test_split(make_pose("pose0-syn")).to(dev)
     torch.manual_seed(1111)
@@ -116,9 +116,9 @@ def train_step_entry(dev, steps=20):
         sampler.sample(seed=0, out=neg, step=drawn)            # gn_negative_sampler_sample_stepped
         opt.zero_grad()
         z = model.encode(data)
-        pos = model.dmt(z, data.train_idx, data.train_et)
-        negs = model.dmt(z, neg, data.train_et)
-        loss = link_loss(pos, negs)                            # GripNet-pose.py:140-142 in one launch (gn_link_loss_*)
+        # GripNet-pose.py:137-142 (both decoder calls + the loss) as one autograd node: its backward computes the loss's derivative
+        # inside the two decoder-backward launches (utils.link_prediction_loss; the same bits as the three separate calls)
+        loss, pos, negs = link_prediction_loss(model.dmt, z, data.train_idx, neg, data.train_et)
         loss.backward(one)                                     # (the seed gradient is kept: backward() would fill a new 1 per step)
         opt.step()
         kept[:] = [z, pos, negs]                               # what the epoch's metrics and test() read (GripNet-pose.py:148-160,213-215)
@@ -189,7 +189,7 @@ def train_step_entry(dev, steps=20):
     return {"workload": "pose0-syn training step", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
             "epoch": epoch,
             "ms_per_step_eager": round(eager_ms, 4),
-            "what": "negative sampling + forward + DistMult on positives and on the fresh negatives + loss (utils.link_loss) + backward + Adam (gripnet_amd.optim.Adam, one launch): "
+            "what": "negative sampling + forward + DistMult on positives and on the fresh negatives + loss (utils.link_prediction_loss: the loss derivative computed inside the decoder backward launches) + backward + Adam (gripnet_amd.optim.Adam, one launch): "
                     "ms_per_step = one hipGraph replay per step and nothing else; the draw (typed sampler) is the graph's first node, its seed moves with a counter on the device; "
                     "ms_per_step_eager = the same step as a Python loop over the modules (host-bound)",
             "algorithmic_bytes": alg_total, "algorithmic_bytes_by_part": {k: int(v) for k, v in alg.items()},
@@ -590,9 +590,32 @@ def cold_start_entry(model, data, fence):
     per["decoder: row classes of the static list (host)"] = timed_ms(
         lambda: _hip.DistMultPlan(d.train_idx, d.train_et, d.n_d_node, d.n_dd_edge_type, model.dmt.in_dim))
     out["plan_build_ms_sum"] = round(sum(per.values()), 2)
-    out["note"] = ("forward_ms_decoder_uncached: the eager step with the decoder scoring the raw int64 list (no plan, no remembered list); the "
-                   "relational layer has no plan-less form (every relational kernel reads a destination-major encoding): a caller whose "
-                   "dd edge list changes pays the relational plan's build time per change")
+    # ... and with NOTHING kept on the relational layer's side either: two copies of the dd edge list in turn, so that every
+    # call sees a list it did not see the call before - a light plan (device sort only) + the general O(E) kernel per call
+    conv = model.dd.conv_list[0]
+    x48 = stages.x
+    lists = [(d.train_idx.clone(), d.train_range.clone()) for _ in range(2)]
+    per["relational layer, LIGHT plan (static_graph = False: the device-sorted key list only)"] = timed_ms(
+        lambda: _hip.RgcnPlan(d.train_idx, d.train_range, d.n_d_node, light=True))
+    conv.static_graph = False
+    kept = (conv._plan, conv._plan_key)
+    try:
+        for k in range(4):
+            model.dd(x48, lists[k & 1][0], edge_type=d.train_et, range_list=lists[k & 1][1], if_catout=True)
+        fence()
+        t = time.perf_counter()
+        for k in range(10):
+            model.dd(x48, lists[k & 1][0], edge_type=d.train_et, range_list=lists[k & 1][1], if_catout=True)
+        fence()
+        out["relational_layer_ms_uncached"] = round(1e3 * (time.perf_counter() - t) / 10, 4)
+    finally:
+        conv.static_graph = True
+        conv._plan, conv._plan_key = kept
+        model.dd.__dict__.pop("_memo", None)
+    out["note"] = ("forward_ms_decoder_uncached: the eager step with the decoder scoring the raw int64 list (no plan, no remembered list); "
+                   "relational_layer_ms_uncached: the dd layer alone on an edge list it did not see the call before (myRGCN.static_graph = False: "
+                   "a light plan - the device-sorted key list - built per call, then the general O(E) kernel); every relational kernel reads a "
+                   "destination-major encoding, so a sort per new list is the floor")
     return out
 
 

@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 148                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 150                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     "gn_softmax_rows_backward_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     "gn_class_scores_f32": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "gn_rgcn_plan_create": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_p)]),
+    "gn_rgcn_plan_create_ex": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _int, _p, C.POINTER(_p)]),
     "gn_rgcn_plan_destroy": (None, [_p]),
     "gn_rgcn_plan_input_edges": (_i64, [_p]),
     "gn_rgcn_workspace_bytes": (_sz, [_p, _i64, _i64, _i64, _int]),
@@ -89,6 +90,8 @@ SIGNATURES = {
     "gn_distmult_bwd_plan_destroy": (None, [_p]),
     "gn_distmult_bwd_plan_workspace_bytes": (_sz, [_p, _i64]),
     "gn_distmult_backward_planned_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
+    "gn_distmult_backward_loss_packed_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _int, _p, _p, _sz, _p]),
+    "gn_distmult_backward_loss_planned_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
     "gn_negative_sampler_sample": (_int, [_p, C.c_uint64, _p, _p, _p, _p]),
@@ -790,7 +793,9 @@ class GraphPlan:
 class RgcnPlan:
     """Owner of a gn_rgcn_plan handle (static multi-relational graph of one supervertex)."""
 
-    def __init__(self, edge_index, range_list, num_nodes, edge_lo=None, edge_hi=None):
+    def __init__(self, edge_index, range_list, num_nodes, edge_lo=None, edge_hi=None, light=False):
+        """`light`: only what the general O(E) kernel reads (GN_RGCN_PLAN_LIGHT) - no host-built schedules: the plan of an edge
+        list that will not be seen again."""
         lib = load()
         require_gpu(edge_index)
         ei, src, dst, e = edge_rows(edge_index)
@@ -801,8 +806,9 @@ class RgcnPlan:
         hi = e if edge_hi is None else int(edge_hi)
         h = _p()
         with torch.cuda.device(ei.device):
-            check(lib.gn_rgcn_plan_create(src, dst, rl.data_ptr(), 1, rl.shape[0], e, int(num_nodes), lo, hi,
-                                          stream_ptr(ei.device), C.byref(h)))
+            check(lib.gn_rgcn_plan_create_ex(src, dst, rl.data_ptr(), 1, rl.shape[0], e, int(num_nodes), lo, hi, 1 if light else 0,
+                                             stream_ptr(ei.device), C.byref(h)))
+        self.light = bool(light)
         self._h, self.device = h, ei.device
         self.num_nodes, self.num_relations, self.num_edges = int(num_nodes), int(rl.shape[0]), e
         self.edge_lo, self.edge_hi = lo, hi
@@ -1096,11 +1102,18 @@ class DistMultBwdPlan:
         self._h, self.device, self.num_edges = h, ei.device, e
         self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)
 
-    def backward(self, z, weight, grad_logit, dz, dd, probs=None):
-        if grad_logit.numel() != self.num_edges:
-            raise ValueError("the plan was built from {} edges, got {} gradients".format(self.num_edges, grad_logit.numel()))
+    def backward(self, z, weight, grad_logit, dz, dd, probs=None, loss=None):
+        """`loss` (a LinkLossGrad; then grad_logit is None and probs the forward's probabilities): the scores feed the link loss
+        directly - its derivative is computed where the records are built (gn_distmult_backward_loss_planned_f32)."""
+        n_grad = probs.numel() if loss is not None else grad_logit.numel()
+        if n_grad != self.num_edges:
+            raise ValueError("the plan was built from {} edges, got {} gradients".format(self.num_edges, n_grad))
         need = int(load().gn_distmult_bwd_plan_workspace_bytes(self._h, z.shape[1]))
         ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
+        if loss is not None:
+            _call("gn_distmult_backward_loss_planned_f32", self._h, ptr(z), ld(z), z.shape[1], ptr(weight), ld(weight),
+                  loss.ref(), ptr(probs), ptr(dz), ld(dz), ptr(dd), ld(dd), ptr(ws), need, stream_ptr(z.device))
+            return dz, dd
         _call("gn_distmult_backward_planned_f32", self._h, ptr(z), ld(z), z.shape[1], ptr(weight), ld(weight),
               ptr(grad_logit), ptr(probs), ptr(dz), ld(dz), ptr(dd), ld(dd), ptr(ws), need, stream_ptr(z.device))
         return dz, dd
@@ -1167,6 +1180,44 @@ def type_offsets(et, num_relations):
     _sorted_types.append((et, et._version, num_relations, off))
     del _sorted_types[:-4]
     return off
+
+
+class LinkLossGrad:
+    """gn_link_loss_grad: where the decoder's backward gets d loss / d probability from when its scores feed the link loss of
+    GripNet-pose.py:140-142 directly (upstream: the loss's one upstream gradient, a device scalar, or None for 1)."""
+
+    class _S(C.Structure):
+        _fields_ = [("upstream", C.c_void_p), ("eps", C.c_float), ("negative", C.c_int)]
+
+    def __init__(self, upstream, eps, negative):
+        self.upstream = upstream                               # (kept alive with the call's operands)
+        self._s = LinkLossGrad._S(None if upstream is None else upstream.data_ptr(), float(eps), 1 if negative else 0)
+
+    def ref(self):
+        if _recorder is not None:
+            _recorder.keep.append(self)
+        return C.addressof(self._s)
+
+
+def distmult_backward_loss_packed(z, u_v, edge_type, weight, probs, dz, dd, loss):
+    """The loss-fed backward on the sampler's packed pairs (gn_distmult_backward_loss_packed_f32), or False where that path
+    does not apply (no packed pairs, unsorted types, tables beyond the counting-sort path): the caller takes the two-step path."""
+    e = e_count(u_v)
+    offsets = type_offsets(edge_type, weight.shape[0])
+    packed = packed_pairs(u_v)
+    if packed is None or offsets is None or z.shape[0] > 65535 or weight.shape[0] > 32767:
+        return False
+    need = int(load().gn_distmult_backward_workspace_bytes(z.shape[0], z.shape[1], weight.shape[0], e))
+    ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=z.device)
+    try:
+        _call("gn_distmult_backward_loss_packed_f32", ptr(z), ld(z), z.shape[0], z.shape[1], ptr(packed), ptr(relation_ids16(edge_type)),
+              ptr(weight), ld(weight), weight.shape[0], e, loss.ref(), ptr(probs), ptr(dz), ld(dz), ptr(dd), ld(dd),
+              GN_DM_TYPES_SORTED | GN_DM_TYPE_TASKS, ptr(offsets), ptr(ws), need, stream_ptr(z.device))
+    except GripNetHipError as err:
+        if err.status != GN_ERR_UNSUPPORTED:
+            raise
+        return False
+    return True
 
 
 def distmult_backward(z, u_v, edge_type, weight, grad_logit, dz, dd, probs=None):

@@ -349,6 +349,86 @@ class LinkLossFn(torch.autograd.Function):
         return (dp if ctx.needs_input_grad[0] else None), (dn if ctx.needs_input_grad[1] else None), None
 
 
+class LinkPredictionLossFn(torch.autograd.Function):
+    """``loss, pos_score, neg_score = f(z, D, pos_index, neg_index, edge_type)``: the two decoder calls of a training step and
+    the loss over them (GripNet-pose.py:137-142) as ONE autograd node.  Forward: the same launches as the three separate calls
+    (same bits).  Backward: the loss's derivative is a function of an edge's own probability, so each decoder backward computes
+    it where it builds its edge records (gn_distmult_backward_loss_*_f32, csrc/distmult_bwd.hip: GradSrc) - no loss-backward
+    launch, no [E] gradient vectors through memory, and dz / dD of the two lists are added here instead of by two engine
+    launches on strided views.  The scores are returned for the epoch's metrics (GripNet-pose.py:148-160) and carry no
+    gradient.  Where a fused launch does not apply (no static plan for the positives, no packed pairs for the negatives) that
+    list takes the two-step path."""
+
+    @staticmethod
+    def forward(ctx, z, weight, pos_index, neg_index, edge_type, eps, plan):
+        zc, w = _hip.f32_rows(z.detach()), weight.detach()
+        E = pos_index.shape[1]
+        pos = torch.empty((E,), dtype=torch.float32, device=zc.device)
+        neg = torch.empty((neg_index.shape[1],), dtype=torch.float32, device=zc.device)
+        done = False
+        if plan is not None:
+            try:
+                plan.forward(zc, w, True, pos)
+                done = True
+            except _hip.GripNetHipError as err:
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+        if not done:
+            _hip.distmult_any(zc, pos_index, edge_type, w, True, pos)
+        _hip.distmult_any(zc, neg_index, edge_type, w, True, neg)
+        loss = torch.empty((), dtype=torch.float32, device=zc.device)
+        ws = _loss_workspace(zc.device)
+        _hip._call("gn_link_loss_forward_f32", _hip.ptr(pos), pos.numel(), _hip.ptr(neg), neg.numel(), float(eps), _hip.ptr(loss),
+                   _hip.ptr(ws), ws.numel(), _hip.stream_ptr(zc.device))
+        ctx.eps, ctx.plan = float(eps), plan
+        ctx.save_for_backward(zc, w, pos_index, neg_index, edge_type, pos, neg)
+        ctx.mark_non_differentiable(pos, neg)
+        return loss, pos, neg
+
+    @staticmethod
+    def backward(ctx, g, _gp, _gn):
+        z, w, pos_index, neg_index, et, pos, neg = ctx.saved_tensors
+        g = g.contiguous().float()
+        dz, dd = torch.empty_like(z), torch.empty_like(w)
+        dz2, dd2 = torch.empty_like(z), torch.empty_like(w)
+        # ---- the positives: a static list with a backward plan -> the loss-fed planned launch ----
+        bwd = None
+        if ctx.plan is not None:
+            bwd = getattr(ctx.plan, "bwd", None)
+            if bwd is None:
+                try:
+                    bwd = _hip.DistMultBwdPlan(pos_index, et, z.shape[0], w.shape[0])
+                except _hip.GripNetHipError as err:
+                    if err.status != _hip.GN_ERR_UNSUPPORTED:
+                        raise
+                    bwd = False
+                ctx.plan.bwd = bwd
+        done = False
+        if bwd:
+            try:
+                bwd.backward(z, w, None, dz, dd, pos, loss=_hip.LinkLossGrad(g, ctx.eps, False))
+                done = True
+            except _hip.GripNetHipError as err:
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+        dn = None
+        if not done:                                           # the two-step path: the loss's own backward, then the decoder's
+            dp, dn = torch.empty_like(pos), torch.empty_like(neg)
+            _hip._call("gn_link_loss_backward_f32", _hip.ptr(pos), pos.numel(), _hip.ptr(neg), neg.numel(), ctx.eps, _hip.ptr(g), _hip.ptr(dp),
+                       _hip.ptr(dn), _hip.stream_ptr(z.device))
+            _hip.distmult_backward(z, pos_index, et, w, dp, dz, dd, probs=pos)
+        # ---- the negatives: the sampler's packed pairs -> the loss-fed packed launch ----
+        if not _hip.distmult_backward_loss_packed(z, neg_index, et, w, neg, dz2, dd2, _hip.LinkLossGrad(g, ctx.eps, True)):
+            if dn is None:
+                dp, dn = torch.empty_like(pos), torch.empty_like(neg)
+                _hip._call("gn_link_loss_backward_f32", _hip.ptr(pos), pos.numel(), _hip.ptr(neg), neg.numel(), ctx.eps, _hip.ptr(g), _hip.ptr(dp),
+                           _hip.ptr(dn), _hip.stream_ptr(z.device))
+            _hip.distmult_backward(z, neg_index, et, w, dn, dz2, dd2, probs=neg)
+        dz.add_(dz2)
+        dd.add_(dd2)
+        return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
 _node_plans = []            # (node_list tensor, _version, rows of z, plan): the row-gather plans of the last few node lists
 
 

@@ -43,7 +43,19 @@ struct Rec { uint32_t a, b; float g; };       // 12 bytes: factor rows and the e
 struct GradSrc {
     const float* g;            // null: the "gradient" of triple e is the bit pattern of e (a plan sorts the triples' positions once)
     const float* p;            // nullable
+    // loss != 0 (round 6): the scores feed the link loss of GripNet-pose.py:140-142 directly - p are the probabilities, g points
+    // at the loss's ONE upstream gradient (or is null: 1), and d loss / d p is computed here, exactly as gn_link_loss_backward_f32
+    // computes it (-g / count / (p + eps) for the positives, +g / count / (1 - p + eps) for the negatives): the same bits without
+    // the loss's backward launch and the gradient vector's round trip through memory
+    int loss = 0;              // 0: none, 1: positives, 2: negatives
+    float count = 1.f, eps = 0.f;
     __device__ __forceinline__ float at(int64_t e) const {
+        if (loss) {
+            const float up = g ? *g : 1.0f;
+            const float q = p[e];
+            const float v = loss == 1 ? (-up / count) / (q + eps) : (up / count) / (1.0f - q + eps);
+            return v * q * (1.0f - q);
+        }
         if (!g) return __int_as_float((int)e);
         const float v = g[e];
         if (!p) return v;
@@ -51,6 +63,14 @@ struct GradSrc {
         return v * q * (1.0f - q);
     }
 };
+
+GradSrc make_grad_src(const float* grad_logit, const float* sigmoid_scores, const gn_link_loss_grad* loss, int64_t count) {
+    GradSrc gs = {grad_logit, sigmoid_scores};
+    if (loss) {
+        gs.g = loss->upstream; gs.loss = loss->negative ? 2 : 1; gs.count = (float)count; gs.eps = loss->eps;
+    }
+    return gs;
+}
 
 // Where a call's triples come from: the int64 arrays of the reference's tensors, or - the negative samples as the sampler
 // leaves them next to its int64 output - one 32-bit word per pair (u | v << 16) and a 16-bit relation id per position:
@@ -901,7 +921,7 @@ gn_status backward_impl(const float* z, int64_t ld_z, int64_t n, int64_t f, cons
                         int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
                         float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
                         const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+                        void* stream, const gn_link_loss_grad* loss = nullptr) {
     const int64_t* u = edges.u;
     const int64_t* v = edges.v;
     const int64_t* et = edges.et;
@@ -917,8 +937,8 @@ gn_status backward_impl(const float* z, int64_t ld_z, int64_t n, int64_t f, cons
         GN_REQUIRE(e == 0 || f == 0 || (n > 0 && r > 0), "edges given but the node or relation table is empty");
         return GN_OK;
     }
-    GN_REQUIRE(z && d && grad_logit && (from_words ? edges.rel16 != nullptr : (u && v && et)), "operand pointer is null");
-    const GradSrc grad = {grad_logit, sigmoid_scores};
+    GN_REQUIRE(z && d && (loss ? sigmoid_scores != nullptr : grad_logit != nullptr) && (from_words ? edges.rel16 != nullptr : (u && v && et)), "operand pointer is null");
+    const GradSrc grad = make_grad_src(grad_logit, sigmoid_scores, loss, e);
     GN_REQUIRE(ld_z >= f && ld_d >= f, "leading dimension smaller than the row length");
     const WsLayout l = ws_layout(e, std::max(n, r));
     const LdsLayout ll = lds_layout(e, n, r, f);
@@ -1094,6 +1114,18 @@ extern "C" gn_status gn_distmult_backward_packed_f32(const float* z, int64_t ld_
     GN_REQUIRE(n <= 65536 && r <= 65536, "packed pairs hold ids of 16 bits");
     return backward_impl(z, ld_z, n, f, EdgeSrc{nullptr, nullptr, nullptr, packed_uv, rel16}, d, ld_d, r, e, grad_logit, dz, ld_dz, dd,
                          ld_dd, flags, sigmoid_scores, type_offsets, workspace, workspace_bytes, stream);
+}
+
+extern "C" gn_status gn_distmult_backward_loss_packed_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const uint32_t* packed_uv,
+                                                          const uint16_t* rel16, const float* d, int64_t ld_d, int64_t r, int64_t e,
+                                                          const gn_link_loss_grad* loss, const float* sigmoid_scores, float* dz, int64_t ld_dz,
+                                                          float* dd, int64_t ld_dd, int flags, const int32_t* type_offsets,
+                                                          void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(loss != nullptr && (e == 0 || sigmoid_scores), "the loss source and the forward's probabilities are required");
+    GN_REQUIRE(e == 0 || (packed_uv && rel16), "packed pairs or relation ids are null");
+    GN_REQUIRE(n <= 65536 && r <= 65536, "packed pairs hold ids of 16 bits");
+    return backward_impl(z, ld_z, n, f, EdgeSrc{nullptr, nullptr, nullptr, packed_uv, rel16}, d, ld_d, r, e, nullptr, dz, ld_dz, dd,
+                         ld_dd, flags, sigmoid_scores, type_offsets, workspace, workspace_bytes, stream, loss);
 }
 
 extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,
@@ -1384,10 +1416,30 @@ extern "C" size_t gn_distmult_bwd_plan_workspace_bytes(const gn_distmult_bwd_pla
     return plan_ws(plan, num_features).total;
 }
 
+static gn_status backward_planned_impl(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z, int64_t f,
+                                       const float* d, int64_t ld_d, const float* grad_logit,
+                                       const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd,
+                                       int64_t ld_dd, void* workspace, size_t workspace_bytes, void* stream, const gn_link_loss_grad* loss);
+
 extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z, int64_t f,
                                                       const float* d, int64_t ld_d, const float* grad_logit,
                                                       const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd,
                                                       int64_t ld_dd, void* workspace, size_t workspace_bytes, void* stream) {
+    return backward_planned_impl(plan, z, ld_z, f, d, ld_d, grad_logit, sigmoid_scores, dz, ld_dz, dd, ld_dd, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" gn_status gn_distmult_backward_loss_planned_f32(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z, int64_t f,
+                                                           const float* d, int64_t ld_d, const gn_link_loss_grad* loss,
+                                                           const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd,
+                                                           int64_t ld_dd, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(loss != nullptr && sigmoid_scores != nullptr, "the loss source and the forward's probabilities are required");
+    return backward_planned_impl(plan, z, ld_z, f, d, ld_d, nullptr, sigmoid_scores, dz, ld_dz, dd, ld_dd, workspace, workspace_bytes, stream, loss);
+}
+
+static gn_status backward_planned_impl(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z, int64_t f,
+                                       const float* d, int64_t ld_d, const float* grad_logit,
+                                       const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd,
+                                       int64_t ld_dd, void* workspace, size_t workspace_bytes, void* stream, const gn_link_loss_grad* loss) {
     GN_REQUIRE(plan != nullptr, "plan is null");
     GN_REQUIRE(f >= 0 && f < (1ll << 31), "bad feature count");
     GN_REQUIRE(f == 0 || (dz && dd && ld_dz >= f && ld_dd >= f), "gradient output pointer is null or its leading dimension too small");
@@ -1399,7 +1451,7 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
         GN_HIP(hipMemset2DAsync(dd, ld_dd * sizeof(float), 0, f * sizeof(float), r, st));
         return GN_OK;
     }
-    GN_REQUIRE(z && d && grad_logit && ld_z >= f && ld_d >= f, "operand pointer is null or a leading dimension too small");
+    GN_REQUIRE(z && d && (loss || grad_logit) && ld_z >= f && ld_d >= f, "operand pointer is null or a leading dimension too small");
     if (f % 4 != 0 || ld_z % 4 != 0 || ld_d % 4 != 0 || ld_dz % 4 != 0 || ld_dd % 4 != 0 ||
         ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dd)) & 15) != 0)
         return gn::fail(GN_ERR_UNSUPPORTED, "rows are not 16-byte aligned float4 columns: use gn_distmult_backward_f32");
@@ -1410,7 +1462,7 @@ extern "C" gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan
     uint64_t* pr = reinterpret_cast<uint64_t*>(ws + w.pr);
     float* part = reinterpret_cast<float*>(ws + w.partial);
     float* gpair = reinterpret_cast<float*>(ws + w.g);
-    k_pair_grad<<<gn::stream_grid(e, 256), 256, 0, st>>>(plan->own.p, plan->mir.p, e, GradSrc{grad_logit, sigmoid_scores}, gpair, plan->pr_static.p, pr);
+    k_pair_grad<<<gn::stream_grid(e, 256), 256, 0, st>>>(plan->own.p, plan->mir.p, e, make_grad_src(grad_logit, sigmoid_scores, loss, plan->e_list), gpair, plan->pr_static.p, pr);
     GN_LAUNCH_CHECK();
     k_place_g<<<(unsigned)std::min<int64_t>(gn::ceil_div(2 * e, 4 * 256), 4096), 256, 0, st>>>(plan->he_static.p, 2 * e, gpair, he);
     GN_LAUNCH_CHECK();

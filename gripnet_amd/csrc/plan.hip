@@ -551,6 +551,12 @@ gn_status gn_graph_plan_build_transpose(gn_graph_plan* plan, void* stream) {
 gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int64_t* range_list, int on_host,
                               int64_t R, int64_t E, int64_t N, int64_t lo, int64_t hi, void* stream,
                               gn_rgcn_plan** out) {
+    return gn_rgcn_plan_create_ex(src, dst, range_list, on_host, R, E, N, lo, hi, 0, stream, out);
+}
+
+gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const int64_t* range_list, int on_host,
+                                 int64_t R, int64_t E, int64_t N, int64_t lo, int64_t hi, int flags, void* stream,
+                                 gn_rgcn_plan** out) {
     GN_REQUIRE(out != nullptr, "plan output pointer is null");
     *out = nullptr;
     GN_REQUIRE(R >= 0 && E >= 0 && N >= 0, "negative size");
@@ -658,10 +664,14 @@ gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, const int6
             GN_TRY(hipStreamSynchronize(st));
         }
     }
-    gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
-    if (fs != GN_OK) return bail(fs);
-    fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
-    if (fs != GN_OK) return bail(fs);
+    if (!(flags & GN_RGCN_PLAN_LIGHT)) {
+        // the encodings of the LDS-resident kernels (host-side schedules: most of the build time); a light plan serves every
+        // forward on the general O(E) path, from the device-sorted key list above alone
+        gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
+        if (fs != GN_OK) return bail(fs);
+        fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
+        if (fs != GN_OK) return bail(fs);
+    }
 #undef GN_TRY
     *out = p;
     return GN_OK;

@@ -172,6 +172,12 @@ class myRGCN(Module):
         # relational kernel for tests and measurements ("auto": the library decides).
         self.arithmetic = "fp32"
         self.kernel = "auto"
+        # static_graph = True (default): the layer's edge list is the same tensor call after call (a training loop's
+        # train_idx, GripNet-pose.py:121-127) and gets the full plan - every kernel's schedule, ~15 ms once on PoSE-0.
+        # False: edge lists change from call to call; each gets a LIGHT plan (the device-sorted key list only, a fraction of
+        # the build) and runs on the general O(E) kernel - closer to the reference's myRGCN, which has no set-up cost at all
+        # (layers.py:165-169).
+        self.static_graph = True
         self.reset_parameters()
 
     def _fast(self):
@@ -191,10 +197,10 @@ class myRGCN(Module):
         """Plan of the static relational graph, rebuilt when another edge tensor or range list arrives or one of them
         is modified in place.  The cache entry holds the caller's objects (compared with `is`), so an address or id
         reused by a later tensor cannot pass for the old one."""
-        key = (edge_index._version, getattr(range_list, "_version", 0), num_nodes, edge_lo, edge_hi)
+        key = (edge_index._version, getattr(range_list, "_version", 0), num_nodes, edge_lo, edge_hi, bool(self.static_graph))
         held = self._plan_key
         if (self._plan is None or held is None or held[0] is not edge_index or held[1] is not range_list or held[2] != key):
-            self._plan = _hip.RgcnPlan(edge_index, range_list, num_nodes, edge_lo, edge_hi)
+            self._plan = _hip.RgcnPlan(edge_index, range_list, num_nodes, edge_lo, edge_hi, light=not self.static_graph)
             self._plan_key = (edge_index, range_list, key)
         return self._plan
 

@@ -246,6 +246,24 @@ def link_loss(pos_score: torch.Tensor, neg_score: torch.Tensor, eps: float = EPS
     return LinkLossFn.apply(pos_score, neg_score, float(eps))
 
 
+def link_prediction_loss(decoder, z: torch.Tensor, pos_index: torch.Tensor, neg_index: torch.Tensor, edge_type: torch.Tensor,
+                         eps: float = EPS):
+    """``loss, pos_score, neg_score``: the two decoder calls and the loss of a training step (GripNet-pose.py:137-142:
+    ``pos_score = dmt(z, pos_index, et); neg_score = dmt(z, neg_index, et); loss = -log(pos + EPS).mean() - log(1 - neg + EPS).mean()``)
+    as one autograd node.  Values and gradients are those of the three separate calls (bit for bit where the fused launches
+    apply); the backward pass makes two decoder launches that compute the loss's derivative inline instead of a loss launch, two
+    [E] gradient vectors and two decoder launches.  The scores are returned for the metrics and carry no gradient.  The
+    reference's spelled-out expression keeps working; this is the build's own counterpart of those three lines."""
+    from .autograd import LinkPredictionLossFn
+    _hip.require_gpu(z, pos_index, neg_index, edge_type, decoder.weight)
+    if z.shape[1] != decoder.in_dim:
+        raise ValueError("expected {} features, got {}".format(decoder.in_dim, z.shape[1]))
+    plan = decoder.plan_for(z, pos_index, edge_type)
+    if plan is not None and plan.num_nodes != z.shape[0]:
+        plan = None
+    return LinkPredictionLossFn.apply(z, decoder.weight, pos_index, neg_index, edge_type, float(eps), plan)
+
+
 def class_loss(score: torch.Tensor, classes: torch.Tensor, eps: float = EPS) -> torch.Tensor:
     """``-log(score[range(n), classes] + EPS).mean()``: the training loss of GripNet-aminer.py:133 (and of every freebase
     driver) as one launch forward and one backward (gn_class_loss_*), differentiable.  The drivers spell it out with torch

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 148 /* 0.1.44 */
+#define GN_VERSION 150 /* 0.1.46 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -260,6 +260,15 @@ GN_API gn_status gn_rgcn_plan_create(const int64_t* src, const int64_t* dst, con
                               int range_list_on_host, int64_t num_relations, int64_t num_edges,
                               int64_t num_nodes, int64_t edge_lo, int64_t edge_hi, void* stream,
                               gn_rgcn_plan** plan);
+/* flags & GN_RGCN_PLAN_LIGHT: only what the general O(E) kernel reads (the destination-major key list, sorted on the device,
+ * in-degrees, the rows' degree order) - none of the host-built schedules of the LDS-resident kernels: for a caller whose edge
+ * list changes from call to call (the reference's myRGCN has no set-up cost at all, layers.py:165-169), a fraction of the
+ * full plan's build time; its forwards take GN_RGCN_PATH_GENERAL (or the table path beyond its shapes). */
+#define GN_RGCN_PLAN_LIGHT 1
+GN_API gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const int64_t* range_list,
+                                 int range_list_on_host, int64_t num_relations, int64_t num_edges,
+                                 int64_t num_nodes, int64_t edge_lo, int64_t edge_hi, int flags, void* stream,
+                                 gn_rgcn_plan** plan);
 GN_API void gn_rgcn_plan_destroy(gn_rgcn_plan* plan);
 GN_API int64_t gn_rgcn_plan_input_edges(const gn_rgcn_plan* plan);
 
@@ -469,6 +478,29 @@ GN_API gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan* pl
                                            const float* grad_logit, const float* sigmoid_scores /* nullable */,
                                            float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, void* workspace,
                                            size_t workspace_bytes, void* stream);
+
+/* The decoder's backward fed by the LINK LOSS directly (round 6): the scores of a list go into the loss of
+ * GripNet-pose.py:140-142, -mean(log(p + eps)) over the positives' list or -mean(log(1 - p + eps)) over the negatives', and
+ * d loss / d s_e = (-+ upstream / num_edges) / (p_e (or 1 - p_e) + eps) * p_e (1 - p_e) is a function of the edge's own probability
+ * only - it is computed where the edge records are built, in the arithmetic of gn_link_loss_backward_f32 followed by the
+ * sigmoid factor (the SAME bits as the two-step path), and the loss's backward launch and the [E] gradient vector's round
+ * trip through memory disappear.  upstream: the loss's one upstream gradient on the device (NULL: 1). */
+typedef struct gn_link_loss_grad {
+    const float* upstream;
+    float eps;
+    int negative;              /* 0: the list's scores are the loss's positives, 1: its negatives */
+} gn_link_loss_grad;
+GN_API gn_status gn_distmult_backward_loss_packed_f32(const float* z, int64_t ld_z, int64_t num_nodes, int64_t num_features,
+                                               const uint32_t* packed_uv, const uint16_t* rel16, const float* d, int64_t ld_d,
+                                               int64_t num_relations, int64_t num_edges, const gn_link_loss_grad* loss,
+                                               const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd, int64_t ld_dd,
+                                               int flags, const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
+                                               void* stream);
+GN_API gn_status gn_distmult_backward_loss_planned_f32(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z,
+                                                int64_t num_features, const float* d, int64_t ld_d,
+                                                const gn_link_loss_grad* loss, const float* sigmoid_scores,
+                                                float* dz, int64_t ld_dz, float* dd, int64_t ld_dd, void* workspace,
+                                                size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Typed negative sampling on the device (replaces gripnet/utils.py:98-119 and its per-epoch host round

@@ -910,6 +910,45 @@ def test_pose0_syn_training_step_gradients(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+@pytest.mark.parametrize("workload", ["small", "pose0-syn"])
+def test_link_prediction_loss_is_the_three_calls_bit_for_bit(gpu, workload):
+    """utils.link_prediction_loss (round 6): the two decoder calls and the loss as one autograd node whose backward computes
+    the loss's derivative inside the decoder's backward launches (gn_distmult_backward_loss_planned_f32 on the static
+    positives, gn_distmult_backward_loss_packed_f32 on the sampler's negatives).  Loss, scores and the gradients of z and D are
+    those of `link_loss(dmt(z, pos), dmt(z, neg))` BIT FOR BIT, with an upstream gradient other than one as well; on int64
+    negatives without packed pairs (the two-step path for that list) too."""
+    from gripnet_amd.pipeline import PoseModel
+    from gripnet_amd.synth import make_pose
+    from gripnet_amd.utils import link_loss, link_prediction_loss
+    data = make_pose(workload).to(gpu)
+    torch.manual_seed(71)
+    model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(gpu)
+    sampler = _hip.NegativeSampler(data.train_idx, data.n_d_node, data.train_range)
+    neg_packed = sampler.sample(seed=5)                              # carries the sampler's 32-bit pairs
+    neg_plain = neg_packed.clone()                                   # the same pairs as a plain int64 tensor
+    with torch.no_grad():
+        z0 = model.encode(data)
+    dmt = model.dmt
+    for neg in (neg_packed, neg_plain):
+        for scale in (1.0, 0.37):
+            outs = []
+            for fused in (False, True):
+                for _ in range(2):                                   # the second pass runs on the static list's plans
+                    z = z0.clone().requires_grad_(True)
+                    dmt.weight.grad = None
+                    if fused:
+                        loss, pos, negs = link_prediction_loss(dmt, z, data.train_idx, neg, data.train_et)
+                    else:
+                        pos, negs = dmt(z, data.train_idx, data.train_et), dmt(z, neg, data.train_et)
+                        loss = link_loss(pos, negs)
+                    (scale * loss).backward()
+                outs.append((loss.detach().clone(), pos.detach().clone(), negs.detach().clone(), z.grad.clone(), dmt.weight.grad.clone()))
+            for a, b, name in zip(outs[0], outs[1], ("loss", "pos", "neg", "dz", "dD")):
+                assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert not pos.requires_grad and not negs.requires_grad          # (the scores of the fused call feed the metrics only)
+    _hip.raise_if_index_errors(gpu)
+
+
 def test_class_loss_and_softmax_gradients(gpu):
     """utils.class_loss (gn_class_loss_*) against the expression the NC drivers spell out (GripNet-aminer.py:133), and the
     row softmax's gradient (gn_softmax_rows_backward_f32) against torch's, through the class decoder under autograd."""

@@ -462,6 +462,36 @@ def test_relational_layer_as_two_launches_gives_the_same_bits(gpu, n, fin, bases
     assert rg.start_pair_sums(rei, rl, n) is False                       # training: the autograd path keeps the one-launch layer
 
 
+def test_relational_layer_on_changing_edge_lists(gpu):
+    """myRGCN.static_graph = False (round 6): every new edge list gets a LIGHT plan (GN_RGCN_PLAN_LIGHT: the device-sorted key
+    list only, none of the host-built schedules) and runs on the general O(E) kernel - the reference's myRGCN has no set-up
+    cost (layers.py:165-169).  Two different lists in turn, each against the oracle; the same layer with static_graph = True
+    agrees to rounding."""
+    gen = torch.Generator().manual_seed(77)
+    n, fin, R, bases = 500, 48, 6, 32
+    x = torch.randn(n, fin, generator=gen).to(gpu)
+    rg = gripnet_amd.myRGCN(fin, 32, R, bases, False).to(gpu)
+    for prm in rg.parameters():
+        prm.requires_grad_(False)
+    sd = {k: v.detach().cpu() for k, v in rg.state_dict().items()}
+    lists = []
+    for k in range(2):
+        blocks = [torch.randint(0, n, (2, s), generator=gen) for s in (2000 + 100 * k, 0, 30, 700, 1, 400)]
+        lists.append((torch.cat(blocks, dim=1).to(gpu), gripnet_amd.utils.get_range_list(blocks)))
+    rg.static_graph = False
+    for rep in range(2):
+        for rei, rl in lists:
+            y = rg(x, rei, None, rl, _relu=True)
+            assert rg._plan.light and rg._plan.path(fin, 32, bases) == "general"
+            ref = torch.relu(orc.rgcn_forward(x.cpu(), rei.cpu(), rl, sd["basis"], sd["att"], sd["root"], None))
+            close(y, ref, TIGHT)
+    rg.static_graph = True
+    rei, rl = lists[0]
+    y_full = rg(x, rei, None, rl, _relu=True)
+    assert not rg._plan.light
+    close(y_full, torch.relu(orc.rgcn_forward(x.cpu(), rei.cpu(), rl, sd["basis"], sd["att"], sd["root"], None)), TIGHT)
+
+
 @needs_fast_paths
 def test_pose_forward_with_the_split_relational_layer(gpu):
     """PoseModel.split_relational: the whole forward with the pair sums started in front of the gene layers - eager modules,
