@@ -50,6 +50,9 @@ struct GradSrc {
     int loss = 0;              // 0: none, 1: positives, 2: negatives
     float count = 1.f, eps = 0.f;
     __device__ __forceinline__ float at(int64_t e) const {
+        // (no contraction of these products into a caller's add: the loss-fed form and the two-step form - the same expression
+        // behind different branches - must round the same way, whatever the compiler makes of the code around them)
+#pragma clang fp contract(off)
         if (loss) {
             const float up = g ? *g : 1.0f;
             const float q = p[e];
