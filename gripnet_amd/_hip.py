@@ -350,9 +350,10 @@ def replay(calls):
 # memo key, so that a shortcut recorded under one setting is not replayed under another.
 _ENV_HOOKS = ("GN_DISABLE_FAST", "GN_DISABLE_QUAD", "GN_DISABLE_BLOCKED", "GN_BLOCKED_ANY", "GN_DISABLE_LDS_TABLE")
 # hooks the C side reads that can NOT change what a memoised inference forward launches: the host threads of the plan builders
-# (plans do not depend on them) and the sampler's kernel choice (same draws; no module forward calls the sampler).
+# (plans do not depend on them), the sampler's kernel choice (same draws; no module forward calls the sampler) and the slab size of the
+# general relational path (read inside the entry point at every call: a slab is a range of rows, the bits do not depend on it).
 # tests/test_abi.py::test_env_hooks_cover_the_library holds the two lists to the getenv calls of csrc/.
-_ENV_NEUTRAL = ("GN_PLAN_THREADS", "GN_SAMPLER_TASKS")
+_ENV_NEUTRAL = ("GN_PLAN_THREADS", "GN_SAMPLER_TASKS", "GN_RGCN_SLAB_MB")
 _ENV_DATA = getattr(os.environ, "_data", None)
 _ENV_KEYS = tuple(k.encode() for k in _ENV_HOOKS) if isinstance(_ENV_DATA, dict) and all(isinstance(k, bytes) for k in list(_ENV_DATA)[:1]) else None
 

@@ -11,7 +11,7 @@
 // so that U_i (bases x in) accumulates in registers over the row's edges - every product and sum is an fp32 FMA, the
 // same arithmetic as the reference's fp32 matmuls.  The row leaves as one line  [ U_i / max(1, deg_i) | x_i | 0 ]  of a
 // slab of rows, and ONE dense product per slab with [basis ; root] (gn_gemm_f32: K = (B + 1) in, fp32-faithful) adds
-// the root term, the bias and the activation.  Workspace: the slab (<= 64 MB) + the stacked weights, independent of
+// the root term, the bias and the activation.  Workspace: the slab (<= 256 MB) + the stacked weights, independent of
 // R and N; the edges come from the plan's destination-major list (key = relation * N + source), 4 bytes per edge.
 #include "common.h"
 
@@ -33,7 +33,9 @@ __device__ __forceinline__ f32x4 basis_mfma(float a, float b, f32x4 c) { return 
 
 constexpr int kBasisThreads = 512, kBasisWaves = kBasisThreads / 64;   // eight waves: a destination row per wave at a time, or a heavy row per workgroup
 constexpr int kHeavyEdges = gn_layout::kBasisHeavyEdges;               // rows with more incoming edges are walked by a whole workgroup
-constexpr int64_t kSlabBytes = 64ll << 20;         // rows of U in flight between the gather and the dense product
+constexpr int64_t kSlabBytes = 256ll << 20;        // rows of U in flight between the gather and the dense product (round 6: 64 MB cut the all-nodes
+                                                   // baseline's first layer - 19,726 rows of 4.3 KB - into two slabs: two gather launches that each
+                                                   // drew every work item of all rows, two products)
 
 struct BasisArgs {
     const float* x; int64_t ld_x; int fin;
@@ -278,7 +280,12 @@ struct BasisLayout {
 BasisLayout basis_layout(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
     BasisLayout l;
     l.kp = (int)(gn::ceil_div((bases + 1) * fin, 32) * 32);
-    l.slab_rows = std::min<int64_t>(std::max<int64_t>(plan->num_nodes, 1), std::max<int64_t>(256, kSlabBytes / ((int64_t)l.kp * 4)));
+    int64_t slab_bytes = kSlabBytes;
+    if (const char* e = getenv("GN_RGCN_SLAB_MB")) {                       // test hook: small slabs (the same bits: a slab is a range of rows)
+        const long mb = atol(e);
+        if (mb >= 1 && mb <= 4096) slab_bytes = (int64_t)mb << 20;
+    }
+    l.slab_rows = std::min<int64_t>(std::max<int64_t>(plan->num_nodes, 1), std::max<int64_t>(256, slab_bytes / ((int64_t)l.kp * 4)));
     l.slab_rows = std::max<int64_t>(l.slab_rows, gn::ceil_div(std::max<int64_t>(plan->num_nodes, 1), 256));   // at most 256 slabs (one work counter each)
     l.slabs = gn::ceil_div(std::max<int64_t>(plan->num_nodes, 1), l.slab_rows);
     l.w_off = 0;

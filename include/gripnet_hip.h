@@ -287,7 +287,7 @@ GN_API gn_status gn_stream_order(void* earlier_stream, void* later_stream);
 GN_API int gn_time_launch_pending(void);
 
 /* Bytes of caller-provided scratch a gn_rgcn_forward_f32 call with these shapes and flags needs: none on the
- * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, a slab of rows (<= 64 MB) and the stacked
+ * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, a slab of rows (<= 256 MB) and the stacked
  * weights on the general path (independent of R and N), the [R, N, out] table on the table path.  (The forward checks the workspace against the kernel IT takes and refuses a smaller one.) */
 GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_features, int64_t out_features,
                                int64_t num_bases, int flags);

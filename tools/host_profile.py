@@ -22,7 +22,8 @@ n = 300
 if "--train" in sys.argv:
     from gripnet_amd import _hip
     from gripnet_amd.optim import Adam
-    from gripnet_amd.utils import link_loss
+    from gripnet_amd.utils import link_loss, link_prediction_loss
+    fused = "--fused" in sys.argv
     opt = Adam(model.parameters(), lr=0.01)
     sampler = _hip.NegativeSampler(data.train_idx, data.n_d_node, data.train_range)
     neg = sampler.sample(seed=0)
@@ -33,7 +34,10 @@ if "--train" in sys.argv:
         sampler.sample(seed=0, out=neg, step=drawn)
         opt.zero_grad()
         z = model.encode(data)
-        loss = link_loss(model.dmt(z, data.train_idx, data.train_et), model.dmt(z, neg, data.train_et))
+        if fused:
+            loss, _, _ = link_prediction_loss(model.dmt, z, data.train_idx, neg, data.train_et)
+        else:
+            loss = link_loss(model.dmt(z, data.train_idx, data.train_et), model.dmt(z, neg, data.train_et))
         loss.backward(one)
         opt.step()
 
