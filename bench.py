@@ -129,8 +129,8 @@ def train_step_entry(dev, steps=20):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3):                                     # plans, relation-order check, optimizer state
-            step()
+        for _ in range(5):                                     # plans (the decoder's on the second sighting of its list, its backward
+            step()                                             # plan in that step's backward), relation-order check, optimizer state
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     # the eager step (the Python loop a caller of GripNet-pose.py:112-146 runs), and its entry points between HIP events
