@@ -939,7 +939,7 @@ def main():
         records_us = round(1e3 * rtot / rc, 2) if rc else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (PMC passes of tools/prof.sh step r05: warm-up + recorded steps of tools/step_only.py and nothing else, same round; not counters of this run)" if traffic else None,
+                "traffic_source": "profiles/traffic.json (PMC passes of tools/prof.sh step r06: warm-up + recorded steps of tools/step_only.py and nothing else, same round; not counters of this run)" if traffic else None,
                 "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_us": round(dom_us, 2),
                 "timing_method": "dispatch stamps (hipExtLaunchKernel start / stop events of the kernel itself)" if dom in _hip._STAMPED else "event records around the launch",
                 "avg_launch_us_event_records": records_us,
@@ -1007,7 +1007,7 @@ def main():
         "roofline_fast": roofline_fast,
         "roofline_all": roofline_all,
         "mfma_util": mfma,
-        "mfma_util_source": "profiles/mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES pass of tools/prof.sh step r05, same command as the traffic passes; not a counter of this run)" if mfma else None,
+        "mfma_util_source": "profiles/mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES pass of tools/prof.sh step r06, same command as the traffic passes; not a counter of this run)" if mfma else None,
         "plan_build_ms": round(plan_build_ms, 1),
         "entry_point_us_per_step": {k: round(v, 2) for k, v in sorted(breakdown.items())},
         "edges_scored_per_sec": (hi - lo) / (per_call0.get("gn_distmult_plan_forward_f32",

@@ -910,6 +910,45 @@ def test_pose0_syn_training_step_gradients(gpu):
     _hip.raise_if_index_errors(gpu)
 
 
+@pytest.mark.parametrize("n,fin,fout,bases,slabs", [(300, 160, 16, 4, False), (300, 160, 16, 4, True), (250, 48, 24, 80, False)])
+def test_relational_gradients_outside_every_kernel(gpu, n, fin, fout, bases, slabs, monkeypatch):
+    """The shapes NO relational gradient kernel covers (more than 128 input features: the weight gradient of neither
+    rel_grad.hip nor rgcn_basis.hip; more than 64 bases: `att^T dW`) take torch expressions inside autograd.rgcn_edge_gradients
+    (a dense (relation, source) sum + matmul, its slabbed form when that sum would be huge, `att.t() @ dw`).  Unreachable from
+    any caller of the reference (its widest relational layer is 64 -> 32 on 32 bases) - so this test forces them, against torch
+    autograd through the oracle."""
+    from gripnet_amd import autograd as ag
+    if slabs:
+        monkeypatch.setattr(ag, "Q_BUDGET_FLOATS", 2 * n * fout)      # (two relations per slab)
+    gen = torch.Generator().manual_seed(n + fin + bases)
+    torch.manual_seed(fin + bases)
+    R = 6
+    sizes = [900, 0, 1, 300, 40, 120]
+    blocks = [torch.randint(0, n - n // 11, (2, s), generator=gen) for s in sizes]
+    ei = torch.cat(blocks, dim=1)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen)
+    proj = torch.randn(n, fout, generator=gen)
+    rg = gripnet_amd.myRGCN(fin, fout, R, bases, False, bias=True).to(gpu)
+    rg.bias.data.normal_()
+    xg, eig = leaf(x.to(gpu)), ei.to(gpu)
+    y = rg(xg, eig, None, rl, _relu=True)
+    plan = rg._plan
+    wg = plan.weight_grad_plan()
+    assert (wg is None or not wg.supported(fin, fout)) and (fin <= 128 or plan.general_weight_grad(x.to(gpu), proj.to(gpu)) is None)
+    (y * proj.to(gpu)).sum().backward()
+    sd = {k: leaf(v.cpu()) for k, v in rg.state_dict().items()}
+    xr = leaf(x)
+    yr = torch.relu(orc.rgcn_forward(xr, ei, rl, sd["basis"], sd["att"], sd["root"], sd["bias"]))
+    (yr * proj).sum().backward()
+    close(y, yr, 2e-5 * max(1.0, float(yr.abs().max())), what="forward")
+    close(xg.grad / max(1.0, float(xr.grad.abs().max())), xr.grad / max(1.0, float(xr.grad.abs().max())), 1e-4, what="dx")
+    for k, p in rg.named_parameters():
+        scale_k = max(1.0, float(sd[k].grad.abs().max()))
+        close(p.grad / scale_k, sd[k].grad / scale_k, 1e-4, what=k)
+    _hip.raise_if_index_errors(gpu)
+
+
 @pytest.mark.parametrize("workload", ["small", "pose0-syn"])
 def test_link_prediction_loss_is_the_three_calls_bit_for_bit(gpu, workload):
     """utils.link_prediction_loss (round 6): the two decoder calls and the loss as one autograd node whose backward computes
