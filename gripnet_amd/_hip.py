@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 150                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 151                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -90,7 +90,7 @@ SIGNATURES = {
     "gn_distmult_bwd_plan_destroy": (None, [_p]),
     "gn_distmult_bwd_plan_workspace_bytes": (_sz, [_p, _i64]),
     "gn_distmult_backward_planned_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
-    "gn_distmult_backward_loss_packed_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _int, _p, _p, _sz, _p]),
+    "gn_distmult_backward_loss_packed_f32": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _int, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_distmult_backward_loss_planned_f32": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "gn_negative_sampler_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
     "gn_negative_sampler_destroy": (None, [_p]),
@@ -1200,9 +1200,10 @@ class LinkLossGrad:
         return C.addressof(self._s)
 
 
-def distmult_backward_loss_packed(z, u_v, edge_type, weight, probs, dz, dd, loss):
+def distmult_backward_loss_packed(z, u_v, edge_type, weight, probs, dz, dd, loss, dz_add=None, dd_add=None):
     """The loss-fed backward on the sampler's packed pairs (gn_distmult_backward_loss_packed_f32), or False where that path
-    does not apply (no packed pairs, unsorted types, tables beyond the counting-sort path): the caller takes the two-step path."""
+    does not apply (no packed pairs, unsorted types, tables beyond the counting-sort path): the caller takes the two-step path.
+    `dz_add` / `dd_add`: the other list's gradients of z and D, added where this call stores its sums (they may be dz / dd)."""
     e = e_count(u_v)
     offsets = type_offsets(edge_type, weight.shape[0])
     packed = packed_pairs(u_v)
@@ -1213,7 +1214,8 @@ def distmult_backward_loss_packed(z, u_v, edge_type, weight, probs, dz, dd, loss
     try:
         _call("gn_distmult_backward_loss_packed_f32", ptr(z), ld(z), z.shape[0], z.shape[1], ptr(packed), ptr(relation_ids16(edge_type)),
               ptr(weight), ld(weight), weight.shape[0], e, loss.ref(), ptr(probs), ptr(dz), ld(dz), ptr(dd), ld(dd),
-              GN_DM_TYPES_SORTED | GN_DM_TYPE_TASKS, ptr(offsets), ptr(ws), need, stream_ptr(z.device))
+              GN_DM_TYPES_SORTED | GN_DM_TYPE_TASKS, ptr(offsets), ptr(dz_add), 0 if dz_add is None else ld(dz_add),
+              ptr(dd_add), 0 if dd_add is None else ld(dd_add), ptr(ws), need, stream_ptr(z.device))
     except GripNetHipError as err:
         if err.status != GN_ERR_UNSUPPORTED:
             raise

@@ -383,14 +383,16 @@ class LinkPredictionLossFn(torch.autograd.Function):
         ctx.eps, ctx.plan = float(eps), plan
         ctx.save_for_backward(zc, w, pos_index, neg_index, edge_type, pos, neg)
         ctx.mark_non_differentiable(pos, neg)
+        ctx.set_materialize_grads(False)                       # (the scores carry no gradient: no [E] zeros filled for them per step)
         return loss, pos, neg
 
     @staticmethod
     def backward(ctx, g, _gp, _gn):
         z, w, pos_index, neg_index, et, pos, neg = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None, None, None
         g = g.contiguous().float()
         dz, dd = torch.empty_like(z), torch.empty_like(w)
-        dz2, dd2 = torch.empty_like(z), torch.empty_like(w)
         # ---- the positives: a static list with a backward plan -> the loss-fed planned launch ----
         bwd = None
         if ctx.plan is not None:
@@ -418,6 +420,10 @@ class LinkPredictionLossFn(torch.autograd.Function):
                        _hip.ptr(dn), _hip.stream_ptr(z.device))
             _hip.distmult_backward(z, pos_index, et, w, dp, dz, dd, probs=pos)
         # ---- the negatives: the sampler's packed pairs -> the loss-fed packed launch ----
+        # (the positives' gradients ride on its combine launch as addends: dz / dD of the two lists need no adding launch)
+        if _hip.distmult_backward_loss_packed(z, neg_index, et, w, neg, dz, dd, _hip.LinkLossGrad(g, ctx.eps, True), dz_add=dz, dd_add=dd):
+            return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None, None
+        dz2, dd2 = torch.empty_like(z), torch.empty_like(w)
         if not _hip.distmult_backward_loss_packed(z, neg_index, et, w, neg, dz2, dd2, _hip.LinkLossGrad(g, ctx.eps, True)):
             if dn is None:
                 dp, dn = torch.empty_like(pos), torch.empty_like(neg)

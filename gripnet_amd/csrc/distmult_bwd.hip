@@ -704,7 +704,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_seg_lds(SegLdsArgs a) {
 // out[key, :] = the key's task partials.  One workgroup per key: eight slices take every eighth task each (four
 // loads in flight), then the slices are added in slice order - a fixed order, whatever the number of tasks (a hub
 // relation has hundreds).
-struct CombineSet { const int32_t* taskptr; const float* partial; float* out; int64_t ld_out; };
+struct CombineSet {
+    const int32_t* taskptr; const float* partial; float* out; int64_t ld_out;
+    const float* add = nullptr; int64_t ld_add = 0;      // (optional) another gradient of the same tensor, added where the sum is stored
+};
 
 __global__ __launch_bounds__(256) void k_seg_lds_combine(CombineSet first, int first_keys, CombineSet second, int f) {
     // (both reductions of a call in one launch: the node keys, then the relation keys)
@@ -713,6 +716,8 @@ __global__ __launch_bounds__(256) void k_seg_lds_combine(CombineSet first, int f
     const float* __restrict__ partial = in_first ? first.partial : second.partial;
     float* __restrict__ out = in_first ? first.out : second.out;
     const int64_t ld_out = in_first ? first.ld_out : second.ld_out;
+    const float* __restrict__ add = in_first ? first.add : second.add;
+    const int64_t ld_add = in_first ? first.ld_add : second.ld_add;
     __shared__ f32x4 fold[8][32];
     const int key = in_first ? (int)blockIdx.x : (int)blockIdx.x - first_keys, slice = threadIdx.x >> 5, j = threadIdx.x & 31;
     const int t0 = taskptr[key], t1 = taskptr[key + 1];
@@ -739,6 +744,7 @@ __global__ __launch_bounds__(256) void k_seg_lds_combine(CombineSet first, int f
             f32x4 r = fold[0][j];
 #pragma unroll
             for (int k = 1; k < 8; ++k) r += fold[k][j];
+            if (add) r += *reinterpret_cast<const f32x4*>(add + (int64_t)key * ld_add + c0 + 4 * j);
             *reinterpret_cast<f32x4*>(out + (int64_t)key * ld_out + c0 + 4 * j) = r;
         }
     }
@@ -924,7 +930,8 @@ gn_status backward_impl(const float* z, int64_t ld_z, int64_t n, int64_t f, cons
                         int64_t r, int64_t e, const float* grad_logit, float* dz, int64_t ld_dz,
                         float* dd, int64_t ld_dd, int flags, const float* sigmoid_scores,
                         const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
-                        void* stream, const gn_link_loss_grad* loss = nullptr) {
+                        void* stream, const gn_link_loss_grad* loss = nullptr, const float* dz_add = nullptr, int64_t ld_dz_add = 0,
+                        const float* dd_add = nullptr, int64_t ld_dd_add = 0) {
     const int64_t* u = edges.u;
     const int64_t* v = edges.v;
     const int64_t* et = edges.et;
@@ -982,6 +989,8 @@ gn_status backward_impl(const float* z, int64_t ld_z, int64_t n, int64_t f, cons
         // ... when the relation-major one brings its task list (the scratch holds one list: the node-major one's must outlive its combine)
         const bool listed = lds_dd && (flags & GN_DM_TYPES_SORTED) && type_offsets && (flags & GN_DM_TYPE_TASKS);
         const bool both = lds_dz && listed;
+        if ((dz_add || dd_add) && !both)
+            return gn::fail(GN_ERR_UNSUPPORTED, "addends ride on the common combine launch of the two LDS reductions: not taken for these shapes / flags");
         size_t sort2 = ll.sort_tmp_bytes;
         if (lds_dz && n <= kSortMaxKeys) {
             static thread_local bool sort_configured = false;
@@ -1052,9 +1061,14 @@ gn_status backward_impl(const float* z, int64_t ld_z, int64_t n, int64_t f, cons
             }
             gn_status rc = launch_seg_lds(recs_dd, rp_dd, 1, tp_dd, tk_dd, r, z, ld_z, n, z, ld_z, n, f, part_dd, dd, ld_dd, st, listed,
                                           both ? &cd : nullptr);
-            if (rc == GN_OK && both) rc = combine_both(cz, n, cd, r, f, st);
+            if (rc == GN_OK && both) {
+                cz.add = dz_add; cz.ld_add = ld_dz_add; cd.add = dd_add; cd.ld_add = ld_dd_add;
+                rc = combine_both(cz, n, cd, r, f, st);
+            }
             if (rc != GN_OK) return rc;
         }
+    } else if (dz_add || dd_add) {
+        return gn::fail(GN_ERR_UNSUPPORTED, "addends ride on the common combine launch of the two LDS reductions: not taken for these shapes");
     }
     for (int mode = 0; mode < 3; ++mode) {
         if (mode == 2 ? lds_dd : lds_dz) continue;       // done above
@@ -1123,12 +1137,16 @@ extern "C" gn_status gn_distmult_backward_loss_packed_f32(const float* z, int64_
                                                           const uint16_t* rel16, const float* d, int64_t ld_d, int64_t r, int64_t e,
                                                           const gn_link_loss_grad* loss, const float* sigmoid_scores, float* dz, int64_t ld_dz,
                                                           float* dd, int64_t ld_dd, int flags, const int32_t* type_offsets,
+                                                          const float* dz_add, int64_t ld_dz_add, const float* dd_add, int64_t ld_dd_add,
                                                           void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(loss != nullptr && (e == 0 || sigmoid_scores), "the loss source and the forward's probabilities are required");
+    GN_REQUIRE((!dz_add || (ld_dz_add >= f && ld_dz_add % 4 == 0 && (reinterpret_cast<uintptr_t>(dz_add) & 15) == 0)) &&
+               (!dd_add || (ld_dd_add >= f && ld_dd_add % 4 == 0 && (reinterpret_cast<uintptr_t>(dd_add) & 15) == 0)) && (e > 0 || (!dz_add && !dd_add)),
+               "addends: 16-byte aligned rows of at least num_features floats, and a non-empty list");
     GN_REQUIRE(e == 0 || (packed_uv && rel16), "packed pairs or relation ids are null");
     GN_REQUIRE(n <= 65536 && r <= 65536, "packed pairs hold ids of 16 bits");
     return backward_impl(z, ld_z, n, f, EdgeSrc{nullptr, nullptr, nullptr, packed_uv, rel16}, d, ld_d, r, e, nullptr, dz, ld_dz, dd,
-                         ld_dd, flags, sigmoid_scores, type_offsets, workspace, workspace_bytes, stream, loss);
+                         ld_dd, flags, sigmoid_scores, type_offsets, workspace, workspace_bytes, stream, loss, dz_add, ld_dz_add, dd_add, ld_dd_add);
 }
 
 extern "C" gn_status gn_distmult_backward_f32(const float* z, int64_t ld_z, int64_t n, int64_t f, const int64_t* u,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 150 /* 0.1.46 */
+#define GN_VERSION 151 /* 0.1.47 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -484,7 +484,10 @@ GN_API gn_status gn_distmult_backward_planned_f32(const gn_distmult_bwd_plan* pl
  * d loss / d s_e = (-+ upstream / num_edges) / (p_e (or 1 - p_e) + eps) * p_e (1 - p_e) is a function of the edge's own probability
  * only - it is computed where the edge records are built, in the arithmetic of gn_link_loss_backward_f32 followed by the
  * sigmoid factor (the SAME bits as the two-step path), and the loss's backward launch and the [E] gradient vector's round
- * trip through memory disappear.  upstream: the loss's one upstream gradient on the device (NULL: 1). */
+ * trip through memory disappear.  upstream: the loss's one upstream gradient on the device (NULL: 1).
+ * dz_addend / dd_addend (packed form): the gradients of the SAME z and D from the step's other list (the positives' call): added
+ * where this call stores its sums (dz = sums + dz_addend, may alias dz), so that the two lists' gradients need no adding launch;
+ * GN_ERR_UNSUPPORTED where the two reductions do not share their combine launch (call without addends and add). */
 typedef struct gn_link_loss_grad {
     const float* upstream;
     float eps;
@@ -494,8 +497,10 @@ GN_API gn_status gn_distmult_backward_loss_packed_f32(const float* z, int64_t ld
                                                const uint32_t* packed_uv, const uint16_t* rel16, const float* d, int64_t ld_d,
                                                int64_t num_relations, int64_t num_edges, const gn_link_loss_grad* loss,
                                                const float* sigmoid_scores, float* dz, int64_t ld_dz, float* dd, int64_t ld_dd,
-                                               int flags, const int32_t* type_offsets, void* workspace, size_t workspace_bytes,
-                                               void* stream);
+                                               int flags, const int32_t* type_offsets,
+                                               const float* dz_addend /* nullable */, int64_t ld_dz_addend,
+                                               const float* dd_addend /* nullable */, int64_t ld_dd_addend,
+                                               void* workspace, size_t workspace_bytes, void* stream);
 GN_API gn_status gn_distmult_backward_loss_planned_f32(const gn_distmult_bwd_plan* plan, const float* z, int64_t ld_z,
                                                 int64_t num_features, const float* d, int64_t ld_d,
                                                 const gn_link_loss_grad* loss, const float* sigmoid_scores,
