@@ -164,6 +164,7 @@ struct gn_rgcn_plan {
     // general path: destination-major CSR over the shard, column = relation * N + src
     gn::DevBuf<int32_t> rowptr;    // [N + 1]
     gn::DevBuf<uint32_t> key;      // [shard_edges]
+    gn::DevBuf<uint32_t> skey;     // [shard_edges] the same rows' edges as src * R + relation, sorted by (destination, source, relation)
     gn::DevBuf<int32_t> row_order; // [N] destination rows by the shard's in-degree, largest first (rgcn_basis.hip deals rows in this order)
     int64_t heavy_rows = 0;        // rows of more than gn_layout::kBasisHeavyEdges edges (the first entries of row_order)
     // relation-major work items of the general weight gradient (rgcn_basis.hip): (relation, first edge, end edge, part | parts << 16)

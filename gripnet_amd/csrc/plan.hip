@@ -409,7 +409,7 @@ __global__ void k_i32_to_f32(const int32_t* __restrict__ a, int n, float* __rest
 // key = relation(e) * N + src(e); relation found from the range starts (edges are type-sorted).
 __global__ void k_rel_keys(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                            const int64_t* __restrict__ range_start, int R, int64_t lo, int64_t hi, int64_t N,
-                           int32_t* __restrict__ dst32, uint32_t* __restrict__ key, int32_t* __restrict__ err) {
+                           int32_t* __restrict__ dst32, uint32_t* __restrict__ key, uint32_t* __restrict__ skey, int32_t* __restrict__ err) {
     for (int64_t e = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x) {
         int a = 0, b = R;  // last r with range_start[r] <= e
         while (b - a > 1) {
@@ -421,6 +421,7 @@ __global__ void k_rel_keys(const int64_t* __restrict__ src, const int64_t* __res
         if (!ok) { atomicOr(err, 1); s = 0; d = 0; }
         dst32[e - lo] = (int32_t)d;
         key[e - lo] = (uint32_t)((int64_t)a * N + s);
+        if (skey) skey[e - lo] = (uint32_t)(s * (int64_t)R + a);       // source-major: sorted, a (destination, source) pair's edges are neighbours
     }
 }
 
@@ -620,15 +621,31 @@ gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const i
         GN_TRY(hipGetLastError());
     }
     if (p->shard_edges > 0) {
+        uint32_t *skey = nullptr, *skey_s = nullptr;
+        int32_t *dst_s = nullptr, *dst_s2 = nullptr;
+        GN_TRY(tmp.get(&skey, p->shard_edges));
+        GN_TRY(tmp.get(&skey_s, p->shard_edges));
+        GN_TRY(tmp.get(&dst_s, p->shard_edges));
+        GN_TRY(tmp.get(&dst_s2, p->shard_edges));
+        GN_TRY(p->skey.alloc(p->shard_edges));
         k_rel_keys<<<gn::stream_grid(p->shard_edges, 256), 256, 0, st>>>(src, dst, starts_dev, (int)R, lo, hi, N,
-                                                                        dst32, key, err);
+                                                                        dst32, key, skey, err);
         GN_TRY(hipGetLastError());
-        size_t bytes = 0;
+        size_t bytes = 0, bytes2 = 0;
         GN_TRY(rocprim::radix_sort_pairs(nullptr, bytes, dst32, sorted_dst, key, p->key.p, (size_t)p->shard_edges, 0,
                                          bits_for(N), st));
+        GN_TRY(rocprim::radix_sort_pairs(nullptr, bytes2, skey, skey_s, dst32, dst_s, (size_t)p->shard_edges, 0,
+                                         bits_for(std::max<int64_t>(R * N, 2)), st));
+        bytes = std::max(bytes, bytes2);
         char* scratch = nullptr;
         GN_TRY(tmp.get(&scratch, bytes));
         GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, dst32, sorted_dst, key, p->key.p, (size_t)p->shard_edges, 0,
+                                         bits_for(N), st));
+        // the same edges by (destination, source, relation) (round 6: rgcn_basis.hip sums the att rows of a (destination, source)
+        // pair's edges first and fetches x[source] once per pair): by the source-major key, then - stably - by destination
+        GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, skey, skey_s, dst32, dst_s, (size_t)p->shard_edges, 0,
+                                         bits_for(std::max<int64_t>(R * N, 2)), st));
+        GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, dst_s, dst_s2, skey_s, p->skey.p, (size_t)p->shard_edges, 0,
                                          bits_for(N), st));
     }
     k_rowptr<<<(int)gn::ceil_div(N + 1, 256), 256, 0, st>>>(sorted_dst, (int)p->shard_edges, (int)N, p->rowptr.p);
@@ -682,6 +699,7 @@ void gn_rgcn_plan_destroy(gn_rgcn_plan* p) {
     p->indeg.release();
     p->rowptr.release();
     p->key.release();
+    p->skey.release();
     p->row_order.release();
     p->dw_items.release();
     p->dw_multi.release();

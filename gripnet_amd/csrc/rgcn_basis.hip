@@ -41,6 +41,8 @@ struct BasisArgs {
     const float* x; int64_t ld_x; int fin;
     const float* att; int bases;
     const int32_t* rowptr; const uint32_t* key; const float* indeg; const int32_t* order;
+    const uint32_t* skey;                          // the rows' edges as source * R + relation, sorted by (source, relation) inside a row; or null
+    uint32_t R;
     uint32_t n;                                    // nodes (key = relation * n + source)
     int row_lo, row_hi;                            // this launch's slab of destination rows
     float* u; int64_t ld_u;                        // [row_hi - row_lo][ld_u]: U_i (bases outermost) | x_i | zeros up to kp
@@ -131,10 +133,84 @@ __device__ __forceinline__ void chunk_full(const BasisArgs& a, f32x4 (&acc)[BT][
     }
 }
 
+// Round 6: a chunk of up to 64 edges of a row whose edges are sorted by SOURCE (the plan's skey list).  The edges of one (destination,
+// source) pair are neighbours: the att rows of a pair's edges are summed first (fixed order), x[source] is fetched ONCE per pair, and
+// the matrix instruction contracts four PAIRS per step instead of four edges - on the hub rows of the all-nodes baseline (the 645
+// drugs: 4.8 edges per pair) the row gathers of x and the matrix instructions shrink 4.8-fold.  A pair that straddles two chunks is two
+// partial pairs (the sums are linear).  Pair starts: a ballot of "my source differs from my left neighbour's"; the start lanes write
+// their lane number into the wave's table in LDS, a lane group reads its pair's bounds from there.
+template <int BT, int NT>
+__device__ __forceinline__ void chunk_pairs(const BasisArgs& a, f32x4 (&acc)[BT][NT], uint32_t xo, uint32_t ao, uint32_t src, int cnt, int lane, int kg,
+                                            uint32_t lane_x, const uint32_t (&lane_a)[BT], const bool (&base_ok)[BT], int* __restrict__ tab) {
+    const char* __restrict__ xb = reinterpret_cast<const char*>(a.x);
+    const char* __restrict__ ab = reinterpret_cast<const char*>(a.att);
+    const uint32_t left = (uint32_t)__shfl_up((int)src, 1);
+    const bool live = lane < cnt;
+    const bool start = live && (lane == 0 || src != left);
+    const unsigned long long starts = __ballot(start);
+    const int np = __popcll(starts);
+    const int rank = __popcll(starts & ((2ull << lane) - 1ull)) - 1;
+    if (start) tab[rank] = lane;
+    if (lane == 0) tab[np] = cnt;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                      // (the wave's own LDS writes, then its reads: in order)
+    __builtin_amdgcn_wave_barrier();
+    const int steps = (np + 3) >> 2;
+    for (int j = 0; j < steps; ++j) {
+        const int q = 4 * j + kg;
+        const bool has = q < np;
+        const int s0 = has ? tab[q] : 0, s1 = has ? tab[q + 1] : 0;
+        const int len = s1 - s0;
+        int longest = max(len, __shfl_xor(len, 16));
+        longest = max(longest, __shfl_xor(longest, 32));                       // uniform: the longest of the step's four pairs
+        const uint32_t xs = (uint32_t)__shfl((int)xo, s0) + lane_x;            // the pair's source row (requested first: it travels during the sums)
+        float xv[NT];
+#pragma unroll
+        for (int t4 = 0; t4 < NT / 4; ++t4) {
+            const f32x4 v = has ? *reinterpret_cast<const f32x4u*>(xb + (xs + 16u * t4)) : (f32x4)(0.f);
+            xv[4 * t4] = v[0]; xv[4 * t4 + 1] = v[1]; xv[4 * t4 + 2] = v[2]; xv[4 * t4 + 3] = v[3];
+        }
+        if constexpr (NT % 4 == 2) {
+            const f32x2 v = has ? *reinterpret_cast<const f32x2u*>(xb + (xs + 4u * (NT - 2))) : (f32x2)(0.f);
+            xv[NT - 2] = v[0]; xv[NT - 1] = v[1];
+        } else if constexpr (NT % 4 == 1) {
+            xv[NT - 1] = has ? *reinterpret_cast<const float*>(xb + (xs + 4u * (NT - 1))) : 0.f;
+        } else if constexpr (NT % 4 == 3) {
+            const f32x2 v = has ? *reinterpret_cast<const f32x2u*>(xb + (xs + 4u * (NT - 3))) : (f32x2)(0.f);
+            xv[NT - 3] = v[0]; xv[NT - 2] = v[1];
+            xv[NT - 1] = has ? *reinterpret_cast<const float*>(xb + (xs + 4u * (NT - 1))) : 0.f;
+        }
+        float av[BT];
+#pragma unroll
+        for (int jm = 0; jm < BT; ++jm) av[jm] = 0.f;
+        for (int t0 = 0; t0 < longest; t0 += 4) {                              // four edges of every pair requested together, added in edge order
+            float v[4][BT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = t0 + u < len;
+                const uint32_t as = (uint32_t)__shfl((int)ao, ok ? s0 + t0 + u : 0);
+#pragma unroll
+                for (int jm = 0; jm < BT; ++jm) {
+                    const float w = *reinterpret_cast<const float*>(ab + (as + lane_a[jm]));
+                    v[u][jm] = (ok && base_ok[jm]) ? w : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int jm = 0; jm < BT; ++jm) av[jm] += v[u][jm];
+        }
+#pragma unroll
+        for (int jm = 0; jm < BT; ++jm)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[jm][t] = basis_mfma(av[jm], xv[t], acc[jm][t]);
+    }
+    __builtin_amdgcn_wave_barrier();                                           // (the table is rewritten by the next chunk)
+}
+
 // acc += sum over the edges of chunks first, first + step, ... (64 edges each) of [e0, e1): K = four edges per instruction
 template <int BT, int NT>
 __device__ __forceinline__ void accumulate_chunks(const BasisArgs& a, f32x4 (&acc)[BT][NT], int e0, int e1, int first, int step, int lane,
-                                                  int c, int kg) {
+                                                  int c, int kg, int* __restrict__ tab) {
     const uint32_t lane_x = (uint32_t)(NT * c) * 4u, sel0 = (uint32_t)kg * 4u;
     uint32_t lane_a[BT];
     bool base_ok[BT];
@@ -145,6 +221,18 @@ __device__ __forceinline__ void accumulate_chunks(const BasisArgs& a, f32x4 (&ac
     }
     const uint32_t ldx4 = (uint32_t)a.ld_x * 4u, b4 = (uint32_t)a.bases * 4u;
     int eb = e0 + 64 * first;
+    if (a.skey && a.fast_addr) {                               // the edges by source: sums per (destination, source) pair (uniform branch)
+        uint32_t k_next = (eb < e1 && eb + lane < e1) ? a.skey[eb + lane] : 0u;
+        for (; eb < e1; eb += 64 * step) {
+            const int cnt = min(64, e1 - eb);
+            const uint32_t k = k_next;
+            const int en = eb + 64 * step + lane;
+            k_next = en < e1 ? a.skey[en] : 0u;
+            const uint32_t src = k / a.R, rel = k - src * a.R;
+            chunk_pairs<BT, NT>(a, acc, src * ldx4, rel * b4, src, cnt, lane, kg, lane_x, lane_a, base_ok, tab);
+        }
+        return;
+    }
     uint32_t k_next = (eb < e1 && eb + lane < e1) ? a.key[eb + lane] : 0u;
     for (; eb < e1; eb += 64 * step) {
         const int cnt = min(64, e1 - eb);
@@ -168,6 +256,7 @@ __device__ __forceinline__ void write_tail(const BasisArgs& a, float* __restrict
 template <int BT, int NT>
 __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
     __shared__ f32x4 red[kBasisWaves][64];                                     // one accumulator tile of every wave (heavy rows)
+    __shared__ int pair_tab[kBasisWaves][68];                                  // every wave's pair starts of its current chunk
     if (a.side.dst) {                                                          // concat slot 0 (layers.py:264-266), by the whole grid
         const int64_t total = a.side.rows * a.side.cols;
         for (int64_t t = (int64_t)blockIdx.x * kBasisThreads + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBasisThreads) {
@@ -202,7 +291,7 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
             for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[jm][t] = (f32x4)(0.f);
-            accumulate_chunks<BT, NT>(a, acc, e0, e1, wv, kBasisWaves, lane, c, kg);
+            accumulate_chunks<BT, NT>(a, acc, e0, e1, wv, kBasisWaves, lane, c, kg, pair_tab[wv]);
             const float inv = a.scale ? 1.0f / fmaxf(a.indeg[row], 1.0f) : 1.0f;
             float* __restrict__ ur = a.u + (size_t)(row - a.row_lo) * a.ld_u;
 #pragma unroll
@@ -237,7 +326,7 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
         for (int jm = 0; jm < BT; ++jm)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[jm][t] = (f32x4)(0.f);
-        accumulate_chunks<BT, NT>(a, acc, e0, e1, 0, 1, lane, c, kg);
+        accumulate_chunks<BT, NT>(a, acc, e0, e1, 0, 1, lane, c, kg, pair_tab[wv]);
         // acc[jm][t][i] = U_i[base 16 jm + 4 kg + i][feature NT c + t]
         const float inv = a.scale ? 1.0f / fmaxf(a.indeg[row], 1.0f) : 1.0f;
         float* __restrict__ ur = a.u + (size_t)(row - a.row_lo) * a.ld_u;
@@ -508,6 +597,9 @@ gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_
     BasisArgs a;
     a.x = x; a.ld_x = ld_x; a.fin = (int)fin; a.att = att; a.bases = (int)bases;
     a.rowptr = plan->rowptr.p; a.key = plan->key.p; a.indeg = plan->indeg.p; a.order = plan->row_order.p;
+    const char* by_edge = getenv("GN_RGCN_BASIS_BY_EDGE");                     // (test hook: the per-edge form of round 5)
+    a.skey = (by_edge && by_edge[0] == '1') ? nullptr : plan->skey.p;
+    a.R = (uint32_t)plan->num_relations;
     a.n = (uint32_t)N; a.u = U; a.ld_u = l.kp; a.kp = l.kp; a.n_heavy = (int)plan->heavy_rows;
     a.scale = partial ? 0 : 1; a.with_x = partial ? 0 : 1;
     a.vec = (fin % 16 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
