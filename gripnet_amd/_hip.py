@@ -348,7 +348,7 @@ def replay(calls):
 
 # Test hooks the library reads from the environment at call time (common.h, aggregate.cuh, gcn_blocked.hip): part of every
 # memo key, so that a shortcut recorded under one setting is not replayed under another.
-_ENV_HOOKS = ("GN_DISABLE_FAST", "GN_DISABLE_QUAD", "GN_DISABLE_BLOCKED", "GN_BLOCKED_ANY", "GN_DISABLE_LDS_TABLE", "GN_RGCN_BASIS_BY_EDGE")
+_ENV_HOOKS = ("GN_DISABLE_FAST", "GN_DISABLE_QUAD", "GN_DISABLE_BLOCKED", "GN_BLOCKED_ANY", "GN_DISABLE_LDS_TABLE", "GN_RGCN_BASIS_ORDER")
 # hooks the C side reads that can NOT change what a memoised inference forward launches: the host threads of the plan builders
 # (plans do not depend on them), the sampler's kernel choice (same draws; no module forward calls the sampler) and the slab size of the
 # general relational path (read inside the entry point at every call: a slab is a range of rows, the bits do not depend on it).

@@ -1239,7 +1239,10 @@ gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, cons
             return gn::fail(GN_ERR_UNSUPPORTED, "GN_GEMM_OUT_BF16: a tall-skinny product (m >= 2048, k %% 32 == 0) with n %% 4 == 0, 8-byte aligned rows, no accumulate / addend");
         g.out_bf16 = 1; g.c_vec_ok = 1;
     }
-    if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
+    // (a TALL product with at most 32 columns - the general relational path's slab of rows times [basis ; root], 19,726 x 1,088 x 32 -
+    // is streamed by the tall-skinny split kernel below, not cut into K slices here: 43 -> 2x us for its 86 MB, round 6)
+    const bool tall_split = !at && m >= 2048 && k >= 32 && k % 32 == 0 && g.a_vec_ok;
+    if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && !tall_split && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
         if (batch_open && (flags & GN_GEMM_JOIN_BATCH)) {         // between gn_dense_batch_begin / _end: leaves with the others
             BatchOp op;

@@ -621,21 +621,26 @@ gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const i
         GN_TRY(hipGetLastError());
     }
     if (p->shard_edges > 0) {
+        // (the source-ordered list of rgcn_basis.hip's measurement hook GN_RGCN_BASIS_ORDER: only built when it is set)
+        const bool want_skey = getenv("GN_RGCN_BASIS_ORDER") != nullptr;
         uint32_t *skey = nullptr, *skey_s = nullptr;
         int32_t *dst_s = nullptr, *dst_s2 = nullptr;
-        GN_TRY(tmp.get(&skey, p->shard_edges));
-        GN_TRY(tmp.get(&skey_s, p->shard_edges));
-        GN_TRY(tmp.get(&dst_s, p->shard_edges));
-        GN_TRY(tmp.get(&dst_s2, p->shard_edges));
-        GN_TRY(p->skey.alloc(p->shard_edges));
+        if (want_skey) {
+            GN_TRY(tmp.get(&skey, p->shard_edges));
+            GN_TRY(tmp.get(&skey_s, p->shard_edges));
+            GN_TRY(tmp.get(&dst_s, p->shard_edges));
+            GN_TRY(tmp.get(&dst_s2, p->shard_edges));
+            GN_TRY(p->skey.alloc(p->shard_edges));
+        }
         k_rel_keys<<<gn::stream_grid(p->shard_edges, 256), 256, 0, st>>>(src, dst, starts_dev, (int)R, lo, hi, N,
                                                                         dst32, key, skey, err);
         GN_TRY(hipGetLastError());
         size_t bytes = 0, bytes2 = 0;
         GN_TRY(rocprim::radix_sort_pairs(nullptr, bytes, dst32, sorted_dst, key, p->key.p, (size_t)p->shard_edges, 0,
                                          bits_for(N), st));
-        GN_TRY(rocprim::radix_sort_pairs(nullptr, bytes2, skey, skey_s, dst32, dst_s, (size_t)p->shard_edges, 0,
-                                         bits_for(std::max<int64_t>(R * N, 2)), st));
+        if (want_skey)
+            GN_TRY(rocprim::radix_sort_pairs(nullptr, bytes2, skey, skey_s, dst32, dst_s, (size_t)p->shard_edges, 0,
+                                             bits_for(std::max<int64_t>(R * N, 2)), st));
         bytes = std::max(bytes, bytes2);
         char* scratch = nullptr;
         GN_TRY(tmp.get(&scratch, bytes));
@@ -643,10 +648,12 @@ gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const i
                                          bits_for(N), st));
         // the same edges by (destination, source, relation) (round 6: rgcn_basis.hip sums the att rows of a (destination, source)
         // pair's edges first and fetches x[source] once per pair): by the source-major key, then - stably - by destination
-        GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, skey, skey_s, dst32, dst_s, (size_t)p->shard_edges, 0,
-                                         bits_for(std::max<int64_t>(R * N, 2)), st));
-        GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, dst_s, dst_s2, skey_s, p->skey.p, (size_t)p->shard_edges, 0,
-                                         bits_for(N), st));
+        if (want_skey) {
+            GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, skey, skey_s, dst32, dst_s, (size_t)p->shard_edges, 0,
+                                             bits_for(std::max<int64_t>(R * N, 2)), st));
+            GN_TRY(rocprim::radix_sort_pairs(scratch, bytes, dst_s, dst_s2, skey_s, p->skey.p, (size_t)p->shard_edges, 0,
+                                             bits_for(N), st));
+        }
     }
     k_rowptr<<<(int)gn::ceil_div(N + 1, 256), 256, 0, st>>>(sorted_dst, (int)p->shard_edges, (int)N, p->rowptr.p);
     GN_TRY(hipGetLastError());

@@ -43,6 +43,7 @@ struct BasisArgs {
     const int32_t* rowptr; const uint32_t* key; const float* indeg; const int32_t* order;
     const uint32_t* skey;                          // the rows' edges as source * R + relation, sorted by (source, relation) inside a row; or null
     uint32_t R;
+    int mode;                                      // 0: per edge, relation order (round 5); 1: pair sums on the hub rows; 2: per edge, source order
     uint32_t n;                                    // nodes (key = relation * n + source)
     int row_lo, row_hi;                            // this launch's slab of destination rows
     float* u; int64_t ld_u;                        // [row_hi - row_lo][ld_u]: U_i (bases outermost) | x_i | zeros up to kp
@@ -93,7 +94,10 @@ __device__ __forceinline__ void chunk_full(const BasisArgs& a, f32x4 (&acc)[BT][
     const char* __restrict__ ab = reinterpret_cast<const char*>(a.att);
     // steps whose operands are requested together: eight while they fit the registers next to the accumulators (a row's
     // time is a chain of memory round trips - few rows are in flight per compute unit - so fewer, fatter requests win)
-    constexpr int G = (BT + NT) * 8 + BT * NT * 4 <= 72 ? 8 : 4;
+#ifndef GN_BASIS_G16_LIMIT
+#define GN_BASIS_G16_LIMIT 0
+#endif
+    constexpr int G = (BT + NT) * 16 + BT * NT * 4 <= GN_BASIS_G16_LIMIT ? 16 : ((BT + NT) * 8 + BT * NT * 4 <= 72 ? 8 : 4);
 #pragma unroll
     for (int g = 0; g < 16 / G; ++g) {
         float av[G][BT], xv[G][NT];
@@ -221,7 +225,11 @@ __device__ __forceinline__ void accumulate_chunks(const BasisArgs& a, f32x4 (&ac
     }
     const uint32_t ldx4 = (uint32_t)a.ld_x * 4u, b4 = (uint32_t)a.bases * 4u;
     int eb = e0 + 64 * first;
-    if (a.skey && a.fast_addr) {                               // the edges by source: sums per (destination, source) pair (uniform branch)
+    // the edges by source: sums per (destination, source) pair (uniform branch).  Only the rows a whole workgroup walks - the hubs,
+    // where pairs have several edges; on light rows (a pair is mostly one edge) the pair bookkeeping costs more than it saves:
+    // 196 against 148 us per layer with every row on this path, 164 with the hub rows only: the pair's sums are a chain of
+    // dependent round trips (bounds from the table, shuffle, att row, add) where the per-edge form requests eight steps' operands at once
+    if (a.skey && a.fast_addr && a.mode == 1 && step > 1) {
         uint32_t k_next = (eb < e1 && eb + lane < e1) ? a.skey[eb + lane] : 0u;
         for (; eb < e1; eb += 64 * step) {
             const int cnt = min(64, e1 - eb);
@@ -233,13 +241,17 @@ __device__ __forceinline__ void accumulate_chunks(const BasisArgs& a, f32x4 (&ac
         }
         return;
     }
-    uint32_t k_next = (eb < e1 && eb + lane < e1) ? a.key[eb + lane] : 0u;
+    // (mode 2: the per-edge contraction on the edges in SOURCE order - a row's edges from one source are neighbours, their x rows hit the L1)
+    const bool by_source = a.skey && a.mode == 2;
+    const uint32_t* __restrict__ keys = by_source ? a.skey : a.key;
+    uint32_t k_next = (eb < e1 && eb + lane < e1) ? keys[eb + lane] : 0u;
     for (; eb < e1; eb += 64 * step) {
         const int cnt = min(64, e1 - eb);
         const uint32_t k = k_next;
         const int en = eb + 64 * step + lane;                                  // the next chunk's keys travel while this one is contracted
-        k_next = en < e1 ? a.key[en] : 0u;
-        const uint32_t rel = k / a.n, src = k - rel * a.n;                     // (one division per lane and 64 edges)
+        k_next = en < e1 ? keys[en] : 0u;
+        uint32_t rel = k / a.n, src = k - rel * a.n;                           // (one division per lane and 64 edges)
+        if (by_source) { src = k / a.R; rel = k - src * a.R; }
         if (cnt == 64 && a.fast_addr) chunk_full<BT, NT>(a, acc, src * ldx4, rel * b4, sel0, lane_x, lane_a, base_ok);
         else chunk_any<BT, NT>(a, acc, src, rel, cnt, c, kg);
     }
@@ -597,8 +609,13 @@ gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_
     BasisArgs a;
     a.x = x; a.ld_x = ld_x; a.fin = (int)fin; a.att = att; a.bases = (int)bases;
     a.rowptr = plan->rowptr.p; a.key = plan->key.p; a.indeg = plan->indeg.p; a.order = plan->row_order.p;
-    const char* by_edge = getenv("GN_RGCN_BASIS_BY_EDGE");                     // (test hook: the per-edge form of round 5)
-    a.skey = (by_edge && by_edge[0] == '1') ? nullptr : plan->skey.p;
+    // Measurement hook (round 6, profiles/r06_experiments.md 5): GN_RGCN_BASIS_ORDER=pairs - the att rows of a (destination, source) pair's
+    // edges summed first, x once per pair, on the hub rows; =source - the per-edge contraction on source-ordered edges.  Both need the
+    // plan's source-ordered list (built when the variable is set at plan creation) and both measured SLOWER or equal: the default stays
+    // the per-edge contraction on the relation-ordered list.
+    const char* order = getenv("GN_RGCN_BASIS_ORDER");
+    a.skey = plan->skey.p;
+    a.mode = (a.skey && order && order[0] == 'p') ? 1 : ((a.skey && order && order[0] == 's') ? 2 : 0);
     a.R = (uint32_t)plan->num_relations;
     a.n = (uint32_t)N; a.u = U; a.ld_u = l.kp; a.kp = l.kp; a.n_heavy = (int)plan->heavy_rows;
     a.scale = partial ? 0 : 1; a.with_x = partial ? 0 : 1;
