@@ -14,6 +14,8 @@ index_add_ + batched matmul per slab of relations; more than 64 bases: att^T dW)
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _hip
@@ -436,19 +438,22 @@ class LinkPredictionLossFn(torch.autograd.Function):
 
 
 _node_plans = []            # (node_list tensor, _version, rows of z, plan): the row-gather plans of the last few node lists
+_node_plans_lock = threading.Lock()
 
 
 def node_gather_plan(nodes: torch.Tensor, num_rows: int):
     """Plain-sum plan with ONE edge per listed node (table row nodes[i] -> output row i): its aggregation is the row gather
     z[node_list] (decoder.py:42), its transposed aggregation the scatter-add of the gathered rows' gradients.  Built once
     per node list (the label splits of a training loop are static, GripNet-aminer.py:124-147)."""
-    for t, ver, rows, plan in _node_plans:
-        if t is nodes and ver == nodes._version and rows == num_rows:
-            return plan
+    with _node_plans_lock:                                     # (autograd runs a device's backward on its own thread)
+        for t, ver, rows, plan in _node_plans:
+            if t is nodes and ver == nodes._version and rows == num_rows:
+                return plan
     ei = torch.stack([nodes, torch.arange(nodes.shape[0], dtype=torch.int64, device=nodes.device)])
     plan = _hip.GraphPlan.plain_sum(ei, num_rows, nodes.shape[0])
-    _node_plans.append((nodes, nodes._version, num_rows, plan))
-    del _node_plans[:-4]
+    with _node_plans_lock:
+        _node_plans.append((nodes, nodes._version, num_rows, plan))
+        del _node_plans[:-4]
     return plan
 
 
