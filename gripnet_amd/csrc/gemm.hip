@@ -1241,7 +1241,8 @@ gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, cons
     }
     // (a TALL product with at most 32 columns - the general relational path's slab of rows times [basis ; root], 19,726 x 1,088 x 32 -
     // is streamed by the tall-skinny split kernel below, not cut into K slices here: 43 -> 2x us for its 86 MB, round 6)
-    const bool tall_split = !at && m >= 2048 && k >= 32 && k % 32 == 0 && g.a_vec_ok;
+    const bool want_split = (flags & GN_GEMM_SPLIT_KERNEL) != 0;   // (the caller's products must not change kernel - and bits - with their row count)
+    const bool tall_split = !at && (m >= 2048 || want_split) && k >= 32 && k % 32 == 0 && g.a_vec_ok;
     if (batch == 1 && !a_rows && (m <= 64 || n <= 32) && !tall_split && (at || (k >= 256 && !gn::fast_paths_disabled()))) {
         // deep and narrow (and every product with A given transposed): a workgroup per output tile, K over its waves
         if (batch_open && (flags & GN_GEMM_JOIN_BATCH)) {         // between gn_dense_batch_begin / _end: leaves with the others
@@ -1257,7 +1258,7 @@ gn_status gn_gemm_addend_f32(const float* a, int64_t lda, int64_t stride_a, cons
     GN_REQUIRE(!at, "A given transposed: at most 64 rows or 32 columns of output (the deep and narrow kernel)");
     const size_t lds_bytes = (size_t)gn::ceil_div(k, 16) * kColTiles * 64 * sizeof(f32x4);
     const int row_tiles = (int)gn::ceil_div(m, 16);
-    if (batch == 1 && m >= 2048 && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled()) {
+    if (batch == 1 && (m >= 2048 || want_split) && !a_rows && k >= 32 && k % 32 == 0 && g.a_vec_ok && !gn::fast_paths_disabled()) {
         // tall-skinny, one shared B (as stored, or given transposed: the dx = g W^T of the wide layers' backward): the bf16 matrix
         // instruction on split operands.  (Not queued in a dense batch: on 50,000 x 128 x 128 it takes a third of the fp32 instruction's time.)
         const int terms = fast ? 2 : 3;

@@ -641,7 +641,7 @@ gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_
         }
         if (s != GN_OK) return s;
         s = gn_gemm_f32(U, l.kp, 0, nullptr, 0, W, fout, 0, out + r0 * ld_out, ld_out, 0, r1 - r0, fout, l.kp, 1,
-                        partial ? nullptr : bias, ((relu && !partial) ? GN_GEMM_RELU : 0) | (fast_arith ? GN_GEMM_ARITH_FAST : 0), st);
+                        partial ? nullptr : bias, ((relu && !partial) ? GN_GEMM_RELU : 0) | (fast_arith ? GN_GEMM_ARITH_FAST : 0) | GN_GEMM_SPLIT_KERNEL, st);
         if (s != GN_OK) return s;
     }
     return GN_OK;

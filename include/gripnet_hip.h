@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 151 /* 0.1.47 */
+#define GN_VERSION 152 /* 0.1.48 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -189,6 +189,8 @@ GN_API gn_status gn_graph_aggregate_t_f32(const gn_graph_plan* plan, const float
 #define GN_GEMM_ACCUMULATE 8    /* c += a b (+ bias) instead of c = ... */
 #define GN_GEMM_A_TRANSPOSED 16  /* a is given as [k, m] row-major (lda >= m): c = a^T b; m <= 64 or n <= 32 only: dbasis = att^T dW */
 #define GN_GEMM_JOIN_BATCH 32   /* the product may leave with the open batch (gn_dense_batch_begin / _end, below) */
+#define GN_GEMM_SPLIT_KERNEL 128 /* take the tall-skinny split kernel whatever the row count (k % 32 == 0, aligned rows): a caller that cuts one
+                                 * product into slabs of rows gets the same bits for every slab size */
 #define GN_GEMM_OUT_BF16 64     /* c is a bf16 table [m, n] (ldc in bf16 elements, rows 8-byte aligned, n % 4 == 0): every value is rounded to
                                  * nearest even ONCE, where the product is stored - gn_cast_bf16's rounding without its pass (the table of a
                                  * bf16-storage layer, gn_graph_aggregate_bf16).  Tall-skinny products only (m >= 2048, k % 32 == 0, no
