@@ -502,8 +502,8 @@ def extra_workloads(dev, budget_s, with_cpu):
                 assert entry["parity"]["ok"], "{}: GPU result differs from the CPU oracle: {}".format(name, entry["parity"])
                 entry["cpu_oracle_forward_s"] = cpu_s
                 entry["cpu_threads"] = torch.get_num_threads()
-            if storage == "fp32" and left() > 12:
-                # the model's training step (the loop body of GripNet-aminer.py:120-147 / GripNet-freebase-c.py:146-176: forward, class
+            if left() > 12:
+                # the model's training step (with bf16 table storage too, round 6: the forward gathers the rounded table, the backward is the fp32 layer's) (the loop body of GripNet-aminer.py:120-147 / GripNet-freebase-c.py:146-176: forward, class
                 # loss, backward, Adam - every launch the library's own): eager, and as one hipGraph replay per step
                 with torch.enable_grad():
                     tr = nc_train_entry(model, data, nodes_dev, data.a_label[nodes_dev].contiguous())

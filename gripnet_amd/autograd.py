@@ -86,7 +86,7 @@ class GcnConvFn(torch.autograd.Function):
     external layer's closed form."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None, planes=None, passthrough=False):
+    def forward(ctx, x, weight, bias, plan, n_out, relu, slot=None, side=None, planes=None, passthrough=False, storage="fp32"):
         # slot: a Slot of a concat buffer the output is written into (the concat of layers.py:309,376 without a copy, SlotsCatFn);
         # side: (tensor, Slot, mode) copied by the same launch, as on the inference path; planes: (SplitPlanes, col_main, col_side) -
         # the launch leaves its output and side copy as bf16 split planes too (the external layer in front of a relational layer);
@@ -101,7 +101,21 @@ class GcnConvFn(torch.autograd.Function):
         if side is not None:
             side = (side[0].detach(), side[1].view(), side[2])
         b = None if bias is None else bias.detach()
-        if _hip.transform_fusable(w.shape[0], w.shape[1], x) and w.is_contiguous():
+        if (storage == "bf16" and planes is None and w.shape[1] % 8 == 0 and _hip.ld(out) % 4 == 0 and out.data_ptr() % 16 == 0):
+            # bf16 storage of the gathered table under training (round 6; BASELINE config 5): the forward is the inference path's
+            # (x W rounded to bf16 where the product stores it, fp32 sums); the backward below is the fp32 layer's - rounding
+            # the table has the identity as its (straight-through) derivative, and neither dx = A^T g W^T nor dW = x^T A^T g
+            # reads the table.  What differs from fp32 training is the forward's values (and the ReLU mask they give).
+            xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.bfloat16, device=x.device)
+            try:
+                _hip.gemm(x, w, xw, out_bf16=True)
+            except _hip.GripNetHipError as err:
+                if err.status != _hip.GN_ERR_UNSUPPORTED:
+                    raise
+                xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
+                _hip.gemm(x, w, xw)
+            plan.aggregate_bf16(xw, b, relu, out, side)
+        elif _hip.transform_fusable(w.shape[0], w.shape[1], x) and w.is_contiguous():
             plan.aggregate(x, b, relu, out, side, weight=w, planes=planes)    # (A_norm x) W in one launch, as the inference path
         else:
             xw = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float32, device=x.device)
@@ -115,7 +129,7 @@ class GcnConvFn(torch.autograd.Function):
     def backward(ctx, g, g_pass=None):
         x, w, out = ctx.saved_tensors
         if g is None:                                              # only the passed-through input is used downstream
-            return (g_pass if ctx.needs_input_grad[0] else None,) + (None,) * 9
+            return (g_pass if ctx.needs_input_grad[0] else None,) + (None,) * 10
         # one launch: the ReLU mask by the saved output (gradient passes where the output is positive), the bias gradient
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.relu or need_db or g.stride(1) != 1:
@@ -135,7 +149,7 @@ class GcnConvFn(torch.autograd.Function):
             dw = _hip.xtg(x, gxw, join_batch=True) if ctx.needs_input_grad[1] else None
         if late is not None:
             dx = dx + late
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class RgcnConvFn(torch.autograd.Function):

@@ -52,7 +52,8 @@ class myGCN(Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.improved, self.cached = improved, cached
         # "fp32" (the reference's arithmetic) or "bf16": the gathered table x W is rounded to bf16 once and read at
-        # half the bytes, everything else stays fp32 (inference path; gripnet_amd.utils.set_table_storage)
+        # half the bytes, everything else stays fp32 (gripnet_amd.utils.set_table_storage; under training since round 6: the
+        # forward takes the rounded table, the backward is the fp32 layer's - GcnConvFn)
         self.table_storage = kwargs.get("table_storage", "fp32")
         self.arithmetic = "fp32"          # dense x W: "fp32" (fp32-faithful, default) or "fast" (two-term bf16 splits)
         self.cached_result = None
@@ -92,7 +93,7 @@ class myGCN(Module):
     def _run(self, plan, x, n_out, out, relu, side, planes=None, passthrough=False):
         self._planes_written = False                 # did this call's launch leave the split planes it was offered?
         if recording(x, self.weight, self.bias):                                 # training: autograd path (out / side: Slots)
-            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side, planes, passthrough)
+            y = GcnConvFn.apply(x, self.weight, self.bias, plan, n_out, relu, out, side, planes, passthrough, self.table_storage)
             self._planes_written = planes is not None
             return y
         if passthrough:                                                          # (a frozen layer: x goes to the concat as it is)

@@ -287,7 +287,8 @@ def forget_call_memos(module) -> int:
 def set_table_storage(module, storage: str = "bf16"):
     """Switch every GCN-style layer under `module` to "bf16" (or back to "fp32") storage of its gathered table:
     x W is rounded to bf16 once per forward and read at half the bytes; sums, bias, activation, outputs and every
-    parameter stay fp32 (inference path; training is unchanged).  The reference has no reduced precision; this is
+    parameter stay fp32.  Under training (round 6) the forward takes the rounded table too and the backward is the fp32
+    layer's (the rounding's straight-through derivative).  The reference has no reduced precision; this is
     the build's own variant for the node-classification suite.  Returns the layers touched."""
     from .layers import myGCN
     if storage not in ("fp32", "bf16"):

@@ -225,6 +225,47 @@ def test_freebase_c_training_step_gradients(gpu):
         close(p.grad, sd[k].grad, 1e-4, what=k)
 
 
+@pytest.mark.parametrize("scale", ["tiny", "aminer-syn"])
+def test_freebase_c_training_step_with_bf16_tables(gpu, scale):
+    """BASELINE config 5 under training (round 6): with `table_storage = "bf16"` the forward of a training step gathers from the
+    bf16-rounded x W (the inference path's launches) and the backward is the fp32 layer's (the rounding's straight-through
+    derivative).  No reference exists for reduced precision: the step is held to the SAME model's fp32 step - loss within 2e-2
+    relative, every parameter gradient within 5e-2 of its largest entry (one bf16 rounding, 2^-8, of every gathered element
+    through four stacked layers and the ReLU masks they flip), and the bf16 forward under autograd gives the bits of the bf16
+    inference forward."""
+    from gripnet_amd.utils import class_loss, set_table_storage
+    data = make_nc(scale)
+    torch.manual_seed(43)
+    kw = dict(pp_nhids=(16, 8, 8), qq_nhids=(16, 8, 8), pa_out=(8, 8), aa_hidden=(8,)) if scale == "tiny" else {}
+    model = FreebaseCModel(data.n_p_node, data.n_q_node, data.n_a_node, data.n_a_type, **kw).to(gpu)
+    nodes = torch.arange(1, data.n_a_node, 2).to(gpu)
+    dg = make_nc(scale).to(gpu)
+    labels = dg.a_label[nodes].contiguous()
+    grads, losses = {}, {}
+    for storage in ("fp32", "bf16"):
+        touched = set_table_storage(model, storage)
+        assert len(touched) == 7
+        model.zero_grad()
+        z, pred = model(dg, nodes)
+        loss = class_loss(pred, labels)
+        loss.backward()
+        losses[storage] = float(loss)
+        grads[storage] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        if storage == "bf16":
+            with torch.no_grad():
+                z_inf, pred_inf = model(dg, nodes)
+            assert torch.equal(z_inf, z.detach()) and torch.equal(pred_inf, pred.detach())
+    set_table_storage(model, "fp32")
+    assert abs(losses["bf16"] - losses["fp32"]) <= 2e-2 * abs(losses["fp32"]), losses
+    assert set(grads["bf16"]) == set(grads["fp32"])
+    for k, g32 in grads["fp32"].items():
+        scale_k = float(g32.abs().max())
+        if scale_k == 0.0:
+            continue
+        assert float((grads["bf16"][k] - g32).abs().max()) <= 5e-2 * scale_k, k
+    _hip.raise_if_index_errors(gpu)
+
+
 @pytest.mark.parametrize("n,fin,fout,bias", [(100, 48, 32, False), (40, 12, 20, True), (645, 48, 32, False)])
 def test_rgcn_conv_gradients(gpu, n, fin, fout, bias):
     gen = torch.Generator().manual_seed(47 + n)
