@@ -254,7 +254,8 @@ def test_freebase_c_training_step_with_bf16_tables(gpu, scale):
         if storage == "bf16":
             with torch.no_grad():
                 z_inf, pred_inf = model(dg, nodes)
-            assert torch.equal(z_inf, z.detach()) and torch.equal(pred_inf, pred.detach())
+            assert torch.equal(z_inf, z.detach())          # (the class decoder's training path is other launches: its probabilities agree to rounding)
+            assert float((pred_inf - pred.detach()).abs().max()) <= 1e-6
     set_table_storage(model, "fp32")
     assert abs(losses["bf16"] - losses["fp32"]) <= 2e-2 * abs(losses["fp32"]), losses
     assert set(grads["bf16"]) == set(grads["fp32"])
