@@ -8,7 +8,7 @@
 // launches and 715 us for the 2 x 2 M scores of pose0-syn's training list - more than the training step itself).  The scores of
 // a relation are CONTIGUOUS in both vectors (type-sorted edge list, range_list), so every (relation, class) pair is a
 // SEGMENT that is sorted on its own:
-//   1. k_metric_sort_chunks: a segment is cut into chunks of <= 8,192 scores; a workgroup turns a chunk's scores into
+//   1. k_metric_sort_chunks: a segment is cut into chunks of <= 4,096 scores; a workgroup turns a chunk's scores into
 //      32-bit keys (ascending key = descending score), sorts them in LDS (bitonic) and writes them back in place;
 //   2. k_metric_merge (only when a segment has more than one chunk; log2(chunks) rounds, ping-pong): pairs of adjacent
 //      sorted runs of one segment are merged by merge path, a workgroup per 1,024 outputs;
@@ -29,7 +29,7 @@
 
 namespace {
 
-constexpr int kChunk = 8192;               // keys a workgroup sorts in LDS (32 KB; 32 per thread in registers)
+constexpr int kChunk = 4096;               // keys a workgroup sorts in LDS (16 KB)
 constexpr int kSortThreads = 256;
 constexpr int kTile = 1024;                // outputs of a merge workgroup, elements of a terms workgroup
 constexpr int kTileThreads = 256;
@@ -85,7 +85,7 @@ struct Segs {
 // that keeps the keys in LDS (measured: 91 us per launch for that one, the launch ending with its slowest workgroup).
 template <int EPT>
 __device__ __forceinline__ void sort_in_registers(uint32_t* __restrict__ buf, int tid) {
-    constexpr int LOGN = EPT == 32 ? 13 : (EPT == 16 ? 12 : (EPT == 4 ? 10 : 8));
+    constexpr int LOGN = EPT == 16 ? 12 : (EPT == 4 ? 10 : 8);
     uint32_t v[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) v[e] = buf[EPT * tid + e];
@@ -143,13 +143,12 @@ __global__ __launch_bounds__(kSortThreads) void k_metric_sort_chunks(const float
     const int n_seg = sg.len(s);
     const int off = c * kChunk, n = min(kChunk, n_seg - off);
     const float* __restrict__ src = ((s & 1) ? neg : pos) + sg.start[s >> 1] + off;
-    const int N = n <= kSortThreads ? kSortThreads : (n <= 4 * kSortThreads ? 4 * kSortThreads : (n <= 16 * kSortThreads ? 16 * kSortThreads : 32 * kSortThreads));   // uniform
+    const int N = n <= kSortThreads ? kSortThreads : (n <= 4 * kSortThreads ? 4 * kSortThreads : 16 * kSortThreads);   // uniform
     for (int i = threadIdx.x; i < N; i += kSortThreads) buf[i] = i < n ? descending_bits(src[i]) : 0xffffffffu;
     __syncthreads();
     if (N == kSortThreads) sort_in_registers<1>(buf, threadIdx.x);
     else if (N == 4 * kSortThreads) sort_in_registers<4>(buf, threadIdx.x);
-    else if (N == 16 * kSortThreads) sort_in_registers<16>(buf, threadIdx.x);
-    else sort_in_registers<32>(buf, threadIdx.x);
+    else sort_in_registers<16>(buf, threadIdx.x);
     uint32_t* __restrict__ dst = key + sg.base(s) + off;
     for (int i = threadIdx.x; i < n; i += kSortThreads) dst[i] = buf[i];
 }

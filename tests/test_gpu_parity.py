@@ -782,10 +782,10 @@ def test_relation_metrics_match_sklearn(gpu):
             assert abs(a - b) <= 1e-9, "relation {} {}: {} vs sklearn {}".format(r, name, a, b)
 
 
-@pytest.mark.parametrize("sizes", [[5000, 7, 8192, 8193, 0, 17000], [70000, 300, 4096, 20000], [33000, 1, 1024], [150000, 12]])
+@pytest.mark.parametrize("sizes", [[5000, 7, 4096, 4097, 0, 9000], [70000, 300, 8192, 20000], [33000, 1, 1024], [150000, 12]])
 def test_relation_metrics_with_relations_beyond_one_chunk(gpu, sizes):
-    """Round 6 (own segment sort): relations longer than the 8,192 scores a workgroup sorts go through merge rounds (2, 4, 3
-    and 5 here: even and odd numbers of ping-pong rounds; lengths on and next to chunk and tile boundaries); all scores of a
+    """Round 6 (own segment sort): relations longer than the 4,096 scores a workgroup sorts in LDS go through merge rounds (1, 2, 4
+    and 6 here: even and odd numbers of ping-pong rounds; lengths on and next to chunk and tile boundaries); all scores of a
     relation tied, ties that straddle chunk boundaries, ties BETWEEN the classes; against scikit-learn per block (<= 1e-9), the
     same bits twice in a row, and the plan-less entry point agrees bit for bit."""
     from gripnet_amd.utils import auprc_auroc_ap, relation_metrics
