@@ -557,20 +557,11 @@ def cold_start_entry(model, data, fence):
         for _ in range(3):
             stages.step()
         fence()
-        prof = None
-        if os.environ.get("GN_BENCH_PROFILE_COLD") == "1":     # (development: where does the host time of these steps go?)
-            import cProfile
-            prof = cProfile.Profile()
-            prof.enable()
         t = time.perf_counter()
         for _ in range(20):
             z, score = stages.step()
         fence()
         out["forward_ms_decoder_uncached"] = round(1e3 * (time.perf_counter() - t) / 20, 5)
-        if prof is not None:
-            import pstats
-            prof.disable()
-            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
         with _hip.KernelTimer() as kt:
             for _ in range(5):
                 stages.step()
