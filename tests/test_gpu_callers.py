@@ -667,6 +667,12 @@ def _oneshot_worker(rank, world, port, q, skip_rank):
                     z, s = fwd()
                 torch.cuda.synchronize()
                 _hip.raise_if_index_errors(dev)
+                run = fwd.record()                                         # the recorded form (bench.py's launch mode at N > 1) on the same exchange
+                for _ in range(3):
+                    z_rec, s_rec = run()
+                torch.cuda.synchronize()
+                _hip.raise_if_index_errors(dev)
+                out["recorded_same"] = bool(torch.equal(z_rec, z) and torch.equal(s_rec, s))
             zs = [torch.empty(z.shape) for _ in range(world)]
             dist.all_gather(zs, z.cpu())
             out["z_same_on_all_ranks"] = all(torch.equal(zs[0], other) for other in zs)
@@ -704,6 +710,6 @@ def test_one_shot_exchange_between_processes_on_one_gpu(gpu, world, skip_rank):
     if skip_rank is None:
         for o in outs:
             assert o["same"] == [True] * 6, o
-            assert o["z_same_on_all_ranks"] and o["z_err"] <= 1e-5, o
+            assert o["z_same_on_all_ranks"] and o["z_err"] <= 1e-5 and o["recorded_same"], o
     else:
         assert outs[0]["same"] == [True] * 3 and outs[0]["timed_out"], outs     # three good steps, then the peer is gone
