@@ -556,12 +556,16 @@ def cold_start_entry(model, data, fence):
         stages = PoseStages(model, data, graphs=False)
         for _ in range(3):
             stages.step()
-        fence()
-        t = time.perf_counter()
-        for _ in range(20):
-            z, score = stages.step()
-        fence()
-        out["forward_ms_decoder_uncached"] = round(1e3 * (time.perf_counter() - t) / 20, 5)
+        reps = []
+        for _ in range(3):                                     # (the fastest of three repeats: a one-time stall of the host - an allocator
+            fence()                                            # trim, a collection - read 2 ms per step in some runs and 0.116 in others)
+            t = time.perf_counter()
+            for _ in range(20):
+                z, score = stages.step()
+            fence()
+            reps.append((time.perf_counter() - t) / 20)
+        out["forward_ms_decoder_uncached"] = round(1e3 * min(reps), 5)
+        out["forward_ms_decoder_uncached_repeats"] = [round(1e3 * r, 5) for r in reps]
         with _hip.KernelTimer() as kt:
             for _ in range(5):
                 stages.step()
