@@ -993,6 +993,8 @@ def main():
                        world, "one-shot direct exchange (peer-mapped buffers)" if getattr(sharded, "one_shot", None) is not None else "RCCL all-reduce"),
                    "launch": launch_note},
         "ms_per_step_min": spread["ms_per_step_min"],
+        # the same step with nothing kept on the decoder's side (the reference's decoder has no set-up; cold_start has the plans' build times)
+        "ms_per_step_decoder_uncached": None if not cold else cold.get("forward_ms_decoder_uncached"),
         "spread": spread,
         "launch_modes_ms_per_step": launch_ms if sharded is None else None,
         "two_streams": two_streams,
