@@ -398,44 +398,29 @@ gn_status launch_class(const gn_distmult_plan* plan, const DmClassArgs& a, int64
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
-                                  int64_t num_nodes, int64_t num_relations, int64_t num_features, void* stream,
-                                  gn_distmult_plan** out) {
-    GN_REQUIRE(out != nullptr, "plan output pointer is null");
-    *out = nullptr;
-    GN_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_relations >= 0, "negative size");
-    GN_REQUIRE(num_edges == 0 || (u && v && edge_type), "edge pointers are null");
-    if (num_nodes > (int64_t)kNodeMask + 1 || num_relations > 65535 || num_edges >= ((int64_t)1 << 31))
-        return gn::fail(GN_ERR_UNSUPPORTED, "edge list too large for the packed plan encoding (nodes <= %u, relations <= 65535)",
-                        kNodeMask + 1);
-    hipStream_t st = gn::as_stream(stream);
-    const int64_t E = num_edges;
-    std::vector<int64_t> hu(E), hv(E), hr(E);
-    if (E > 0) {
-        GN_HIP(hipMemcpyAsync(hu.data(), u, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        GN_HIP(hipMemcpyAsync(hv.data(), v, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        GN_HIP(hipMemcpyAsync(hr.data(), edge_type, E * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        GN_HIP(hipStreamSynchronize(st));
+// The triples as the builders read them: 16 bits a value (nodes <= 2^13, relations < 2^16 - checked by the caller), narrowed
+// and range-checked on the device so that a quarter of the bytes cross to the host and the host never walks the int64 lists.
+// bad = the first edge outside the ranges (the smallest index), ~0 when every edge is inside.
+__global__ __launch_bounds__(256) void k_narrow_triples(const int64_t* __restrict__ u, const int64_t* __restrict__ v,
+                                                        const int64_t* __restrict__ r, int64_t E, int64_t n, int64_t R,
+                                                        uint16_t* __restrict__ nu, uint16_t* __restrict__ nv,
+                                                        uint16_t* __restrict__ nr, unsigned long long* __restrict__ bad) {
+    unsigned long long first = ~0ull;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = u[e], b = v[e], c = r[e];
+        if (((uint64_t)a >= (uint64_t)n || (uint64_t)b >= (uint64_t)n || (uint64_t)c >= (uint64_t)R) && (unsigned long long)e < first)
+            first = (unsigned long long)e;
+        nu[e] = (uint16_t)a; nv[e] = (uint16_t)b; nr[e] = (uint16_t)c;
     }
-    {
-        // validation on the builder threads: the first offending edge of every slice, the smallest of them reported
-        std::vector<int64_t> bad(64, -1);
-        gn::parallel_for(64, 1, [&](int64_t s0, int64_t s1) {
-            for (int64_t sl = s0; sl < s1; ++sl)
-                for (int64_t e = E * sl / 64; e < E * (sl + 1) / 64; ++e)
-                    if ((uint64_t)hu[e] >= (uint64_t)num_nodes || (uint64_t)hv[e] >= (uint64_t)num_nodes || (uint64_t)hr[e] >= (uint64_t)num_relations) {
-                        bad[(size_t)sl] = e;
-                        break;
-                    }
-        });
-        for (int64_t e : bad)
-            if (e >= 0)
-                return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
-                                (long long)e, (long long)hu[e], (long long)hv[e], (long long)hr[e], (long long)num_nodes,
-                                (long long)num_nodes, (long long)num_relations);
-    }
+    if (first != ~0ull) atomicMin(bad, first);
+}
+
+template <typename I>
+gn_status build_distmult_plan(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int64_t E,
+                              int64_t num_nodes, int64_t num_relations, int64_t num_features, hipStream_t st,
+                              gn_distmult_plan** out) {
     std::vector<int64_t> mirror_of;
     std::vector<char> covered;
     gn_layout::pair_mirrors(hu, hv, hr, kNodeBits, mirror_of, covered);
@@ -520,6 +505,57 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
     }
     *out = p;
     return GN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int64_t* edge_type, int64_t num_edges,
+                                  int64_t num_nodes, int64_t num_relations, int64_t num_features, void* stream,
+                                  gn_distmult_plan** out) {
+    GN_REQUIRE(out != nullptr, "plan output pointer is null");
+    *out = nullptr;
+    GN_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_relations >= 0, "negative size");
+    GN_REQUIRE(num_edges == 0 || (u && v && edge_type), "edge pointers are null");
+    if (num_nodes > (int64_t)kNodeMask + 1 || num_relations > 65535 || num_edges >= ((int64_t)1 << 31))
+        return gn::fail(GN_ERR_UNSUPPORTED, "edge list too large for the packed plan encoding (nodes <= %u, relations <= 65535)",
+                        kNodeMask + 1);
+    hipStream_t st = gn::as_stream(stream);
+    const int64_t E = num_edges;
+    std::vector<uint16_t> hu(E), hv(E), hr(E);
+    if (E > 0) {
+        gn::DevBuf<uint16_t> narrow;
+        gn::DevBuf<unsigned long long> bad;
+        auto give_up = [&](hipError_t e) {
+            narrow.release(); bad.release();
+            return gn::fail(GN_ERR_HIP, "DistMult plan: reading the edge list failed: %s", hipGetErrorString(e));
+        };
+        hipError_t he;
+        if ((he = narrow.alloc((size_t)3 * E)) != hipSuccess) return give_up(he);
+        if ((he = bad.alloc(1)) != hipSuccess) return give_up(he);
+        unsigned long long first = ~0ull;
+        if ((he = hipMemsetAsync(bad.p, 0xff, sizeof(unsigned long long), st)) != hipSuccess) return give_up(he);
+        k_narrow_triples<<<gn::stream_grid(E, 256), 256, 0, st>>>(u, v, edge_type, E, num_nodes, num_relations, narrow.p, narrow.p + E,
+                                                                  narrow.p + 2 * E, bad.p);
+        if ((he = hipGetLastError()) != hipSuccess) return give_up(he);
+        if ((he = hipMemcpyAsync(&first, bad.p, sizeof(first), hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he);
+        if ((he = hipMemcpyAsync(hu.data(), narrow.p, E * sizeof(uint16_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he);
+        if ((he = hipMemcpyAsync(hv.data(), narrow.p + E, E * sizeof(uint16_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he);
+        if ((he = hipMemcpyAsync(hr.data(), narrow.p + 2 * E, E * sizeof(uint16_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he);
+        if ((he = hipStreamSynchronize(st)) != hipSuccess) return give_up(he);
+        narrow.release(); bad.release();
+        if (first != ~0ull) {
+            int64_t t[3] = {0, 0, 0};
+            GN_HIP(hipMemcpy(&t[0], u + first, sizeof(int64_t), hipMemcpyDeviceToHost));
+            GN_HIP(hipMemcpy(&t[1], v + first, sizeof(int64_t), hipMemcpyDeviceToHost));
+            GN_HIP(hipMemcpy(&t[2], edge_type + first, sizeof(int64_t), hipMemcpyDeviceToHost));
+            return gn::fail(GN_ERR_INDEX_RANGE, "edge %lld = (%lld, %lld, type %lld) is outside [0,%lld) x [0,%lld) x [0,%lld)",
+                            (long long)first, (long long)t[0], (long long)t[1], (long long)t[2], (long long)num_nodes,
+                            (long long)num_nodes, (long long)num_relations);
+        }
+    }
+    return build_distmult_plan(hu, hv, hr, E, num_nodes, num_relations, num_features, st, out);
 }
 
 void gn_distmult_plan_destroy(gn_distmult_plan* p) {

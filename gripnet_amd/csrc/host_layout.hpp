@@ -52,14 +52,17 @@ constexpr int64_t kClsWindowBytes = 1 << 20;   // scores of one sub-range: what 
 // edge in both directions, utils.py:132-138): they are paired up, the first of a pair is scored and writes both positions.
 // mirror_of[e] = the later copy that takes e's score (-1: none); covered[e] = e is such a later copy.
 // (the serial form: any order of relations)
-inline void pair_mirrors_serial(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
+template <typename I>
+inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
                                 std::vector<int64_t>& mirror_of, std::vector<char>& covered);
 
 // Round 6: a type-sorted list (the reference's layout, utils.py:168-198) pairs up inside every relation on its own - the
 // relations are dealt to the builder threads in contiguous runs of about equal edge counts, each thread with one small
 // open-addressing table that it wipes by the slots it touched.  Same pairs as the serial pass (within a relation the
 // edges are visited in list order).  2 M edges: 92 -> 14 ms on eight threads.
-inline void pair_mirrors(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
+// (I: int64_t - the reference's index type - or a narrower unsigned type the caller narrowed the validated ids to on the device)
+template <typename I>
+inline void pair_mirrors(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
                          std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
     const int64_t E = (int64_t)hu.size();
     bool sorted = true;
@@ -115,7 +118,8 @@ inline void pair_mirrors(const std::vector<int64_t>& hu, const std::vector<int64
     });
 }
 
-inline void pair_mirrors_serial(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr, int node_bits,
+template <typename I>
+inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
                                 std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
     const int64_t E = (int64_t)hu.size();
     mirror_of.assign((size_t)E, -1);
@@ -259,7 +263,8 @@ struct ClassLayout {
     std::vector<int32_t> wg;
 };
 
-inline ClassLayout build_class_layout(const std::vector<int64_t>& hu, const std::vector<int64_t>& hv, const std::vector<int64_t>& hr,
+template <typename I>
+inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr,
                                       const std::vector<int64_t>& scored, const std::vector<int64_t>& mirror_of, int64_t n,
                                       int64_t features, int cus, int64_t window_bytes = kClsWindowBytes) {
     static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
