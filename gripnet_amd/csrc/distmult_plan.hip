@@ -421,13 +421,10 @@ template <typename I>
 gn_status build_distmult_plan(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int64_t E,
                               int64_t num_nodes, int64_t num_relations, int64_t num_features, hipStream_t st,
                               gn_distmult_plan** out) {
-    std::vector<int64_t> mirror_of;
-    std::vector<char> covered;
+    gn::RawVec<int64_t> mirror_of;
+    gn::RawVec<char> covered;
     gn_layout::pair_mirrors(hu, hv, hr, kNodeBits, mirror_of, covered);
-    std::vector<int64_t> scored;
-    scored.reserve((size_t)E);
-    for (int64_t e = 0; e < E; ++e)
-        if (!covered[e]) scored.push_back(e);
+    const gn::RawVec<int64_t> scored = gn_layout::scored_edges(covered);
     gn_distmult_plan* p = new gn_distmult_plan();
     p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = 0;
     auto bail = [&](hipError_t e) {

@@ -5,9 +5,16 @@
 #pragma once
 
 #include <algorithm>
+#ifdef GN_LAYOUT_TIMES
+#include <chrono>
+#include <cstdio>
+#endif
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
+#include <type_traits>
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -35,9 +42,40 @@ inline void parallel_for(int64_t n, int64_t grain, F fn) {
     for (std::thread& t : pool) t.join();
 }
 
+// A vector whose resize() leaves new elements uninitialised (the builders' large arrays are written whole by the parallel
+// passes that follow: a value-initialising resize was a serial walk - and the first touch - of every page).
+template <typename T>
+struct DefaultInit : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInit<U>; };
+    template <typename U> void construct(U* ptr) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(ptr)) U; }
+    template <typename U, typename... A> void construct(U* ptr, A&&... a) { ::new (static_cast<void*>(ptr)) U(std::forward<A>(a)...); }
+};
+template <typename T>
+using RawVec = std::vector<T, DefaultInit<T>>;
+
+// v = n copies of `value`, written (and first touched) by the builder threads
+template <typename V, typename T>
+inline void parallel_assign(V& v, size_t n, T value) {
+    v.resize(n);
+    parallel_for((int64_t)n, 1 << 16, [&](int64_t i0, int64_t i1) { std::fill(v.begin() + i0, v.begin() + i1, value); });
+}
+
 }  // namespace gn
 
 namespace gn_layout {
+
+// Stage times of the builders on stderr when compiled with -DGN_LAYOUT_TIMES (tools/probes/plan_host_time.cpp); nothing otherwise.
+#ifdef GN_LAYOUT_TIMES
+inline void lap(const char* what) {
+    static thread_local double last = 0.0;
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (what) std::fprintf(stderr, "    %-34s %7.2f ms\n", what, 1e3 * (t - last));
+    last = t;
+}
+#define GN_LAP(what) gn_layout::lap(what)
+#else
+#define GN_LAP(what) ((void)0)
+#endif
 
 constexpr uint32_t kNoMirror = 0xffffffffu;
 constexpr int kRelDwItemEdges = 512;  // rgcn_basis.hip: edges of one work item of the general relational weight gradient
@@ -54,7 +92,7 @@ constexpr int64_t kClsWindowBytes = 1 << 20;   // scores of one sub-range: what 
 // (the serial form: any order of relations)
 template <typename I>
 inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
-                                std::vector<int64_t>& mirror_of, std::vector<char>& covered);
+                                gn::RawVec<int64_t>& mirror_of, gn::RawVec<char>& covered);
 
 // Round 6: a type-sorted list (the reference's layout, utils.py:168-198) pairs up inside every relation on its own - the
 // relations are dealt to the builder threads in contiguous runs of about equal edge counts, each thread with one small
@@ -63,16 +101,28 @@ inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& 
 // (I: int64_t - the reference's index type - or a narrower unsigned type the caller narrowed the validated ids to on the device)
 template <typename I>
 inline void pair_mirrors(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
-                         std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
+                         gn::RawVec<int64_t>& mirror_of, gn::RawVec<char>& covered) {
     const int64_t E = (int64_t)hu.size();
+    GN_LAP(nullptr);
+    // sorted by relation?  and the first edge of every run of equal relation ids: 64 slices of the list on the builder threads
+    constexpr int kSlices = 64;
+    std::vector<std::vector<int64_t>> slice_starts(kSlices);
+    std::vector<char> slice_unsorted(kSlices, 0);
+    gn::parallel_for(kSlices, 1, [&](int64_t s0, int64_t s1) {
+        for (int64_t sl = s0; sl < s1; ++sl)
+            for (int64_t e = E * sl / kSlices; e < E * (sl + 1) / kSlices; ++e)
+                if (e == 0 || hr[e] != hr[e - 1]) {
+                    slice_starts[(size_t)sl].push_back(e);
+                    if (e > 0 && hr[e - 1] > hr[e]) slice_unsorted[(size_t)sl] = 1;
+                }
+    });
     bool sorted = true;
-    for (int64_t e = 1; e < E && sorted; ++e) sorted = hr[e - 1] <= hr[e];
+    for (char c : slice_unsorted) sorted = sorted && !c;
     if (!sorted || E < (1 << 16)) { pair_mirrors_serial(hu, hv, hr, node_bits, mirror_of, covered); return; }
-    mirror_of.assign((size_t)E, -1);
-    covered.assign((size_t)E, 0);
+    mirror_of.resize((size_t)E);                                 // (every task below wipes its own range first)
+    covered.resize((size_t)E);
     std::vector<int64_t> rel_start;                              // first edge of every run of equal relation ids, then E
-    for (int64_t e = 0; e < E; ++e)
-        if (e == 0 || hr[e] != hr[e - 1]) rel_start.push_back(e);
+    for (const auto& v : slice_starts) rel_start.insert(rel_start.end(), v.begin(), v.end());
     rel_start.push_back(E);
     const int64_t runs = (int64_t)rel_start.size() - 1;
     // tasks: contiguous runs of relations of ~E / 64 edges each (a relation is never cut)
@@ -86,11 +136,14 @@ inline void pair_mirrors(const std::vector<I>& hu, const std::vector<I>& hv, con
         }
         task_first.push_back(runs);
     }
+    GN_LAP("mirrors: runs + tasks");
     gn::parallel_for((int64_t)task_first.size() - 1, 1, [&](int64_t t0, int64_t t1) {
         std::vector<uint64_t> keys;
         std::vector<int64_t> vals;
         std::vector<uint32_t> touched;
-        for (int64_t t = t0; t < t1; ++t)
+        for (int64_t t = t0; t < t1; ++t) {
+            std::fill(mirror_of.begin() + rel_start[task_first[t]], mirror_of.begin() + rel_start[task_first[t + 1]], (int64_t)-1);
+            std::fill(covered.begin() + rel_start[task_first[t]], covered.begin() + rel_start[task_first[t + 1]], (char)0);
             for (int64_t r = task_first[t]; r < task_first[t + 1]; ++r) {
                 const int64_t lo_e = rel_start[r], hi_e = rel_start[r + 1];
                 size_t cap = 16;
@@ -115,12 +168,14 @@ inline void pair_mirrors(const std::vector<I>& hu, const std::vector<I>& hv, con
                 }
                 for (uint32_t h : touched) { keys[h] = ~(uint64_t)0; vals[h] = -1; }
             }
+        }
     });
+    GN_LAP("mirrors: tables (parallel)");
 }
 
 template <typename I>
 inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
-                                std::vector<int64_t>& mirror_of, std::vector<char>& covered) {
+                                gn::RawVec<int64_t>& mirror_of, gn::RawVec<char>& covered) {
     const int64_t E = (int64_t)hu.size();
     mirror_of.assign((size_t)E, -1);
     covered.assign((size_t)E, 0);
@@ -144,6 +199,30 @@ inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& 
             vals[h] = e;
         }
     }
+}
+
+// The edges the decoder scores (the others are written as their pair's mirror), in list order.
+inline gn::RawVec<int64_t> scored_edges(const gn::RawVec<char>& covered) {
+    constexpr int kSlices = 64;
+    const int64_t E = (int64_t)covered.size();
+    std::vector<int64_t> first(kSlices + 1, 0);
+    gn::parallel_for(kSlices, 1, [&](int64_t s0, int64_t s1) {
+        for (int64_t sl = s0; sl < s1; ++sl) {
+            int64_t c = 0;
+            for (int64_t e = E * sl / kSlices; e < E * (sl + 1) / kSlices; ++e) c += !covered[(size_t)e];
+            first[(size_t)sl + 1] = c;
+        }
+    });
+    for (int sl = 0; sl < kSlices; ++sl) first[(size_t)sl + 1] += first[(size_t)sl];
+    gn::RawVec<int64_t> scored((size_t)first[kSlices]);
+    gn::parallel_for(kSlices, 1, [&](int64_t s0, int64_t s1) {
+        for (int64_t sl = s0; sl < s1; ++sl) {
+            int64_t at = first[(size_t)sl];
+            for (int64_t e = E * sl / kSlices; e < E * (sl + 1) / kSlices; ++e)
+                if (!covered[(size_t)e]) scored[(size_t)at++] = e;
+        }
+    });
+    return scored;
 }
 
 // A bucket of the dealers below: at most 64 entries, no allocation (with std::vector buckets a deal of 64 pairs cost ~50 us -
@@ -259,13 +338,14 @@ struct ClassLayout {
     int groups = 0;
     int walks = 1;                      // batch ranges per workgroup (descriptor: 4 + 4 walks ints)
     int64_t batches = 0;
-    std::vector<uint32_t> packed, own, mirror, rel32;
+    gn::RawVec<uint32_t> packed, own, mirror;
+    std::vector<uint32_t> rel32;
     std::vector<int32_t> wg;
 };
 
 template <typename I>
 inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr,
-                                      const std::vector<int64_t>& scored, const std::vector<int64_t>& mirror_of, int64_t n,
+                                      const gn::RawVec<int64_t>& scored, const gn::RawVec<int64_t>& mirror_of, int64_t n,
                                       int64_t features, int cus, int64_t window_bytes = kClsWindowBytes) {
     static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
     ClassLayout L;
@@ -294,20 +374,32 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
     // written for them, the lines leaving L2 a third at a time), the XCD's range is cut into `walks` sub-ranges that its
     // workgroups walk one after the other: the live window is one sub-range.
     const int64_t S = (int64_t)scored.size();
+    GN_LAP(nullptr);
     // The scored pairs' endpoints, relation and block ids as compact arrays in list order (round 6): every pass below walks
     // THESE (8 bytes per pair) instead of chasing scored[] into four int64 arrays of the whole list (64 MB at pose0-syn: the
     // builder was bound by cache misses, 120 ms on eight threads).
-    std::vector<uint16_t> su((size_t)S), sv((size_t)S), sr((size_t)S);
-    std::vector<uint8_t> sbu((size_t)S), sbv((size_t)S);
-    std::vector<uint32_t> sm((size_t)S);                         // the pair's mirror position (kNoMirror: none)
-    gn::parallel_for(S, 1 << 14, [&](int64_t i0, int64_t i1) {
-        for (int64_t i = i0; i < i1; ++i) {
-            const int64_t e = scored[(size_t)i];
-            sm[(size_t)i] = mirror_of[(size_t)e] >= 0 ? (uint32_t)mirror_of[(size_t)e] : kNoMirror;
-            su[(size_t)i] = (uint16_t)hu[(size_t)e]; sv[(size_t)i] = (uint16_t)hv[(size_t)e]; sr[(size_t)i] = (uint16_t)hr[(size_t)e];
-            sbu[(size_t)i] = (uint8_t)(hu[(size_t)e] / blk); sbv[(size_t)i] = (uint8_t)(hv[(size_t)e] / blk);
+    gn::RawVec<uint16_t> su((size_t)S), sv((size_t)S), sr((size_t)S);
+    gn::RawVec<uint8_t> sbu((size_t)S), sbv((size_t)S);
+    gn::RawVec<uint32_t> sm((size_t)S);                          // the pair's mirror position (kNoMirror: none)
+    // (the passes over the pairs below run on the builder threads in FIXED chunks (2^15 pairs, or a 64th of the list) - what a chunk computes does
+    // not depend on the thread count - or one position part per task)
+    const int64_t kChunkPairs = std::max<int64_t>(1 << 15, gn::ceil_div(S, 64));   // (at most 64 chunks: their histograms stay small)
+    const int64_t nchunks = gn::ceil_div(S, kChunkPairs);
+    std::vector<int64_t> chunk_max_rel((size_t)nchunks, 0);
+    gn::parallel_for(nchunks, 1, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+            int64_t mx = 0;
+            for (int64_t i = c * kChunkPairs; i < std::min(S, (c + 1) * kChunkPairs); ++i) {
+                const int64_t e = scored[(size_t)i];
+                sm[(size_t)i] = mirror_of[(size_t)e] >= 0 ? (uint32_t)mirror_of[(size_t)e] : kNoMirror;
+                su[(size_t)i] = (uint16_t)hu[(size_t)e]; sv[(size_t)i] = (uint16_t)hv[(size_t)e]; sr[(size_t)i] = (uint16_t)hr[(size_t)e];
+                sbu[(size_t)i] = (uint8_t)(hu[(size_t)e] / blk); sbv[(size_t)i] = (uint8_t)(hv[(size_t)e] / blk);
+                mx = std::max<int64_t>(mx, (int64_t)sr[(size_t)i] + 1);
+            }
+            chunk_max_rel[(size_t)c] = mx;
         }
     });
+    GN_LAP("class: compact arrays (parallel)");
     const int parts = (cus % 8 == 0 && cus >= 24 && S >= (int64_t)64 * 4 * cus) ? 8 : 1;
     const int64_t list_bytes = (int64_t)hu.size() * 4;
     const int walks = parts == 8 ? (int)std::max<int64_t>(1, std::min<int64_t>(kClsMaxWalks, gn::ceil_div(list_bytes / 8, window_bytes))) : 1;
@@ -326,22 +418,59 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
     // equal pair counts, 65 batches per workgroup against 61).  Every pair weighs 1 + 24 / (its relation's pairs).
     // (Walks of equal weight: cutting them in whole wave trips - 17 trips of sixteen batches per workgroup at pose2-syn instead
     // of 5 x 4 - changed nothing, 47.4 us either way: the loop follows a compute unit's batches, not its waves' trips.)
-    std::vector<int32_t> part_of((size_t)S);
+    gn::RawVec<int32_t> part_of((size_t)S);
     int64_t n_rel = 0;
+    for (int64_t c = 0; c < nchunks; ++c) n_rel = std::max(n_rel, chunk_max_rel[(size_t)c]);
+    std::vector<int64_t> part_first((size_t)nparts + 1, S);      // part p = pairs [part_first[p], part_first[p + 1]) (list order: monotone)
     {
-        for (int64_t i = 0; i < S; ++i) n_rel = std::max<int64_t>(n_rel, (int64_t)sr[(size_t)i] + 1);
+        // a relation's pair count: per-chunk histograms, added up
+        std::vector<int32_t> hist((size_t)nchunks * (size_t)n_rel, 0);
+        gn::parallel_for(nchunks, 1, [&](int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; ++c) {
+                int32_t* h = hist.data() + (size_t)c * (size_t)n_rel;
+                for (int64_t i = c * kChunkPairs; i < std::min(S, (c + 1) * kChunkPairs); ++i) h[sr[(size_t)i]]++;
+            }
+        });
         std::vector<int64_t> rel_cnt((size_t)n_rel, 0);
-        for (int64_t i = 0; i < S; ++i) rel_cnt[(size_t)sr[(size_t)i]]++;
+        for (int64_t c = 0; c < nchunks; ++c)
+            for (int64_t r = 0; r < n_rel; ++r) rel_cnt[(size_t)r] += hist[(size_t)c * (size_t)n_rel + (size_t)r];
         double total_w = 0.0;
-        for (int64_t r = 0; r < n_rel; ++r) total_w += rel_cnt[(size_t)r] > 0 ? (double)rel_cnt[(size_t)r] + 24.0 : 0.0;
-        double cum = 0.0;
-        for (int64_t i = 0; i < S; ++i) {
-            const double w = 1.0 + 24.0 / (double)rel_cnt[(size_t)sr[(size_t)i]];
-            part_of[(size_t)i] = (int32_t)std::min<int64_t>(nparts - 1, (int64_t)((cum + 0.5 * w) * nparts / total_w));
-            cum += w;
+        std::vector<double> rel_w((size_t)n_rel, 0.0);
+        for (int64_t r = 0; r < n_rel; ++r) {
+            total_w += rel_cnt[(size_t)r] > 0 ? (double)rel_cnt[(size_t)r] + 24.0 : 0.0;
+            rel_w[(size_t)r] = rel_cnt[(size_t)r] > 0 ? 1.0 + 24.0 / (double)rel_cnt[(size_t)r] : 0.0;
         }
-        for (int64_t i = 1; i < S; ++i) part_of[(size_t)i] = std::max(part_of[(size_t)i], part_of[(size_t)i - 1]);   // (list order: monotone)
+        // the weight before every chunk (from its histogram), then the chunks on their own
+        std::vector<double> chunk_cum((size_t)nchunks + 1, 0.0);
+        for (int64_t c = 0; c < nchunks; ++c) {
+            double w = 0.0;
+            for (int64_t r = 0; r < n_rel; ++r) w += (double)hist[(size_t)c * (size_t)n_rel + (size_t)r] * rel_w[(size_t)r];
+            chunk_cum[(size_t)c + 1] = chunk_cum[(size_t)c] + w;
+        }
+        std::vector<int32_t> chunk_last((size_t)nchunks, 0);
+        gn::parallel_for(nchunks, 1, [&](int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; ++c) {
+                double cum = chunk_cum[(size_t)c];
+                int32_t run_max = 0;
+                for (int64_t i = c * kChunkPairs; i < std::min(S, (c + 1) * kChunkPairs); ++i) {
+                    const double w = rel_w[sr[(size_t)i]];
+                    run_max = std::max(run_max, (int32_t)std::min<int64_t>(nparts - 1, (int64_t)((cum + 0.5 * w) * nparts / total_w)));
+                    part_of[(size_t)i] = run_max;
+                    cum += w;
+                }
+                chunk_last[(size_t)c] = run_max;
+            }
+        });
+        // monotone over the chunks' borders too: a chunk starts no lower than the one before it ended
+        for (int64_t c = 1; c < nchunks; ++c) {
+            const int32_t carry = chunk_last[(size_t)c - 1];
+            chunk_last[(size_t)c] = std::max(chunk_last[(size_t)c], carry);
+            for (int64_t i = c * kChunkPairs; i < std::min(S, (c + 1) * kChunkPairs) && part_of[(size_t)i] < carry; ++i) part_of[(size_t)i] = carry;
+        }
+        for (int p = 0; p <= nparts; ++p)
+            part_first[(size_t)p] = p == nparts ? S : std::lower_bound(part_of.begin(), part_of.end(), (int32_t)p) - part_of.begin();
     }
+    GN_LAP("class: position parts");
     // (A group of a few hundred pairs or more - the head of the list is one or two relations - is CUT between its two classes
     // where that evens them out: the first free_cut pairs of the group, in list order, go to the block's own class.)
     std::vector<int32_t> free_cut;                               // [part][relation][block]: pairs of the group that go to class `block`
@@ -349,13 +478,16 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
         free_cut.assign((size_t)nparts * n_rel * 3, 0);
         const int W = cus / 8;
         std::vector<int64_t> fixed((size_t)nparts * 3, 0), flex((size_t)nparts * n_rel * 3, 0);
-        for (int64_t i = 0; i < S; ++i) {
-            const int part = part_of[(size_t)i];
-            const int bu = sbu[(size_t)i], bv = sbv[(size_t)i];
-            if (bu != bv) fixed[(size_t)part * 3 + ((bu + 1) % 3 == bv ? bu : bv)]++;
-            else flex[((size_t)part * n_rel + sr[(size_t)i]) * 3 + bu]++;
-        }
-        for (int part = 0; part < nparts; ++part) {
+        gn::parallel_for(nparts, 1, [&](int64_t p0, int64_t p1) {
+            for (int64_t part = p0; part < p1; ++part)
+                for (int64_t i = part_first[(size_t)part]; i < part_first[(size_t)part + 1]; ++i) {
+                    const int bu = sbu[(size_t)i], bv = sbv[(size_t)i];
+                    if (bu != bv) fixed[(size_t)part * 3 + ((bu + 1) % 3 == bv ? bu : bv)]++;
+                    else flex[((size_t)part * n_rel + sr[(size_t)i]) * 3 + bu]++;
+                }
+        });
+        gn::parallel_for(nparts, 1, [&](int64_t p0, int64_t p1) {
+        for (int part = (int)p0; part < (int)p1; ++part) {
             // the units of the classes: as even as W allows, the smaller shares to the classes with the least fixed load - of the
             // whole RANGE (its workgroups keep their class through all its walks)
             const int x0 = part / walks * walks;
@@ -385,49 +517,59 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
                 free_cut[(size_t)part * n_rel * 3 + gq.second] = (int32_t)x;
             }
         }
+        });
     }
-    // scored pairs by (part, class, relation), list order inside
-    std::vector<uint32_t> key((size_t)S);
-    std::vector<int64_t> idx((size_t)S);
+    GN_LAP("class: free cuts");
+    // scored pairs by (part, class, relation), list order inside: a stable counting sort, one position part per task (the
+    // buckets of a part are its own; round 6: std::stable_sort with a comparator over 10^6 indices was the builder's longest
+    // serial stretch, then the serial counting sort was)
+    gn::RawVec<uint32_t> key((size_t)S), idx((size_t)S);
     std::vector<int32_t> free_seen(free_cut.size(), 0);
-    for (int64_t i = 0; i < S; ++i) {
-        const int part = part_of[(size_t)i];
-        const int bu = sbu[(size_t)i], bv = sbv[(size_t)i], rel = sr[(size_t)i];
-        int c = 0;                                               // (cls_of, on the compact arrays)
-        if (nblocks != 1) c = bu != bv ? ((bu + 1) % 3 == bv ? bu : bv) : ((rel & 1) ? (bu + 2) % 3 : bu);
-        if (!free_cut.empty() && bu == bv) {
-            const size_t cell = ((size_t)part * n_rel + rel) * 3 + (size_t)bu;
-            c = free_seen[cell]++ < free_cut[cell] ? bu : (bu + 2) % 3;
-        }
-        key[i] = (uint32_t)(part * nclasses + c) << 16 | (uint32_t)rel;
-        idx[i] = i;
-    }
-    {
-        // stable counting sort by (group, relation): the keys take ngroups x n_rel values (round 6: std::stable_sort with a
-        // comparator over 10^6 indices was the builder's longest serial stretch)
-        std::vector<int64_t> first((size_t)ngroups * (size_t)n_rel + 1, 0);
-        auto bucket = [&](int64_t i) { return (size_t)(key[(size_t)i] >> 16) * (size_t)n_rel + (size_t)(key[(size_t)i] & 0xffffu); };
-        for (int64_t i = 0; i < S; ++i) first[bucket(i) + 1]++;
-        for (size_t b = 1; b < first.size(); ++b) first[b] += first[b - 1];
-        for (int64_t i = 0; i < S; ++i) idx[(size_t)first[bucket(i)]++] = i;
-    }
-    // runs -> steps of 16 slots
+    const size_t nbuckets = (size_t)ngroups * (size_t)n_rel;
+    std::vector<int64_t> first(nbuckets + 1, 0);
+    auto bucket = [&](int64_t i) { return (size_t)(key[(size_t)i] >> 16) * (size_t)n_rel + (size_t)(key[(size_t)i] & 0xffffu); };
+    gn::parallel_for(nparts, 1, [&](int64_t p0, int64_t p1) {
+        for (int64_t part = p0; part < p1; ++part)
+            for (int64_t i = part_first[(size_t)part]; i < part_first[(size_t)part + 1]; ++i) {
+                const int bu = sbu[(size_t)i], bv = sbv[(size_t)i], rel = sr[(size_t)i];
+                int c = 0;                                       // (cls_of, on the compact arrays)
+                if (nblocks != 1) c = bu != bv ? ((bu + 1) % 3 == bv ? bu : bv) : ((rel & 1) ? (bu + 2) % 3 : bu);
+                if (!free_cut.empty() && bu == bv) {
+                    const size_t cell = ((size_t)part * n_rel + rel) * 3 + (size_t)bu;
+                    c = free_seen[cell]++ < free_cut[cell] ? bu : (bu + 2) % 3;
+                }
+                key[(size_t)i] = (uint32_t)(part * nclasses + c) << 16 | (uint32_t)rel;
+                first[bucket(i) + 1]++;
+            }
+    });
+    GN_LAP("class: keys");
+    for (size_t b = 1; b < first.size(); ++b) first[b] += first[b - 1];
+    gn::parallel_for(nparts, 1, [&](int64_t p0, int64_t p1) {
+        for (int64_t part = p0; part < p1; ++part)
+            for (int64_t i = part_first[(size_t)part]; i < part_first[(size_t)part + 1]; ++i) idx[(size_t)first[bucket(i)]++] = (uint32_t)i;
+    });
+    GN_LAP("class: counting sort");
+    // runs (the non-empty buckets: first[b] is now bucket b's end) -> steps of 16 slots
     struct Run { int64_t lo, hi; int grp, rel; int64_t step0; };
     std::vector<Run> runs;
     std::vector<int64_t> grp_steps(ngroups, 0);
-    for (int64_t i = 0; i < S;) {
-        int64_t j = i;
-        while (j < S && key[idx[j]] == key[idx[i]]) ++j;
-        const int g = (int)(key[idx[i]] >> 16);
-        runs.push_back({i, j, g, (int)(key[idx[i]] & 0xffffu), grp_steps[g]});
-        grp_steps[g] += gn::ceil_div(j - i, 16);
-        i = j;
+    for (size_t b = 0; b < nbuckets; ++b) {
+        const int64_t lo = b ? first[b - 1] : 0, hi = first[b];
+        if (hi <= lo) continue;
+        const int g = (int)(b / (size_t)n_rel);
+        runs.push_back({lo, hi, g, (int)(b % (size_t)n_rel), grp_steps[g]});
+        grp_steps[g] += gn::ceil_div(hi - lo, 16);
     }
     std::vector<int64_t> grp_batch0(ngroups + 1, 0);
     for (int g = 0; g < ngroups; ++g) grp_batch0[g + 1] = grp_batch0[g] + gn::ceil_div(grp_steps[g], 4);
     const int64_t NB = grp_batch0[ngroups], NBA = NB + kClsSlack;
-    std::vector<uint32_t> packed((size_t)NBA * 64, 0u), own((size_t)NBA * 64, kNoMirror), mirror((size_t)NBA * 64, kNoMirror);
+    GN_LAP("class: runs");
+    gn::RawVec<uint32_t> packed, own, mirror;
+    gn::parallel_assign(packed, (size_t)NBA * 64, 0u);
+    gn::parallel_assign(own, (size_t)NBA * 64, kNoMirror);
+    gn::parallel_assign(mirror, (size_t)NBA * 64, kNoMirror);
     std::vector<uint16_t> rel16((size_t)NBA * 4, 0);
+    GN_LAP("class: output arrays");
     // tasks of about equal PAIR counts (contiguous runs): the runs of the list's head are two orders of magnitude longer than
     // those of its tail, and equal numbers of runs per builder thread left one thread with most of the pairs
     std::vector<int64_t> task_first(1, 0);
@@ -440,6 +582,7 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
         }
         task_first.push_back((int64_t)runs.size());
     }
+    GN_LAP("class: tasks");
     gn::parallel_for((int64_t)task_first.size() - 1, 1, [&](int64_t t0, int64_t t1) {
         std::vector<int> lu, lv, order;
         for (int64_t ri = task_first[(size_t)t0]; ri < task_first[(size_t)t1]; ++ri) {
@@ -484,6 +627,7 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
             }
         }
     });
+    GN_LAP("class: deal (parallel)");
     // steps that pad a group to whole batches: the relation of the step before them (no reload), pair (0, 0), no positions
     for (int g = 0; g < ngroups; ++g)
         for (int64_t gstep = grp_batch0[g] * 4 + grp_steps[g]; gstep < grp_batch0[g + 1] * 4; ++gstep)
@@ -548,6 +692,7 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
         }
     std::vector<uint32_t> rel32((size_t)NBA * 2);
     for (size_t i = 0; i < rel32.size(); ++i) rel32[i] = (uint32_t)rel16[2 * i] | (uint32_t)rel16[2 * i + 1] << 16;
+    GN_LAP("class: workgroups + rel32");
     L.packed.swap(packed); L.own.swap(own); L.mirror.swap(mirror); L.rel32.swap(rel32); L.wg.swap(wg);
     L.groups = G; L.batches = NB; L.walks = walks;
     L.ok = true;

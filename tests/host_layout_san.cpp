@@ -36,12 +36,10 @@ gn_layout::ClassLayout decoder_case(int64_t n, int R, int64_t e_dir, int64_t fea
         for (int64_t k = 0; k < cnt; ++k) { hu.push_back(v[k]); hv.push_back(u[k]); hr.push_back(r); }   // to_bidirection
     }
     const int64_t E = (int64_t)hu.size();
-    std::vector<int64_t> mirror_of;
-    std::vector<char> covered;
+    gn::RawVec<int64_t> mirror_of;
+    gn::RawVec<char> covered;
     gn_layout::pair_mirrors(hu, hv, hr, 13, mirror_of, covered);
-    std::vector<int64_t> scored;
-    for (int64_t e = 0; e < E; ++e)
-        if (!covered[e]) scored.push_back(e);
+    const gn::RawVec<int64_t> scored = gn_layout::scored_edges(covered);
     gn_layout::ClassLayout L = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, n, features, 256, window_bytes);
     if (!check) return L;
     if (!expect_ok) { CHECK(!L.ok); return L; }             // (a list the row-class kernel does not take: the column-phase kernel serves it)
@@ -226,8 +224,8 @@ gn_layout::RelGradLayout rel_grad_case(int64_t n, int64_t R, int64_t E, int grou
     return L;
 }
 
-template <typename T>
-bool same(const std::vector<T>& a, const std::vector<T>& b) { return a == b; }
+template <typename V>
+bool same(const V& a, const V& b) { return a == b; }
 
 }  // namespace
 

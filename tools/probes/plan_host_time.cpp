@@ -1,6 +1,9 @@
-// Host time of the decoder plan's builders at pose0-syn scale (no GPU): g++ -O3 -std=c++17 -pthread -I gripnet_amd/csrc tools/probes/plan_host_time.cpp
+// Host time of the decoder plan's builders at pose0-syn scale (no GPU), stage by stage on stderr:
+//   g++ -O3 -std=c++17 -pthread -DGN_LAYOUT_TIMES -I gripnet_amd/csrc tools/probes/plan_host_time.cpp
+// (the ids as the plan sees them: narrowed to 16 bits on the device)
 #include <chrono>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <random>
 #include "host_layout.hpp"
@@ -8,7 +11,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 int main(int argc, char** argv) {
     const int64_t n = 645; const int R = 964; const int64_t e_dir = argc > 1 ? atoll(argv[1]) : 1000000;
     std::mt19937_64 rng(7);
-    std::vector<int64_t> hu, hv, hr;
+    std::vector<uint16_t> hu, hv, hr;
     double wsum = 0; for (int r = 1; r <= R; ++r) wsum += std::pow((double)r, -0.8);
     for (int r = 0; r < R; ++r) {
         const int64_t cnt = std::max<int64_t>(1, (int64_t)(e_dir * std::pow((double)(r + 1), -0.8) / wsum));
@@ -20,11 +23,10 @@ int main(int argc, char** argv) {
     const int64_t E = hu.size();
     for (int rep = 0; rep < 2; ++rep) {
         double t0 = now();
-        std::vector<int64_t> mirror_of; std::vector<char> covered;
+        gn::RawVec<int64_t> mirror_of; gn::RawVec<char> covered;
         gn_layout::pair_mirrors(hu, hv, hr, 13, mirror_of, covered);
         double t1 = now();
-        std::vector<int64_t> scored;
-        for (int64_t e = 0; e < E; ++e) if (!covered[e]) scored.push_back(e);
+        const gn::RawVec<int64_t> scored = gn_layout::scored_edges(covered);
         double t2 = now();
         const int64_t NBs = (scored.size() + 63) / 64;
         std::vector<int> slots((size_t)NBs * 64);
