@@ -90,6 +90,47 @@ struct DevBuf {
     }
 };
 
+// Scoped device scratch of a plan builder, carved out of a few large blocks: a builder asks for ten to twenty arrays, and a
+// hipMalloc / hipFree pair per array (the free waits for the device and unmaps) was a third of a relational plan's build
+// time.  Every array is 256-byte aligned; a request that does not fit the current block opens a new one.
+struct Scratch {
+    static constexpr size_t kBlockBytes = (size_t)2 << 20;
+    std::vector<void*> blocks;
+    char* at = nullptr;
+    size_t left = 0;
+    Scratch() = default;
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() {
+        GN_LAP(nullptr);
+        for (void* b : blocks) (void)hipFree(b);
+        GN_LAP("  scratch: frees");
+    }
+    // `reserve_bytes`: what the builder knows it will ask for in total (one block then serves all of it)
+    hipError_t reserve(size_t reserve_bytes) { return reserve_bytes > left ? open(reserve_bytes) : hipSuccess; }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        *out = nullptr;
+        if (bytes > left) {
+            const hipError_t e = open(std::max(bytes, kBlockBytes << std::min<size_t>(blocks.size(), 5)));
+            if (e != hipSuccess) return e;
+        }
+        *out = reinterpret_cast<T*>(at);
+        at += bytes; left -= bytes;
+        return hipSuccess;
+    }
+  private:
+    hipError_t open(size_t bytes) {
+        void* b = nullptr;
+        const hipError_t e = hipMalloc(&b, bytes);
+        if (e != hipSuccess) return e;
+        blocks.push_back(b);
+        at = static_cast<char*>(b); left = bytes;
+        return hipSuccess;
+    }
+};
+
 // Grid size for a memory-bound grid-stride kernel: enough blocks to fill 256 CUs, capped.
 inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 8) {
     int64_t g = ceil_div(work_items, block);

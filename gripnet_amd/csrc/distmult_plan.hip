@@ -425,6 +425,7 @@ gn_status build_distmult_plan(const std::vector<I>& hu, const std::vector<I>& hv
     gn::RawVec<char> covered;
     gn_layout::pair_mirrors(hu, hv, hr, kNodeBits, mirror_of, covered);
     const gn::RawVec<int64_t> scored = gn_layout::scored_edges(covered);
+    GN_LAP("decoder: scored list");
     gn_distmult_plan* p = new gn_distmult_plan();
     p->num_edges = E; p->num_nodes = num_nodes; p->num_relations = num_relations; p->batches = 0;
     auto bail = [&](hipError_t e) {
@@ -438,6 +439,7 @@ gn_status build_distmult_plan(const std::vector<I>& hu, const std::vector<I>& hv
     if (num_features > 0 && !gn::fast_paths_disabled()) {
         gn_layout::ClassLayout cl = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, num_nodes, num_features, gn::compute_units());
         if (cl.ok) {
+            GN_LAP(nullptr);
             if ((he = p->cls_packed.alloc(cl.packed.size())) != hipSuccess) return bail(he);
             if ((he = p->cls_own.alloc(cl.own.size())) != hipSuccess) return bail(he);
             if ((he = p->cls_mirror.alloc(cl.mirror.size())) != hipSuccess) return bail(he);
@@ -449,6 +451,8 @@ gn_status build_distmult_plan(const std::vector<I>& hu, const std::vector<I>& hv
             if ((he = hipMemcpyAsync(p->cls_rel.p, cl.rel32.data(), cl.rel32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
             if ((he = hipMemcpyAsync(p->cls_wg.p, cl.wg.data(), cl.wg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he);
             if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he);
+            GN_LAP("decoder: allocations + upload (sync)");
+            GN_LAP(nullptr);
             p->cls_features = (int)num_features; p->cls_groups = cl.groups; p->cls_batches = cl.batches; p->cls_walks = cl.walks;
             p->cls_ok = 1;
             *out = p;
@@ -520,7 +524,12 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
                         kNodeMask + 1);
     hipStream_t st = gn::as_stream(stream);
     const int64_t E = num_edges;
+    GN_LAP(nullptr);
+#ifdef GN_LAYOUT_TIMES
+    struct ExitLap { ~ExitLap() { GN_LAP("decoder: host vectors freed"); } } exit_lap;
+#endif
     std::vector<uint16_t> hu(E), hv(E), hr(E);
+    GN_LAP("decoder: host vectors");
     if (E > 0) {
         gn::DevBuf<uint16_t> narrow;
         gn::DevBuf<unsigned long long> bad;
@@ -541,7 +550,9 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
         if ((he = hipMemcpyAsync(hv.data(), narrow.p + E, E * sizeof(uint16_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he);
         if ((he = hipMemcpyAsync(hr.data(), narrow.p + 2 * E, E * sizeof(uint16_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he);
         if ((he = hipStreamSynchronize(st)) != hipSuccess) return give_up(he);
+        GN_LAP("decoder: narrow + D2H (sync)");
         narrow.release(); bad.release();
+        GN_LAP("decoder: frees");
         if (first != ~0ull) {
             int64_t t[3] = {0, 0, 0};
             GN_HIP(hipMemcpy(&t[0], u + first, sizeof(int64_t), hipMemcpyDeviceToHost));

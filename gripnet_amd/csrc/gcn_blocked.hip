@@ -380,6 +380,7 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     const int groups = (int)(cols / cw);
     const int R = std::max(1, std::min<int>(256 / groups, (int)gn::ceil_div(N, 64)));     // ranges of destination rows
 
+    GN_LAP(nullptr);
     std::vector<int32_t> rp(N + 1), col(nnz);
     GN_HIP(hipMemcpyAsync(rp.data(), plan->rowptr.p, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipMemcpyAsync(col.data(), plan->col.p, nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -387,7 +388,9 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     GN_HIP(hipMemcpyAsync(dis_host.data(), plan->dis.p, N * sizeof(float), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
 
+    GN_LAP("blocked: CSR to the host");
     gn_layout::BlockedLayout bl = gn_layout::build_blocked_layout(N, R, rp, col, dis_host);
+    GN_LAP("blocked: host schedule");
     if (bl.failed) return gn::fail(GN_ERR_UNSUPPORTED, "internal: an edge was not scheduled");
     if (!bl.ok) return GN_OK;
     std::vector<int32_t>& tile_off = bl.tile_off; std::vector<int32_t>& tile_rows = bl.tile_rows; std::vector<int32_t>& cell = bl.cell;
@@ -410,6 +413,7 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     GN_HIP(hipMemcpyAsync(plan->blk_ids.p, ids.data(), ids.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->blk_cell.p, cell.data(), cell.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("blocked: upload");
     plan->blk_cols = (int)cols; plan->blk_cw = cw; plan->blk_rows = (int)rows_pad; plan->blk_cells = R;
     plan->blk_iters = iters_total;
     plan->blk_ok = 1;

@@ -297,33 +297,34 @@ inline void deal_run(const int* lu, const int* lv, int count, std::vector<int>& 
                                       {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
     const int steps = (count + 15) / 16;
     order.assign((size_t)steps * 16, -1);
-    SmallStack bucket[4][4];
-    for (int e = count - 1; e >= 0; --e) bucket[lu[e] & 3][lv[e] & 3].push_back(e);   // (popped from the back: list order)
+    // sixteen stacks by (lu % 4, lv % 4), their sizes side by side in one cache line: the search below reads nothing else
+    int stack[16][64], sz[16] = {0};
+    for (int e = count - 1; e >= 0; --e) { const int b = (lu[e] & 3) * 4 + (lv[e] & 3); stack[b][sz[b]++] = e; }   // (popped from the back: list order)
     int left = count;
     for (int cell = 0; cell < steps * 4 && left > 0; ++cell) {
         int chosen[4] = {-1, -1, -1, -1};
+        // a full cell: one pair from each (c, sigma(c)) for the permutation whose scarcest bucket is fullest (the first of equals)
+        int mins[24];
+        for (int p = 0; p < 24; ++p)
+            mins[p] = std::min(std::min(sz[kPerms[p][0]], sz[4 + kPerms[p][1]]), std::min(sz[8 + kPerms[p][2]], sz[12 + kPerms[p][3]]));
         int best = -1, best_min = 0;
-        for (int p = 0; p < 24; ++p) {
-            int mn = 1 << 30;
-            for (int c = 0; c < 4; ++c) mn = std::min(mn, (int)bucket[c][kPerms[p][c]].size());
-            if (mn > best_min) { best_min = mn; best = p; }
-        }
+        for (int p = 0; p < 24; ++p)
+            if (mins[p] > best_min) { best_min = mins[p]; best = p; }
         if (best >= 0) {
-            for (int c = 0; c < 4; ++c) { auto& bk = bucket[c][kPerms[best][c]]; chosen[c] = bk.back(); bk.pop_back(); }
+            for (int c = 0; c < 4; ++c) { const int b = c * 4 + kPerms[best][c]; chosen[c] = stack[b][--sz[b]]; }
         } else {
+            // no conflict-free quadruple left: pairs one by one, preferring unused u and v classes
             unsigned used_u = 0, used_v = 0;
             for (int k = 0; k < 4; ++k) {
-                int bc = -1, bd = -1, bscore = -1;
-                for (int c = 0; c < 4; ++c)
-                    for (int dd = 0; dd < 4; ++dd) {
-                        if (bucket[c][dd].empty()) continue;
-                        const int score = 2 * (!((used_u >> c) & 1) + !((used_v >> dd) & 1)) * 64 + (int)bucket[c][dd].size();
-                        if (score > bscore) { bscore = score; bc = c; bd = dd; }
-                    }
-                if (bc < 0) break;
-                chosen[k] = bucket[bc][bd].back();
-                bucket[bc][bd].pop_back();
-                used_u |= 1u << bc; used_v |= 1u << bd;
+                int bb = -1, bscore = -1;
+                for (int b = 0; b < 16; ++b) {
+                    if (sz[b] == 0) continue;
+                    const int score = 2 * (!((used_u >> (b >> 2)) & 1) + !((used_v >> (b & 3)) & 1)) * 64 + sz[b];
+                    if (score > bscore) { bscore = score; bb = b; }
+                }
+                if (bb < 0) break;
+                chosen[k] = stack[bb][--sz[bb]];
+                used_u |= 1u << (bb >> 2); used_v |= 1u << (bb & 3);
             }
         }
         for (int k = 0; k < 4; ++k)
@@ -348,6 +349,9 @@ inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vecto
                                       const gn::RawVec<int64_t>& scored, const gn::RawVec<int64_t>& mirror_of, int64_t n,
                                       int64_t features, int cus, int64_t window_bytes = kClsWindowBytes) {
     static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+#ifdef GN_LAYOUT_TIMES
+    struct ExitLap { ~ExitLap() { GN_LAP("class: locals freed"); } } exit_lap;
+#endif
     ClassLayout L;
     if (features < 16 || features % 16 != 0 || features > 128 || scored.empty() || n < 1) return L;
     const int J = (int)(features / 16), str4 = (J & 1) ? 4 * J : 4 * J + 4;
@@ -762,30 +766,37 @@ constexpr int kPairSlackBlocks = 192;      // readable blocks behind the last wa
 inline void lay_out_section(const uint32_t* const (&list)[4], const int (&len)[4], int nb, uint32_t R, std::vector<uint32_t>& out) {
     const int P = 4 * nb;
     const uint32_t none = 0xffffffffu;
-    std::vector<uint32_t> pos[4];
+    // (on the stack, and without data-dependent branches: a plan lays out 10^5 sections of a dozen rows each, and the parity
+    // of a relation id is a coin flip - with a branch per row the mispredictions were most of the layout's time)
+    uint32_t pos[4][4 * kPairSectionCap], lead[4 * kPairSectionCap + 1], trail[4 * kPairSectionCap + 1];
     for (int k = 0; k < 4; ++k) {
-        pos[k].assign(P, none);
-        const bool even_first = (k & 1) == 0;
-        int left = 0, right = P - 1;
-        // first the rows of the leading parity, left aligned, in list order; then the others, right aligned
-        for (int i = 0; i < len[k]; ++i)
-            if (((list[k][i] & 1u) == 0u) == even_first) pos[k][left++] = list[k][i];
-        for (int i = len[k] - 1; i >= 0; --i)
-            if (((list[k][i] & 1u) == 0u) != even_first) pos[k][right--] = list[k][i];
+        const uint32_t lead_parity = (k & 1) ? 1u : 0u;
+        // first the rows of the leading parity, left aligned, in list order; then the others, right aligned, in list order
+        int nl = 0, nt = 0;
+        for (int i = 0; i < len[k]; ++i) {
+            const uint32_t v = list[k][i];
+            const int is_lead = (v & 1u) == lead_parity;
+            lead[nl] = v; trail[nt] = v;
+            nl += is_lead; nt += 1 - is_lead;
+        }
+        uint32_t* pk = pos[k];
+        for (int i = 0; i < nl; ++i) pk[i] = lead[i];
+        for (int i = nl; i < P - nt; ++i) pk[i] = none;
+        for (int i = 0; i < nt; ++i) pk[P - nt + i] = trail[i];
     }
     const uint32_t zero_even = (R & 1u) ? R + 1 : R, zero_odd = (R & 1u) ? R : R + 1;
     const size_t base = out.size();
     out.resize(base + (size_t)nb * 16);
+    uint32_t* o = out.data() + base;
     for (int k = 0; k < 4; ++k) {
-        const int partner = k ^ 1;
+        const uint32_t* mine = pos[k];
+        const uint32_t* theirs = pos[k ^ 1];
+        const uint32_t both_padded = (k & 1) ? zero_odd : zero_even;             // two padded partners: one of each
         for (int i = 0; i < P; ++i) {
-            uint32_t row = pos[k][i];
-            if (row == none) {
-                const uint32_t other = pos[partner][i];
-                row = (other != none && (other & 1u) == 0u) ? zero_odd : zero_even;
-                if (other == none && (k & 1)) row = zero_odd;                  // two padded partners: one of each
-            }
-            out[base + (size_t)(i >> 2) * 16 + k * 4 + (i & 3)] = row * (uint32_t)kPairRowBytes;
+            const uint32_t row = mine[i], other = theirs[i];
+            uint32_t pad = (other & 1u) == 0u ? zero_odd : zero_even;             // the zero row of the parity the partner does not use
+            pad = other == none ? both_padded : pad;
+            o[(size_t)(i >> 2) * 16 + k * 4 + (i & 3)] = (row == none ? pad : row) * (uint32_t)kPairRowBytes;
         }
     }
 }
@@ -810,14 +821,29 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
     // the rounding to blocks of four (pose0-syn: 1.83 -> 1.32 x the edges, tools/pair_sim.py).  kord[i][pos] = the global
     // K position (cell of `rp`) that sits at operand position pos = 32 chunk + 8 group + t of destination i; the sources
     // of a (destination, chunk) are a row of `perm2` (the kernel reads its x rows through it).
+    GN_LAP(nullptr);
     std::vector<int32_t> kord((size_t)N * kpad);
     std::vector<int32_t> perm2((size_t)N * kpad);
     gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
         std::vector<int32_t> idx(kpad);
+        std::vector<uint64_t> keyed(kpad);
         for (int64_t i = b; i < e; ++i) {
             const int32_t* r = rp.data() + (size_t)i * kpad;
-            std::iota(idx.begin(), idx.end(), 0);
-            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return r[x + 1] - r[x] > r[y + 1] - r[y]; });
+            // longest first, equal lengths in K order: a counting sort when the lengths are small (they are: a few edges per
+            // (destination, source) pair), else one sort of (complement of the length, position) words
+            int longest = 0;
+            for (int q = 0; q < kpad; ++q) longest = std::max(longest, r[q + 1] - r[q]);
+            if (longest < 1024) {
+                int32_t start[1025];
+                std::fill(start, start + longest + 2, 0);
+                for (int q = 0; q < kpad; ++q) start[longest - (r[q + 1] - r[q]) + 1]++;
+                for (int l = 0; l <= longest; ++l) start[l + 1] += start[l];
+                for (int q = 0; q < kpad; ++q) idx[start[longest - (r[q + 1] - r[q])]++] = q;
+            } else {
+                for (int q = 0; q < kpad; ++q) keyed[q] = (uint64_t)(0x7fffffff - (r[q + 1] - r[q])) << 32 | (uint32_t)q;
+                std::sort(keyed.begin(), keyed.end());
+                for (int q = 0; q < kpad; ++q) idx[q] = (int32_t)(uint32_t)keyed[q];
+            }
             for (int q = 0; q < kpad; ++q) {
                 const int ch = q >> 5, t = (q & 31) >> 2, k = q & 3;
                 const size_t pos = (size_t)i * kpad + 32 * ch + 8 * k + t;
@@ -836,6 +862,7 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
         for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
         return std::max(1, (longest + 3) / 4);
     };
+    GN_LAP("pair: K order (parallel)");
     std::vector<int64_t> cost(N, 0);
     gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
         for (int64_t i = b; i < e; ++i) {
@@ -853,6 +880,7 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
             cost[i] = blocks;
         }
     });
+    GN_LAP("pair: costs (parallel)");
     // destinations to workgroups: longest first, each to the least loaded workgroup that still has room
     std::vector<std::vector<int32_t>> wg_rows(G);
     {
@@ -871,6 +899,7 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
     // per workgroup: every destination row gets a share of the sixteen waves in proportion to its cost (at least one), a
     // wave a contiguous run of its row's units (chunk order) of equal cost; per wave the descriptors (eight dwords a unit,
     // pages of eight units) and the stream
+    GN_LAP("pair: rows to workgroups");
     std::vector<std::vector<uint32_t>> wg_stream((size_t)G * kPairWaves), wg_desc((size_t)G * kPairWaves);
     std::vector<uint32_t> wave_units((size_t)G * kPairWaves, 0u);
     std::vector<int32_t> wg_dst((size_t)G * 4, -1);
@@ -957,6 +986,7 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
             }
         }
     });
+    GN_LAP("pair: streams (parallel)");
     std::vector<uint32_t> wave_desc((size_t)G * kPairWaves);
     std::vector<uint32_t> desc;
     for (size_t i = 0; i < wg_desc.size(); ++i) {
@@ -973,6 +1003,7 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
         for (int64_t i = b; i < e; ++i)
             if (!wg_stream[i].empty()) memcpy(stream.data() + (size_t)first[i] * 16, wg_stream[i].data(), wg_stream[i].size() * sizeof(uint32_t));
     });
+    GN_LAP("pair: concatenate");
     L.blocks = (int64_t)(total / 16);
     L.stream.swap(stream); L.wave_first.swap(first); L.desc.swap(desc); L.wave_units.swap(wave_units); L.wave_desc.swap(wave_desc);
     L.wg_dst.swap(wg_dst);
@@ -998,6 +1029,7 @@ struct BlockedLayout {
 inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<int32_t>& rp, const std::vector<int32_t>& col,
                                           const std::vector<float>& dis_host) {
     BlockedLayout L;
+    GN_LAP(nullptr);
     // destination rows by degree (descending, stable), dealt to the ranges in a snake: every range gets the same number
     // of edges (to within a row) and rows of every degree; inside a range the rows stay in degree order, so that the 16
     // rows of a tile have similar lengths
@@ -1013,56 +1045,76 @@ inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<in
     // goes into which (iteration, slot) is free (the order of a sum), so it is chosen for the LDS: ds_read_b64 (and
     // b32) serves lanes 0-31 and 32-63 as two access groups, conflict-free when the ids of a group differ mod 32.
     // (the ranges are scheduled independently of each other, on the plan builders' threads, and concatenated in order)
+    GN_LAP("blocked: rows by degree, ranges");
     struct RangeOut { std::vector<int32_t> tile_iters, tile_rows; std::vector<uint16_t> ids; bool failed = false; };
     std::vector<RangeOut> built(R);
     const uint16_t zero_id = (uint16_t)N;
     gn::parallel_for(R, 1, [&](int64_t r0, int64_t r1) {
-        std::vector<uint16_t> bucket[16][32];
+        // a row's ids by (id mod 32): thirty-two stacks in one flat array (filled in CSR order, popped from the back), their
+        // live sizes in cnt[row][class] - the scheduler's inner loop is "the fullest class of this row that this instruction's
+        // access group has not used yet", a scan of 32 counters (round 6: with a std::vector per stack the scan chased 64
+        // pointers and the gene plan spent 10 ms of sixteen threads here)
+        std::vector<uint16_t> flat;
+        int32_t cnt[16][32], first[16][32];
         for (int64_t r = r0; r < r1; ++r) {
             const std::vector<int32_t>& rows = range_rows[r];
             RangeOut& o = built[r];
             const int tiles_r = (int)gn::ceil_div((int64_t)rows.size(), 16);
+            o.tile_rows.reserve((size_t)tiles_r * 16);
+            o.tile_iters.reserve((size_t)tiles_r);
             for (int tl = 0; tl < tiles_r; ++tl) {
                 int32_t trow[16], rem[16];
                 int iters = 0;
+                size_t total = 0;
                 for (int qi = 0; qi < 16; ++qi) {
-                    for (int c = 0; c < 32; ++c) bucket[qi][c].clear();
                     const size_t k = (size_t)tl * 16 + qi;
                     trow[qi] = k < rows.size() ? rows[k] : -1;
-                    rem[qi] = 0;
-                    if (trow[qi] < 0) continue;
-                    for (int32_t p = rp[trow[qi]]; p < rp[trow[qi] + 1]; ++p) bucket[qi][col[p] & 31].push_back((uint16_t)col[p]);
-                    rem[qi] = rp[trow[qi] + 1] - rp[trow[qi]];
+                    rem[qi] = trow[qi] < 0 ? 0 : rp[trow[qi] + 1] - rp[trow[qi]];
+                    total += (size_t)rem[qi];
                     iters = std::max(iters, (rem[qi] + 15) / 16);
+                }
+                if (flat.size() < total) flat.resize(total);
+                size_t at = 0;
+                for (int qi = 0; qi < 16; ++qi) {
+                    for (int c = 0; c < 32; ++c) cnt[qi][c] = 0;
+                    if (trow[qi] < 0) { for (int c = 0; c < 32; ++c) first[qi][c] = 0; continue; }
+                    const int32_t p0 = rp[trow[qi]], p1 = rp[trow[qi] + 1];
+                    for (int32_t p = p0; p < p1; ++p) cnt[qi][col[p] & 31]++;
+                    for (int c = 0; c < 32; ++c) { first[qi][c] = (int32_t)at; at += (size_t)cnt[qi][c]; cnt[qi][c] = 0; }
+                    for (int32_t p = p0; p < p1; ++p) { const int c = col[p] & 31; flat[(size_t)first[qi][c] + cnt[qi][c]++] = (uint16_t)col[p]; }
                 }
                 for (int qi = 0; qi < 16; ++qi) o.tile_rows.push_back(trow[qi]);
                 const size_t base = o.ids.size();
                 o.ids.resize(base + (size_t)iters * 256, zero_id);
+                uint16_t* out_ids = o.ids.data() + base;
                 for (int itn = 0; itn < iters; ++itn)
                     for (int s = 0; s < 4; ++s)                               // one LDS instruction: slot s of every lane
                         for (int half = 0; half < 2; ++half) {                // its two access groups: rows 0-7, rows 8-15
-                            bool used[32] = {false};
+                            int32_t open_mask[32];                            // -1: class not used by this access group yet
+                            for (int c = 0; c < 32; ++c) open_mask[c] = -1;
                             int rows_by_need[8];
                             for (int k = 0; k < 8; ++k) rows_by_need[k] = half * 8 + k;
                             std::sort(rows_by_need, rows_by_need + 8, [&](int x, int y) { return rem[x] > rem[y]; });
                             const int left = (iters - itn) * 4 - s;           // instructions left, this one included
                             for (int k = 0; k < 8; ++k) {
                                 const int qi = rows_by_need[k];
+                                int32_t* cq = cnt[qi];
                                 for (int jl = 0; jl < 4; ++jl) {
                                     if (rem[qi] == 0) break;
                                     // must this lane take an edge now?  (4 lanes x (left - 1) instructions remain after this one)
                                     const bool must = rem[qi] > (left - 1) * 4 + (3 - jl);
-                                    int best = -1; size_t bestn = 0;
-                                    for (int c = 0; c < 32; ++c)
-                                        if (!used[c] && bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                    // the fullest open class, the lowest of equals: the largest of (count << 5 | 31 - class)
+                                    int32_t bestkey = 0;
+                                    for (int c = 0; c < 32; ++c) bestkey = std::max(bestkey, ((cq[c] << 5) | (31 - c)) & open_mask[c]);
+                                    int best = bestkey >> 5 ? 31 - (bestkey & 31) : -1;
                                     if (best < 0) {
                                         if (!must) continue;                  // sits this slot out: the zero row
-                                        for (int c = 0; c < 32; ++c)
-                                            if (bucket[qi][c].size() > bestn) { best = c; bestn = bucket[qi][c].size(); }
+                                        bestkey = 0;
+                                        for (int c = 0; c < 32; ++c) bestkey = std::max(bestkey, (cq[c] << 5) | (31 - c));
+                                        best = 31 - (bestkey & 31);
                                     }
-                                    o.ids[base + ((size_t)itn * 64 + qi * 4 + jl) * 4 + s] = bucket[qi][best].back();
-                                    bucket[qi][best].pop_back();
-                                    used[best] = true;
+                                    out_ids[((size_t)itn * 64 + qi * 4 + jl) * 4 + s] = flat[(size_t)first[qi][best] + --cq[best]];
+                                    open_mask[best] = 0;
                                     --rem[qi];
                                 }
                             }
@@ -1073,6 +1125,7 @@ inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<in
             }
         }
     });
+    GN_LAP("blocked: tiles (parallel)");
     std::vector<int32_t> tile_off(1, 0), tile_rows, cell;
     std::vector<uint16_t> ids;
     for (int r = 0; r < R; ++r) {
@@ -1110,6 +1163,7 @@ inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<in
     ids.resize(ids.size() + (size_t)kColLayoutSlack * 256, zero_id);
     if (ids.size() / 2 >= ((size_t)1 << 31)) return L;
 
+    GN_LAP("blocked: concatenate");
     L.iters_total = iters_total;
     L.tile_off.swap(tile_off); L.tile_rows.swap(tile_rows); L.cell.swap(cell); L.tile_dis.swap(tile_dis); L.ids.swap(ids);
     L.ok = true;

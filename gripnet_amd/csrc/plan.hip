@@ -217,18 +217,7 @@ int bits_for(int64_t n) {
     return b;
 }
 
-struct Temp {  // scoped device scratch for plan construction
-    std::vector<void*> ptrs;
-    ~Temp() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T>
-    hipError_t get(T** out, size_t count) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = static_cast<T*>(p);
-        return e;
-    }
-};
+using Temp = gn::Scratch;   // scoped device scratch for plan construction (common.h)
 
 gn_status sort_by_dst(Temp& tmp, const int32_t* keys_in, int32_t* keys_out, const int32_t* vals_in,
                       int32_t* vals_out, int64_t n, int64_t key_range, hipStream_t st) {
@@ -247,7 +236,9 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
                            int64_t n_dst, bool gcn, int improved, hipStream_t st, gn_graph_plan* plan,
                            bool raw = false) {
     const int64_t n_loops = gcn ? n_dst : 0;
+    GN_LAP(nullptr);
     Temp tmp;
+    GN_HIP(tmp.reserve((size_t)64 * (size_t)(E + n_dst) + ((size_t)1 << 20)));
     int32_t *keep, *pos, *last_loop, *err;
     GN_HIP(tmp.get(&keep, E + 1));
     GN_HIP(tmp.get(&pos, E + 1));
@@ -269,6 +260,7 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
     GN_HIP(hipMemcpyAsync(&kept, pos + E, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipMemcpyAsync(&bad, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("graph: mark + scan (sync)");
     if (bad) return gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld) x [0,%lld)",
                              (long long)n_src, (long long)n_dst);
     const int64_t nnz = (int64_t)kept + n_loops;
@@ -338,6 +330,7 @@ gn_status build_graph_plan(const int64_t* src, const int64_t* dst, const float* 
     std::vector<int32_t> rp(n_dst + 1);
     GN_HIP(hipMemcpyAsync(rp.data(), plan->rowptr.p, (n_dst + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("graph: compact, sort, CSR (sync)");
     plan->unit_weights = ones;
     plan->plain_ones = (raw && w == nullptr) ? 1 : 0;
     int64_t mx = 0;
@@ -589,12 +582,14 @@ gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const i
         return gn::fail(GN_ERR_INVALID_ARG, "range_list covers %lld edges but edge_index has %lld", (long long)cursor,
                         (long long)E);
 
+    GN_LAP(nullptr);
     gn_rgcn_plan* p = new gn_rgcn_plan();
     auto bail = [&](gn_status s) { gn_rgcn_plan_destroy(p); return s; };
 #define GN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(gn::fail(GN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
     p->input_edges = E; p->edge_lo = lo; p->edge_hi = hi; p->shard_edges = hi - lo;
     p->num_nodes = N; p->num_relations = R;
     Temp tmp;
+    GN_TRY(tmp.reserve((size_t)24 * (size_t)(hi - lo) + (size_t)8 * (size_t)(N + R) + ((size_t)1 << 20)));
     int32_t *cnt, *err, *dst32, *sorted_dst;
     int64_t* starts_dev;
     uint32_t* key;
@@ -662,6 +657,7 @@ gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const i
     GN_TRY(hipMemcpyAsync(&bad, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_TRY(hipMemcpyAsync(rp.data(), p->rowptr.p, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_TRY(hipStreamSynchronize(st));
+    GN_LAP("rgcn: keys + sort + rowptr (sync)");
     if (bad) return bail(gn::fail(GN_ERR_INDEX_RANGE, "edge_index holds a node id outside [0,%lld)", (long long)N));
     for (int64_t i = 0; i < N; ++i) p->max_row_nnz = std::max<int64_t>(p->max_row_nnz, rp[i + 1] - rp[i]);
     if (N > 0) {
@@ -688,13 +684,16 @@ gn_status gn_rgcn_plan_create_ex(const int64_t* src, const int64_t* dst, const i
             GN_TRY(hipStreamSynchronize(st));
         }
     }
+    GN_LAP("rgcn: row order + dw items");
     if (!(flags & GN_RGCN_PLAN_LIGHT)) {
         // the encodings of the LDS-resident kernels (host-side schedules: most of the build time); a light plan serves every
         // forward on the general O(E) path, from the device-sorted key list above alone
         gn_status fs = gn_rgcn_build_fast_segments(p, src, dst, ranges, st);
         if (fs != GN_OK) return bail(fs);
+        GN_LAP("rgcn: LDS-accumulator segments (total)");
         fs = gn_rgcn_build_pair_plan(p, src, dst, ranges, st);
         if (fs != GN_OK) return bail(fs);
+        GN_LAP("rgcn: destination-major units (total)");
     }
 #undef GN_TRY
     *out = p;

@@ -613,18 +613,7 @@ int bits_for(int64_t n) {
     return b;
 }
 
-struct Scratch {
-    std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T>
-    hipError_t get(T** out, size_t count) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = static_cast<T*>(p);
-        return e;
-    }
-};
+using gn::Scratch;   // scoped device scratch (common.h)
 
 template <typename K, typename V>
 gn_status sort_pairs(Scratch& tmp, const K* kin, K* kout, const V* vin, V* vout, size_t n, int bits, hipStream_t st) {
@@ -684,6 +673,7 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     if (g.tiles == 0 || R * g.tiles >= (1 << 20)) return GN_OK;
 
     Scratch tmp;
+    GN_HIP(tmp.reserve((size_t)48 * (size_t)E + (size_t)8 * (size_t)(R * g.tiles + R) + ((size_t)1 << 20)));
     int64_t* starts_dev;
     uint32_t *key, *key_sorted, *packed, *packed_sorted;
     int32_t* seg_off;
@@ -707,6 +697,7 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     std::vector<int32_t> seg(n_seg + 1);
     GN_HIP(hipMemcpyAsync(seg.data(), seg_off, (n_seg + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("  lds: segment keys + sort (sync)");
 
     // work items: every non-empty (relation, tile) segment, cut into chunks of <= kItemEdges edges
     std::vector<int32_t> item_rel, item_tile, item_begin;
@@ -758,6 +749,7 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
     }
+    GN_LAP("  lds: items, pieces, LPT (host)");
     // destination -> slot assignment inside every item, balanced by edge count
     const int64_t cells = (int64_t)n_items * N;
     int32_t *item_begin_dev, *item_id, *cnt;
@@ -811,6 +803,7 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     GN_HIP(hipMemcpy2DAsync(item_pad.data(), sizeof(int32_t), plan->seg_begin.p, kNB * sizeof(int32_t), sizeof(int32_t),
                             (size_t)n_items + 1, hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("  lds: slots, two sorts, scan (sync)");
     const int64_t padded = item_pad[n_items];
     GN_HIP(plan->packed.alloc(padded + 8));
     GN_HIP(hipMemsetAsync(plan->packed.p, 0, (padded + 8) * sizeof(uint32_t), st));   // padding word: dst 0, src 0, no flag
@@ -838,6 +831,7 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     GN_HIP(hipMemcpyAsync(plan->wg_begin.p, wg_begin.data(), (groups + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->wg_items.p, work.data(), work.size() * sizeof(WorkDesc), hipMemcpyHostToDevice, st));
     GN_HIP(hipStreamSynchronize(st));       // host vectors go out of scope after this
+    GN_LAP("  lds: emit + descriptors (sync)");
     plan->n_seg = n_items;
     plan->fast_groups = groups;
     plan->fast_ts = g.ts;

@@ -748,18 +748,7 @@ __global__ void k_pair_rowptr(const uint32_t* __restrict__ sorted, int n, int64_
     out[i] = lo;
 }
 
-struct Scratch {
-    std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T>
-    hipError_t get(T** out, size_t count) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = static_cast<T*>(p);
-        return e;
-    }
-};
+using gn::Scratch;   // scoped device scratch (common.h)
 
 int bits_for(int64_t n) {
     int b = 1;
@@ -844,7 +833,9 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     if (ring0 + kWaves * kRingBytes > kLdsBytes) return GN_OK;
     const int G = (int)std::min<int64_t>(N, cus);
 
+    GN_LAP(nullptr);
     Scratch tmp;
+    GN_HIP(tmp.reserve((size_t)24 * (size_t)E + (size_t)4 * (size_t)N * kpad + (size_t)8 * (size_t)(N + R) + ((size_t)1 << 20)));
     int64_t* starts_dev;
     int32_t *outdeg_dev, *kpos_dev, *rowptr_dev;
     uint32_t *key, *key_sorted, *val, *val_sorted;
@@ -865,6 +856,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     }
     GN_HIP(hipMemcpyAsync(outdeg.data(), outdeg_dev, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("  pair: allocations + out-degrees (sync)");
     std::vector<int32_t> perm(kpad, (int32_t)N), kpos(N);
     {
         std::vector<int32_t> order(N);
@@ -894,7 +886,9 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
         GN_HIP(hipStreamSynchronize(st));
     }
 
+    GN_LAP("  pair: keys + sort + D2H (sync)");
     gn_layout::PairLayout pl = gn_layout::build_pair_layout(N, R, chunks, kpad, G, D, rp, rels, perm);
+    GN_LAP("  pair: host layout");
     if (!pl.ok) return GN_OK;
     std::vector<uint32_t>& stream = pl.stream; std::vector<uint32_t>& first = pl.wave_first; std::vector<uint32_t>& desc = pl.desc;
     std::vector<uint32_t>& wave_units = pl.wave_units; std::vector<uint32_t>& wave_desc = pl.wave_desc;
@@ -913,6 +907,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     GN_HIP(hipMemcpyAsync(plan->pair_wave_desc.p, wave_desc.data(), wave_desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipMemcpyAsync(plan->pair_wg_dst.p, wg_dst.data(), wg_dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     GN_HIP(hipStreamSynchronize(st));
+    GN_LAP("  pair: upload (sync)");
     plan->pair_groups = G;
     plan->pair_unit_slots = (int64_t)desc.size() / 32 + 2;      // descriptors (one per unit; a wave's last page may be half empty)
     plan->pair_d = D;

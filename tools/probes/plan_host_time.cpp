@@ -41,6 +41,10 @@ int main(int argc, char** argv) {
         double t3 = now();
         gn_layout::ClassLayout L = gn_layout::build_class_layout(hu, hv, hr, scored, mirror_of, n, 80, 256);
         double t4 = now();
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t v : L.packed) h = (h ^ v) * 1099511628211ull;
+        for (uint32_t v : L.own) h = (h ^ v) * 1099511628211ull;
+        std::printf("hash %016llx ", (unsigned long long)h);
         std::printf("E=%lld: pair_mirrors %.1f ms, scored %.1f ms, column-phase deal %.1f ms, class layout %.1f ms (ok=%d)\n", (long long)E,
                     1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), (int)L.ok);
     }
