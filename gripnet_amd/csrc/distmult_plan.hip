@@ -417,8 +417,8 @@ __global__ __launch_bounds__(256) void k_narrow_triples(const int64_t* __restric
     if (first != ~0ull) atomicMin(bad, first);
 }
 
-template <typename I>
-gn_status build_distmult_plan(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int64_t E,
+template <typename V>
+gn_status build_distmult_plan(const V& hu, const V& hv, const V& hr, int64_t E,
                               int64_t num_nodes, int64_t num_relations, int64_t num_features, hipStream_t st,
                               gn_distmult_plan** out) {
     gn::RawVec<int64_t> mirror_of;
@@ -528,7 +528,8 @@ gn_status gn_distmult_plan_create(const int64_t* u, const int64_t* v, const int6
 #ifdef GN_LAYOUT_TIMES
     struct ExitLap { ~ExitLap() { GN_LAP("decoder: host vectors freed"); } } exit_lap;
 #endif
-    std::vector<uint16_t> hu(E), hv(E), hr(E);
+    gn::ArenaHold arena;                                       // (before every host array of this build: host_layout.hpp)
+    gn::RawVec<uint16_t> hu(E), hv(E), hr(E);
     GN_LAP("decoder: host vectors");
     if (E > 0) {
         gn::DevBuf<uint16_t> narrow;

@@ -5,6 +5,8 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #ifdef GN_LAYOUT_TIMES
 #include <chrono>
 #include <cstdio>
@@ -12,7 +14,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <numeric>
@@ -20,9 +24,53 @@
 #include <utility>
 #include <vector>
 
+#include <unistd.h>
+
 namespace gn {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// The builder threads: parked between builds (a plan of pose0-syn runs thirty parallel passes of a fraction of a
+// millisecond each, and starting fifteen threads for every pass was 0.3-0.5 ms of it - a quarter of the decoder plan's build
+// time).  One pass at a time uses the pool (a second builder, or a pass started from inside a pass, starts its own threads
+// as before); the pool belongs to the process that made it - after a fork the child makes its own at its first pass (the
+// parent's threads do not exist there) - and is never torn down.
+struct WorkerPool {
+    std::mutex run_lock;               // held by the pass that is using the pool
+    std::mutex m;                      // guards everything below
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    std::function<void(int64_t)> job;  // job(chunk)
+    int64_t chunks = 0, next = 0, pending = 0;
+    uint64_t generation = 0;
+    long owner = 0;                    // the process the threads live in
+};
+inline void pool_worker(WorkerPool* p, uint64_t seen) {
+    std::unique_lock<std::mutex> lk(p->m);
+    for (;;) {
+        p->wake.wait(lk, [&] { return p->generation != seen; });
+        seen = p->generation;
+        while (p->next < p->chunks) {
+            const int64_t c = p->next++;
+            lk.unlock();
+            p->job(c);
+            lk.lock();
+            if (--p->pending == 0) p->done.notify_one();
+        }
+    }
+}
+inline WorkerPool* worker_pool() {
+    static std::atomic<WorkerPool*> pool{nullptr};
+    WorkerPool* p = pool.load(std::memory_order_acquire);
+    const long me = (long)getpid();
+    if (p != nullptr && p->owner == me) return p;
+    WorkerPool* fresh = new WorkerPool();                     // (a pool inherited through fork is left alone: its threads are gone)
+    fresh->owner = me;
+    if (pool.compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) return fresh;
+    delete fresh;
+    p = pool.load(std::memory_order_acquire);
+    return (p != nullptr && p->owner == me) ? p : nullptr;
+}
 
 // Host side of the plan builders: fn(begin, end) over contiguous chunks of [0, n) on up to GN_PLAN_THREADS (default 16:
 // the CPU share of one GPU on the boxes this runs on) threads.  The chunks are fixed by n and the thread count only and
@@ -35,6 +83,31 @@ inline void parallel_for(int64_t n, int64_t grain, F fn) {
     if (hw > 0) want = std::min<int>(want, (int)hw);
     const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(want, (n + grain - 1) / std::max<int64_t>(grain, 1)));
     if (chunks <= 1 || n <= 0) { if (n > 0) fn((int64_t)0, n); return; }
+    WorkerPool* p = worker_pool();
+    if (p != nullptr && p->run_lock.try_lock()) {
+        std::unique_lock<std::mutex> lk(p->m);
+        while ((int64_t)p->threads.size() < chunks - 1) p->threads.emplace_back(pool_worker, p, p->generation);
+        p->job = [&](int64_t c) { fn(n * c / chunks, n * (c + 1) / chunks); };
+        p->chunks = chunks; p->next = 1; p->pending = chunks - 1;
+        ++p->generation;
+        lk.unlock();
+        p->wake.notify_all();
+        fn((int64_t)0, n / chunks);
+        lk.lock();
+        while (p->next < p->chunks) {                          // (chunks no parked thread has picked up yet)
+            const int64_t c = p->next++;
+            lk.unlock();
+            fn(n * c / chunks, n * (c + 1) / chunks);
+            lk.lock();
+            --p->pending;
+        }
+        p->done.wait(lk, [&] { return p->pending == 0; });
+        p->job = nullptr;
+        p->chunks = 0; p->next = 0;
+        lk.unlock();
+        p->run_lock.unlock();
+        return;
+    }
     std::vector<std::thread> pool;
     pool.reserve((size_t)chunks - 1);
     for (int64_t c = 1; c < chunks; ++c) pool.emplace_back([=]() { fn(n * c / chunks, n * (c + 1) / chunks); });
@@ -42,13 +115,88 @@ inline void parallel_for(int64_t n, int64_t grain, F fn) {
     for (std::thread& t : pool) t.join();
 }
 
+// The builders' large host arrays come out of ONE block of the process that is kept between builds (grow-only up to
+// kMaxBytes, never given back).  A plan of pose0-syn asks for ~90 MB in arrays of 2-16 MB; malloc serves each with a fresh
+// mapping and free unmaps it, and in a long-lived process (bench.py after its training epochs) that traffic with the kernel
+// - page faults on every first touch, the unmapping at the end - cost as much as the builders' own work: decoder plan 17 ms of
+// builders, 27-32 ms measured; 17.8 ms with glibc told to keep its heap (MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_).
+// A builder takes the arena for its scope (ArenaHold, FIRST local of the entry point: every array dies before it); arrays
+// of at least kMinBytes are bump-allocated from it on the holder's thread, everything else - and everything while another
+// builder holds the arena, and what does not fit - is plain malloc.  The block grows to 5/4 of what the last holder asked
+// for, at the next acquire.  No array may outlive its hold.
+struct HostArena {
+    static constexpr size_t kMaxBytes = (size_t)1 << 30;
+    static constexpr size_t kMinBytes = (size_t)256 << 10;
+    std::mutex lock;
+    char* base = nullptr;
+    size_t bytes = 0;
+    size_t want = 0;                   // what the block should hold at the next acquire
+    std::atomic<size_t> used{0};       // bump pointer of the current hold
+    std::atomic<size_t> asked{0};      // bytes requested during the current hold (served or not)
+};
+inline HostArena& host_arena() {
+    static HostArena arena;
+    return arena;
+}
+inline HostArena*& arena_of_this_thread() {
+    static thread_local HostArena* held = nullptr;
+    return held;
+}
+struct ArenaHold {
+    bool held = false;
+    ArenaHold() {
+        HostArena& a = host_arena();
+        if (arena_of_this_thread() != nullptr || !a.lock.try_lock()) return;     // (nested, or another builder has it: malloc)
+        held = true;
+        if (a.want > a.bytes) {
+            std::free(a.base);
+            a.base = static_cast<char*>(std::malloc(a.want));
+            a.bytes = a.base ? a.want : 0;
+        }
+        a.used.store(0); a.asked.store(0);
+        arena_of_this_thread() = &a;
+    }
+    ArenaHold(const ArenaHold&) = delete;
+    ArenaHold& operator=(const ArenaHold&) = delete;
+    ~ArenaHold() {
+        if (!held) return;
+        HostArena& a = host_arena();
+        arena_of_this_thread() = nullptr;
+        const size_t asked = a.asked.load();
+        a.want = std::max(a.want, std::min(HostArena::kMaxBytes, asked + asked / 4));
+        a.lock.unlock();
+    }
+};
+inline void* arena_allocate(size_t bytes) {
+    HostArena* a = arena_of_this_thread();
+    if (a == nullptr || bytes < HostArena::kMinBytes) return nullptr;
+    const size_t padded = (bytes + 63) & ~(size_t)63;
+    a->asked.fetch_add(padded);
+    const size_t at = a->used.fetch_add(padded);
+    if (at + padded > a->bytes) { a->used.fetch_sub(padded); return nullptr; }
+    return a->base + at;
+}
+inline bool arena_owns(const void* p) {
+    const HostArena& a = host_arena();
+    return a.base != nullptr && static_cast<const char*>(p) >= a.base && static_cast<const char*>(p) < a.base + a.bytes;
+}
+
 // A vector whose resize() leaves new elements uninitialised (the builders' large arrays are written whole by the parallel
-// passes that follow: a value-initialising resize was a serial walk - and the first touch - of every page).
+// passes that follow: a value-initialising resize was a serial walk - and the first touch - of every page), and whose large
+// blocks come from the arena above while the calling thread holds it.
 template <typename T>
 struct DefaultInit : std::allocator<T> {
     template <typename U> struct rebind { using other = DefaultInit<U>; };
     template <typename U> void construct(U* ptr) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(ptr)) U; }
     template <typename U, typename... A> void construct(U* ptr, A&&... a) { ::new (static_cast<void*>(ptr)) U(std::forward<A>(a)...); }
+    T* allocate(size_t n) {
+        if (void* p = arena_allocate(n * sizeof(T))) return static_cast<T*>(p);
+        return std::allocator<T>::allocate(n);
+    }
+    void deallocate(T* p, size_t n) {
+        if (arena_owns(p)) return;                           // (the block is reused whole by the next holder)
+        std::allocator<T>::deallocate(p, n);
+    }
 };
 template <typename T>
 using RawVec = std::vector<T, DefaultInit<T>>;
@@ -90,17 +238,17 @@ constexpr int64_t kClsWindowBytes = 1 << 20;   // scores of one sub-range: what 
 // edge in both directions, utils.py:132-138): they are paired up, the first of a pair is scored and writes both positions.
 // mirror_of[e] = the later copy that takes e's score (-1: none); covered[e] = e is such a later copy.
 // (the serial form: any order of relations)
-template <typename I>
-inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
+template <typename V>
+inline void pair_mirrors_serial(const V& hu, const V& hv, const V& hr, int node_bits,
                                 gn::RawVec<int64_t>& mirror_of, gn::RawVec<char>& covered);
 
 // Round 6: a type-sorted list (the reference's layout, utils.py:168-198) pairs up inside every relation on its own - the
 // relations are dealt to the builder threads in contiguous runs of about equal edge counts, each thread with one small
 // open-addressing table that it wipes by the slots it touched.  Same pairs as the serial pass (within a relation the
 // edges are visited in list order).  2 M edges: 92 -> 14 ms on eight threads.
-// (I: int64_t - the reference's index type - or a narrower unsigned type the caller narrowed the validated ids to on the device)
-template <typename I>
-inline void pair_mirrors(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
+// (V: a vector of int64_t - the reference's index type - or of a narrower unsigned type the caller narrowed the validated ids to on the device)
+template <typename V>
+inline void pair_mirrors(const V& hu, const V& hv, const V& hr, int node_bits,
                          gn::RawVec<int64_t>& mirror_of, gn::RawVec<char>& covered) {
     const int64_t E = (int64_t)hu.size();
     GN_LAP(nullptr);
@@ -173,8 +321,8 @@ inline void pair_mirrors(const std::vector<I>& hu, const std::vector<I>& hv, con
     GN_LAP("mirrors: tables (parallel)");
 }
 
-template <typename I>
-inline void pair_mirrors_serial(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr, int node_bits,
+template <typename V>
+inline void pair_mirrors_serial(const V& hu, const V& hv, const V& hr, int node_bits,
                                 gn::RawVec<int64_t>& mirror_of, gn::RawVec<char>& covered) {
     const int64_t E = (int64_t)hu.size();
     mirror_of.assign((size_t)E, -1);
@@ -344,8 +492,8 @@ struct ClassLayout {
     std::vector<int32_t> wg;
 };
 
-template <typename I>
-inline ClassLayout build_class_layout(const std::vector<I>& hu, const std::vector<I>& hv, const std::vector<I>& hr,
+template <typename V>
+inline ClassLayout build_class_layout(const V& hu, const V& hv, const V& hr,
                                       const gn::RawVec<int64_t>& scored, const gn::RawVec<int64_t>& mirror_of, int64_t n,
                                       int64_t features, int cus, int64_t window_bytes = kClsWindowBytes) {
     static const int kGroupQuads[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
@@ -824,6 +972,15 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
     GN_LAP(nullptr);
     std::vector<int32_t> kord((size_t)N * kpad);
     std::vector<int32_t> perm2((size_t)N * kpad);
+    auto cell = [&](int64_t i, int pos) { return (size_t)i * kpad + kord[(size_t)i * kpad + pos]; };
+    auto pair_len = [&](int64_t i, int pos) { const size_t c = cell(i, pos); return rp[c + 1] - rp[c]; };
+    auto chunk_empty = [&](int64_t i, int ch) { return pair_len(i, 32 * ch) == 0; };   // (position 32 ch holds the chunk's longest pair)
+    auto section_blocks = [&](int64_t i, int ch, int t) {
+        int longest = 0;
+        for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
+        return std::max(1, (longest + 3) / 4);
+    };
+    std::vector<int64_t> cost(N, 0);
     gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
         std::vector<int32_t> idx(kpad);
         std::vector<uint64_t> keyed(kpad);
@@ -852,20 +1009,7 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
                 // reaches only the destinations s has an edge to (0 . inf would be NaN), as in the reference's edge sum
                 perm2[pos] = r[idx[q] + 1] > r[idx[q]] ? perm[idx[q]] : (int32_t)N;
             }
-        }
-    });
-    auto cell = [&](int64_t i, int pos) { return (size_t)i * kpad + kord[(size_t)i * kpad + pos]; };
-    auto pair_len = [&](int64_t i, int pos) { const size_t c = cell(i, pos); return rp[c + 1] - rp[c]; };
-    auto chunk_empty = [&](int64_t i, int ch) { return pair_len(i, 32 * ch) == 0; };   // (position 32 ch holds the chunk's longest pair)
-    auto section_blocks = [&](int64_t i, int ch, int t) {
-        int longest = 0;
-        for (int k = 0; k < 4; ++k) longest = std::max(longest, pair_len(i, 32 * ch + 8 * k + t));
-        return std::max(1, (longest + 3) / 4);
-    };
-    GN_LAP("pair: K order (parallel)");
-    std::vector<int64_t> cost(N, 0);
-    gn::parallel_for(N, 8, [&](int64_t b, int64_t e) {
-        for (int64_t i = b; i < e; ++i) {
+            // the row's cost (its K order is known now): blocks of all its sections, + a unit's split and matrix products
             int64_t blocks = 0;
             for (int ch = 0; ch < chunks; ++ch) {
                 if (chunk_empty(i, ch)) continue;
@@ -875,12 +1019,12 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
                     deepest = std::max(deepest, nb);
                     blocks += nb;
                 }
-                blocks += 12 * gn::ceil_div(deepest, kPairSectionCap);             // a unit's split and matrix products, in block times
+                blocks += 12 * gn::ceil_div(deepest, kPairSectionCap);             // in block times
             }
             cost[i] = blocks;
         }
     });
-    GN_LAP("pair: costs (parallel)");
+    GN_LAP("pair: K order + costs (parallel)");
     // destinations to workgroups: longest first, each to the least loaded workgroup that still has room
     std::vector<std::vector<int32_t>> wg_rows(G);
     {

@@ -752,6 +752,8 @@ gn_status gn_rgcn_build_fast_segments(gn_rgcn_plan* plan, const int64_t* src, co
     GN_LAP("  lds: items, pieces, LPT (host)");
     // destination -> slot assignment inside every item, balanced by edge count
     const int64_t cells = (int64_t)n_items * N;
+    // (everything the rest of the build asks for in one more block of the scratch)
+    GN_HIP(tmp.reserve((size_t)cells * 40 + (size_t)E * 40 + (size_t)n_items * (kNB + 1) * 8 + ((size_t)2 << 20)));
     int32_t *item_begin_dev, *item_id, *cnt;
     uint64_t *rkey, *rkey_sorted, *key2, *key2_sorted;
     uint8_t* slot_of;

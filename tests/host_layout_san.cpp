@@ -4,9 +4,14 @@
 // a plan does not depend on the thread count.  No HIP, no GPU.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <random>
+#include <thread>
 #include <utility>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "host_layout.hpp"
 
@@ -313,7 +318,28 @@ void general_case(int64_t N, int64_t R, int64_t E, unsigned seed) {
     }
 }
 
-int main() {
+// After a fork the child has none of the parent's parked builder threads (host_layout.hpp, WorkerPool): its first parallel pass
+// must make its own instead of waiting for threads that do not exist there.
+int fork_case() {
+    set_threads(16);
+    gn_layout::ClassLayout before = decoder_case(645, 40, 20000, 80, 7, true);      // the parent's pool exists from here on
+    const pid_t child = fork();
+    CHECK(child >= 0);
+    if (child == 0) {
+        gn_layout::ClassLayout in_child = decoder_case(645, 40, 20000, 80, 7, true);
+        _exit(same(before.packed, in_child.packed) && same(before.own, in_child.own) ? 0 : 3);
+    }
+    int status = 0;
+    CHECK(waitpid(child, &status, 0) == child);
+    CHECK(WIFEXITED(status) && WEXITSTATUS(status) == 0);
+    gn_layout::ClassLayout after = decoder_case(645, 40, 20000, 80, 7, true);       // ... and still works in the parent
+    CHECK(same(before.packed, after.packed));
+    std::printf("host layout: builder threads ok across fork\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::strcmp(argv[1], "fork") == 0) return fork_case();
     balance_case(5);
     general_case(20000, 600, 300000, 21);
     general_case(50, 3, 40, 22);
@@ -329,6 +355,32 @@ int main() {
         set_threads(16);
         gn_layout::ClassLayout b = decoder_case(c.n, c.R, c.e, c.f, 7, true, gn_layout::kClsWindowBytes, c.ok);
         CHECK(same(a.packed, b.packed) && same(a.own, b.own) && same(a.mirror, b.mirror) && same(a.rel32, b.rel32) && same(a.wg, b.wg));
+    }
+    // the builders' host arena (host_layout.hpp): the same plan with its large arrays out of the kept block - the first hold finds no
+    // block (everything by malloc, the demand noted), the later ones are served from it; a second builder meanwhile gets malloc
+    {
+        set_threads(16);
+        std::vector<uint32_t> want_packed;
+        {
+            gn_layout::ClassLayout plain = decoder_case(645, 40, 20000, 80, 7, false);
+            want_packed.assign(plain.packed.begin(), plain.packed.end());
+            CHECK(!gn::arena_owns(plain.packed.data()));
+        }
+        for (int pass = 0; pass < 3; ++pass) {
+            gn::ArenaHold hold;
+            CHECK(hold.held);
+            gn_layout::ClassLayout l = decoder_case(645, 40, 20000, 80, 7, true);
+            CHECK(l.packed.size() == want_packed.size() && std::equal(want_packed.begin(), want_packed.end(), l.packed.begin()));
+            CHECK(l.packed.size() * sizeof(uint32_t) >= gn::HostArena::kMinBytes);
+            CHECK(gn::arena_owns(l.packed.data()) == (pass > 0));
+            std::thread other([] {
+                gn::ArenaHold second;
+                CHECK(!second.held);
+                gn::RawVec<int> v((size_t)1 << 20);
+                CHECK(!gn::arena_owns(v.data()));
+            });
+            other.join();
+        }
     }
     for (int64_t window : {(int64_t)8 << 10, (int64_t)40 << 10}) {     // an XCD's position range walked in several sub-ranges
         set_threads(16);

@@ -150,3 +150,8 @@ def test_plan_builders_host_layout_under_sanitizers(tmp_path, sanitizer, flags):
         pytest.skip("the sanitizer runtime does not start in this sandbox: " + run.stderr.strip()[:200])
     assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
     assert "all builders ok" in run.stdout
+    if sanitizer == "asan":            # (TSan does not follow new threads in the child of a multi-threaded fork)
+        # the builder threads are parked between builds; a forked child (a DataLoader worker, multiprocessing) has none of them
+        run = subprocess.run([str(exe), "fork"], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
+        assert "ok across fork" in run.stdout
