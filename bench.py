@@ -557,8 +557,10 @@ def cold_start_entry(model, data, fence):
         for _ in range(3):
             stages.step()
         reps = []
-        for _ in range(3):                                     # (the fastest of three repeats: a one-time stall of the host - an allocator
-            fence()                                            # trim, a collection - read 2 ms per step in some runs and 0.116 in others)
+        import gc
+        gc.collect()                                           # (a generation-2 collection of THIS process - 40-50 ms with sklearn, the oracle and
+        for _ in range(3):                                     # three models alive - used to land in the first repeat: 2 ms per step instead of
+            fence()                                            # 0.11, tools/uncached_steps_probe.py; collected here, and the fastest of three kept)
             t = time.perf_counter()
             for _ in range(20):
                 z, score = stages.step()
@@ -824,7 +826,9 @@ def main():
         # (every fourth launch of the dominant entry point is timed - its kernel carries the events as its dispatch's own stamps
         # where it can, else event records bracket the launch; `timed_launches` says how many went into the average)
         timer = _hip.KernelTimer(only=(dom,), pool=2 * (args.steps + max(args.warmup, 1)) + 8, every=timed_every)
-        fence()
+        import gc
+        gc.collect()                                  # (a full collection of this process is 40-50 ms: not inside the K steps by accident;
+        fence()                                       # the collector stays ON through the timed region)
         with timer:
             for _ in range(max(args.warmup, 1)):
                 z, score = step()

@@ -25,6 +25,9 @@
 #include <vector>
 
 #include <unistd.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 namespace gn {
 
@@ -438,28 +441,92 @@ inline void deal_batch(const int64_t* u, const int64_t* v, int count, int* slot_
 // 16-lane access group of ds_read_b128, so they should have four different (local row of u) % 4 and four different
 // (local row of v) % 4 - the 64-byte bank slot of a row is (row * odd stride) % 4.  Cells fill whole steps first
 // (step = cell / 4): a run is padded to a multiple of 16 pairs, not 64.  order[cell * 4 + k] = pair of the run, or -1.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define GN_DEAL_SSSE3 1
+// The permutation search of deal_run in six byte shuffles: sz = the sixteen stack sizes (bytes, index 4 c + d); returns the first
+// of the 24 permutations (kPerms order) whose scarcest bucket is fullest, -1 when every permutation has an empty bucket.
+__attribute__((target("ssse3"))) inline int best_permutation_ssse3(const uint8_t* sz, const uint8_t (*idx)[16]) {
+    const __m128i s = _mm_loadu_si128(reinterpret_cast<const __m128i*>(sz));   // (sz: sixteen bytes the caller keeps 16-byte stores to)
+    const __m128i lo = _mm_min_epu8(_mm_min_epu8(_mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[0]))),
+                                                 _mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[1])))),
+                                    _mm_min_epu8(_mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[2]))),
+                                                 _mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[3])))));
+    const __m128i hi = _mm_min_epu8(_mm_min_epu8(_mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[4]))),
+                                                 _mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[5])))),
+                                    _mm_min_epu8(_mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[6]))),
+                                                 _mm_shuffle_epi8(s, _mm_loadu_si128(reinterpret_cast<const __m128i*>(idx[7])))));
+    __m128i m = _mm_max_epu8(lo, hi);
+    m = _mm_max_epu8(m, _mm_srli_si128(m, 8));
+    m = _mm_max_epu8(m, _mm_srli_si128(m, 4));
+    m = _mm_max_epu8(m, _mm_srli_si128(m, 2));
+    m = _mm_max_epu8(m, _mm_srli_si128(m, 1));
+    const int best_min = _mm_cvtsi128_si32(m) & 0xff;
+    if (best_min == 0) return -1;
+    const __m128i all = _mm_set1_epi8((char)best_min);
+    const int first_lo = _mm_movemask_epi8(_mm_cmpeq_epi8(lo, all));
+    if (first_lo) return __builtin_ctz((unsigned)first_lo);
+    return 16 + __builtin_ctz((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(hi, all)));
+}
+__attribute__((target("ssse3"))) inline void take_permutation_ssse3(uint8_t* szv, const uint8_t* take) {
+    _mm_store_si128(reinterpret_cast<__m128i*>(szv), _mm_sub_epi8(_mm_load_si128(reinterpret_cast<const __m128i*>(szv)),
+                                                                 _mm_load_si128(reinterpret_cast<const __m128i*>(take))));
+}
+#endif
+
 inline void deal_run(const int* lu, const int* lv, int count, std::vector<int>& order) {
     static const int kPerms[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
                                       {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
                                       {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
                                       {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
+#ifdef GN_DEAL_SSSE3
+    // shuffle controls: idx[c] = the bucket 4 c + sigma_p(c) of permutations p = 0..15, idx[4 + c] of p = 16..23 (then 0x80: a zero)
+    struct ShuffleTable {
+        uint8_t idx[8][16];
+        alignas(16) uint8_t take[24][16];             // 1 at the four buckets of a permutation
+        ShuffleTable() {
+            for (int c = 0; c < 4; ++c)
+                for (int p = 0; p < 32; ++p) idx[(p >> 4) * 4 + c][p & 15] = p < 24 ? (uint8_t)(4 * c + kPerms[p][c]) : (uint8_t)0x80;
+            for (int p = 0; p < 24; ++p) {
+                for (int b = 0; b < 16; ++b) take[p][b] = 0;
+                for (int c = 0; c < 4; ++c) take[p][4 * c + kPerms[p][c]] = 1;
+            }
+        }
+    };
+    static const ShuffleTable table;
+    static const bool use_ssse3 = __builtin_cpu_supports("ssse3");
+#endif
     const int steps = (count + 15) / 16;
     order.assign((size_t)steps * 16, -1);
-    // sixteen stacks by (lu % 4, lv % 4), their sizes side by side in one cache line: the search below reads nothing else
-    int stack[16][64], sz[16] = {0};
+    // sixteen stacks by (lu % 4, lv % 4), their sizes side by side in sixteen bytes: the search below reads nothing else
+    int stack[16][64];
+    uint8_t sz[16] = {0};
     for (int e = count - 1; e >= 0; --e) { const int b = (lu[e] & 3) * 4 + (lv[e] & 3); stack[b][sz[b]++] = e; }   // (popped from the back: list order)
+#ifdef GN_DEAL_SSSE3
+    alignas(16) uint8_t szv[16];                      // the sizes again, only ever stored whole (a vector load behind byte stores stalls)
+    std::memcpy(szv, sz, 16);
+#endif
     int left = count;
     for (int cell = 0; cell < steps * 4 && left > 0; ++cell) {
         int chosen[4] = {-1, -1, -1, -1};
         // a full cell: one pair from each (c, sigma(c)) for the permutation whose scarcest bucket is fullest (the first of equals)
-        int mins[24];
-        for (int p = 0; p < 24; ++p)
-            mins[p] = std::min(std::min(sz[kPerms[p][0]], sz[4 + kPerms[p][1]]), std::min(sz[8 + kPerms[p][2]], sz[12 + kPerms[p][3]]));
-        int best = -1, best_min = 0;
-        for (int p = 0; p < 24; ++p)
-            if (mins[p] > best_min) { best_min = mins[p]; best = p; }
+        int best = -1;
+#ifdef GN_DEAL_SSSE3
+        if (use_ssse3) {
+            best = best_permutation_ssse3(szv, table.idx);
+        } else
+#endif
+        {
+            int best_min = 0;
+            for (int p = 0; p < 24; ++p) {
+                const int mn = std::min(std::min((int)sz[kPerms[p][0]], (int)sz[4 + kPerms[p][1]]), std::min((int)sz[8 + kPerms[p][2]], (int)sz[12 + kPerms[p][3]]));
+                if (mn > best_min) { best_min = mn; best = p; }
+            }
+        }
         if (best >= 0) {
             for (int c = 0; c < 4; ++c) { const int b = c * 4 + kPerms[best][c]; chosen[c] = stack[b][--sz[b]]; }
+#ifdef GN_DEAL_SSSE3
+            if (use_ssse3) take_permutation_ssse3(szv, table.take[best]);
+#endif
         } else {
             // no conflict-free quadruple left: pairs one by one, preferring unused u and v classes
             unsigned used_u = 0, used_v = 0;
@@ -467,13 +534,16 @@ inline void deal_run(const int* lu, const int* lv, int count, std::vector<int>& 
                 int bb = -1, bscore = -1;
                 for (int b = 0; b < 16; ++b) {
                     if (sz[b] == 0) continue;
-                    const int score = 2 * (!((used_u >> (b >> 2)) & 1) + !((used_v >> (b & 3)) & 1)) * 64 + sz[b];
+                    const int score = 2 * (!((used_u >> (b >> 2)) & 1) + !((used_v >> (b & 3)) & 1)) * 64 + (int)sz[b];
                     if (score > bscore) { bscore = score; bb = b; }
                 }
                 if (bb < 0) break;
                 chosen[k] = stack[bb][--sz[bb]];
                 used_u |= 1u << (bb >> 2); used_v |= 1u << (bb & 3);
             }
+#ifdef GN_DEAL_SSSE3
+            std::memcpy(szv, sz, 16);
+#endif
         }
         for (int k = 0; k < 4; ++k)
             if (chosen[k] >= 0) { order[(size_t)cell * 4 + k] = chosen[k]; --left; }
