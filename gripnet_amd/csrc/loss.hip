@@ -119,14 +119,35 @@ __global__ __launch_bounds__(256) void k_link_loss_grad(const float* __restrict_
 
 // The node-classification loss of the training loops (GripNet-aminer.py:133, every freebase driver alike):
 // loss = - mean_i log(score[i, class_i] + eps).  A few thousand labelled nodes: one workgroup, a fixed slice per thread summed
-// in double, a fixed tree over the threads.
+// in double, a fixed tree over the threads; logf, not the hardware's fast logarithm (the reference's torch.log: a class
+// probability near 1 has a logarithm near 0, where the fast intrinsic's absolute error is the whole value); four nodes per
+// thread in flight (the loads are a gather: one score of every labelled row).
 __global__ __launch_bounds__(1024) void k_class_loss(const float* __restrict__ score, int64_t ld, const int64_t* __restrict__ cls, int64_t n,
                                                      int classes, float eps, float* __restrict__ loss, int32_t* __restrict__ err) {
     __shared__ double red[16];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        int64_t c[4];
+        float v[4];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = cls[i + k * 1024]; bad = bad || (uint64_t)c[k] >= (uint64_t)classes; }
+        if (bad) {                                              // (rare: report, and count only the rows with a class inside the table)
+            if (err) atomicOr(err, 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((uint64_t)c[k] < (uint64_t)classes) s += (double)logf(score[(i + k * 1024) * ld + c[k]] + eps);
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = score[(i + k * 1024) * ld + c[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += (double)logf(v[k] + eps);
+    }
+    for (; i < n; i += 1024) {
         const int64_t c = cls[i];
-        if ((uint64_t)c < (uint64_t)classes) s += (double)__logf(score[i * ld + c] + eps);
+        if ((uint64_t)c < (uint64_t)classes) s += (double)logf(score[i * ld + c] + eps);
         else if (err) atomicOr(err, 1);
     }
 #pragma unroll

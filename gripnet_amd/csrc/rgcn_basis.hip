@@ -45,6 +45,8 @@ struct BasisArgs {
     uint32_t R;
     int mode;                                      // 0: per edge, relation order (round 5); 1: pair sums on the hub rows; 2: per edge, source order
     uint32_t n;                                    // nodes (key = relation * n + source)
+    int n_rows;                                    // entries of `order` (all rows; with several slabs: the slab's own rows, its heavy ones first)
+    const int32_t* slab_heavy;                     // (several slabs) the slab's heavy rows, counted on the device; or null: n_heavy
     int row_lo, row_hi;                            // this launch's slab of destination rows
     float* u; int64_t ld_u;                        // [row_hi - row_lo][ld_u]: U_i (bases outermost) | x_i | zeros up to kp
     int kp;
@@ -286,15 +288,16 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
     // groups of kBasisWaves light rows, a row per wave.  Every row is summed by one wave (or one workgroup) in a fixed
     // order, so the results do not depend on who drew what. ----
     __shared__ unsigned int item_s;
-    const int n_rows = (int)a.n;
-    const unsigned int n_items = (unsigned int)(a.n_heavy + (n_rows - a.n_heavy + kBasisWaves - 1) / kBasisWaves);
+    const int n_rows = a.n_rows;
+    const int n_heavy = a.slab_heavy ? *a.slab_heavy : a.n_heavy;
+    const unsigned int n_items = (unsigned int)(n_heavy + (n_rows - n_heavy + kBasisWaves - 1) / kBasisWaves);
     for (;;) {
         __syncthreads();                                                       // (item_s and red of the previous item have been read)
         if (threadIdx.x == 0) item_s = atomicAdd(a.next_item, 1u);
         __syncthreads();
         const unsigned int item = item_s;
         if (item >= n_items) break;
-        if ((int)item < a.n_heavy) {
+        if ((int)item < n_heavy) {
             const int row = a.order[item];
             if (row < a.row_lo || row >= a.row_hi) continue;                   // (uniform over the workgroup)
             const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
             if (wv == 0) write_tail(a, ur, row, lane);
             continue;
         }
-        const int idx = a.n_heavy + (int)(item - (unsigned int)a.n_heavy) * kBasisWaves + wv;
+        const int idx = n_heavy + (int)(item - (unsigned int)n_heavy) * kBasisWaves + wv;
         if (idx >= n_rows) continue;
         const int row = a.order[idx];
         if (row < a.row_lo || row >= a.row_hi) continue;
@@ -364,6 +367,45 @@ __global__ __launch_bounds__(kBasisThreads) void k_rgcn_basis(BasisArgs a) {
     }
 }
 
+// Several slabs: every slab's own rows in the plan's order (in-degree, largest first; heavy rows in front), so that a slab's launch
+// draws its own items only - with the plan's whole order every launch drew every item of all N rows (an atomic and two barriers
+// each) and skipped the rows of the other slabs: O(slabs x N / 8) draws, ~8 M per layer at N = 10^6.  Slab s holds the rows
+// [s slab_rows, (s + 1) slab_rows), each exactly once in `order`: its list starts at out[s slab_rows].  One workgroup per slab walks
+// the order and keeps its rows, in order (a block-wide prefix sum per 1,024 entries: stable, the same list every run).
+__global__ __launch_bounds__(1024) void k_slab_orders(const int32_t* __restrict__ order, int n, int n_heavy, int slab_rows,
+                                                      int32_t* __restrict__ out, int32_t* __restrict__ heavy_out) {
+    __shared__ int wave_total[16];
+    __shared__ int running_s, heavy_s;
+    const int slab = blockIdx.x, lo = slab * slab_rows, hi = min(n, lo + slab_rows);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { running_s = 0; heavy_s = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + (int)threadIdx.x;
+        const int row = i < n ? order[i] : -1;
+        const bool mine = row >= lo && row < hi;
+        const unsigned long long m = __ballot(mine);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_total[wv] = __popcll(m);
+        __syncthreads();
+        int base = running_s, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wv) base += wave_total[w]; total += wave_total[w]; }
+        if (mine) out[lo + base + before] = row;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            running_s += total;
+            if (i0 + 1024 <= n_heavy) heavy_s = running_s;                      // (every entry so far was a heavy row)
+        }
+        // the tile that straddles the end of the heavy rows: count its heavy members on their own
+        if (i0 < n_heavy && i0 + 1024 > n_heavy) {
+            const unsigned long long mh = __ballot(mine && i < n_heavy);
+            if (lane == 0 && mh) atomicAdd(&heavy_s, __popcll(mh));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) heavy_out[slab] = heavy_s;
+}
+
 // [basis ; root ; 0]: the right-hand side of the slab's dense product
 __global__ void k_basis_weights(const float* __restrict__ basis, const float* __restrict__ root, int64_t nb, int64_t nr, int64_t total,
                                 float* __restrict__ w, unsigned int* __restrict__ counters, int n_counters) {
@@ -375,7 +417,7 @@ __global__ void k_basis_weights(const float* __restrict__ basis, const float* __
 struct BasisLayout {
     int kp;
     int64_t slab_rows, slabs;
-    size_t w_off, q_off, u_off, total;
+    size_t w_off, q_off, o_off, u_off, total;     // o_off: (several slabs) [slabs] heavy counts, then [N] the slabs' own orders
 };
 
 BasisLayout basis_layout(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, int64_t bases) {
@@ -391,7 +433,8 @@ BasisLayout basis_layout(const gn_rgcn_plan* plan, int64_t fin, int64_t fout, in
     l.slabs = gn::ceil_div(std::max<int64_t>(plan->num_nodes, 1), l.slab_rows);
     l.w_off = 0;
     l.q_off = ((size_t)l.kp * fout * sizeof(float) + 255) & ~size_t(255);
-    l.u_off = l.q_off + (((size_t)l.slabs * sizeof(unsigned int) + 255) & ~size_t(255));
+    l.o_off = l.q_off + (((size_t)l.slabs * sizeof(unsigned int) + 255) & ~size_t(255));
+    l.u_off = l.o_off + (l.slabs > 1 ? ((((size_t)l.slabs + (size_t)plan->num_nodes) * sizeof(int32_t) + 255) & ~size_t(255)) : 0);
     l.total = l.u_off + (size_t)l.slab_rows * l.kp * sizeof(float);
     return l;
 }
@@ -618,6 +661,13 @@ gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_
     a.mode = (a.skey && order && order[0] == 'p') ? 1 : ((a.skey && order && order[0] == 's') ? 2 : 0);
     a.R = (uint32_t)plan->num_relations;
     a.n = (uint32_t)N; a.u = U; a.ld_u = l.kp; a.kp = l.kp; a.n_heavy = (int)plan->heavy_rows;
+    a.n_rows = (int)N; a.slab_heavy = nullptr;
+    int32_t* slab_heavy = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + l.o_off);
+    int32_t* slab_order = slab_heavy + l.slabs;
+    if (l.slabs > 1) {
+        k_slab_orders<<<(int)l.slabs, 1024, 0, st>>>(plan->row_order.p, (int)N, (int)plan->heavy_rows, (int)l.slab_rows, slab_order, slab_heavy);
+        GN_LAUNCH_CHECK();
+    }
     a.scale = partial ? 0 : 1; a.with_x = partial ? 0 : 1;
     a.vec = (fin % 16 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     // (measured and dropped: the att table staged in LDS - a fifth of the gathered bytes - made the layer 8 % SLOWER: the
@@ -631,6 +681,7 @@ gn_status gn_rgcn_basis_forward(const gn_rgcn_plan* plan, const float* x, int64_
         const int64_t r1 = std::min(N, r0 + l.slab_rows);
         a.row_lo = (int)r0; a.row_hi = (int)r1;
         a.next_item = counters + r0 / l.slab_rows;
+        if (l.slabs > 1) { a.order = slab_order + r0; a.n_rows = (int)(r1 - r0); a.slab_heavy = slab_heavy + r0 / l.slab_rows; }
         a.side = r0 == 0 ? side : gn_side_copy{nullptr, 0, nullptr, 0, 0, 0, 0};
         gn_status s;
         switch (bt) {
