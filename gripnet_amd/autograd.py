@@ -451,23 +451,47 @@ class LinkPredictionLossFn(torch.autograd.Function):
         return (dz if ctx.needs_input_grad[0] else None), (dd if ctx.needs_input_grad[1] else None), None, None, None, None, None
 
 
-_node_plans = []            # (node_list tensor, _version, rows of z, plan): the row-gather plans of the last few node lists
+_node_plans = []            # [node_list tensor of the caller, _version, rows of z, plan or None]: the row-gather plans of the last few node lists
 _node_plans_lock = threading.Lock()
+_node_plan_misses = 0       # lists in a row that were not in the cache
 
 
-def node_gather_plan(nodes: torch.Tensor, num_rows: int):
+def node_gather_plan(key: torch.Tensor, nodes: torch.Tensor, num_rows: int):
     """Plain-sum plan with ONE edge per listed node (table row nodes[i] -> output row i): its aggregation is the row gather
     z[node_list] (decoder.py:42), its transposed aggregation the scatter-add of the gathered rows' gradients.  Built once
-    per node list (the label splits of a training loop are static, GripNet-aminer.py:124-147)."""
+    per node list (the label splits of a training loop are static, GripNet-aminer.py:124-147) and remembered under the
+    CALLER's tensor `key` (identity + version: an int32 or strided list is converted on every forward, the caller's object is
+    what repeats; a data pointer would not do - the allocator hands a freed list's address to the next one).
+    Returns None when the list should not get a plan now: a caller that makes a new list every step (two misses in a row: a
+    build synchronises the stream and walks the list on the host - every step) or a stream that is being captured (a build
+    cannot be captured); the caller then gathers and scatters without a plan, and a list that does come back gets its plan
+    at its second sighting."""
+    global _node_plan_misses
+    capturing = torch.cuda.is_current_stream_capturing()
     with _node_plans_lock:                                     # (autograd runs a device's backward on its own thread)
-        for t, ver, rows, plan in _node_plans:
-            if t is nodes and ver == nodes._version and rows == num_rows:
-                return plan
+        entry = None
+        for e in _node_plans:
+            if e[0] is key and e[1] == key._version and e[2] == num_rows:
+                entry = e
+                break
+        if entry is not None:
+            _node_plan_misses = 0
+            if entry[3] is not None or capturing:
+                return entry[3]
+        else:
+            _node_plan_misses += 1
+            if _node_plan_misses > 2 or capturing:
+                _node_plans.append([key, key._version, num_rows, None])
+                del _node_plans[:-4]
+                return None
     ei = torch.stack([nodes, torch.arange(nodes.shape[0], dtype=torch.int64, device=nodes.device)])
     plan = _hip.GraphPlan.plain_sum(ei, num_rows, nodes.shape[0])
     with _node_plans_lock:
-        _node_plans.append((nodes, nodes._version, num_rows, plan))
-        del _node_plans[:-4]
+        if entry is not None:
+            entry[3] = plan
+        else:
+            _node_plans.append([key, key._version, num_rows, plan])
+            del _node_plans[:-4]
     return plan
 
 
@@ -509,7 +533,7 @@ class ClassLogitsFn(torch.autograd.Function):
         nodes = _hip.i64_vec(node_list)
         out = torch.empty((nodes.shape[0], w.shape[1]), dtype=torch.float32, device=zc.device)
         _hip.class_scores(zc, w, nodes, out, False)
-        ctx.nodes = node_list if nodes is node_list else nodes     # (the caller's tensor keys the gather plan's cache)
+        ctx.nodes, ctx.key = nodes, node_list                      # (the caller's tensor keys the gather plan's cache)
         ctx.save_for_backward(zc, w)
         return out
 
@@ -519,13 +543,16 @@ class ClassLogitsFn(torch.autograd.Function):
         nodes = ctx.nodes
         dz = dw = None
         g = _hip.f32_rows(g.contiguous())
-        plan = node_gather_plan(nodes, z.shape[0]) if nodes.shape[0] > 0 else None
-        if plan is None:
+        if nodes.shape[0] == 0:
             return (torch.zeros_like(z) if ctx.needs_input_grad[0] else None), (torch.zeros_like(w) if ctx.needs_input_grad[1] else None), None
+        plan = node_gather_plan(ctx.key, nodes, z.shape[0])    # (None: a list that is new every step, or a captured stream - no plan)
         zsel = None
         if ctx.needs_input_grad[1]:                            # z[nodes]: a one-edge-per-row aggregation
-            zsel = torch.empty((nodes.shape[0], z.shape[1]), dtype=torch.float32, device=z.device)
-            plan.aggregate(z, None, False, zsel)
+            if plan is None:
+                zsel = z.index_select(0, nodes)
+            else:
+                zsel = torch.empty((nodes.shape[0], z.shape[1]), dtype=torch.float32, device=z.device)
+                plan.aggregate(z, None, False, zsel)
         gw = None
         with _hip.dense_batch(g.device):                       # the two products do not depend on each other: one launch
             if ctx.needs_input_grad[0]:                        # rows of g W^T (gn_gemm_f32, W as it is stored) ...
@@ -534,8 +561,11 @@ class ClassLogitsFn(torch.autograd.Function):
             if zsel is not None:                               # z[nodes]^T g (gn_xtg_f32)
                 dw = _hip.xtg(zsel, g, join_batch=True)
         if gw is not None:                                     # ... added at the listed nodes (rows named twice add up)
-            dz = torch.empty_like(z)
-            plan.aggregate_t(gw, dz)
+            if plan is None:
+                dz = torch.zeros_like(z).index_add_(0, nodes, gw)
+            else:
+                dz = torch.empty_like(z)
+                plan.aggregate_t(gw, dz)
         return dz, dw, None
 
 

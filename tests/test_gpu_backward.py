@@ -164,6 +164,55 @@ def test_multiclass_decoder_gradients(gpu):
         close(mc.weight.grad, wr.grad, what="dW")
 
 
+def test_multiclass_decoder_node_lists_that_change_every_step(gpu):
+    """The backward's row-gather plan (autograd.node_gather_plan) is remembered under the CALLER's list: a strided list that is
+    the same object every step is made contiguous on every forward and still builds ONE plan; lists that are new every step stop
+    getting plans after two misses (a build synchronises the stream and walks the list on the host) and take the plan-less
+    gather / scatter - the same gradients either way."""
+    from gripnet_amd import autograd as ag
+    gen = torch.Generator().manual_seed(33)
+    n, f, c = 200, 24, 5
+    z = torch.randn(n, f, generator=gen)
+    torch.manual_seed(39)
+    mc = gripnet_amd.multiClassInnerProductDecoder(f, c).to(gpu)
+    built = []
+    real = _hip.GraphPlan.plain_sum.__func__
+    def counting(cls, *args, **kw):
+        built.append(1)
+        return real(cls, *args, **kw)
+    _hip.GraphPlan.plain_sum = classmethod(counting)
+    try:
+        with ag._node_plans_lock:
+            ag._node_plans.clear()
+            ag._node_plan_misses = 0
+        def grads(node_list, nodes_cpu):
+            mc.zero_grad()
+            zg = leaf(z.to(gpu))
+            p = mc(zg, node_list, softmax=True)
+            proj = torch.linspace(-1, 1, p.numel()).reshape(p.shape)
+            (p * proj.to(gpu)).sum().backward()
+            zr, wr = leaf(z), leaf(mc.weight.cpu())
+            (orc.multiclass(zr, nodes_cpu, wr, softmax=True) * proj).sum().backward()
+            close(zg.grad, zr.grad, what="dz")
+            close(mc.weight.grad, wr.grad, what="dW")
+        same = torch.randint(0, n, (64,), generator=gen)
+        same32 = torch.stack([same, same], dim=1).to(gpu)[:, 0]   # a strided view: copied on every forward, the caller's object repeats
+        assert not same32.is_contiguous()
+        for _ in range(4):
+            grads(same32, same)
+        assert len(built) == 1
+        for k in range(6):                                     # a new list (with repeated nodes) every step
+            fresh = torch.randint(0, n, (64,), generator=gen)
+            grads(fresh.to(gpu), fresh)
+        assert len(built) <= 3, built                          # two more builds, then none
+        grads(same32, same)                                    # (dropped from the four remembered lists meanwhile: a plan again or not - right either way)
+    finally:
+        _hip.GraphPlan.plain_sum = classmethod(real)
+        with ag._node_plans_lock:
+            ag._node_plans.clear()
+            ag._node_plan_misses = 0
+
+
 def _nll(pred, labels):
     return -torch.log(pred[torch.arange(labels.shape[0]), labels] + 1e-13).mean()      # GripNet-aminer.py:133
 
