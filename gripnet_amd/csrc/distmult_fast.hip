@@ -26,6 +26,11 @@ struct DmFastArgs {
     int64_t e; int64_t edges_per_wg; int sigmoid; float* out; int32_t* err;
     int n_phases; int c0[kMaxPhases]; int width[kMaxPhases];
     int stride4;           // LDS row stride in float4, the same in every phase (see gn_distmult_fast_forward)
+    // Raw int64 triples, several column phases: the first phase leaves every edge's triple in LDS behind the table, narrowed to
+    // `stage_bytes` (4: u | v << 10 | r << 20 for n <= 1023, r <= 4096; 8: u | v << 16, r; 0: no staging), and the later phases
+    // read it there - 24 bytes per edge cross from HBM once instead of once per phase (pose0-syn: 155 MB moved for 56 MB of
+    // algorithmic bytes before).  A workgroup whose range does not fit walks it in tiles of `tile_edges`, all phases per tile.
+    int stage_bytes; int64_t tile_edges; int stage_off;
 };
 
 struct Batch {            // one lane's edge of a 64-edge batch
@@ -33,8 +38,9 @@ struct Batch {            // one lane's edge of a 64-edge batch
     float carried;
 };
 
+// stage: the tile's narrowed triples in LDS (null: none); first: this is the phase that reads them from memory and leaves them there
 template <bool PACKED>
-__device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, int64_t hi, bool carry) {
+__device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, int64_t lo, int64_t hi, bool carry, char* stage, bool first) {
     Batch b;
     b.u = b.v = b.r = 0;
     b.carried = 0.f;
@@ -43,7 +49,24 @@ __device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, i
             const uint32_t w = a.packed[mine];
             b.u = w & 0xffffu; b.v = w >> 16; b.r = a.rel16[mine];
         } else {
-            b.u = a.u[mine]; b.v = a.v[mine]; b.r = a.et[mine];
+            if (stage != nullptr && !first) {
+                if (a.stage_bytes == 4) {
+                    const uint32_t w = reinterpret_cast<const uint32_t*>(stage)[mine - lo];
+                    b.u = w & 1023u; b.v = (w >> 10) & 1023u; b.r = w >> 20;     // (an edge with an id outside its table: u = 1023 >= n)
+                } else {
+                    const uint2 w = reinterpret_cast<const uint2*>(stage)[mine - lo];
+                    b.u = w.x & 0xffffu; b.v = w.x >> 16; b.r = (int64_t)w.y;     // (... : r = 2^32 - 1)
+                }
+            } else {
+                b.u = a.u[mine]; b.v = a.v[mine]; b.r = a.et[mine];
+                if (stage != nullptr) {
+                    const bool ok = (uint64_t)b.u < (uint64_t)a.n && (uint64_t)b.v < (uint64_t)a.n && (uint64_t)b.r < (uint64_t)a.r;
+                    if (a.stage_bytes == 4)
+                        reinterpret_cast<uint32_t*>(stage)[mine - lo] = ok ? ((uint32_t)b.u | (uint32_t)b.v << 10 | (uint32_t)b.r << 20) : 1023u;
+                    else
+                        reinterpret_cast<uint2*>(stage)[mine - lo] = ok ? make_uint2((uint32_t)b.u | (uint32_t)b.v << 16, (uint32_t)b.r) : make_uint2(0u, 0xffffffffu);
+                }
+            }
         }
         if (carry) b.carried = a.out[mine];
     }
@@ -52,7 +75,7 @@ __device__ __forceinline__ Batch load_batch(const DmFastArgs& a, int64_t mine, i
 
 template <int W4, int CPL, bool PACKED>
 __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, int stride_bytes, int c0, int w4, bool first, bool last,
-                                          int64_t wg_lo, int64_t wg_hi, int wave, int lane) {
+                                          int64_t wg_lo, int64_t wg_hi, int wave, int lane, char* stage) {
     const int l4 = lane & 3;
     const float* dcol = a.d + c0 + 4 * l4;
     int cur_r = -1;                                         // wave-uniform: relation whose chunks sit in dreg
@@ -62,11 +85,11 @@ __device__ __forceinline__ void run_phase(const DmFastArgs& a, const char* lds, 
     constexpr int64_t kStride = (kThreads / 64) * 64;
 
     int64_t e0 = wg_lo + wave * 64;
-    Batch nxt = load_batch<PACKED>(a, e0 + lane, wg_hi, !first);
+    Batch nxt = load_batch<PACKED>(a, e0 + lane, wg_lo, wg_hi, !first, stage, first);
     for (; e0 < wg_hi; e0 += kStride) {
         const int64_t mine = e0 + lane;
         const Batch cur = nxt;
-        nxt = load_batch<PACKED>(a, mine + kStride, wg_hi, !first);   // in flight while this batch computes
+        nxt = load_batch<PACKED>(a, mine + kStride, wg_lo, wg_hi, !first, stage, first);   // in flight while this batch computes
         const bool ok = (uint64_t)cur.u < (uint64_t)a.n && (uint64_t)cur.v < (uint64_t)a.n &&
                         (uint64_t)cur.r < (uint64_t)a.r;
         const int iu = ok ? (int)cur.u : 0, iv = ok ? (int)cur.v : 0;
@@ -115,24 +138,31 @@ __global__ __launch_bounds__(kThreads) void k_distmult_lds(DmFastArgs a) {
     const int64_t wg_lo = (int64_t)blockIdx.x * a.edges_per_wg;
     const int64_t wg_hi = min(a.e, wg_lo + a.edges_per_wg);
     const char* lds = reinterpret_cast<const char*>(lds4);
+    char* stage = (!PACKED && a.stage_bytes > 0) ? reinterpret_cast<char*>(lds4) + a.stage_off : nullptr;
+    const int64_t tile = stage ? a.tile_edges : max((int64_t)1, wg_hi - wg_lo);
+    bool table_in_use = false;
 
-    for (int ph = 0; ph < a.n_phases; ++ph) {
-        const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
-        if (ph > 0) __syncthreads();                        // everyone is done with the previous phase's table
-        switch (w4) {                                       // compile-time row width where it is a common one
-            case 16: fill_table<16>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
-            case 12: fill_table<12>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
-            case 8: fill_table<8>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
-            default: fill_table<0>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
-        }
-        __syncthreads();
-        const bool first = ph == 0, last = ph == a.n_phases - 1;
-        switch (w4) {                                       // common widths get compile-time addressing
-            case 16: run_phase<16, 4, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 12: run_phase<12, 3, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 8: run_phase<8, 2, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            case 4: run_phase<4, 1, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
-            default: run_phase<0, 4, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, wg_lo, wg_hi, wave, lane); break;
+    for (int64_t t_lo = wg_lo; t_lo < wg_hi; t_lo += tile) {
+        const int64_t t_hi = min(wg_hi, t_lo + tile);
+        for (int ph = 0; ph < a.n_phases; ++ph) {
+            const int c0 = a.c0[ph], w4 = a.width[ph] >> 2;
+            if (table_in_use) __syncthreads();                  // everyone is done with the previous phase's table (and the previous tile's triples)
+            table_in_use = true;
+            switch (w4) {                                       // compile-time row width where it is a common one
+                case 16: fill_table<16>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+                case 12: fill_table<12>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+                case 8: fill_table<8>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+                default: fill_table<0>(lds4, a.z, a.ld_z, a.n, c0, w4, a.stride4, tid); break;
+            }
+            __syncthreads();
+            const bool first = ph == 0, last = ph == a.n_phases - 1;
+            switch (w4) {                                       // common widths get compile-time addressing
+                case 16: run_phase<16, 4, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, t_lo, t_hi, wave, lane, stage); break;
+                case 12: run_phase<12, 3, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, t_lo, t_hi, wave, lane, stage); break;
+                case 8: run_phase<8, 2, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, t_lo, t_hi, wave, lane, stage); break;
+                case 4: run_phase<4, 1, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, t_lo, t_hi, wave, lane, stage); break;
+                default: run_phase<0, 4, PACKED>(a, lds, a.stride4 * 16, c0, w4, first, last, t_lo, t_hi, wave, lane, stage); break;
+            }
         }
     }
 }
@@ -157,12 +187,30 @@ static gn_status distmult_lds_launch(DmFastArgs& a, int64_t n, int64_t f, int64_
     for (int k = 0; k < a.n_phases; ++k) max_w = std::max(max_w, a.width[k]);
     const int stride4 = lds_stride4(n, max_w);
     a.stride4 = stride4;
-    const size_t lds_bytes = (size_t)n * stride4 * 16;
+    size_t lds_bytes = (size_t)n * stride4 * 16;
     // one workgroup per CU; every workgroup's range is a multiple of 64 edges
     int64_t groups = std::min<int64_t>(256, gn::ceil_div(e, 64 * (kThreads / 64)));
     if (groups < 1) groups = 1;
     a.edges_per_wg = gn::ceil_div(gn::ceil_div(e, groups), 64) * 64;
     groups = gn::ceil_div(e, a.edges_per_wg);
+    // the triples of the raw int64 list staged in LDS behind the table (see DmFastArgs): where a tile of a useful size fits, and
+    // the table fills of the extra tiles (every workgroup reads the whole phase table again: ~3 us each at this size) cost less
+    // than the passes over the list they save (24 bytes per edge and phase at ~5 TB/s)
+    a.stage_bytes = 0; a.tile_edges = 0; a.stage_off = (int)lds_bytes;
+    if (!packed && a.n_phases > 1) {
+        const int sb = (n <= 1023 && a.r <= 4096) ? 4 : 8;
+        const int64_t room = (int64_t)160 * 1024 - (int64_t)lds_bytes;
+        const int64_t tile = room / sb / 64 * 64;
+        if (tile >= 1024) {
+            const int64_t tiles = gn::ceil_div(a.edges_per_wg, tile);
+            const double fill_us = (double)lds_bytes * (double)groups / 1.0e7, pass_us = (double)e * 24.0 / 5.0e6;
+            if ((double)(tiles - 1) * a.n_phases * fill_us < (double)(a.n_phases - 1) * pass_us) {
+                a.stage_bytes = sb;
+                a.tile_edges = std::min<int64_t>(tile, a.edges_per_wg);
+                lds_bytes += (size_t)a.tile_edges * sb;
+            }
+        }
+    }
     if (packed) {
         { gn_status lds_status = gn::allow_large_lds(reinterpret_cast<const void*>(k_distmult_lds<true>), 160 * 1024); if (lds_status != GN_OK) return lds_status; }
         k_distmult_lds<true><<<(unsigned)groups, kThreads, lds_bytes, st>>>(a);
