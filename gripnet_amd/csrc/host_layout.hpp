@@ -131,8 +131,8 @@ struct HostArena {
     static constexpr size_t kMaxBytes = (size_t)1 << 30;
     static constexpr size_t kMinBytes = (size_t)256 << 10;
     std::mutex lock;
-    char* base = nullptr;
-    size_t bytes = 0;
+    std::atomic<char*> base{nullptr};  // (read by arena_owns on any thread, without the lock: see the order of the stores in ArenaHold)
+    std::atomic<size_t> bytes{0};
     size_t want = 0;                   // what the block should hold at the next acquire
     std::atomic<size_t> used{0};       // bump pointer of the current hold
     std::atomic<size_t> asked{0};      // bytes requested during the current hold (served or not)
@@ -151,10 +151,17 @@ struct ArenaHold {
         HostArena& a = host_arena();
         if (arena_of_this_thread() != nullptr || !a.lock.try_lock()) return;     // (nested, or another builder has it: malloc)
         held = true;
-        if (a.want > a.bytes) {
-            std::free(a.base);
-            a.base = static_cast<char*>(std::malloc(a.want));
-            a.bytes = a.base ? a.want : 0;
+        if (a.want > a.bytes.load()) {
+            // a thread without the arena may be asking arena_owns() about a pointer of its own right now: it reads `bytes`, then
+            // `base` - the size goes to zero before the block changes and comes back after it, so that no mix of old and new spans
+            // memory that is not the block's
+            char* old = a.base.load();
+            a.bytes.store(0);
+            a.base.store(nullptr);
+            std::free(old);
+            char* fresh = static_cast<char*>(std::malloc(a.want));
+            a.base.store(fresh);
+            a.bytes.store(fresh ? a.want : 0);
         }
         a.used.store(0); a.asked.store(0);
         arena_of_this_thread() = &a;
@@ -176,12 +183,14 @@ inline void* arena_allocate(size_t bytes) {
     const size_t padded = (bytes + 63) & ~(size_t)63;
     a->asked.fetch_add(padded);
     const size_t at = a->used.fetch_add(padded);
-    if (at + padded > a->bytes) { a->used.fetch_sub(padded); return nullptr; }
-    return a->base + at;
+    if (at + padded > a->bytes.load()) { a->used.fetch_sub(padded); return nullptr; }
+    return a->base.load() + at;
 }
 inline bool arena_owns(const void* p) {
     const HostArena& a = host_arena();
-    return a.base != nullptr && static_cast<const char*>(p) >= a.base && static_cast<const char*>(p) < a.base + a.bytes;
+    const size_t bytes = a.bytes.load();
+    const char* base = a.base.load();
+    return base != nullptr && static_cast<const char*>(p) >= base && static_cast<const char*>(p) < base + bytes;
 }
 
 // A vector whose resize() leaves new elements uninitialised (the builders' large arrays are written whole by the parallel
