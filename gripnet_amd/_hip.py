@@ -19,13 +19,13 @@ _lib = None
 _lock = threading.Lock()
 
 GN_OK, GN_ERR_INVALID_ARG, GN_ERR_HIP, GN_ERR_INDEX_RANGE, GN_ERR_UNSUPPORTED, GN_ERR_EDGE_COUNT = range(6)
-GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST, GN_RGCN_PAIR_SUMS_ONLY, GN_RGCN_PAIR_SUMS_READY = 1, 4, 16, 32                                  # flags of gn_rgcn_forward_f32
+GN_RGCN_PARTIAL, GN_RGCN_ARITH_FAST, GN_RGCN_PAIR_SUMS_ONLY, GN_RGCN_PAIR_SUMS_READY, GN_RGCN_BASIS_TRANSPOSED = 1, 4, 16, 32, 64        # flags of gn_rgcn_forward_f32
 GN_RGCN_PATH_SHIFT = 8
 RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}                  # kernel choice (tests, measurements)
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 152                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 153                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -880,11 +880,24 @@ class RgcnPlan:
         return {v: k for k, v in RGCN_PATHS.items()}.get(code, "?")
 
     def forward(self, x, basis, att, root, bias, relu, out, partial=False, side=None, fast=False, path="auto", x_planes=None,
-                pair_sums=False):
+                pair_sums=False, basis_transposed=False):
         """`x_planes`: SplitPlanes of x left by its producer (the destination-major kernel then skips its own split of x;
         the other kernels ignore them).  `pair_sums`: the sums of this step are on their way (start_pair_sums): the launch is
-        ordered behind them and contracts them (GN_RGCN_PAIR_SUMS_READY)."""
+        ordered behind them and contracts them (GN_RGCN_PAIR_SUMS_READY).  `basis_transposed`: `basis` is [bases, out, in] (the
+        forward's parameter seen from the reversed layer of its backward; destination-major kernel only: GN_RGCN_BASIS_TRANSPOSED)."""
         mode = self.mode_flags(fast, path)
+        if basis_transposed:
+            if pair_sums:
+                raise ValueError("basis_transposed does not combine with pair_sums")
+            fout = basis.shape[1]
+            ws, need = self._workspace(x.shape[1], fout, basis.shape[0], mode)
+            sc = side_copy(side)
+            flags = (GN_RGCN_PARTIAL if partial else 0) | mode | GN_RGCN_BASIS_TRANSPOSED
+            _call("gn_rgcn_forward_f32", self._h, ptr(x), ld(x), x.shape[1], ptr(basis), ptr(att), basis.shape[0],
+                  ptr(root), ptr(bias), fout, int(bool(relu)), flags,
+                  ptr(out), ld(out), _ref(sc), None if x_planes is None else x_planes.buf.data_ptr(), ptr(ws), need,
+                  stream_ptr(x.device))
+            return out
         if pair_sums:
             sc = side_copy(side)
             flags = (GN_RGCN_PARTIAL if partial else 0) | mode | GN_RGCN_PAIR_SUMS_READY

@@ -226,6 +226,9 @@ def rgcn_edge_gradients(plan, x, basis, att, gm, need_x=True, need_basis=True, n
                 tmp = torch.empty((n, 32), dtype=torch.float32, device=x.device)
                 rev.forward(gm, blk, att, None, None, False, tmp, partial=True)
                 dxe[:, c0:c0 + w] = tmp[:, :w]
+        elif rev.path(fout, fin, B) == "pair" and basis.is_contiguous() and basis.data_ptr() % 16 == 0:
+            # (the destination-major kernel reads W_r^T out of the forward's own parameter: no transposed copy per step)
+            rev.forward(gm, basis, att, None, None, False, dxe, partial=True, basis_transposed=True)
         else:
             rev.forward(gm, bt.contiguous(), att, None, None, False, dxe, partial=True)
     if need_basis or need_att:

@@ -23,7 +23,7 @@ bool gn_rgcn_pair_applicable(const gn_rgcn_plan* plan, int64_t fin, int64_t fout
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
-                               const void* x_planes, hipStream_t st, int mode, void* pair_sums);
+                               const void* x_planes, hipStream_t st, int mode, void* pair_sums, int basis_transposed = 0);
 size_t gn_rgcn_pair_sums_bytes(const gn_rgcn_plan* plan, int64_t bases);
 
 bool gn_rgcn_fast_finalize_applicable(int64_t fin, int64_t fout, int64_t ld_summed, const void* summed);
@@ -149,6 +149,8 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
     const int path = select_path(plan, fin, fout, bases, flags, basis);
     if (split && (path != GN_RGCN_PATH_PAIR || !x_planes || (flags & GN_RGCN_ARITH_FAST)))
         return gn::fail(GN_ERR_UNSUPPORTED, "GN_RGCN_PAIR_SUMS_READY: the destination-major kernel with x as split planes, default arithmetic");
+    if ((flags & GN_RGCN_BASIS_TRANSPOSED) && path != GN_RGCN_PATH_PAIR)
+        return gn::fail(GN_ERR_UNSUPPORTED, "GN_RGCN_BASIS_TRANSPOSED: only the destination-major kernel reads a transposed basis (pass a transposed copy)");
     const size_t need = path_workspace_bytes(plan, fin, fout, bases, path, flags);
     GN_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "workspace too small: this call needs %zu bytes, got %zu",
                need, workspace_bytes);
@@ -159,7 +161,8 @@ gn_status gn_rgcn_forward_f32(const gn_rgcn_plan* plan, const float* x, int64_t 
 
     if (path == GN_RGCN_PATH_PAIR)
         return gn_rgcn_pair_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
-                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, x_planes, st, split ? 2 : 0, split ? workspace : nullptr);
+                                    flags & GN_RGCN_ARITH_FAST, out, ld_out, sc, x_planes, st, split ? 2 : 0, split ? workspace : nullptr,
+                                    flags & GN_RGCN_BASIS_TRANSPOSED);
     if (path == GN_RGCN_PATH_LDS)
         return gn_rgcn_fast_forward(plan, x, ld_x, fin, basis, att, bases, root, bias, fout, relu, partial,
                                     out, ld_out, sc, workspace, workspace_bytes, st);

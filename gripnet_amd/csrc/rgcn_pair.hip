@@ -63,6 +63,7 @@ struct PairArgs {
     const uint32_t* desc;
     const int32_t* wg_dst;
     int n, R, B, fout, chunks, relu, partial, att_dma;
+    int basis_t = 0;                     // basis is stored [B][fout][fin] (GN_RGCN_BASIS_TRANSPOSED: the backward's W_r^T from the forward's own parameter)
     gn_side_copy side;
     float* psum = nullptr;               // MODE 1 writes, MODE 2 reads: the pair sums of every unit, [unit slot][4][64 lanes] 16-byte words
 };
@@ -538,7 +539,10 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     const int fout = a.fout, og = fout >> 2;                                   // fout % 4 == 0, og in 1..16
     const int slices = kThreads / og;
     const int rows = a.B * FIN;                                                // rows of basis
-    const int o4 = tid % og, sl = tid / og;
+    // (a transposed basis is contiguous along the FEATURE: there consecutive lanes take consecutive rows - slices - of one output
+    // group, so that a wave's loads are whole lines again; which thread holds which (slice, output group) changes nothing else)
+    const int o4 = a.basis_t ? tid / slices : tid % og;
+    const int sl = a.basis_t ? (tid < slices * og ? tid - o4 * slices : slices) : tid / og;
     const int per = (rows + slices - 1) / slices;                              // <= kRowsMax (checked on the host)
     // (twelve rows are requested here, while this wave's accumulators are still alive; rows 12.. of the narrow layers - kRowsMax 16 -
     // behind the shares' store, where the accumulators are dead: with all sixteen alive next to them the NT <= 2 kernels spilled
@@ -546,10 +550,19 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
     constexpr int kRowsPre = 12;
     f32x4 bv[kRowsMax];
     const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(a.basis);
+    // row nr = base * FIN + feature, outputs 4 o4 .. 4 o4 + 3: one 16-byte load, or - basis stored transposed, [B][fout][FIN]: the
+    // reversed layer of a training step reads the forward's parameter as it is, a transposed copy was a launch of its own - four
+    // loads FIN floats apart (196 KB, L2-resident)
+    auto basis_row = [&](int nr) -> f32x4 {
+        if (!a.basis_t) return bp[(uint32_t)(nr * og + o4)];
+        const int b = nr / FIN, f = nr - b * FIN;
+        const float* __restrict__ q = a.basis + ((size_t)b * fout + 4 * o4) * FIN + f;
+        return (f32x4){q[0], q[FIN], q[2 * FIN], q[3 * FIN]};
+    };
 #pragma unroll
     for (int j = 0; j < kRowsPre; ++j) {
         const int nr = j * slices + sl;                                        // row base * FIN + feature of basis
-        bv[j] = (sl < slices && j < per && nr < rows) ? bp[(uint32_t)(min(nr, rows - 1) * og + o4)] : (f32x4)(0.f);
+        bv[j] = (sl < slices && j < per && nr < rows) ? basis_row(min(nr, rows - 1)) : (f32x4)(0.f);
     }
     // the output element this thread writes at the very end: its divisor, bias and share of the root term x_i . root
     // (eight adjacent lanes per element), requested before the barrier too
@@ -593,7 +606,7 @@ __global__ __launch_bounds__(kThreads) void k_rgcn_pair(PairArgs a, int stamp_se
 #pragma unroll
         for (int j = kRowsPre; j < kRowsMax; ++j) {
             const int nr = j * slices + sl;
-            bv[j] = (sl < slices && j < per && nr < rows) ? bp[(uint32_t)(min(nr, rows - 1) * og + o4)] : (f32x4)(0.f);
+            bv[j] = (sl < slices && j < per && nr < rows) ? basis_row(min(nr, rows - 1)) : (f32x4)(0.f);
         }
     }
     __syncthreads();
@@ -952,8 +965,9 @@ size_t gn_rgcn_pair_sums_bytes(const gn_rgcn_plan* plan, int64_t bases) {
 gn_status gn_rgcn_pair_forward(const gn_rgcn_plan* plan, const float* x, int64_t ld_x, int64_t fin, const float* basis,
                                const float* att, int64_t bases, const float* root, const float* bias, int64_t fout,
                                int relu, int partial, int fast_arith, float* out, int64_t ld_out, const gn_side_copy& side,
-                               const void* x_planes, hipStream_t st, int mode, void* pair_sums) {
+                               const void* x_planes, hipStream_t st, int mode, void* pair_sums, int basis_transposed) {
     PairArgs a;
+    a.basis_t = basis_transposed ? 1 : 0;
     a.psum = static_cast<float*>(pair_sums);
     GN_REQUIRE(mode == kModeFused || (pair_sums && (reinterpret_cast<uintptr_t>(pair_sums) & 15) == 0), "the pair sums need a 16-byte aligned buffer");
     a.xp = static_cast<const unsigned char*>(x_planes);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 152 /* 0.1.48 */
+#define GN_VERSION 153 /* 0.1.48 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -307,6 +307,10 @@ GN_API size_t gn_rgcn_workspace_bytes(const gn_rgcn_plan* plan, int64_t in_featu
  * be - every step, never kept across steps.  GN_ERR_UNSUPPORTED where the destination-major kernel does not apply. */
 #define GN_RGCN_PAIR_SUMS_ONLY 16
 #define GN_RGCN_PAIR_SUMS_READY 32
+/* GN_RGCN_BASIS_TRANSPOSED: `basis` is stored [bases][fout][fin] - the layer's own parameter seen from the reversed layer of
+ * its backward (dx = the same layer on the reversed graph with W_r^T, autograd.rgcn_edge_gradients): no transposed copy per
+ * step.  Read by the destination-major kernel only; GN_ERR_UNSUPPORTED on the others (pass a transposed copy there). */
+#define GN_RGCN_BASIS_TRANSPOSED 64
 /* Kernel choice, for tests and measurements (0 = the library decides; a kernel that does not cover the shapes is not
  * forced): (GN_RGCN_PATH_x << GN_RGCN_PATH_SHIFT) in flags.  gn_rgcn_forward_path tells which one a call would take. */
 #define GN_RGCN_PATH_SHIFT 8

@@ -606,6 +606,29 @@ def test_rgcn_destination_major_output_widths(gpu, n, fin, fout, bases):
     close(y, ref.float())
 
 
+@pytest.mark.parametrize("n,fin,fout,bases", [(645, 32, 48, 32), (300, 16, 64, 8), (700, 48, 20, 5), (645, 64, 32, 8)])
+def test_rgcn_reads_a_transposed_basis(gpu, n, fin, fout, bases):
+    """GN_RGCN_BASIS_TRANSPOSED: the destination-major kernel on `basis` stored [bases, out, in] - how the reversed layer of the
+    backward sees the forward's parameter (autograd.rgcn_edge_gradients: dx = the layer on the reversed graph with W_r^T) - gives
+    the bits of the same call on a transposed copy; the other kernels refuse the flag."""
+    gen = torch.Generator().manual_seed(n + fout)
+    sizes = [4000, 0, 3, 1200, 900]
+    blocks = [torch.randint(0, n, (2, s), generator=gen) for s in sizes]
+    rei = torch.cat(blocks, dim=1).to(gpu)
+    rl = gripnet_amd.utils.get_range_list(blocks)
+    x = torch.randn(n, fin, generator=gen).to(gpu)
+    stored = torch.randn(bases, fout, fin, generator=gen).to(gpu)          # [bases, out, in]
+    att = torch.randn(len(sizes), bases, generator=gen).to(gpu)
+    plan = _hip.RgcnPlan(rei, rl, n)
+    assert plan.path(fin, fout, bases) == "pair"
+    want, got = torch.empty(n, fout, device=gpu), torch.full((n, fout), float("nan"), device=gpu)
+    plan.forward(x, stored.transpose(1, 2).contiguous(), att, None, None, False, want, partial=True)
+    plan.forward(x, stored, att, None, None, False, got, partial=True, basis_transposed=True)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        plan.forward(x, stored, att, None, None, False, got, partial=True, basis_transposed=True, path="general")
+
+
 @pytest.mark.parametrize("formulation", ["pair", "lds"])
 def test_rgcn_sharded_partials_sum_to_full(gpu, formulation):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
