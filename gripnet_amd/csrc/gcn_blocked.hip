@@ -381,6 +381,7 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     const int R = std::max(1, std::min<int>(256 / groups, (int)gn::ceil_div(N, 64)));     // ranges of destination rows
 
     GN_LAP(nullptr);
+    gn::ArenaHold arena;                                       // (before every host array of this build: host_layout.hpp)
     std::vector<int32_t> rp(N + 1), col(nnz);
     GN_HIP(hipMemcpyAsync(rp.data(), plan->rowptr.p, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GN_HIP(hipMemcpyAsync(col.data(), plan->col.p, nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -394,7 +395,7 @@ extern "C" gn_status gn_graph_plan_build_blocked(gn_graph_plan* plan, int64_t co
     if (bl.failed) return gn::fail(GN_ERR_UNSUPPORTED, "internal: an edge was not scheduled");
     if (!bl.ok) return GN_OK;
     std::vector<int32_t>& tile_off = bl.tile_off; std::vector<int32_t>& tile_rows = bl.tile_rows; std::vector<int32_t>& cell = bl.cell;
-    std::vector<float>& tile_dis = bl.tile_dis; std::vector<uint16_t>& ids = bl.ids;
+    std::vector<float>& tile_dis = bl.tile_dis; gn::RawVec<uint16_t>& ids = bl.ids;
     const int64_t iters_total = bl.iters_total;
     plan->blk_ok = 0;
     plan->blk_dis.release(); plan->blk_tile_off.release(); plan->blk_ids.release(); plan->blk_cell.release();

@@ -1034,7 +1034,8 @@ inline void lay_out_section(const uint32_t* const (&list)[4], const int (&len)[4
 struct PairLayout {
     bool ok = false;
     int64_t blocks = 0;
-    std::vector<uint32_t> stream, wave_first, desc, wave_units, wave_desc;
+    gn::RawVec<uint32_t> stream;
+    std::vector<uint32_t> wave_first, desc, wave_units, wave_desc;
     std::vector<int32_t> wg_dst;
 };
 
@@ -1221,7 +1222,8 @@ inline PairLayout build_pair_layout(int64_t N, int64_t R, int chunks, int kpad, 
     size_t total = 0;
     for (size_t i = 0; i < wg_stream.size(); ++i) { first[i] = (uint32_t)(total / 16); total += wg_stream[i].size(); }
     if (total / 16 + kPairSlackBlocks >= ((size_t)1 << 31)) return L;
-    std::vector<uint32_t> stream(total + (size_t)kPairSlackBlocks * 16, (uint32_t)R * kPairRowBytes);
+    gn::RawVec<uint32_t> stream(total + (size_t)kPairSlackBlocks * 16);         // (the waves' streams tile [0, total): only the slack is filled)
+    std::fill(stream.begin() + (std::ptrdiff_t)total, stream.end(), (uint32_t)R * kPairRowBytes);
     gn::parallel_for((int64_t)wg_stream.size(), 64, [&](int64_t b, int64_t e) {
         for (int64_t i = b; i < e; ++i)
             if (!wg_stream[i].empty()) memcpy(stream.data() + (size_t)first[i] * 16, wg_stream[i].data(), wg_stream[i].size() * sizeof(uint32_t));
@@ -1246,7 +1248,7 @@ struct BlockedLayout {
     int64_t iters_total = 0;
     std::vector<int32_t> tile_off, tile_rows, cell;
     std::vector<float> tile_dis;
-    std::vector<uint16_t> ids;
+    gn::RawVec<uint16_t> ids;
 };
 
 inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<int32_t>& rp, const std::vector<int32_t>& col,
@@ -1350,15 +1352,25 @@ inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<in
     });
     GN_LAP("blocked: tiles (parallel)");
     std::vector<int32_t> tile_off(1, 0), tile_rows, cell;
-    std::vector<uint16_t> ids;
+    // the ranges' id streams one after the other: sized once, copied on the builder threads (6 MB at pose0-syn; appended
+    // range by range on one thread this was a third of the schedule's time)
+    std::vector<size_t> ids_first((size_t)R + 1, 0);
+    for (int r = 0; r < R; ++r) {
+        if (built[r].failed) { L.failed = true; return L; }
+        ids_first[(size_t)r + 1] = ids_first[(size_t)r] + built[r].ids.size();
+    }
+    gn::RawVec<uint16_t> ids(ids_first[(size_t)R] + (size_t)kColLayoutSlack * 256);
+    std::fill(ids.begin() + (std::ptrdiff_t)ids_first[(size_t)R], ids.end(), zero_id);
+    gn::parallel_for(R, 1, [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r)
+            if (!built[r].ids.empty()) memcpy(ids.data() + ids_first[(size_t)r], built[r].ids.data(), built[r].ids.size() * sizeof(uint16_t));
+    });
     for (int r = 0; r < R; ++r) {
         RangeOut& o = built[r];
-        if (o.failed) { L.failed = true; return L; }
         const int tiles_r = (int)o.tile_iters.size();
         const int first_tile = (int)tile_off.size() - 1;
         for (int tl = 0; tl < tiles_r; ++tl) tile_off.push_back(tile_off.back() + o.tile_iters[tl]);
         tile_rows.insert(tile_rows.end(), o.tile_rows.begin(), o.tile_rows.end());
-        ids.insert(ids.end(), o.ids.begin(), o.ids.end());
         // the range's tiles, cut into the contiguous ranges of the workgroup's waves by iterations (+ a cost per tile)
         auto cost_upto = [&](int tl) { return (int64_t)(tile_off[first_tile + tl] - tile_off[first_tile]) + 2 * (int64_t)tl; };
         int wt = 0;
@@ -1383,7 +1395,6 @@ inline BlockedLayout build_blocked_layout(int64_t N, int R, const std::vector<in
     std::vector<float> tile_dis(tile_rows.size(), 0.f);
     for (size_t k = 0; k < tile_rows.size(); ++k)
         if (tile_rows[k] >= 0) tile_dis[k] = dis_host[tile_rows[k]];
-    ids.resize(ids.size() + (size_t)kColLayoutSlack * 256, zero_id);
     if (ids.size() / 2 >= ((size_t)1 << 31)) return L;
 
     GN_LAP("blocked: concatenate");

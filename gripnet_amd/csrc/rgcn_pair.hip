@@ -847,6 +847,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     const int G = (int)std::min<int64_t>(N, cus);
 
     GN_LAP(nullptr);
+    gn::ArenaHold arena;                                       // (before every host array of this build: host_layout.hpp)
     Scratch tmp;
     GN_HIP(tmp.reserve((size_t)24 * (size_t)E + (size_t)4 * (size_t)N * kpad + (size_t)8 * (size_t)(N + R) + ((size_t)1 << 20)));
     int64_t* starts_dev;
@@ -903,7 +904,7 @@ gn_status gn_rgcn_build_pair_plan(gn_rgcn_plan* plan, const int64_t* src, const 
     gn_layout::PairLayout pl = gn_layout::build_pair_layout(N, R, chunks, kpad, G, D, rp, rels, perm);
     GN_LAP("  pair: host layout");
     if (!pl.ok) return GN_OK;
-    std::vector<uint32_t>& stream = pl.stream; std::vector<uint32_t>& first = pl.wave_first; std::vector<uint32_t>& desc = pl.desc;
+    gn::RawVec<uint32_t>& stream = pl.stream; std::vector<uint32_t>& first = pl.wave_first; std::vector<uint32_t>& desc = pl.desc;
     std::vector<uint32_t>& wave_units = pl.wave_units; std::vector<uint32_t>& wave_desc = pl.wave_desc;
     std::vector<int32_t>& wg_dst = pl.wg_dst;
     const size_t total = (size_t)pl.blocks * 16;
