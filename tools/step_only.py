@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="pose0-syn")
     ap.add_argument("--launch", default="recorded", choices=["recorded", "eager"])
+    ap.add_argument("--spin-up", type=int, default=0, help="un-timed steps in front of the warm-up that bring the device's clocks up "
+                    "(an A / B of kernels in the steady state: 4000; under the profiler: 0 - they would all be traced)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     data = make_pose(args.workload).to(dev)
@@ -30,7 +32,7 @@ def main():
     model = PoseModel(data.n_g_node, data.n_d_node, data.n_dd_edge_type).to(dev)
     with torch.no_grad():
         stages = PoseStages(model, data, graphs=False, recorded=args.launch == "recorded")
-        for _ in range(args.warmup):
+        for _ in range(args.spin_up + args.warmup):
             stages.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -39,7 +41,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     _hip.raise_if_index_errors(dev)
-    print("STEP_ONLY " + json.dumps({"workload": args.workload, "launch": args.launch, "steps": args.steps,
+    print("STEP_ONLY " + json.dumps({"workload": args.workload, "launch": args.launch, "steps": args.steps, "spin_up": args.spin_up,
                                      "us_per_step_wall": round(1e6 * dt / args.steps, 2)}))
 
 
