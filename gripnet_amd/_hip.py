@@ -25,7 +25,7 @@ RGCN_PATHS = {"auto": 0, "pair": 1, "lds": 3, "general": 4, "table": 5}         
 GN_GEMM_RELU, GN_GEMM_ARITH_FAST, GN_GEMM_B_TRANSPOSED, GN_GEMM_ACCUMULATE, GN_GEMM_A_TRANSPOSED, GN_GEMM_JOIN_BATCH, GN_GEMM_OUT_BF16 = 1, 2, 4, 8, 16, 32, 64                                    # flags of gn_gemm_f32
 GN_DM_TYPES_SORTED = 1                                 # flags of gn_distmult_backward_ex_f32
 GN_DM_TYPE_TASKS = 2
-ABI_VERSION = 153                                       # GN_VERSION of include/gripnet_hip.h this module binds
+ABI_VERSION = 154                                       # GN_VERSION of include/gripnet_hip.h this module binds
 
 _p, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
@@ -35,6 +35,7 @@ SIGNATURES = {
     "gn_last_error": (C.c_char_p, []),
     "gn_time_next_launch": (_int, [_p, _p]),
     "gn_stream_order": (_int, [_p, _p]),
+    "gn_host_scratch_release": (_sz, []),
     "gn_time_launch_pending": (_int, []),
     "gn_gcn_plan_create": (_int, [_p, _p, _p, _i64, _i64, _int, _p, C.POINTER(_p)]),
     "gn_bipartite_plan_create": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, C.POINTER(_p)]),
@@ -356,6 +357,11 @@ _ENV_HOOKS = ("GN_DISABLE_FAST", "GN_DISABLE_QUAD", "GN_DISABLE_BLOCKED", "GN_BL
 _ENV_NEUTRAL = ("GN_PLAN_THREADS", "GN_SAMPLER_TASKS", "GN_RGCN_SLAB_MB")
 _ENV_DATA = getattr(os.environ, "_data", None)
 _ENV_KEYS = tuple(k.encode() for k in _ENV_HOOKS) if isinstance(_ENV_DATA, dict) and all(isinstance(k, bytes) for k in list(_ENV_DATA)[:1]) else None
+
+
+def release_host_scratch() -> int:
+    """Give the plan builders' kept block of host memory back to the system (gn_host_scratch_release); the bytes freed."""
+    return int(load().gn_host_scratch_release())
 
 
 def env_stamp():

@@ -52,6 +52,21 @@ int gn_time_launch_pending(void) {
     return (e.start || e.stop) ? 1 : 0;
 }
 
+// The builders' kept host block (host_layout.hpp: HostArena) back to the system.  No array outlives the build that took it from
+// the block (ArenaHold), so a block nobody holds has no users.
+size_t gn_host_scratch_release(void) {
+    gn::HostArena& a = gn::host_arena();
+    if (!a.lock.try_lock()) return 0;
+    const size_t bytes = a.bytes.load();
+    char* old = a.base.load();
+    a.bytes.store(0);
+    a.base.store(nullptr);
+    std::free(old);
+    a.want = 0;
+    a.lock.unlock();
+    return bytes;
+}
+
 // `later` waits for what `earlier` has been given so far.  A wait takes the event's state at the time of the call, so the events
 // are reused round-robin (a ring per device and thread; 64 orderings can be in flight before an event is recorded again - and
 // re-recording an event a stream still waits on is harmless: the wait was bound to the earlier record).

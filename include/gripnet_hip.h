@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GN_VERSION 153 /* 0.1.48 */
+#define GN_VERSION 154 /* 0.1.48 */
 
 #if defined(GN_BUILDING)
 #define GN_API __attribute__((visibility("default")))
@@ -287,6 +287,13 @@ GN_API gn_status gn_time_next_launch(void* start_event, void* stop_event);
  * hipStreamWaitEvent on an event the library owns; no host synchronisation). */
 GN_API gn_status gn_stream_order(void* earlier_stream, void* later_stream);
 GN_API int gn_time_launch_pending(void);
+
+/* The plan builders (`*_plan_create`, gn_graph_plan_build_blocked) keep two things of the PROCESS between builds: their host
+ * threads (GN_PLAN_THREADS of them, parked; a forked child starts its own at its first build) and ONE block of host memory
+ * their large arrays come out of (it grows to 5/4 of what the largest build asked for, at most 1 GB; ~110 MB after the
+ * decoder plan of PoSE-0, ~500 MB after that of a four times larger list).  gn_host_scratch_release gives the block back
+ * to the system (unless a build is using it right now) and returns the bytes freed; the next build starts a new one. */
+GN_API size_t gn_host_scratch_release(void);
 
 /* Bytes of caller-provided scratch a gn_rgcn_forward_f32 call with these shapes and flags needs: none on the
  * destination-major kernel, W_r and the slabs of the LDS-accumulator kernel, a slab of rows (<= 256 MB) and the stacked

@@ -103,6 +103,12 @@ def test_kernel_register_budgets():
             assert r[".private_segment_fixed_size"] <= (64 if narrow else 160), (name, r)
 
 
+def test_host_scratch_release_without_a_build():
+    """gn_host_scratch_release is host-only: in a process that has built no plan there is nothing to free."""
+    assert _hip.release_host_scratch() == 0
+    assert _hip.release_host_scratch() == 0
+
+
 def test_env_hooks_cover_the_library():
     """A memoised forward (_hip.CallMemo) replays recorded kernel choices; its key carries the library's environment hooks.
     Every getenv("GN_...") of the C sources must be in _hip._ENV_HOOKS (part of the key) or in _hip._ENV_NEUTRAL (declared

@@ -629,6 +629,28 @@ def test_rgcn_reads_a_transposed_basis(gpu, n, fin, fout, bases):
         plan.forward(x, stored, att, None, None, False, got, partial=True, basis_transposed=True, path="general")
 
 
+def test_plan_builders_host_scratch_is_kept_and_released(gpu):
+    """The builders' large host arrays come out of one kept block (host_layout.hpp: HostArena): the first decoder plan of a process
+    sizes it, the next ones use it, gn_host_scratch_release gives it back - and the plans are the same plans throughout."""
+    gen = torch.Generator().manual_seed(5)
+    n, R = 300, 12
+    blocks = [gripnet_amd.utils.to_bidirection(torch.randint(0, n, (2, 30000 // (r + 1)), generator=gen)) for r in range(R)]
+    ei = torch.cat(blocks, dim=1).to(gpu)
+    et = torch.cat([torch.full((b.shape[1],), r, dtype=torch.int64) for r, b in enumerate(blocks)]).to(gpu)
+    z, d = torch.randn(n, 32, generator=gen).to(gpu), torch.randn(R, 32, generator=gen).to(gpu)
+    _hip.release_host_scratch()
+    scores = []
+    for k in range(3):
+        plan = _hip.DistMultPlan(ei, et, n, R, 32)
+        out = torch.empty(ei.shape[1], device=gpu)
+        plan.forward(z, d, True, out)
+        scores.append(out)
+        if k == 1:
+            assert _hip.release_host_scratch() > 0             # the block the second build used
+            assert _hip.release_host_scratch() == 0
+    assert torch.equal(scores[0], scores[1]) and torch.equal(scores[1], scores[2])
+
+
 @pytest.mark.parametrize("formulation", ["pair", "lds"])
 def test_rgcn_sharded_partials_sum_to_full(gpu, formulation):
     """G edge-range shards, un-normalised partials summed, then finalised == unsharded layer
