@@ -866,6 +866,16 @@ def main():
         # minute - tools/step_only.py).  The steady state is what is quoted: `spin_up_steps` un-timed steps bring the clocks up, then
         # the W warm-up steps and the K timed ones follow without a pause.
         spin_up_steps = int(os.environ.get("GN_BENCH_SPIN_UP", "4000"))
+        # (for the record: the same W + K steps WITHOUT the spin-up first - what the line would say with the clocks where the
+        # host-side work left them; a side figure in `spread`, never `value`)
+        for _ in range(max(args.warmup, 1)):
+            step()
+        fence()
+        t_cold = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        cold_ms = 1e3 * (time.perf_counter() - t_cold) / max(args.steps, 1)
         for _ in range(spin_up_steps):
             step()
         fence()
@@ -942,7 +952,10 @@ def main():
     rep_ms = sorted(1e3 * r / args.steps for r in repeats)
     spread = {"ms_per_step_min": round(rep_ms[0], 5), "ms_per_step_median": round(rep_ms[len(rep_ms) // 2], 5),
               "ms_per_step_max": round(rep_ms[-1], 5), "repeats": len(rep_ms),
-              "note": "K steps each, rank-local clocks; the first repeat is the timed region `value` is computed from"}
+              "ms_per_step_before_spin_up": round(cold_ms, 5),
+              "note": "K steps each, rank-local clocks; the first repeat is the timed region `value` is computed from; "
+                      "ms_per_step_before_spin_up: W + K steps timed the same way BEFORE the spin_up_steps un-timed steps (the device's clocks "
+                      "where the host-side set-up left them: not the steady state)"}
     value = A * args.steps / elapsed
 
     # ---- roofline of the dominant entry point (HIP events on its stream, inside the timed region) ----
